@@ -1,0 +1,179 @@
+"""fpga-mpeg2-encoder_amd — MI355X-native MPEG-2 I/P encoder, drop-in for RTL/mpeg2encoder.v.
+
+This package is plumbing: it loads libm2v_mi355x.so (hand-written HIP for gfx950 behind the
+C-ABI of include/m2v_mi355x.h) through ctypes and mirrors the module's port contract
+(parameters XL/YL/VECTOR_LEVEL/Q_LEVEL; beats in; 32-byte stream words out).  There is no CPU
+fallback: without the built library or without a GPU every entry point raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+from . import synth  # noqa: F401  (seeded synthetic clips, numpy only)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libm2v_mi355x.so")
+
+_lib = None
+
+EXPORTS = [
+    "m2v_version", "m2v_create", "m2v_destroy", "m2v_reset", "m2v_push_beats", "m2v_push_frames",
+    "m2v_sequence_stop", "m2v_busy", "m2v_pull", "m2v_geometry", "m2v_encode_resident", "m2v_set_option",
+    "m2v_kernel_stats", "m2v_debug_read", "m2v_last_error",
+]
+
+
+class M2VError(RuntimeError):
+    pass
+
+
+def lib():
+    """The C-ABI shared library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise M2VError("libm2v_mi355x.so is missing: run __graft_entry__.build() "
+                           "(hipcc, gfx950); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, sz, u32, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
+        L.m2v_version.restype = ctypes.c_char_p
+        L.m2v_create.restype = vp
+        L.m2v_create.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(ci)]
+        L.m2v_destroy.argtypes = [vp]
+        L.m2v_reset.argtypes = [vp]
+        L.m2v_push_beats.argtypes = [vp, u32, u32, u32, vp, vp, vp, sz, ci]
+        L.m2v_push_frames.argtypes = [vp, u32, u32, u32, vp, sz]
+        L.m2v_sequence_stop.argtypes = [vp]
+        L.m2v_busy.argtypes = [vp]
+        L.m2v_pull.restype = ctypes.c_longlong
+        L.m2v_pull.argtypes = [vp, vp, sz, ctypes.POINTER(ci)]
+        L.m2v_geometry.argtypes = [vp, u32, u32, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.m2v_encode_resident.argtypes = [vp, u32, u32, u32, vp, sz, vp, sz, ctypes.POINTER(sz), vp]
+        L.m2v_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_longlong]
+        L.m2v_kernel_stats.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.m2v_debug_read.restype = ctypes.c_longlong
+        L.m2v_debug_read.argtypes = [vp, ci, vp, sz]
+        L.m2v_last_error.restype = ctypes.c_char_p
+        L.m2v_last_error.argtypes = [vp]
+        L.m2v_debug_table.argtypes = [ci, ci, ci]
+        _lib = L
+    return _lib
+
+
+def build(force=False, verbose=False):
+    return _build.build(force=force, verbose=verbose)
+
+
+def clamp_geometry(xsize16, ysize16, XL=7, YL=7):
+    """Clamped (W, H) of RTL/mpeg2encoder.v:985-1006 (pure host arithmetic)."""
+    def c(s, L):
+        s &= (2 << L) - 1
+        lim = 1 << L
+        return lim - 1 if s > lim else 3 if s < 4 else s - 1
+    return 16 * (c(xsize16, XL) + 1), 16 * (c(ysize16, YL) + 1)
+
+
+class Mpeg2Encoder:
+    """`mpeg2encoder #(XL, YL, VECTOR_LEVEL, Q_LEVEL)` on one MI355X (RTL/mpeg2encoder.v:10-38)."""
+
+    def __init__(self, XL=6, YL=6, VECTOR_LEVEL=3, Q_LEVEL=2, device=0):
+        self.params = (XL, YL, VECTOR_LEVEL, Q_LEVEL)
+        err = ctypes.c_int(0)
+        self._L = lib()
+        self._h = self._L.m2v_create(XL, YL, VECTOR_LEVEL, Q_LEVEL, device, ctypes.byref(err))
+        if not self._h:
+            raise M2VError("m2v_create failed with code %d (parameters %r, device %d)" % (err.value, self.params, device))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.m2v_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, r, what):
+        if r < 0:
+            raise M2VError("%s failed (%d): %s" % (what, r, self._L.m2v_last_error(self._h).decode()))
+        return r
+
+    def set_option(self, name, value):
+        self._chk(self._L.m2v_set_option(self._h, name.encode(), int(value)), "m2v_set_option(%s)" % name)
+
+    def geometry(self, xsize16, ysize16):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        self._chk(self._L.m2v_geometry(self._h, xsize16, ysize16, ctypes.byref(w), ctypes.byref(h)), "m2v_geometry")
+        return w.value, h.value
+
+    # ---- port-level interface ----
+    def push_beats(self, xsize16, ysize16, pframes_count, y4, u4, v4, stop_with_last=False):
+        y4 = np.ascontiguousarray(y4, np.uint8).reshape(-1)
+        u4 = np.ascontiguousarray(u4, np.uint8).reshape(-1)
+        v4 = np.ascontiguousarray(v4, np.uint8).reshape(-1)
+        assert y4.size == u4.size == v4.size and y4.size % 4 == 0
+        self._chk(self._L.m2v_push_beats(self._h, xsize16, ysize16, pframes_count, y4.ctypes.data, u4.ctypes.data,
+                                         v4.ctypes.data, y4.size // 4, int(bool(stop_with_last))), "m2v_push_beats")
+
+    def push_frames(self, xsize16, ysize16, pframes_count, frames444):
+        W, H = self.geometry(xsize16, ysize16)
+        f = np.ascontiguousarray(frames444, np.uint8).reshape(-1)
+        assert f.size % (3 * W * H) == 0
+        self._chk(self._L.m2v_push_frames(self._h, xsize16, ysize16, pframes_count, f.ctypes.data,
+                                          f.size // (3 * W * H)), "m2v_push_frames")
+
+    def sequence_stop(self):
+        self._chk(self._L.m2v_sequence_stop(self._h), "m2v_sequence_stop")
+
+    @property
+    def busy(self):
+        return bool(self._L.m2v_busy(self._h))
+
+    def pull(self, max_bytes=1 << 20):
+        """-> (bytes, last)"""
+        buf = np.empty(max_bytes & ~31, np.uint8)
+        last = ctypes.c_int(0)
+        n = self._chk(self._L.m2v_pull(self._h, buf.ctypes.data, buf.size, ctypes.byref(last)), "m2v_pull")
+        return buf[:n].tobytes(), bool(last.value)
+
+    def pull_all(self):
+        out = []
+        while True:
+            b, last = self.pull()
+            out.append(b)
+            if last or not b:
+                break
+        return b"".join(out)
+
+    def encode(self, frames444, xsize16, ysize16, pframes_count, nbeats=None):
+        """One whole sequence from host memory through the beat interface; returns the stream bytes."""
+        W, H = self.geometry(xsize16, ysize16)
+        f = np.ascontiguousarray(frames444, np.uint8).reshape(-1, 3, H * W)
+        bpf = W * H // 4
+        total = f.shape[0] * bpf if nbeats is None else nbeats
+        full = total // bpf
+        if full:
+            self.push_frames(xsize16, ysize16, pframes_count, f[:full])
+        rem = total - full * bpf
+        if rem:
+            fr = f[full]
+            self.push_beats(xsize16, ysize16, pframes_count, fr[0][:rem * 4], fr[1][:rem * 4], fr[2][:rem * 4])
+        self.sequence_stop()
+        return self.pull_all()
+
+    # ---- HBM-resident interface (what bench.py times) ----
+    def encode_resident(self, d_frames_ptr, nframes, d_out_ptr, cap, xsize16, ysize16, pframes_count, stream=0):
+        n = ctypes.c_size_t(0)
+        self._chk(self._L.m2v_encode_resident(self._h, xsize16, ysize16, pframes_count, d_frames_ptr, nframes,
+                                              d_out_ptr, cap, ctypes.byref(n), stream), "m2v_encode_resident")
+        return n.value
+
+    def kernel_stats(self, kernel):
+        ms, units = ctypes.c_double(0), ctypes.c_double(0)
+        n = self._chk(self._L.m2v_kernel_stats(self._h, kernel, ctypes.byref(ms), ctypes.byref(units)), "m2v_kernel_stats")
+        return n, ms.value, units.value
+
+    def debug_read(self, what, nbytes, dtype):
+        buf = np.zeros(nbytes, np.uint8)
+        n = self._chk(self._L.m2v_debug_read(self._h, what, buf.ctypes.data, nbytes), "m2v_debug_read")
+        return buf[:n].view(dtype)

@@ -1,0 +1,46 @@
+"""Builds libm2v_mi355x.so (HIP kernels + C-ABI) in-tree with hipcc for gfx950."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libm2v_mi355x.so")
+TB = os.path.join(HERE, "m2v_tb")
+SOURCES = ["m2v_mi355x.hip", "m2v_kernels.hpp", "m2v_tables.hpp"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the MI355X path cannot be built (there is no CPU fallback)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "m2v_mi355x.h")]
+    if force or _stale(LIB, deps):
+        cmd = [hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB, os.path.join(CSRC, "m2v_mi355x.hip")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    tb_src = os.path.join(CSRC, "m2v_tb.cpp")
+    if os.path.exists(tb_src) and (force or _stale(TB, [tb_src, LIB])):
+        cmd = [hipcc(), "-O2", "-std=c++17", "-o", TB, tb_src, "-L" + HERE, "-lm2v_mi355x",
+               "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

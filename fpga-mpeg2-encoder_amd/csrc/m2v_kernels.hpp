@@ -1,0 +1,885 @@
+// m2v_kernels.hpp — HIP kernels of the MI355X MPEG-2 I/P encoder (gfx950, wave64).
+//
+// One wavefront per macroblock.  Kernels, in launch order for a chunk of frames:
+//
+//   k_mb<VL,P>      stages A..S of the RTL for one macroblock: 4:4:4->4:2:0, reference window
+//                   into LDS, (2YR+1)^2 full-pel SADs with v_qsad_pk_u16_u8, half-pel refine,
+//                   intra/inter decision, prediction, 6x 8x8 integer DCT, quantise, zig-zag,
+//                   dequantise, Chen-Wang IDCT, reconstruction            (RTL:1086-2468)
+//   k_vlc<false>    bit length of every macroblock layer (stage T, RTL:2718-2847)
+//   k_slice_scan    bit offset of each macroblock in its slice, byte size of each slice
+//   k_frame_scan    byte offset of every frame / slice in the stream (stage V alignment rules)
+//   k_zero          clears the stream bytes this chunk will occupy
+//   k_headers       sequence / GOP / picture headers, sequence end code (RTL:2590-2716)
+//   k_vlc<true>     VLC codes scattered to their final bit positions (stages T,U,V)
+//
+// All arithmetic is integer with the RTL's widths; see oracle/m2v_oracle.c for the plain-C
+// statement of the same semantics that the parity tests compare against.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "m2v_tables.hpp"
+
+namespace m2v {
+
+// ----------------------------------------------------------------------------------------------
+// shared host/device structures
+// ----------------------------------------------------------------------------------------------
+struct Geom {
+    int W, H;        // clamped luma size (RTL:985-1006)
+    int mbw, mbh;    // macroblocks per row / column
+    int cw, ch;      // chroma plane size
+    int Q;           // Q_LEVEL
+    int mbs;         // mbw * mbh
+    uint32_t ysz;    // W*H
+    uint32_t csz;    // cw*ch
+};
+
+struct FrameJob {           // one per frame of the chunk (device memory)
+    const uint8_t *in;      // 4:4:4 planar frame: Y, U, V planes of W*H bytes
+    const uint8_t *ref;     // reconstruction of the previous frame (4:2:0 planar) or nullptr
+    uint8_t       *rec;     // where to store this frame's reconstruction, nullptr = not needed
+    int32_t        i_frame; // index inside the GOP, 0 = I frame (RTL:1078)
+    uint32_t       n;       // frame number inside the sequence (time code, RTL:2685-2698)
+    uint32_t       valid_beats;  // beats of real input in this frame; the rest is black (RTL:1048-1056)
+    uint32_t       pad;
+};
+
+struct StreamCtl {          // device-resident stream bookkeeping, carried across chunks
+    unsigned long long base_bytes;   // bytes of the stream already produced before this chunk
+    unsigned long long total_bytes;  // bytes after this chunk (incl. final padding when last)
+    unsigned long long cap_bytes;    // capacity of the output buffer
+    unsigned long long prior_bytes;  // stream bytes of this sequence that left in earlier buffers (final padding rule)
+    uint32_t overflow;               // 1 = the chunk did not fit, nothing was written
+    uint32_t pad;
+};
+
+// device copies of the tables
+__constant__ int8_t   c_dct[64];
+__constant__ uint8_t  c_intra_w[64];
+__constant__ uint8_t  c_zigzag[64];
+__device__ uint16_t   d_motion_code[17];
+__device__ uint16_t   d_cbp_code[64];
+__device__ uint16_t   d_dc_code[2][12];
+__device__ uint8_t    d_dc_len[2][12];
+__device__ uint16_t   d_ac_code[32 * 40];
+
+// ----------------------------------------------------------------------------------------------
+// wave helpers (wave64)
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ int wave_scan_incl(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int mean2(int a, int b) { return (a + b + 1) >> 1; }                    // RTL:750-757
+__device__ __forceinline__ int mean4(int a, int b, int c, int d) { return (a + b + c + d + 1) >> 2; } // RTL:760-767
+__device__ __forceinline__ int iabs(int a) { return a < 0 ? -a : a; }
+__device__ __forceinline__ int sext(int v, int bits) { return (int)((uint32_t)v << (32 - bits)) >> (32 - bits); }
+
+// XCD-aware block remap: consecutive logical blocks land on the same XCD (shared L2 for the
+// overlapping reference windows of neighbouring macroblocks).  Bijective for any grid size.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
+{
+    const uint32_t xcd = b & 7u, q = n >> 3, r = n & 7u;
+    const uint32_t start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return start + (b >> 3);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Chen-Wang IDCT passes (RTL:844-972).  32-bit wrapping arithmetic like the RTL's reg [31:0].
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ void idct_row(const int a[8], int r[8])
+{
+    int x0 = a[0], x1 = a[4], x2 = a[6], x3 = a[2], x4 = a[1], x5 = a[7], x6 = a[5], x7 = a[3], x8;
+    x0 = (int)((uint32_t)x0 << 11) | 128;      // RTL:857-859
+    x1 = (int)((uint32_t)x1 << 11);
+    x8 = kW7 * (x4 + x5);
+    x4 = x8 + (kW1 - kW7) * x4;
+    x5 = x8 - (kW1 + kW7) * x5;
+    x8 = kW3 * (x6 + x7);
+    x6 = x8 - (kW3 - kW5) * x6;
+    x7 = x8 - (kW3 + kW5) * x7;
+    x8 = x0 + x1;
+    x0 = x0 - x1;
+    x1 = kW6 * (x3 + x2);
+    x2 = x1 - (kW2 + kW6) * x2;
+    x3 = x1 + (kW2 - kW6) * x3;
+    x1 = x4 + x6;
+    x4 = x4 - x6;
+    x6 = x5 + x7;
+    x5 = x5 - x7;
+    x7 = x8 + x3;
+    x8 = x8 - x3;
+    x3 = x0 + x2;
+    x0 = x0 - x2;
+    x2 = (181 * (x4 + x5) + 128) >> 8;
+    x4 = (181 * (x4 - x5) + 128) >> 8;
+    r[0] = sext((x7 + x1) >> 8, 18);           // stored in 18 bits (RTL:886, 2170)
+    r[1] = sext((x3 + x2) >> 8, 18);
+    r[2] = sext((x0 + x4) >> 8, 18);
+    r[3] = sext((x8 + x6) >> 8, 18);
+    r[4] = sext((x8 - x6) >> 8, 18);
+    r[5] = sext((x0 - x4) >> 8, 18);
+    r[6] = sext((x3 - x2) >> 8, 18);
+    r[7] = sext((x7 - x1) >> 8, 18);
+}
+
+__device__ __forceinline__ int clip255(int v) { return v < -255 ? -255 : v > 255 ? 255 : v; }   // RTL:778-783
+
+__device__ __forceinline__ void idct_col(const int a[8], int r[8])
+{
+    int x0 = a[0], x1 = a[4], x2 = a[6], x3 = a[2], x4 = a[1], x5 = a[7], x6 = a[5], x7 = a[3], x8;
+    x0 = (int)((uint32_t)x0 << 8) + 8192;      // RTL:924-926
+    x1 = (int)((uint32_t)x1 << 8);
+    x8 = kW7 * (x4 + x5) + 4;
+    x4 = (x8 + (kW1 - kW7) * x4) >> 3;
+    x5 = (x8 - (kW1 + kW7) * x5) >> 3;
+    x8 = kW3 * (x6 + x7) + 4;
+    x6 = (x8 - (kW3 - kW5) * x6) >> 3;
+    x7 = (x8 - (kW3 + kW5) * x7) >> 3;
+    x8 = x0 + x1;
+    x0 = x0 - x1;
+    x1 = kW6 * (x3 + x2) + 4;
+    x2 = (x1 - (kW2 + kW6) * x2) >> 3;
+    x3 = (x1 + (kW2 - kW6) * x3) >> 3;
+    x1 = x4 + x6;
+    x4 = x4 - x6;
+    x6 = x5 + x7;
+    x5 = x5 - x7;
+    x7 = x8 + x3;
+    x8 = x8 - x3;
+    x3 = x0 + x2;
+    x0 = x0 - x2;
+    x2 = (181 * (x4 + x5) + 128) >> 8;
+    x4 = (181 * (x4 - x5) + 128) >> 8;
+    r[0] = clip255((x7 + x1) >> 14);
+    r[1] = clip255((x3 + x2) >> 14);
+    r[2] = clip255((x0 + x4) >> 14);
+    r[3] = clip255((x8 + x6) >> 14);
+    r[4] = clip255((x8 - x6) >> 14);
+    r[5] = clip255((x0 - x4) >> 14);
+    r[6] = clip255((x3 - x2) >> 14);
+    r[7] = clip255((x7 - x1) >> 14);
+}
+
+// 10-way argmin with the RTL's tree tie-breaks (RTL:804-840)
+__device__ __forceinline__ int find_min_in_10_values(const int v[10])
+{
+    const int wi1 = v[1] < v[0], w01 = wi1 ? v[1] : v[0];
+    const int wi3 = v[3] < v[2], w23 = wi3 ? v[3] : v[2];
+    const int wi5 = v[5] < v[4], w45 = wi5 ? v[5] : v[4];
+    const int wi7 = v[7] < v[6], w67 = wi7 ? v[7] : v[6];
+    const int wi9 = v[9] < v[8], w89 = wi9 ? v[9] : v[8];
+    const int xi23 = w23 < w01, x0123 = xi23 ? w23 : w01;
+    const int xi67 = w67 < w45, x4567 = xi67 ? w67 : w45;
+    if (w89 <= x0123 && w89 <= x4567) return 8 + wi9;
+    if (x0123 < x4567) return xi23 ? 2 + wi3 : wi1;
+    return xi67 ? 6 + wi7 : 4 + wi5;
+}
+
+// half-pel grid sample Hg[2y+hy][2x+hx] from the 3x3 neighbourhood of T[y][x] (RTL:1746-1752)
+//   t[0..2] = rows y-1..y+1, q = column index of x inside the row arrays
+__device__ __forceinline__ int halfpel_sample(const int *t0, const int *t1, const int *t2, int q, int hy, int hx)
+{
+    const int a = t1[q];
+    if (hy == 0) {
+        if (hx == 0) return a;
+        return hx < 0 ? mean2(t1[q - 1], a) : mean2(a, t1[q + 1]);
+    }
+    const int *o = hy < 0 ? t0 : t2;           // the other row
+    if (hx == 0) return mean2(o[q], a);
+    const int q2 = hx < 0 ? q - 1 : q + 1;
+    return mean4(o[q2], o[q], t1[q2], a);      // sum is order independent
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_mb: one wavefront = one macroblock, stages A..S
+// ----------------------------------------------------------------------------------------------
+template <int VL, bool P>
+__global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
+                                           Geom g, int16_t *__restrict__ coef, uint32_t *__restrict__ mbinfo)
+{
+    constexpr int UR = VL, YR = 2 * VL;
+    constexpr int WROWS = 16 + 2 * YR;         // luma window rows -YR .. 16+YR-1 (RTL:1446)
+    constexpr int CROWS = 8 + 2 * UR;          // chroma window rows -UR .. 8+UR-1 (RTL:1447)
+
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[P ? WROWS * 8 : 1];       // luma window: 32 bytes/row = frame cols 16bx-8 .. 16bx+23
+    __shared__ __attribute__((aligned(16))) uint32_t s_cwin[2][P ? CROWS * 4 : 1];    // chroma windows: 16 bytes/row = cols 8bx-4 .. 8bx+11
+    __shared__ __attribute__((aligned(16))) uint32_t s_cur[64];                       // current luma, dword [row][4-px group]
+    __shared__ __attribute__((aligned(16))) uint8_t  s_pred[6][64];                   // prediction, later reconstruction, tile layout
+    __shared__ __attribute__((aligned(16))) int16_t  s_x[6][64];                      // residual, later dequantised coefficients
+    __shared__ __attribute__((aligned(16))) int32_t  s_t[6][64];                      // DCT phase 1, later IDCT row pass
+
+    const int lane = threadIdx.x;
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int fidx = frame_list[blk / (uint32_t)g.mbs];
+    const int mb = (int)(blk % (uint32_t)g.mbs);
+    const int by = mb / g.mbw, bx = mb - by * g.mbw;
+    const FrameJob job = jobs[fidx];
+    const int W = g.W;
+    const int r = lane >> 2, c4 = lane & 3;
+
+    // ---- stages A..E: current macroblock; 4:4:4 -> 4:2:0 with two-stage rounding -------------
+    // (RTL:1086-1089 horizontal mean2, RTL:1167-1170 vertical mean2 of the two means)
+    const uint8_t *inY = job.in, *inU = inY + g.ysz, *inV = inU + g.ysz;
+    const uint32_t pix_off = (uint32_t)(16 * by + r) * (uint32_t)W + (uint32_t)(16 * bx + 4 * c4);
+    uint32_t cur4 = *(const uint32_t *)(inY + pix_off);
+    uint32_t u4 = *(const uint32_t *)(inU + pix_off);
+    uint32_t v4 = *(const uint32_t *)(inV + pix_off);
+    {
+        // beats after i_sequence_stop are black: Y=0, U=V=0x80 (RTL:1036-1056)
+        const uint32_t beat = pix_off >> 2;
+        if (beat >= job.valid_beats) { cur4 = 0u; u4 = 0x80808080u; v4 = 0x80808080u; }
+    }
+    s_cur[lane] = cur4;
+    int cu0, cu1, cv0, cv1;                     // this lane's two 4:2:0 chroma samples (even rows only)
+    {
+        const uint32_t hu = (uint32_t)mean2(u4 & 255, (u4 >> 8) & 255) | ((uint32_t)mean2((u4 >> 16) & 255, u4 >> 24) << 8);
+        const uint32_t hv = (uint32_t)mean2(v4 & 255, (v4 >> 8) & 255) | ((uint32_t)mean2((v4 >> 16) & 255, v4 >> 24) << 8);
+        const uint32_t hu_o = (uint32_t)__shfl_xor((int)hu, 4, 64);     // the other row of the pair
+        const uint32_t hv_o = (uint32_t)__shfl_xor((int)hv, 4, 64);
+        cu0 = mean2(hu & 255, hu_o & 255);  cu1 = mean2(hu >> 8, hu_o >> 8);
+        cv0 = mean2(hv & 255, hv_o & 255);  cv1 = mean2(hv >> 8, hv_o >> 8);
+    }
+
+    int inter = 0, mvx = 0, mvy = 0, hy = 0, hx = 0, fy = 0, fx = 0;
+
+    if constexpr (P) {
+        // ---- stages X..Z: reference window of recon(f-1) into LDS (RTL:1350-1425, 1612-1629) --
+        const uint8_t *refY = job.ref, *refU = refY + g.ysz, *refV = refU + g.csz;
+#pragma unroll
+        for (int i = lane; i < WROWS * 8; i += 64) {
+            const int row = i >> 3, k = i & 7;
+            const int yy = 16 * by - YR + row, xx = 16 * bx - 8 + 4 * k;
+            uint32_t v = 0;                    // outside the frame: never selectable (RTL:1642-1645)
+            if (yy >= 0 && yy < g.H && xx >= 0 && xx < W) v = *(const uint32_t *)(refY + (uint32_t)yy * W + xx);
+            s_win[i] = v;
+        }
+        if (lane < CROWS * 4) {
+            const int row = lane >> 2, k = lane & 3;
+            const int yy = 8 * by - UR + row, xx = 8 * bx - 4 + 4 * k;
+            uint32_t vu = 0, vv = 0;
+            if (yy >= 0 && yy < g.ch && xx >= 0 && xx < g.cw) {
+                vu = *(const uint32_t *)(refU + (uint32_t)yy * g.cw + xx);
+                vv = *(const uint32_t *)(refV + (uint32_t)yy * g.cw + xx);
+            }
+            s_cwin[0][lane] = vu;
+            s_cwin[1][lane] = vv;
+        }
+        __syncthreads();
+
+        // ---- full-pel search: (2YR+1)^2 SADs (RTL:1634-1715) ---------------------------------
+        // lane = (dy, group of 4 consecutive dx); v_qsad_pk_u16_u8 slides the 4 current pixels
+        // over 8 reference bytes and accumulates the 4 SADs as packed u16.
+        {
+            uint32_t key = 0xFFFFFFFFu;
+            const int dyi = lane >> 2, gq = lane & 3;        // dy = dyi - YR, dx = 4*gq - 8 + j
+            if (dyi <= 2 * YR) {
+                unsigned long long acc = 0;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const uint32_t *wrow = &s_win[(rr + dyi) * 8 + gq];
+                    const uint32_t w0 = wrow[0], w1 = wrow[1], w2 = wrow[2], w3 = wrow[3], w4 = wrow[4];
+                    acc = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)w1 << 32) | w0, s_cur[rr * 4 + 0], acc);
+                    acc = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)w2 << 32) | w1, s_cur[rr * 4 + 1], acc);
+                    acc = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)w3 << 32) | w2, s_cur[rr * 4 + 2], acc);
+                    acc = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)w4 << 32) | w3, s_cur[rr * 4 + 3], acc);
+                }
+                const int dy = dyi - YR;
+                const bool rowok = !((by == 0 && dy < 0) || (by == g.mbh - 1 && dy > 0));   // RTL:1644-1645
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int dx = 4 * gq - 8 + j;
+                    const uint32_t sad = (uint32_t)(acc >> (16 * j)) & 0xFFFFu;
+                    const bool ok = rowok && dx >= -YR && dx <= YR && !(bx == 0 && dx < 0) &&
+                                    !(bx == g.mbw - 1 && dx > 0) &&                          // RTL:1642-1643
+                                    sad < 4096u;                                             // RTL:1669-1670
+                    // minimum SAD; among equals the largest dy, then the largest dx (RTL:1694-1710)
+                    const uint32_t k = (sad << 8) | (uint32_t)(255 - ((dyi << 4) | (dx + 8)));
+                    if (ok && k < key) key = k;
+                }
+            }
+            key = wave_min_u32(key);
+            if (key != 0xFFFFFFFFu) {           // no live candidate: (0,0) (RTL:1695, 1707)
+                const int c = 255 - (int)(key & 255u);
+                fy = (c >> 4) - YR;
+                fx = (c & 15) - 8;
+            }
+        }
+
+        // ---- half-pel refinement + intra cost (RTL:1743-1816) ---------------------------------
+        // lane (r, c4) owns pixels (r, 4c4..4c4+3); T[y][x] = window[y+fy+YR][x+fx+8]
+        int t0[6], t1[6], t2[6];
+        {
+            const uint8_t *wb = (const uint8_t *)s_win;
+            int r0 = r - 1 + fy + YR, r1 = r + fy + YR, r2 = r + 1 + fy + YR;
+            r0 = r0 < 0 ? 0 : r0;                              // rows beyond the window are masked cases
+            r2 = r2 > WROWS - 1 ? WROWS - 1 : r2;
+            const int cb = 4 * c4 - 1 + fx + 8;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                t0[k] = wb[r0 * 32 + cb + k];
+                t1[k] = wb[r1 * 32 + cb + k];
+                t2[k] = wb[r2 * 32 + cb + k];
+            }
+        }
+        int sad9[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sad9[k] = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = (cur4 >> (8 * p)) & 255, q = p + 1;
+            const int a = t1[q], l = t1[q - 1], rt = t1[q + 1];
+            const int u = t0[q], ul = t0[q - 1], ur = t0[q + 1];
+            const int d = t2[q], dl = t2[q - 1], dr = t2[q + 1];
+            sad9[0] += iabs(c - mean4(ul, u, l, a));
+            sad9[1] += iabs(c - mean2(u, a));
+            sad9[2] += iabs(c - mean4(u, ur, a, rt));
+            sad9[3] += iabs(c - mean2(l, a));
+            sad9[4] += iabs(c - a);
+            sad9[5] += iabs(c - mean2(a, rt));
+            sad9[6] += iabs(c - mean4(l, a, dl, d));
+            sad9[7] += iabs(c - mean2(a, d));
+            sad9[8] += iabs(c - mean4(a, rt, d, dr));
+        }
+        int v10[10];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int khy = k / 3 - 1, khx = k % 3 - 1;
+            const bool masked = ((bx == 0 || fx == -YR) && khx < 0) || ((bx == g.mbw - 1 || fx == YR) && khx > 0) ||
+                                ((by == 0 || fy == -YR) && khy < 0) || ((by == g.mbh - 1 || fy == YR) && khy > 0);   // RTL:1757-1760
+            const int s = wave_sum(sad9[k]);
+            v10[k] = (masked || s >= 4096) ? 4096 : s;         // {over, diff}: only "over" matters (RTL:1784-1785)
+        }
+        {
+            // "intra cost" accumulates on top of the pixel sum, 16-bit wrap (RTL:1744, 1774-1777, 1791)
+            const int S = wave_sum((int)__builtin_amdgcn_sad_u8(cur4, 0u, 0u));
+            const uint32_t m = ((uint32_t)S >> 8) & 255u;
+            const int dev = wave_sum((int)__builtin_amdgcn_sad_u8(cur4, m * 0x01010101u, 0u));
+            const uint32_t S2 = ((uint32_t)S + (uint32_t)dev) & 0xFFFFu;
+            v10[9] = (S2 >> 12) == 0 ? (int)S2 : 0xFFF;
+        }
+        const int idx = find_min_in_10_values(v10);
+        inter = idx != 9;
+        if (inter) { hy = idx / 3 - 1; hx = idx % 3 - 1; }
+        mvy = 2 * fy + hy;                                      // RTL:1827-1828
+        mvx = 2 * fx + hx;
+
+        // ---- prediction + residual (RTL:1891-1917, 1980-2014) ---------------------------------
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = (cur4 >> (8 * p)) & 255;
+            const int pr = inter ? halfpel_sample(t0, t1, t2, p + 1, hy, hx) : 128;
+            const int x = 4 * c4 + p;
+            const int tile = ((r >> 3) << 1) | (x >> 3), ti = ((r & 7) << 3) | (x & 7);
+            s_pred[tile][ti] = (uint8_t)pr;
+            s_x[tile][ti] = (int16_t)(c - pr);
+        }
+        if (!(r & 1)) {
+            // chroma: integer part mv>>2 (floor), half flag = bit 1 of mv (RTL:1854-1887, 1904-1916)
+            const int yc = r >> 1;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int xc = 2 * c4 + e;
+                int pu = 128, pv = 128;
+                if (inter) {
+                    const int cyi = mvy >> 2, cxi = mvx >> 2, fyh = (mvy >> 1) & 1, fxh = (mvx >> 1) & 1;
+                    int row = yc + cyi + UR, col = xc + cxi + 4;
+                    int row1 = row + 1 > CROWS - 1 ? CROWS - 1 : row + 1;
+                    const uint8_t *ub = (const uint8_t *)s_cwin[0], *vb = (const uint8_t *)s_cwin[1];
+                    const int a_u = ub[row * 16 + col], b_u = ub[row * 16 + col + 1], c_u = ub[row1 * 16 + col], d_u = ub[row1 * 16 + col + 1];
+                    const int a_v = vb[row * 16 + col], b_v = vb[row * 16 + col + 1], c_v = vb[row1 * 16 + col], d_v = vb[row1 * 16 + col + 1];
+                    if (fyh && fxh)   { pu = mean4(a_u, b_u, c_u, d_u); pv = mean4(a_v, b_v, c_v, d_v); }
+                    else if (fxh)     { pu = mean2(a_u, b_u);           pv = mean2(a_v, b_v); }
+                    else if (fyh)     { pu = mean2(a_u, c_u);           pv = mean2(a_v, c_v); }
+                    else              { pu = a_u;                       pv = a_v; }
+                }
+                const int ti = (yc << 3) | xc;
+                s_pred[4][ti] = (uint8_t)pu;
+                s_pred[5][ti] = (uint8_t)pv;
+                s_x[4][ti] = (int16_t)((e ? cu1 : cu0) - pu);
+                s_x[5][ti] = (int16_t)((e ? cv1 : cv0) - pv);
+            }
+        }
+    } else {
+        // I frame: every macroblock intra, prediction 0x80 (RTL:1820-1825, 1894-1903)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = (cur4 >> (8 * p)) & 255;
+            const int x = 4 * c4 + p;
+            const int tile = ((r >> 3) << 1) | (x >> 3), ti = ((r & 7) << 3) | (x & 7);
+            s_pred[tile][ti] = 128;
+            s_x[tile][ti] = (int16_t)(c - 128);
+        }
+        if (!(r & 1)) {
+            const int yc = r >> 1, ti = (yc << 3) | (2 * c4);
+            s_pred[4][ti] = 128; s_pred[4][ti + 1] = 128;
+            s_pred[5][ti] = 128; s_pred[5][ti + 1] = 128;
+            s_x[4][ti] = (int16_t)(cu0 - 128); s_x[4][ti + 1] = (int16_t)(cu1 - 128);
+            s_x[5][ti] = (int16_t)(cv0 - 128); s_x[5][ti + 1] = (int16_t)(cv1 - 128);
+        }
+    }
+    __syncthreads();
+
+    // ---- stage G: 2-D forward DCT (RTL:2029-2062); lane = (i = lane>>3, j = lane&7) ------------
+    const int di = lane >> 3, dj = lane & 7;
+    int bi[8], bj[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { bi[k] = c_dct[di * 8 + k]; bj[k] = c_dct[dj * 8 + k]; }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        int acc = 0;                                    // R1[r][j] = sum_k X[r][k] * DCTM[j][k]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += (int)s_x[t][di * 8 + k] * bj[k];
+        s_t[t][lane] = acc;
+    }
+    __syncthreads();
+
+    // ---- quantise (RTL:2065-2077), zig-zag + coded flags (RTL:2452-2468), dequantise (RTL:2129-2150)
+    const int wq = c_intra_w[lane];
+    const int zz = c_zigzag[lane];
+    const int Q = g.Q;
+    const size_t mbidx = (size_t)fidx * g.mbs + mb;
+    int16_t *cout = coef + mbidx * 384;
+    const bool need_rec = job.rec != nullptr;
+    int cbp = 0;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        int acc = 0;                                    // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += bi[k] * s_t[t][k * 8 + dj];
+        const int C = (acc >> 12) + ((acc >> 11) & 1);
+        uint32_t a = (uint32_t)iabs(C) & 0xFFFFu;
+        if (inter)          a = (a + 2u) >> (4 + Q);
+        else if (lane != 0) a = ((a + (((uint32_t)wq * ((3u << Q) + 2u)) >> 3)) >> Q) / (uint32_t)wq;
+        else                a = (a >> 4) + ((a >> 3) & 1u);
+        if (a > 2047u) a = 2047u;
+        const int q = C < 0 ? -(int)a : (int)a;
+        cout[t * 64 + zz] = (int16_t)q;
+        const unsigned long long nzm = __ballot(q != 0);
+        cbp = (cbp << 1) | ((!inter || nzm != 0ull) ? 1 : 0);
+        if (need_rec) {
+            int x;
+            if (inter) {
+                x = 2 * q;
+                x += (x < 0) ? -1 : (x > 0) ? 1 : 0;
+                x = (int)((uint32_t)x << Q);
+                x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
+            } else if (lane != 0) {
+                x = sext(q * wq, 17);                   // 17-bit temporary (RTL:2093, 2139)
+                x = Q >= 3 ? sext((int)((uint32_t)x << (Q - 3)), 17) : (x >> (3 - Q));
+                x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
+            } else {
+                x = 2 * q;
+            }
+            s_x[t][lane] = (int16_t)x;
+        }
+    }
+    if (lane == 0)
+        mbinfo[mbidx] = (uint32_t)inter | ((uint32_t)cbp << 1) | (((uint32_t)(inter ? mvx : 0) & 255u) << 8) |
+                        (((uint32_t)(inter ? mvy : 0) & 255u) << 16);
+
+    // ---- stages H..R: Chen-Wang IDCT, reconstruction, store as next reference ------------------
+    if (need_rec) {
+        __syncthreads();
+        if (lane < 48) {                                // rows: lane = tile*8 + row (RTL:2159-2189)
+            const int t = lane >> 3, row = lane & 7;
+            int a[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = s_x[t][row * 8 + k];
+            idct_row(a, o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s_t[t][row * 8 + k] = o[k];
+        }
+        __syncthreads();
+        if (lane < 48) {                                // columns: lane = tile*8 + col (RTL:2238-2279)
+            const int t = lane >> 3, col = lane & 7;
+            int a[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = s_t[t][k * 8 + col];
+            idct_col(a, o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {               // add_clip_0_255 (RTL:786-795, 2352)
+                const int v = (int)s_pred[t][k * 8 + col] + o[k];
+                s_pred[t][k * 8 + col] = (uint8_t)(v > 255 ? 255 : v < 0 ? 0 : v);
+            }
+        }
+        __syncthreads();
+        uint8_t *recY = job.rec, *recU = recY + g.ysz, *recV = recU + g.csz;
+        {
+            const int tile = ((r >> 3) << 1) | (c4 >> 1);
+            const uint32_t v = *(const uint32_t *)&s_pred[tile][((r & 7) << 3) | ((c4 & 1) << 2)];
+            *(uint32_t *)(recY + pix_off) = v;
+        }
+        if (lane < 32) {
+            const int pl = lane >> 4, l16 = lane & 15, yc = l16 >> 1, half = l16 & 1;
+            const uint32_t v = *(const uint32_t *)&s_pred[4 + pl][(yc << 3) | (half << 2)];
+            uint8_t *dst = pl ? recV : recU;
+            *(uint32_t *)(dst + (uint32_t)(8 * by + yc) * g.cw + 8 * bx + 4 * half) = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_vlc: stage T macroblock layer, one wavefront per macroblock, lane = zig-zag index.
+// WRITE = false : bit length of the macroblock (+38-bit slice header for the first MB of a row)
+// WRITE = true  : codes assembled MSB-first in LDS, then merged into the stream at the final bit
+// ----------------------------------------------------------------------------------------------
+constexpr int kMbBitWords = 320;      // >= (38 + 33 + 6*(21 + 64*24 + 2) + 31) / 32 + 2
+
+__device__ __forceinline__ void lds_put(uint32_t *buf, uint32_t pos, uint32_t val, uint32_t len)
+{
+    if (!len) return;
+    const uint32_t w = pos >> 5, b = pos & 31u;
+    const unsigned long long v = (unsigned long long)val << (64u - len - b);
+    atomicOr(&buf[w], (uint32_t)(v >> 32));
+    const uint32_t lo = (uint32_t)v;
+    if (lo) atomicOr(&buf[w + 1], lo);
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_vlc(const FrameJob *__restrict__ jobs, Geom g, int nframes,
+                                            const int16_t *__restrict__ coef, const uint32_t *__restrict__ mbinfo,
+                                            uint32_t *__restrict__ mb_len, const uint32_t *__restrict__ mb_bitoff,
+                                            const unsigned long long *__restrict__ slice_off,
+                                            uint32_t *__restrict__ out32, const StreamCtl *__restrict__ ctl)
+{
+    __shared__ uint32_t s_bits[WRITE ? kMbBitWords : 1];
+    const int lane = threadIdx.x;
+    const uint32_t blk = blockIdx.x;
+    const int f = (int)(blk / (uint32_t)g.mbs), mb = (int)(blk % (uint32_t)g.mbs);
+    if (f >= nframes) return;
+    const int by = mb / g.mbw, bx = mb - by * g.mbw;
+    const size_t idx = (size_t)f * g.mbs + mb;
+    if (WRITE && ctl->overflow) return;
+
+    const uint32_t info = mbinfo[idx];
+    const int inter = info & 1, cbp = (info >> 1) & 63;
+    const int mvx = (int8_t)(info >> 8), mvy = (int8_t)(info >> 16);
+    const int i_frame = jobs[f].i_frame;
+    const int16_t *cin = coef + idx * 384;
+
+    // predictors come from the left neighbour only; reset at the start of a slice (RTL:2713-2715)
+    int pmvx = 0, pmvy = 0, pdc[3] = {0, 0, 0};
+    if (bx > 0) {
+        const uint32_t li = mbinfo[idx - 1];
+        if (li & 1) {                           // inter: vectors carry over, DC predictors reset (RTL:2769, 2786-2792)
+            pmvx = (int8_t)(li >> 8);
+            pmvy = (int8_t)(li >> 16);
+        } else {                                // intra: DC of its last Y tile / U / V (RTL:2786-2792), vectors reset (RTL:2772)
+            pdc[0] = cin[-384 + 3 * 64];
+            pdc[1] = cin[-384 + 4 * 64];
+            pdc[2] = cin[-384 + 5 * 64];
+        }
+    }
+
+    uint32_t total = 0;
+    uint32_t nwords = 0;
+    if (WRITE) {
+        total = mb_len[idx];
+        nwords = (total + 31u) / 32u + 1u;
+        for (uint32_t k = lane; k < nwords; k += 64) s_bits[k] = 0u;
+        __syncthreads();
+    }
+
+    uint32_t pos = 0;
+    // slice header: start code, slice_vertical_position, quantiser_scale_code, extra_bit_slice (RTL:2708-2710)
+    if (bx == 0) {
+        if (WRITE && lane == 0) {
+            lds_put(s_bits, 0, 0x000001u, 24);
+            lds_put(s_bits, 24, ((uint32_t)(by + 1) << 6) | (2u << g.Q), 14);
+        }
+        pos = 38;
+    }
+    // macroblock_address_increment '1' + macroblock_type (RTL:2722-2731)
+    {
+        uint32_t code, len;
+        if (!inter && i_frame != 0) { code = 0x23; len = 6; }
+        else if (inter && cbp == 0) { code = 0x09; len = 4; }
+        else                        { code = 0x03; len = 2; }
+        if (WRITE && lane == 0) lds_put(s_bits, pos, code, len);
+        pos += len;
+    }
+    if (inter) {                                // motion vectors then coded_block_pattern (RTL:2734-2767)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            int d = c ? mvy - pmvy : mvx - pmvx;
+            if (d > 15) d -= 32; else if (d < -16) d += 32;
+            const int a = iabs(d);
+            const uint32_t e = d_motion_code[a];
+            uint32_t code = e & 255u, len = e >> 8;
+            if (d != 0) { code = (code << 1) | (d < 0 ? 1u : 0u); len += 1; }
+            if (WRITE && lane == 0) lds_put(s_bits, pos, code, len);
+            pos += len;
+        }
+        const uint32_t e = d_cbp_code[cbp];
+        if (WRITE && lane == 0) lds_put(s_bits, pos, e & 255u, e >> 8);
+        pos += e >> 8;
+    }
+
+    // six tiles (RTL:2777-2847)
+#pragma unroll 1
+    for (int t = 0; t < 6; ++t) {
+        const int v = cin[t * 64 + lane];
+        const int v0 = __shfl(v, 0, 64);
+        const bool coded = (cbp >> (5 - t)) & 1;
+        const int comp = t < 4 ? 0 : t - 3;
+        const int diff = v0 - pdc[comp];
+        pdc[comp] = inter ? 0 : v0;             // updated for every tile, coded or not (RTL:2786-2792)
+        if (!coded) continue;
+
+        uint32_t dc_len = 0;
+        if (!inter) {                           // dct_dc_size + dct_dc_differential (RTL:2808-2821)
+            const int a = iabs(diff);
+            const int size = a ? 32 - __clz(a) : 0;
+            uint32_t bits = (uint32_t)diff & 0xFFFu;
+            if (diff < 0) bits = (bits + ((1u << size) - 1u)) & 0xFFFu;
+            const int ch = t < 4 ? 0 : 1;
+            const uint32_t sl = d_dc_len[ch][size];
+            if (WRITE && lane == 0) {
+                lds_put(s_bits, pos, d_dc_code[ch][size], sl);
+                lds_put(s_bits, pos + sl, bits, (uint32_t)size);
+            }
+            dc_len = sl + (uint32_t)size;
+        }
+        const bool nz = v != 0 && (inter || lane > 0);
+        const unsigned long long mask = __ballot(nz);
+        uint32_t code = 0, len = 0;
+        if (nz) {
+            const unsigned long long below = mask & ((1ull << lane) - 1ull);
+            const int run = below ? lane - (63 - __clzll((long long)below)) - 1 : (inter ? lane : lane - 1);
+            const int a = iabs(v);
+            if (inter && lane == 0 && a == 1) {             // first coefficient '1s' (RTL:2798-2802)
+                code = 2u | (v < 0 ? 1u : 0u);
+                len = 2;
+            } else {
+                uint32_t e = 0;
+                if (run < 32 && a <= 40) e = d_ac_code[run * 40 + a - 1];
+                if (e) {                                     // run/level VLC + sign (RTL:2535-2540)
+                    code = ((e & 255u) << 1) | (v < 0 ? 1u : 0u);
+                    len = (e >> 8) + 1u;
+                } else {                                     // escape (RTL:2542-2543)
+                    code = (1u << 18) | ((uint32_t)run << 12) | ((uint32_t)v & 0xFFFu);
+                    len = 24;
+                }
+            }
+        }
+        const int incl = wave_scan_incl((int)len, lane);
+        const uint32_t ac_total = (uint32_t)__shfl(incl, 63, 64);
+        if (WRITE) {
+            if (nz) lds_put(s_bits, pos + dc_len + (uint32_t)incl - len, code, len);
+            if (lane == 0) lds_put(s_bits, pos + dc_len + ac_total, 2u, 2);   // end_of_block '10' (RTL:2835)
+        }
+        pos += dc_len + ac_total + 2u;
+    }
+
+    if (!WRITE) {
+        if (lane == 0) mb_len[idx] = pos;
+        return;
+    }
+
+    // merge into the stream: big-endian 32-bit words, atomics only on the two boundary words
+    __syncthreads();
+    const unsigned long long q = (ctl->base_bytes + slice_off[(size_t)f * g.mbh + by]) * 8ull + mb_bitoff[idx];
+    const uint32_t sh = (uint32_t)(q & 31ull);
+    const unsigned long long w0 = q >> 5;
+    const uint32_t nout = (sh + total + 31u) / 32u;
+    for (uint32_t k = lane; k < nout; k += 64) {
+        const uint32_t hi = k ? s_bits[k - 1] : 0u;
+        const uint32_t lo = k < nwords ? s_bits[k] : 0u;
+        const uint32_t val = sh ? ((hi << (32u - sh)) | (lo >> sh)) : lo;
+        const uint32_t be = __builtin_bswap32(val);
+        if (k == 0 || k == nout - 1) { if (be) atomicOr(&out32[w0 + k], be); }
+        else out32[w0 + k] = be;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_slice_scan: one block per (frame, slice): exclusive scan of the macroblock bit lengths
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_slice_scan(Geom g, const uint32_t *__restrict__ mb_len,
+                                                    uint32_t *__restrict__ mb_bitoff, uint32_t *__restrict__ slice_bytes)
+{
+    __shared__ uint32_t s[128];
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * g.mbw;        // blockIdx = frame * mbh + by
+    const uint32_t len = tid < g.mbw ? mb_len[base + tid] : 0u;
+    s[tid] = len;
+    __syncthreads();
+    for (int o = 1; o < 128; o <<= 1) {
+        const uint32_t t = tid >= o ? s[tid - o] : 0u;
+        __syncthreads();
+        s[tid] += t;
+        __syncthreads();
+    }
+    if (tid < g.mbw) mb_bitoff[base + tid] = s[tid] - len;
+    if (tid == g.mbw - 1) slice_bytes[blockIdx.x] = (s[tid] + 7u) >> 3;   // next header aligns (RTL:2940-2943)
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_frame_scan: byte offsets of frames and slices inside the chunk; total stream length
+// ----------------------------------------------------------------------------------------------
+constexpr uint32_t kSeqHeaderBytes = 34;   // 269 bits + alignment (RTL:2598-2617)
+constexpr uint32_t kGopHeaderBytes = 8;    // 59 bits + alignment  (RTL:2650-2656)
+
+__device__ __forceinline__ uint32_t frame_header_bytes(int i_frame)
+{
+    return (i_frame == 0 ? kGopHeaderBytes + 17u : 18u);     // RTL:2670-2682
+}
+
+__global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict__ jobs, Geom g, int nframes, int first, int last,
+                                                     const uint32_t *__restrict__ slice_bytes,
+                                                     unsigned long long *__restrict__ slice_off,
+                                                     unsigned long long *__restrict__ frame_off, StreamCtl *ctl)
+{
+    const int tid = threadIdx.x;
+    for (int f = tid; f < nframes; f += blockDim.x) {
+        unsigned long long s = frame_header_bytes(jobs[f].i_frame);
+        for (int y = 0; y < g.mbh; ++y) s += slice_bytes[(size_t)f * g.mbh + y];
+        frame_off[f] = s;                                     // size for now
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = first ? kSeqHeaderBytes : 0ull;
+        for (int f = 0; f < nframes; ++f) { const unsigned long long s = frame_off[f]; frame_off[f] = run; run += s; }
+        unsigned long long total = ctl->base_bytes + run;
+        if (last) {
+            total += 4;                                       // sequence_end_code (RTL:2621-2628)
+            const unsigned long long all = ctl->prior_bytes + total;
+            total = (all / 32ull + 1ull) * 32ull - ctl->prior_bytes;   // final word always leaves (RTL:2932-2937)
+        }
+        ctl->total_bytes = total;
+        ctl->overflow = total > ctl->cap_bytes ? 1u : 0u;
+    }
+    __syncthreads();
+    for (int f = tid; f < nframes; f += blockDim.x) {
+        unsigned long long o = frame_off[f] + frame_header_bytes(jobs[f].i_frame);
+        for (int y = 0; y < g.mbh; ++y) {
+            slice_off[(size_t)f * g.mbh + y] = o;
+            o += slice_bytes[(size_t)f * g.mbh + y];
+        }
+    }
+}
+
+// clears [base_bytes rounded down to 4, total_bytes rounded up to 4) except bytes that belong to
+// the previous chunk (those below base_bytes are preserved)
+__global__ void k_zero(uint8_t *out, const StreamCtl *ctl)
+{
+    if (ctl->overflow) return;
+    const unsigned long long b = ctl->base_bytes, e = (ctl->total_bytes + 3ull) & ~3ull;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x * 4ull;
+    unsigned long long a = ((b + 3ull) & ~3ull) + ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 4ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (unsigned long long i = b; i < ((b + 3ull) & ~3ull) && i < e; ++i) out[i] = 0;
+    for (; a + 4ull <= e; a += stride) *(uint32_t *)(out + a) = 0u;
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_headers: byte-aligned headers, one thread per frame (+ thread 0 for sequence header / end)
+// ----------------------------------------------------------------------------------------------
+struct ByteWriter {
+    uint8_t *p;
+    uint32_t acc;
+    int nbits;
+    __device__ void put(uint32_t v, int len)
+    {
+        for (int i = len - 1; i >= 0; --i) {
+            acc = (acc << 1) | ((v >> i) & 1u);
+            if (++nbits == 8) { *p++ = (uint8_t)acc; acc = 0; nbits = 0; }
+        }
+    }
+    __device__ void align() { if (nbits) put(0, 8 - nbits); }
+};
+
+__global__ void k_headers(const FrameJob *__restrict__ jobs, Geom g, int nframes, int first,
+                          const unsigned long long *__restrict__ frame_off, uint8_t *out, const StreamCtl *ctl)
+{
+    if (ctl->overflow) return;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < nframes) {
+        ByteWriter w{out + ctl->base_bytes + frame_off[f], 0u, 0};
+        const FrameJob job = jobs[f];
+        if (job.i_frame == 0) {
+            // group_of_pictures_header, closed_gop = 1; time code of frame n at 24 fps (RTL:2645-2656, 2685-2698)
+            const uint32_t n = job.n;
+            const uint32_t hh = n / 86400u;
+            w.put(0x000001B8u, 32);
+            w.put(hh > 63u ? 63u : hh, 6);
+            w.put((n / 1440u) % 60u, 6);
+            w.put(1u, 1);
+            w.put((n / 24u) % 60u, 6);
+            w.put(n % 24u, 6);
+            w.put(2u, 2);
+            w.align();
+        }
+        // picture_header + picture_coding_extension (RTL:2670-2682)
+        w.put(0x00000100u, 32);
+        w.put((uint32_t)job.i_frame, 10);       // temporal_reference
+        if (job.i_frame == 0) { w.put(1u, 3); w.put(0u, 16); w.put(0u, 3); }
+        else                  { w.put(2u, 3); w.put(0u, 16); w.put(0u, 1); w.put(7u, 3); w.put(0u, 7); }
+        w.put(0x000001B5u, 32);
+        w.put(8u, 4);                           // picture coding extension
+        w.put(0x1111u, 16);                     // f_code[s][t] = 1
+        w.put(2u, 2);                           // intra_dc_precision 10 bit
+        w.put(3u, 2);                           // frame picture
+        w.put(1u, 1);                           // top_field_first
+        w.put(1u, 1);                           // frame_pred_frame_dct
+        w.put(0u, 8);
+        w.put(0u, 6);
+    }
+    if (f == 0) {
+        if (first) {
+            // sequence_header + sequence_extension + sequence_display_extension (RTL:2598-2617)
+            ByteWriter w{out + ctl->base_bytes, 0u, 0};
+            w.put(0x000001B3u, 32);
+            w.put((uint32_t)g.W, 12); w.put((uint32_t)g.H, 12);
+            w.put(1u, 4); w.put(2u, 4); w.put(10000u, 18); w.put(1u, 1); w.put(0u, 10); w.put(0u, 3);
+            w.put(0x000001B5u, 32);
+            w.put(1u, 4); w.put(0x44u, 8); w.put(0u, 1); w.put(1u, 2); w.put(0u, 4); w.put(0u, 12); w.put(1u, 1);
+            w.put(0u, 8); w.put(0u, 8);
+            w.put(0x000001B5u, 32);
+            w.put(2u, 4); w.put(1u, 3); w.put(1u, 1); w.put(5u, 8); w.put(5u, 8); w.put(5u, 8);
+            w.put((uint32_t)g.W, 14); w.put(1u, 1); w.put((uint32_t)g.H, 14);
+            w.align();
+        }
+    }
+}
+
+// sequence_end_code at the end of the last chunk's body (position = total before padding)
+__global__ void k_seq_end(uint8_t *out, const StreamCtl *ctl, const uint32_t *__restrict__ slice_bytes,
+                          const unsigned long long *__restrict__ slice_off, int nframes, int mbh)
+{
+    if (ctl->overflow) return;
+    // end of the body = offset of the last slice + its size
+    unsigned long long e = ctl->base_bytes;
+    if (nframes > 0) {
+        const size_t li = (size_t)(nframes - 1) * mbh + (mbh - 1);
+        e += slice_off[li] + slice_bytes[li];
+    }
+    out[e + 0] = 0x00; out[e + 1] = 0x00; out[e + 2] = 0x01; out[e + 3] = 0xB7;   // RTL:2625-2628
+}
+
+}  // namespace m2v

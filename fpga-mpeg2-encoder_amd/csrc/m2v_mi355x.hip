@@ -1,0 +1,829 @@
+// m2v_mi355x.hip — host side of libm2v_mi355x.so: the mpeg2encoder port contract
+// (RTL/mpeg2encoder.v:10-38) as a C-ABI over the HIP kernels in m2v_kernels.hpp.
+//
+// Sequence control mirrors stage A of the RTL (RTL:1027-1095): the configuration is latched on
+// the first beat, beats fill raster-order frames, i_sequence_stop black-fills the frame in
+// progress, and the stream ends with sequence_end_code + one final zero-padded 32-byte word.
+// Unlike the 64-clock/macroblock RTL pipeline, frames are buffered and encoded in chunks:
+// closed GOPs (closed_gop = 1, RTL:2656) are independent, so frame k of every GOP in a chunk
+// runs in the same launch — that is what fills 256 CUs with one wavefront per macroblock.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/m2v_mi355x.h"
+#include "m2v_kernels.hpp"
+
+using namespace m2v;
+
+namespace {
+
+struct HipError { hipError_t e; const char *what; };
+
+#define HIPCHK(expr)                                                        \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) throw HipError{_e, #expr};                    \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    void ensure(size_t count)
+    {
+        if (count <= n) return;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct KStat { int launches = 0; double ms = 0, units = 0; };
+
+struct TimedLaunch { hipEvent_t a, b; int kernel; double units; };
+
+}  // namespace
+
+struct m2v_enc {
+    // module parameters (RTL:11-14)
+    int XL, YL, VL, Q;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // options
+    size_t batch_frames = 96;
+    bool profile = false;
+    bool keep_recon = false;      // debug: every frame keeps its own reconstruction buffer
+
+    // sequence state (RTL:1017-1022)
+    enum State { IDLE, DURING, ENDED } state = IDLE;
+    Geom g{};
+    uint32_t pframes = 0;
+    size_t frames_total = 0;      // frames of this sequence handed to the GPU so far
+    bool first_chunk = true;
+
+    // host staging of incoming beats: planar 4:4:4 frames in pinned memory
+    uint8_t *h_in = nullptr;
+    size_t h_in_cap = 0;          // frames
+    size_t buffered = 0;          // complete frames waiting
+    size_t beat_pos = 0;          // beats received of the frame in progress
+    uint32_t last_frame_valid_beats = 0;   // for a black-filled last frame
+
+    // host output FIFO (32-byte words are handed out by m2v_pull)
+    std::vector<uint8_t> fifo;
+    size_t fifo_rd = 0;
+    bool end_pending = false;     // the data in the FIFO ends with the o_last word
+
+    // device buffers
+    DevBuf<uint8_t> d_in;                 // chunk input when it comes from the host
+    DevBuf<uint8_t> d_out;                // chunk output when it goes to the host
+    DevBuf<int16_t> d_coef;
+    DevBuf<uint32_t> d_mbinfo, d_mblen, d_mboff, d_slice_bytes;
+    DevBuf<unsigned long long> d_slice_off, d_frame_off;
+    DevBuf<FrameJob> d_jobs;
+    DevBuf<int> d_lists;
+    DevBuf<StreamCtl> d_ctl;
+    std::vector<uint8_t *> rec_pool;      // reconstruction buffers (4:2:0 planar), each ysz + 2*csz
+    size_t rec_bytes = 0;
+    int persist_slot = -1;                // slot holding recon of the last encoded frame (GOP continues)
+    StreamCtl *h_ctl = nullptr;           // pinned
+    FrameJob *h_jobs = nullptr;           // pinned staging of the per-frame jobs
+    size_t h_jobs_cap = 0;
+    int *h_lists = nullptr;               // pinned staging of the launch lists
+    size_t h_lists_cap = 0;
+    unsigned long long stream_bytes = 0;  // bytes of the current sequence already moved to the FIFO
+    uint8_t *h_out = nullptr;             // pinned readback buffer
+    size_t h_out_cap = 0;
+
+    // debug bookkeeping of the last resident encode
+    size_t dbg_frames = 0;
+    std::vector<int> dbg_rec_slot;
+
+    // profiling
+    KStat stats[5];
+    std::vector<TimedLaunch> timed;
+
+    void set_err(const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+    }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// geometry (RTL:985-1006)
+// ---------------------------------------------------------------------------------------------
+int clamp_size16(uint32_t s, int L)
+{
+    const uint32_t lim = 1u << L;
+    if (s > lim) return (int)lim - 1;
+    if (s < 4) return 3;
+    return (int)s - 1;
+}
+
+Geom make_geom(const m2v_enc *e, uint32_t xs, uint32_t ys)
+{
+    Geom g{};
+    xs &= (2u << e->XL) - 1u;       // the ports are XL+1 / YL+1 bits wide (RTL:20-21)
+    ys &= (2u << e->YL) - 1u;
+    g.mbw = clamp_size16(xs, e->XL) + 1;
+    g.mbh = clamp_size16(ys, e->YL) + 1;
+    g.W = 16 * g.mbw;
+    g.H = 16 * g.mbh;
+    g.cw = g.W / 2;
+    g.ch = g.H / 2;
+    g.Q = e->Q;
+    g.mbs = g.mbw * g.mbh;
+    g.ysz = (uint32_t)g.W * g.H;
+    g.csz = (uint32_t)g.cw * g.ch;
+    return g;
+}
+
+bool g_tables_loaded[64] = {};
+
+void upload_tables(int device)
+{
+    if (device >= 0 && device < 64 && g_tables_loaded[device]) return;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dct), kDctBasis, sizeof kDctBasis));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_intra_w), kIntraW, sizeof kIntraW));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_zigzag), kZigzagPos, sizeof kZigzagPos));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_motion_code), kMotionCode, sizeof kMotionCode));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_cbp_code), kCbpCode, sizeof kCbpCode));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_dc_code), kDcSizeCode, sizeof kDcSizeCode));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_dc_len), kDcSizeLen, sizeof kDcSizeLen));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_ac_code), kAcCode, sizeof kAcCode));
+    if (device >= 0 && device < 64) g_tables_loaded[device] = true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------
+struct Timer {
+    m2v_enc *e; hipStream_t s; int kernel; double units; hipEvent_t a = nullptr, b = nullptr;
+    Timer(m2v_enc *e_, hipStream_t s_, int k, double u) : e(e_), s(s_), kernel(k), units(u)
+    {
+        if (e->profile) {
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            HIPCHK(hipEventRecord(a, s));
+        }
+    }
+    void stop()
+    {
+        if (e->profile) {
+            HIPCHK(hipEventRecord(b, s));
+            e->timed.push_back(TimedLaunch{a, b, kernel, units});
+        }
+    }
+};
+
+void collect_timers(m2v_enc *e)
+{
+    for (auto &t : e->timed) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            e->stats[t.kernel].launches++;
+            e->stats[t.kernel].ms += ms;
+            e->stats[t.kernel].units += t.units;
+        }
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
+    }
+    e->timed.clear();
+}
+
+template <bool P>
+void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g)
+{
+    if (count <= 0) return;
+    const dim3 grid((unsigned)((size_t)count * g.mbs)), block(64);
+    Timer t(e, s, P ? 0 : 1, (double)count * g.ysz);
+    if (P) {
+        switch (e->VL) {
+            case 1: hipLaunchKernelGGL((k_mb<1, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_coef.p, e->d_mbinfo.p); break;
+            case 2: hipLaunchKernelGGL((k_mb<2, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_coef.p, e->d_mbinfo.p); break;
+            default: hipLaunchKernelGGL((k_mb<3, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_coef.p, e->d_mbinfo.p); break;
+        }
+    } else {
+        hipLaunchKernelGGL((k_mb<1, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_coef.p, e->d_mbinfo.p);
+    }
+    HIPCHK(hipGetLastError());
+    t.stop();
+}
+
+// ---------------------------------------------------------------------------------------------
+// encode one chunk of `nf` consecutive frames of the current sequence.
+//   d_frames : device pointer to nf planar 4:4:4 frames
+//   d_stream : device output buffer; ctl (device) carries base/total/cap across chunks
+// Everything is enqueued on `s`; nothing is synchronised here.
+// ---------------------------------------------------------------------------------------------
+void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool first, bool last,
+                  uint32_t last_valid_beats, uint8_t *d_stream)
+{
+    const Geom &g = e->g;
+    const size_t frame_bytes = (size_t)g.ysz * 3;
+    const uint32_t bpf = g.ysz / 4;
+    const uint32_t gop = e->pframes + 1u;
+
+    // ---- per-frame jobs, GOP segments, reconstruction slots ----
+    std::vector<FrameJob> jobs(nf);
+    std::vector<int> seg_start;                   // chunk-frame index where each GOP segment starts
+    for (size_t k = 0; k < nf; ++k) {
+        const size_t n = e->frames_total + k;
+        jobs[k].in = d_frames + k * frame_bytes;
+        jobs[k].i_frame = (int32_t)(n % gop);
+        jobs[k].n = (uint32_t)n;
+        jobs[k].valid_beats = (last && k == nf - 1) ? last_valid_beats : bpf;
+        jobs[k].ref = nullptr;
+        jobs[k].rec = nullptr;
+        jobs[k].pad = 0;
+        if (k == 0 || jobs[k].i_frame == 0) seg_start.push_back((int)k);
+    }
+    const size_t nseg = seg_start.size();
+    e->rec_bytes = (size_t)g.ysz + 2 * (size_t)g.csz;
+    const bool need_any_rec = e->pframes > 0;
+    std::vector<int> rec_slot(nf, -1);
+    if (need_any_rec) {
+        const size_t want = e->keep_recon ? nf + 1 : 2 * nseg + 1;
+        while (e->rec_pool.size() < want) {
+            uint8_t *p = nullptr;
+            HIPCHK(hipMalloc((void **)&p, e->rec_bytes));
+            e->rec_pool.push_back(p);
+        }
+        std::vector<int> free_slots;
+        for (int i = 0; i < (int)e->rec_pool.size(); ++i) if (i != e->persist_slot) free_slots.push_back(i);
+        size_t fs = 0;
+        for (size_t sg = 0; sg < nseg; ++sg) {
+            const size_t a = seg_start[sg], b = sg + 1 < nseg ? (size_t)seg_start[sg + 1] : nf;
+            int slots[2] = {-1, -1};
+            for (size_t k = a; k < b; ++k) {
+                // a frame's reconstruction is needed iff a P frame of the same GOP follows (ref(f+1) = recon(f))
+                const bool known_last = last && k == nf - 1;
+                const bool followed = (uint32_t)jobs[k].i_frame < e->pframes && !known_last;
+                int prev = (k == a) ? (jobs[k].i_frame != 0 ? e->persist_slot : -1) : rec_slot[k - 1];
+                if (jobs[k].i_frame != 0) {
+                    if (prev < 0) throw HipError{hipErrorInvalidValue, "P frame without a reference"};
+                    jobs[k].ref = e->rec_pool[prev];
+                }
+                if (followed) {
+                    int sl;
+                    if (e->keep_recon) sl = free_slots[fs++];
+                    else {
+                        const int which = (int)((k - a) & 1);
+                        if (slots[which] < 0) slots[which] = free_slots[fs++];
+                        sl = slots[which];
+                    }
+                    rec_slot[k] = sl;
+                    jobs[k].rec = e->rec_pool[sl];
+                }
+            }
+        }
+        e->persist_slot = rec_slot[nf - 1];
+    }
+
+    // ---- launch lists: step j = j-th frame of every segment; I and P frames in separate launches ----
+    size_t maxlen = 0;
+    for (size_t sg = 0; sg < nseg; ++sg) {
+        const size_t a = seg_start[sg], b = sg + 1 < nseg ? (size_t)seg_start[sg + 1] : nf;
+        maxlen = std::max(maxlen, b - a);
+    }
+    std::vector<int> lists;
+    struct Step { int off_i, n_i, off_p, n_p; };
+    std::vector<Step> steps(maxlen);
+    for (size_t j = 0; j < maxlen; ++j) {
+        Step st{};
+        st.off_i = (int)lists.size();
+        for (size_t sg = 0; sg < nseg; ++sg) {
+            const size_t a = seg_start[sg], b = sg + 1 < nseg ? (size_t)seg_start[sg + 1] : nf;
+            if (a + j < b && jobs[a + j].i_frame == 0) lists.push_back((int)(a + j));
+        }
+        st.n_i = (int)lists.size() - st.off_i;
+        st.off_p = (int)lists.size();
+        for (size_t sg = 0; sg < nseg; ++sg) {
+            const size_t a = seg_start[sg], b = sg + 1 < nseg ? (size_t)seg_start[sg + 1] : nf;
+            if (a + j < b && jobs[a + j].i_frame != 0) lists.push_back((int)(a + j));
+        }
+        st.n_p = (int)lists.size() - st.off_p;
+        steps[j] = st;
+    }
+
+    // ---- device buffers ----
+    const size_t nmb = nf * (size_t)g.mbs;
+    e->d_jobs.ensure(nf);
+    e->d_lists.ensure(lists.size());
+    e->d_coef.ensure(nmb * 384);
+    e->d_mbinfo.ensure(nmb);
+    e->d_mblen.ensure(nmb);
+    e->d_mboff.ensure(nmb);
+    e->d_slice_bytes.ensure(nf * g.mbh);
+    e->d_slice_off.ensure(nf * g.mbh);
+    e->d_frame_off.ensure(nf);
+    // pinned staging: the caller synchronises the stream before the next chunk reuses it
+    if (e->h_jobs_cap < nf) {
+        if (e->h_jobs) (void)hipHostFree(e->h_jobs);
+        e->h_jobs = nullptr; e->h_jobs_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&e->h_jobs, nf * sizeof(FrameJob)));
+        e->h_jobs_cap = nf;
+    }
+    if (e->h_lists_cap < lists.size()) {
+        if (e->h_lists) (void)hipHostFree(e->h_lists);
+        e->h_lists = nullptr; e->h_lists_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&e->h_lists, lists.size() * sizeof(int)));
+        e->h_lists_cap = lists.size();
+    }
+    memcpy(e->h_jobs, jobs.data(), nf * sizeof(FrameJob));
+    memcpy(e->h_lists, lists.data(), lists.size() * sizeof(int));
+    HIPCHK(hipMemcpyAsync(e->d_jobs.p, e->h_jobs, nf * sizeof(FrameJob), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->d_lists.p, e->h_lists, lists.size() * sizeof(int), hipMemcpyHostToDevice, s));
+
+    // ---- macroblock kernel, step by step (frame f+1 of a GOP needs recon(f)) ----
+    for (size_t j = 0; j < maxlen; ++j) {
+        launch_mb<false>(e, s, e->d_lists.p + steps[j].off_i, steps[j].n_i, g);
+        launch_mb<true>(e, s, e->d_lists.p + steps[j].off_p, steps[j].n_p, g);
+    }
+
+    // ---- entropy coding ----
+    const dim3 vgrid((unsigned)nmb), vblock(64);
+    {
+        Timer t(e, s, 2, (double)nf * g.ysz);
+        hipLaunchKernelGGL((k_vlc<false>), vgrid, vblock, 0, s, e->d_jobs.p, g, (int)nf, e->d_coef.p, e->d_mbinfo.p,
+                           e->d_mblen.p, (const uint32_t *)nullptr, (const unsigned long long *)nullptr,
+                           (uint32_t *)nullptr, e->d_ctl.p);
+        HIPCHK(hipGetLastError());
+        t.stop();
+    }
+    {
+        Timer t(e, s, 4, (double)nf * g.ysz);
+        hipLaunchKernelGGL(k_slice_scan, dim3((unsigned)(nf * g.mbh)), dim3(128), 0, s, g, e->d_mblen.p, e->d_mboff.p,
+                           e->d_slice_bytes.p);
+        hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(1024), 0, s, e->d_jobs.p, g, (int)nf, first ? 1 : 0, last ? 1 : 0,
+                           e->d_slice_bytes.p, e->d_slice_off.p, e->d_frame_off.p, e->d_ctl.p);
+        hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, s, d_stream, e->d_ctl.p);
+        hipLaunchKernelGGL(k_headers, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, s, e->d_jobs.p, g, (int)nf,
+                           first ? 1 : 0, e->d_frame_off.p, d_stream, e->d_ctl.p);
+        if (last)
+            hipLaunchKernelGGL(k_seq_end, dim3(1), dim3(1), 0, s, d_stream, e->d_ctl.p, e->d_slice_bytes.p,
+                               e->d_slice_off.p, (int)nf, g.mbh);
+        HIPCHK(hipGetLastError());
+        t.stop();
+    }
+    {
+        Timer t(e, s, 3, (double)nf * g.ysz);
+        hipLaunchKernelGGL((k_vlc<true>), vgrid, vblock, 0, s, e->d_jobs.p, g, (int)nf, e->d_coef.p, e->d_mbinfo.p,
+                           e->d_mblen.p, e->d_mboff.p, e->d_slice_off.p, (uint32_t *)d_stream, e->d_ctl.p);
+        HIPCHK(hipGetLastError());
+        t.stop();
+    }
+
+    e->frames_total += nf;
+    e->dbg_frames = nf;
+    e->dbg_rec_slot = rec_slot;
+}
+
+// advance the device-side stream cursor after a chunk: base = total
+__global__ void k_ctl_advance(StreamCtl *ctl)
+{
+    if (!ctl->overflow) ctl->base_bytes = ctl->total_bytes;
+}
+
+void ctl_init(m2v_enc *e, hipStream_t s, unsigned long long cap, unsigned long long prior = 0)
+{
+    e->d_ctl.ensure(1);
+    if (!e->h_ctl) HIPCHK(hipHostMalloc((void **)&e->h_ctl, sizeof(StreamCtl)));
+    e->h_ctl->base_bytes = 0;
+    e->h_ctl->total_bytes = 0;
+    e->h_ctl->cap_bytes = cap & ~3ull;
+    e->h_ctl->prior_bytes = prior;
+    e->h_ctl->overflow = 0;
+    e->h_ctl->pad = 0;
+    HIPCHK(hipMemcpyAsync(e->d_ctl.p, e->h_ctl, sizeof(StreamCtl), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));     // h_ctl is reused for the read-back
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-input path: flush the buffered frames through the GPU and append the bytes to the FIFO
+// ---------------------------------------------------------------------------------------------
+void flush_buffered(m2v_enc *e, bool last)
+{
+    const size_t nf = e->buffered;
+    if (nf == 0 && !last) return;
+    const Geom &g = e->g;
+    const size_t frame_bytes = (size_t)g.ysz * 3;
+    hipStream_t s = e->stream;
+    if (nf == 0) {
+        // stop arrived exactly on a frame boundary after an earlier flush: only the end code is owed
+        static const uint8_t endc[4] = {0x00, 0x00, 0x01, 0xB7};          // RTL:2625-2628
+        e->fifo.insert(e->fifo.end(), endc, endc + 4);
+        e->stream_bytes += 4;
+        const unsigned long long padded = (e->stream_bytes / 32ull + 1ull) * 32ull;   // RTL:2932-2937
+        e->fifo.resize(e->fifo.size() + (size_t)(padded - e->stream_bytes), 0);
+        e->stream_bytes = padded;
+        e->end_pending = true;
+        return;
+    }
+    e->d_in.ensure(nf * frame_bytes);
+    HIPCHK(hipMemcpyAsync(e->d_in.p, e->h_in, nf * frame_bytes, hipMemcpyHostToDevice, s));
+    // worst case ~1.2 KB per macroblock; typical streams are ~100x smaller
+    const size_t cap = nf * ((size_t)g.mbs * 1216 + (size_t)g.mbh * 8 + 64) + 256;
+    e->d_out.ensure(cap);
+    ctl_init(e, s, cap, e->stream_bytes);
+    encode_chunk(e, s, e->d_in.p, nf, e->first_chunk, last, e->last_frame_valid_beats, e->d_out.p);
+    HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    collect_timers(e);
+    if (e->h_ctl->overflow) throw HipError{hipErrorOutOfMemory, "stream larger than the worst-case bound"};
+    const size_t bytes = (size_t)e->h_ctl->total_bytes;
+    if (bytes > e->h_out_cap) {
+        if (e->h_out) (void)hipHostFree(e->h_out);
+        e->h_out = nullptr;
+        e->h_out_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&e->h_out, bytes + 4096));
+        e->h_out_cap = bytes + 4096;
+    }
+    HIPCHK(hipMemcpyAsync(e->h_out, e->d_out.p, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    e->fifo.insert(e->fifo.end(), e->h_out, e->h_out + bytes);
+    e->stream_bytes += bytes;
+    if (last) e->end_pending = true;
+    e->buffered = 0;
+    e->first_chunk = false;
+}
+
+void ensure_staging(m2v_enc *e)
+{
+    const size_t frame_bytes = (size_t)e->g.ysz * 3;
+    const size_t want = e->batch_frames;
+    if (e->h_in && e->h_in_cap >= want * frame_bytes) return;
+    if (e->h_in) (void)hipHostFree(e->h_in);
+    e->h_in = nullptr;
+    HIPCHK(hipHostMalloc((void **)&e->h_in, want * frame_bytes));
+    e->h_in_cap = want * frame_bytes;
+}
+
+void start_sequence(m2v_enc *e, uint32_t xs, uint32_t ys, uint32_t pf)
+{
+    e->g = make_geom(e, xs, ys);            // latched on the first beat (RTL:1060-1065)
+    e->pframes = pf & 0xFFu;
+    e->state = m2v_enc::DURING;
+    e->frames_total = 0;
+    e->first_chunk = true;
+    e->buffered = 0;
+    e->beat_pos = 0;
+    e->persist_slot = -1;
+    e->end_pending = false;
+    e->last_frame_valid_beats = e->g.ysz / 4;
+    // the FIFO total counts stream bytes of THIS sequence (padding rule): must be empty
+    e->fifo.clear();
+    e->fifo_rd = 0;
+    e->stream_bytes = 0;
+    for (auto &st : e->stats) st = KStat{};
+    ensure_staging(e);
+}
+
+void do_stop(m2v_enc *e)
+{
+    const Geom &g = e->g;
+    const uint32_t bpf = g.ysz / 4;
+    if (e->beat_pos != 0) {
+        // black-fill the frame in progress (RTL:1036-1056)
+        uint8_t *f = e->h_in + e->buffered * (size_t)g.ysz * 3;
+        const size_t done = e->beat_pos * 4;
+        memset(f + done, 0x00, g.ysz - done);
+        memset(f + g.ysz + done, 0x80, g.ysz - done);
+        memset(f + 2 * (size_t)g.ysz + done, 0x80, g.ysz - done);
+        e->last_frame_valid_beats = bpf;    // the fill is materialised on the host
+        e->buffered++;
+        e->beat_pos = 0;
+    }
+    flush_buffered(e, true);
+    e->state = m2v_enc::ENDED;
+}
+
+int guard(m2v_enc *e, int (*fn)(m2v_enc *, void *), void *arg)
+{
+    try {
+        if (e->device >= 0) HIPCHK(hipSetDevice(e->device));
+        return fn(e, arg);
+    } catch (const HipError &h) {
+        e->set_err("%s: %s", h.what, hipGetErrorString(h.e));
+        return h.e == hipErrorOutOfMemory ? M2V_E_NOMEM : M2V_E_HIP;
+    } catch (const std::bad_alloc &) {
+        e->set_err("host allocation failed");
+        return M2V_E_NOMEM;
+    }
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+const char *m2v_version(void) { return "m2v_mi355x 0.1 (gfx950, wave64, one wavefront per macroblock)"; }
+
+m2v_enc *m2v_create(int XL, int YL, int VECTOR_LEVEL, int Q_LEVEL, int device, int *err)
+{
+    auto fail = [&](int code) -> m2v_enc * { if (err) *err = code; return nullptr; };
+    if (XL < 4 || XL > 7 || YL < 4 || YL > 7 || VECTOR_LEVEL < 1 || VECTOR_LEVEL > 3 || Q_LEVEL < 1 || Q_LEVEL > 4)
+        return fail(M2V_E_PARAM);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return fail(M2V_E_NODEVICE);
+    m2v_enc *e = new (std::nothrow) m2v_enc();
+    if (!e) return fail(M2V_E_NOMEM);
+    e->XL = XL; e->YL = YL; e->VL = VECTOR_LEVEL; e->Q = Q_LEVEL; e->device = device;
+    try {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        upload_tables(device);
+        HIPCHK(hipDeviceSynchronize());
+    } catch (const HipError &h) {
+        fprintf(stderr, "m2v_create: %s: %s\n", h.what, hipGetErrorString(h.e));
+        delete e;
+        return fail(M2V_E_HIP);
+    }
+    if (err) *err = M2V_OK;
+    return e;
+}
+
+void m2v_destroy(m2v_enc *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    e->d_in.release(); e->d_out.release(); e->d_coef.release(); e->d_mbinfo.release(); e->d_mblen.release();
+    e->d_mboff.release(); e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
+    e->d_jobs.release(); e->d_lists.release(); e->d_ctl.release();
+    for (auto p : e->rec_pool) (void)hipFree(p);
+    if (e->h_in) (void)hipHostFree(e->h_in);
+    if (e->h_out) (void)hipHostFree(e->h_out);
+    if (e->h_ctl) (void)hipHostFree(e->h_ctl);
+    if (e->h_jobs) (void)hipHostFree(e->h_jobs);
+    if (e->h_lists) (void)hipHostFree(e->h_lists);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int m2v_reset(m2v_enc *e)
+{
+    if (!e) return M2V_E_PARAM;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    e->state = m2v_enc::IDLE;
+    e->buffered = 0; e->beat_pos = 0; e->frames_total = 0; e->persist_slot = -1;
+    e->fifo.clear(); e->fifo_rd = 0; e->end_pending = false;
+    return M2V_OK;
+}
+
+int m2v_geometry(const m2v_enc *e, uint32_t xsize16, uint32_t ysize16, int *width, int *height)
+{
+    if (!e) return M2V_E_PARAM;
+    const Geom g = make_geom(e, xsize16, ysize16);
+    if (width) *width = g.W;
+    if (height) *height = g.H;
+    return M2V_OK;
+}
+
+struct PushBeatsArgs { uint32_t xs, ys, pf; const uint8_t *y, *u, *v; size_t n; int stop; };
+
+static int push_beats_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (PushBeatsArgs *)argp;
+    if (e->state == m2v_enc::ENDED) return M2V_OK;              // dropped while the sequence ends (RTL:1045-1058)
+    size_t i = 0;
+    if (a->n == 0) {
+        if (a->stop && e->state == m2v_enc::DURING) do_stop(e);
+        return M2V_OK;
+    }
+    if (e->state == m2v_enc::IDLE) start_sequence(e, a->xs, a->ys, a->pf);
+    const Geom &g = e->g;
+    const size_t bpf = g.ysz / 4;
+    while (i < a->n) {
+        uint8_t *f = e->h_in + e->buffered * (size_t)g.ysz * 3;
+        const size_t take = std::min(a->n - i, bpf - e->beat_pos);
+        memcpy(f + e->beat_pos * 4, a->y + i * 4, take * 4);    // raster order: beat b = pixels 4b..4b+3
+        memcpy(f + g.ysz + e->beat_pos * 4, a->u + i * 4, take * 4);
+        memcpy(f + 2 * (size_t)g.ysz + e->beat_pos * 4, a->v + i * 4, take * 4);
+        e->beat_pos += take;
+        i += take;
+        if (e->beat_pos == bpf) {
+            e->beat_pos = 0;
+            e->buffered++;
+            if (e->buffered == e->batch_frames && !(a->stop && i == a->n)) flush_buffered(e, false);
+        }
+    }
+    if (a->stop) do_stop(e);
+    return M2V_OK;
+}
+
+int m2v_push_beats(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const uint8_t *y4,
+                   const uint8_t *u4, const uint8_t *v4, size_t nbeats, int stop_with_last)
+{
+    if (!e || (nbeats && (!y4 || !u4 || !v4))) return M2V_E_PARAM;
+    PushBeatsArgs a{xsize16, ysize16, pframes_count, y4, u4, v4, nbeats, stop_with_last};
+    return guard(e, push_beats_impl, &a);
+}
+
+struct PushFramesArgs { uint32_t xs, ys, pf; const uint8_t *frames; size_t n; };
+
+static int push_frames_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (PushFramesArgs *)argp;
+    if (e->state == m2v_enc::ENDED || a->n == 0) return M2V_OK;
+    if (e->state == m2v_enc::IDLE) start_sequence(e, a->xs, a->ys, a->pf);
+    const Geom &g = e->g;
+    const size_t fb = (size_t)g.ysz * 3;
+    if (e->beat_pos != 0) {
+        e->set_err("m2v_push_frames: a frame is partially filled by m2v_push_beats");
+        return M2V_E_STATE;
+    }
+    for (size_t k = 0; k < a->n; ++k) {
+        memcpy(e->h_in + e->buffered * fb, a->frames + k * fb, fb);
+        e->buffered++;
+        if (e->buffered == e->batch_frames) flush_buffered(e, false);
+    }
+    return M2V_OK;
+}
+
+int m2v_push_frames(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const uint8_t *frames444,
+                    size_t nframes)
+{
+    if (!e || (nframes && !frames444)) return M2V_E_PARAM;
+    PushFramesArgs a{xsize16, ysize16, pframes_count, frames444, nframes};
+    return guard(e, push_frames_impl, &a);
+}
+
+static int stop_impl(m2v_enc *e, void *)
+{
+    if (e->state == m2v_enc::DURING) do_stop(e);       // no effect while idle / already ending (RTL:1090)
+    return M2V_OK;
+}
+
+int m2v_sequence_stop(m2v_enc *e)
+{
+    if (!e) return M2V_E_PARAM;
+    return guard(e, stop_impl, nullptr);
+}
+
+int m2v_busy(const m2v_enc *e) { return e && e->state != m2v_enc::IDLE; }
+
+long long m2v_pull(m2v_enc *e, uint8_t *dst, size_t cap, int *last)
+{
+    if (!e || (!dst && cap)) return M2V_E_PARAM;
+    if (last) *last = 0;
+    const size_t avail = e->fifo.size() - e->fifo_rd;
+    // only whole 32-byte words leave; the residue waits for more data or for the end of the sequence
+    size_t n = std::min(avail, cap) & ~(size_t)31;
+    if (n) memcpy(dst, e->fifo.data() + e->fifo_rd, n);
+    e->fifo_rd += n;
+    if (e->fifo_rd > (1u << 20) && e->fifo_rd * 2 > e->fifo.size()) {      // compact
+        e->fifo.erase(e->fifo.begin(), e->fifo.begin() + (long)e->fifo_rd);
+        e->fifo_rd = 0;
+    }
+    if (e->end_pending && e->fifo_rd == e->fifo.size()) {
+        if (last) *last = 1;
+        e->end_pending = false;
+        e->state = m2v_enc::IDLE;                      // o_last => SEQ_IDLE (RTL:1045-1047)
+        // keep fifo bookkeeping until the next sequence starts
+    }
+    return (long long)n;
+}
+
+struct ResidentArgs { uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; uint8_t *d_out; size_t cap; size_t *bytes; hipStream_t s; };
+
+static int resident_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (ResidentArgs *)argp;
+    if (e->state != m2v_enc::IDLE) { e->set_err("m2v_encode_resident: encoder busy"); return M2V_E_STATE; }
+    if (a->n == 0) { if (a->bytes) *a->bytes = 0; return M2V_OK; }   // no beat: the sequence never starts
+    hipStream_t s = a->s ? a->s : e->stream;
+    e->g = make_geom(e, a->xs, a->ys);
+    e->pframes = a->pf & 0xFFu;
+    e->frames_total = 0;
+    e->persist_slot = -1;
+    for (auto &st : e->stats) st = KStat{};
+    const Geom &g = e->g;
+    const size_t fb = (size_t)g.ysz * 3;
+    ctl_init(e, s, a->cap);
+    const size_t chunk = std::max<size_t>(1, e->batch_frames);
+    // align chunks to GOP boundaries so every chunk starts with an I frame where possible
+    const size_t gop = e->pframes + 1u;
+    size_t step = chunk >= gop ? chunk / gop * gop : chunk;
+    for (size_t k = 0; k < a->n; k += step) {
+        const size_t nf = std::min(step, a->n - k);
+        const bool first = k == 0, last = k + nf == a->n;
+        encode_chunk(e, s, a->d_in + k * fb, nf, first, last, g.ysz / 4, a->d_out);
+        hipLaunchKernelGGL(k_ctl_advance, dim3(1), dim3(1), 0, s, e->d_ctl.p);
+        if (!last) HIPCHK(hipStreamSynchronize(s));    // the per-chunk work buffers are reused
+    }
+    HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    collect_timers(e);
+    if (e->h_ctl->overflow) { e->set_err("output buffer too small"); return M2V_E_OVERFLOW; }
+    if (a->bytes) *a->bytes = (size_t)e->h_ctl->total_bytes;
+    return M2V_OK;
+}
+
+int m2v_encode_resident(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const void *d_frames444,
+                        size_t nframes, void *d_out, size_t cap, size_t *out_bytes, void *hip_stream)
+{
+    if (!e || (nframes && (!d_frames444 || !d_out))) return M2V_E_PARAM;
+    ResidentArgs a{xsize16, ysize16, pframes_count, (const uint8_t *)d_frames444, nframes, (uint8_t *)d_out, cap, out_bytes,
+                   (hipStream_t)hip_stream};
+    return guard(e, resident_impl, &a);
+}
+
+int m2v_set_option(m2v_enc *e, const char *name, long long value)
+{
+    if (!e || !name) return M2V_E_PARAM;
+    if (!strcmp(name, "batch_frames")) {
+        if (value < 1 || e->state != m2v_enc::IDLE) return M2V_E_PARAM;
+        e->batch_frames = (size_t)value;
+        return M2V_OK;
+    }
+    if (!strcmp(name, "profile")) { e->profile = value != 0; return M2V_OK; }
+    if (!strcmp(name, "keep_recon")) { e->keep_recon = value != 0; return M2V_OK; }
+    return M2V_E_PARAM;
+}
+
+int m2v_kernel_stats(const m2v_enc *e, int kernel, double *ms, double *units)
+{
+    if (!e || kernel < 0 || kernel > 4) return M2V_E_PARAM;
+    if (ms) *ms = e->stats[kernel].ms;
+    if (units) *units = e->stats[kernel].units;
+    return e->stats[kernel].launches;
+}
+
+struct DebugArgs { int what; void *dst; size_t cap; long long ret; };
+
+static int debug_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (DebugArgs *)argp;
+    const Geom &g = e->g;
+    const size_t nmb = e->dbg_frames * (size_t)g.mbs;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    switch (a->what) {
+        case 0: src = e->d_mbinfo.p; bytes = nmb * 4; break;
+        case 1: src = e->d_coef.p; bytes = nmb * 768; break;
+        case 2: src = e->d_mblen.p; bytes = nmb * 4; break;
+        case 3: {
+            const size_t rb = e->rec_bytes;
+            bytes = e->dbg_frames * rb;
+            if (bytes > a->cap) return M2V_E_OVERFLOW;
+            memset(a->dst, 0, bytes);
+            for (size_t k = 0; k < e->dbg_frames; ++k)
+                if (k < e->dbg_rec_slot.size() && e->dbg_rec_slot[k] >= 0)
+                    HIPCHK(hipMemcpy((uint8_t *)a->dst + k * rb, e->rec_pool[e->dbg_rec_slot[k]], rb, hipMemcpyDeviceToHost));
+            a->ret = (long long)bytes;
+            return M2V_OK;
+        }
+        default: return M2V_E_PARAM;
+    }
+    if (bytes > a->cap) return M2V_E_OVERFLOW;
+    HIPCHK(hipMemcpy(a->dst, src, bytes, hipMemcpyDeviceToHost));
+    a->ret = (long long)bytes;
+    return M2V_OK;
+}
+
+long long m2v_debug_read(m2v_enc *e, int what, void *dst, size_t cap)
+{
+    if (!e || !dst) return M2V_E_PARAM;
+    DebugArgs a{what, dst, cap, 0};
+    const int r = guard(e, debug_impl, &a);
+    return r < 0 ? r : a.ret;
+}
+
+const char *m2v_last_error(const m2v_enc *e) { return e ? e->err.c_str() : "null handle"; }
+
+/* table accessors (no GPU needed): tests/test_tables_product.py */
+int m2v_debug_table(int which, int i, int j)
+{
+    switch (which) {
+        case 0: return kDctBasis[(i & 7) * 8 + (j & 7)];
+        case 1: return kIntraW[(i & 7) * 8 + (j & 7)];
+        case 2: return kZigzagPos[(i & 7) * 8 + (j & 7)];
+        case 3: return i >= 0 && i < 17 ? kMotionCode[i] : -1;
+        case 4: return i >= 0 && i < 64 ? kCbpCode[i] : -1;
+        case 5: return i >= 0 && i < 2 && j >= 0 && j < 12 ? (kDcSizeLen[i][j] << 16) | kDcSizeCode[i][j] : -1;
+        case 6: return i >= 0 && i < 32 && j >= 1 && j <= 40 ? kAcCode[i * 40 + j - 1] : 0;
+        default: return -1;
+    }
+}
+
+}  // extern "C"

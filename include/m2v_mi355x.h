@@ -1,0 +1,128 @@
+/*
+ * m2v_mi355x.h — C-ABI of the MI355X-native MPEG-2 I/P encoder (libm2v_mi355x.so).
+ *
+ * The reference exposes no software API: its interface is the port list of the Verilog module
+ * `mpeg2encoder` (RTL/mpeg2encoder.v:10-38) driven by SIM/tb_mpeg2encoder.v.  Each entry point
+ * below replaces one part of that port contract and cites it.  Plain pointers and sizes only; no
+ * torch / HIP types in the signatures (a stream is passed as an opaque void*).
+ *
+ * One handle = one encoder instance = one GPU + one HIP stream.  Handles are independent
+ * (config "8 sequences on 8 GPUs" = 8 handles); a handle is not re-entrant.  All functions
+ * return 0 / a count on success and a negative M2V_E_* code on failure;
+ * m2v_last_error() gives the text.  There is NO CPU fallback: without a GPU m2v_create() fails.
+ */
+#ifndef M2V_MI355X_H
+#define M2V_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct m2v_enc m2v_enc;
+
+enum {
+    M2V_OK          = 0,
+    M2V_E_PARAM     = -1,   /* XL/YL/VECTOR_LEVEL/Q_LEVEL outside the ranges of RTL:11-14          */
+    M2V_E_NODEVICE  = -2,   /* no usable HIP device                                                 */
+    M2V_E_HIP       = -3,   /* a HIP call failed                                                    */
+    M2V_E_STATE     = -4,   /* call not legal in the current sequence state                         */
+    M2V_E_NOMEM     = -5,
+    M2V_E_OVERFLOW  = -6    /* caller-provided output buffer too small                              */
+};
+
+/* Library version / build string (for logs). */
+const char *m2v_version(void);
+
+/*
+ * Module instantiation: `mpeg2encoder #(XL, YL, VECTOR_LEVEL, Q_LEVEL)` (RTL:10-15) plus the one
+ * required reset (RTL:16, README "rstn").  XL,YL in 4..7 (max 16<<XL x 16<<YL pixels),
+ * VECTOR_LEVEL in 1..3, Q_LEVEL in 1..4.  `device` = HIP device ordinal.
+ * Returns NULL on failure; *err (optional) receives the M2V_E_* code.
+ */
+m2v_enc *m2v_create(int XL, int YL, int VECTOR_LEVEL, int Q_LEVEL, int device, int *err);
+void     m2v_destroy(m2v_enc *e);
+
+/* `rstn` low (RTL:1028-1039): drop any sequence in flight, return to idle, discard output. */
+int m2v_reset(m2v_enc *e);
+
+/*
+ * Pixel input: `i_en` + i_Y0..3 / i_U0..3 / i_V0..3, 4 horizontally adjacent 4:4:4 pixels per
+ * beat, raster order, frame after frame (RTL:25-28, README:98-197).  y4/u4/v4 hold nbeats*4
+ * bytes each.  i_xsize16 / i_ysize16 / i_pframes_count (RTL:20-22) are sampled on the first beat
+ * of a sequence only (RTL:1060-1065) and ignored afterwards; out-of-range sizes follow the RTL
+ * clamp (RTL:985-991).  `stop_with_last` != 0 raises i_sequence_stop together with the last
+ * beat (RTL:1082-1083).  Beats arriving while the previous sequence is still ending are dropped
+ * like the RTL does (RTL:1045-1058) — pull the output until `last` first.
+ */
+int m2v_push_beats(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
+                   const uint8_t *y4, const uint8_t *u4, const uint8_t *v4, size_t nbeats,
+                   int stop_with_last);
+
+/*
+ * Convenience = nframes * W*H/4 beats from planar frames laid out like the testbench's files
+ * (Y plane, U plane, V plane per frame, each W*H bytes; SIM/tb_mpeg2encoder.v:210-234).
+ * W,H are the CLAMPED sizes (m2v_geometry).
+ */
+int m2v_push_frames(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
+                    const uint8_t *frames444, size_t nframes);
+
+/* `i_sequence_stop` pulse with i_en = 0 (RTL:1090-1091; SIM/tb_mpeg2encoder.v:249-252). A frame
+ * in progress is completed with black pixels (RTL:1048-1056). No effect while idle. */
+int m2v_sequence_stop(m2v_enc *e);
+
+/* `o_sequence_busy` (RTL:1095): 1 from the first beat until the `last` word has been pulled. */
+int m2v_busy(const m2v_enc *e);
+
+/*
+ * Stream output: `o_en` / `o_data[255:0]` / `o_last` (RTL:35-37, 2961-2994).  Copies up to
+ * cap/32 whole 32-byte words, byte 0 = o_data[7:0], in stream order; returns the byte count.
+ * *last (optional) is set to 1 when the returned data ends with the o_last word; the encoder is
+ * idle again after that.  Encoding work is flushed as needed (GPU work is batched by GOP and may
+ * run ahead of the caller).
+ */
+long long m2v_pull(m2v_enc *e, uint8_t *dst, size_t cap, int *last);
+
+/* Clamped geometry the module would use for (xsize16, ysize16) (RTL:985-1006). */
+int m2v_geometry(const m2v_enc *e, uint32_t xsize16, uint32_t ysize16, int *width, int *height);
+
+/*
+ * Whole-sequence entry for inputs and outputs resident in HBM (what bench.py times): encodes
+ * `nframes` planar 4:4:4 frames at device pointer `d_frames444` as ONE sequence (first beat ..
+ * stop after the last beat) and leaves the stream at `d_out` (capacity cap bytes, 4-byte aligned).
+ * The byte count goes to *out_bytes after the work completes; `hip_stream` (a hipStream_t or NULL
+ * for the handle's own stream) is synchronised before returning.  The encoder must be idle.
+ */
+int m2v_encode_resident(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
+                        const void *d_frames444, size_t nframes, void *d_out, size_t cap,
+                        size_t *out_bytes, void *hip_stream);
+
+/* Options: "batch_frames" (frames buffered before the GPU is kicked, default 96),
+ * "profile" (1 = time the per-kernel launches with HIP events). */
+int m2v_set_option(m2v_enc *e, const char *name, long long value);
+
+/* Per-kernel statistics of the last m2v_encode_resident call with "profile" = 1.
+ * kernel: 0 = macroblock kernel on P frames, 1 = macroblock kernel on I frames,
+ * 2 = VLC length pass, 3 = VLC write pass, 4 = everything else.
+ * Returns launches; *ms = summed duration, *units = luma pixels processed. */
+int m2v_kernel_stats(const m2v_enc *e, int kernel, double *ms, double *units);
+
+/*
+ * Stage-level introspection for the parity tests (not part of the port contract): copies an
+ * intermediate of the last m2v_encode_resident call to host memory.
+ *   what: 0 = mb info  uint32 [frames][mbs]  (bit0 inter, bits1-6 cbp, bits8-15 mvx, bits16-23 mvy, two's complement)
+ *         1 = levels   int16  [frames][mbs][6][64] (zig-zag order)
+ *         2 = mb bits  uint32 [frames][mbs]
+ *         3 = recon    uint8  [frames][W*H*3/2]  (only frames that are referenced later; others 0)
+ * Returns bytes copied or a negative error.
+ */
+long long m2v_debug_read(m2v_enc *e, int what, void *dst, size_t cap);
+
+const char *m2v_last_error(const m2v_enc *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,58 @@
+"""-m gpu: the HIP path, through the C-ABI, bit-exact against the CPU oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_util
+    return gpu_util
+
+
+KAT = {
+    "gray": "d108c0900596548e210dcced6b8a348258872691c1eaeaa9f05dac60c90b00fa",
+    "black": "42b21ce6907fdbd3536b16632cdcfafe2bd3a807a3bbd8723c5fbc95a74b8837",
+}
+
+
+@pytest.mark.parametrize("kind", ["gray", "black"])
+def test_kat_64x64(G, kind):
+    f = G.M.synth.degenerate(kind, 64, 64, 1)
+    data = G.resident_encode(f, 4, 4, 0, XL=6, YL=6)
+    assert len(data) == 160
+    assert hashlib.sha256(data).hexdigest() == KAT[kind]
+
+
+def test_intra_only_stages(G):
+    f = G.M.synth.clip(640, 480, 3, clip_index=1)
+    assert G.compare_stages(f, 40, 30, 0, XL=6, YL=5, Q=2) == []
+
+
+def test_ip_gop_stages_small(G):
+    f = G.M.synth.clip(128, 96, 9, clip_index=2)
+    assert G.compare_stages(f, 8, 6, 8) == []
+
+
+@pytest.mark.parametrize("VL,Q", [(1, 1), (2, 3), (3, 4), (1, 4), (2, 2)])
+def test_parameter_matrix(G, VL, Q):
+    f = G.M.synth.clip(160, 128, 5, clip_index=3 + VL)
+    assert G.compare_stages(f, 10, 8, 3, XL=5, YL=5, VL=VL, Q=Q) == []
+
+
+@pytest.mark.parametrize("kind", ["checker", "noise"])
+def test_degenerate_content(G, kind):
+    f = G.M.synth.degenerate(kind, 96, 64, 4)
+    assert G.compare_stages(f, 6, 4, 2, XL=4, YL=4) == []
+
+
+def test_multi_gop_and_chunking(G):
+    from oracle import m2v_oracle_ctypes as orc
+    f = G.M.synth.clip(96, 64, 14, clip_index=9, scene_len=5)
+    want = orc.encode(f, 6, 4, 3, XL=6, YL=6)
+    for bf in (96, 4, 5, 1):
+        got = G.resident_encode(f, 6, 4, 3, XL=6, YL=6, batch_frames=bf)
+        assert got == want, "batch_frames=%d" % bf
