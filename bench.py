@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — MPixels/s of the MI355X MPEG-2 I/P encoder on BASELINE.json's config c3.
+
+One "step" = one pass of the hot path over one batch of synthetic input: a 1920x1152 yuv444p clip
+of 10 closed GOPs (1 I + 8 P frames each, VECTOR_LEVEL=3, Q_LEVEL=2, XL=YL=7) resident in HBM,
+encoded to the final MPEG-2 elementary stream in HBM through the C-ABI (m2v_encode_resident).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank encodes its own clip
+(BASELINE config c4: independent sequences, no data-path collective) -> "scaling": "weak".
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, XS16, YS16 = 1920, 1152, 120, 72
+PFRAMES, GOPS = 8, 10
+XL = YL = 7
+VL, Q = 3, 2
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
+FPGA_MPIXELS = 268.0           # README.md:22, Kintex-7
+
+
+def cpu_baseline(frames_np, gpu_stream_bytes):
+    """The CPU oracle (oracle/, a C restatement of the RTL: kind 'port') timed on ONE GOP of the same
+    clip, 1 core; also used as a byte-level check of the GPU stream's first GOP."""
+    from oracle import m2v_oracle_ctypes as orc
+    orc.build()
+    n = frames_np.shape[0]
+    t0 = time.perf_counter()
+    ref = orc.encode(frames_np, XS16, YS16, PFRAMES, XL, YL, VL, Q)
+    dt = time.perf_counter() - t0
+    body = ref.rfind(b"\x00\x00\x01\xb7")          # everything before the sequence end code
+    identical = gpu_stream_bytes[:body] == ref[:body]
+    return dict(value=round(n * W * H / dt * 1e-6, 4), unit="MPixels/s", cores=1, kind="port",
+                sample="first GOP (%d frames, 1 I + %d P) of the benchmark clip, oracle/m2v_oracle.c, %.1f s"
+                       % (n, n - 1, dt)), identical, body
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gops", type=int, default=GOPS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import m2v_load
+    M = m2v_load.load()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
+
+    M.build()
+    nframes = args.gops * (PFRAMES + 1)
+    clip = M.synth.clip_torch(W, H, nframes, clip_index=rank, device=dev)       # resident in HBM
+    cap = nframes * W * H * 3 // 2
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    enc = M.Mpeg2Encoder(XL, YL, VL, Q, device=local_rank)
+    enc.set_option("batch_frames", nframes)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        return enc.encode_resident(clip.data_ptr(), nframes, d_out.data_ptr(), cap, XS16, YS16, PFRAMES, stream)
+
+    for _ in range(args.warmup):
+        nbytes = step()
+    enc.set_option("profile", 1)       # HIP events around every kernel launch, on the launch stream
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nbytes = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    pixels_per_step = nframes * W * H
+    value = world * args.steps * pixels_per_step / dt * 1e-6
+
+    if rank == 0:
+        # dominant kernel: k_mb<3,true> (P-frame macroblock kernel).  Statistics of the LAST step.
+        launches, ms, px = enc.kernel_stats(0)
+        li, msi, pxi = enc.kernel_stats(1)
+        l2, ms2, _ = enc.kernel_stats(2)
+        l3, ms3, _ = enc.kernel_stats(3)
+        l4, ms4, _ = enc.kernel_stats(4)
+        # algorithmic HBM bytes per luma pixel of a P frame: 3.0 input 4:4:4 + 1.5 reference
+        # load + 1.5 reconstruction store (frames that are referenced later) ; bitstream is written by k_vlc
+        frames_with_rec = args.gops * (PFRAMES - 1)
+        frames_without = args.gops * 1
+        alg_bytes = (frames_with_rec * 6.0 + frames_without * 4.5) * W * H
+        achieved = alg_bytes / (ms * 1e-3) * 1e-9 if ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_mb_p_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "MPixels/s encoded, 1920x1152 I+P",
+            "value": round(value, 2), "unit": "MPixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": round(value / FPGA_MPIXELS, 3), "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "c3: 1920x1152 yuv444p, %d closed GOPs of 1 I + %d P frames (%d frames), "
+                                   "VECTOR_LEVEL=3 Q_LEVEL=2 XL=YL=7, one sequence per GPU" % (args.gops, PFRAMES, nframes),
+                       "frames": nframes, "stream_bytes": int(nbytes),
+                       "bits_per_pixel": round(nbytes * 8 / pixels_per_step, 4),
+                       "baseline": "FPGA Kintex-7 268 MPixels/s (README.md:22)"},
+            "roofline": {"bound": "hbm", "kernel": "k_mb<3,true> (P-frame macroblock kernel)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
+                         "algorithmic_bytes_per_launch": round(alg_bytes / max(launches, 1))},
+            "kernel_ms_per_step": {"k_mb_P": round(ms, 3), "k_mb_I": round(msi, 3), "k_vlc_len": round(ms2, 3),
+                                   "k_vlc_write": round(ms3, 3), "scan_headers": round(ms4, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            gop0 = clip[:PFRAMES + 1].cpu().numpy()
+            gpu_bytes = d_out[:nbytes].cpu().numpy().tobytes()
+            cb, identical, body = cpu_baseline(gop0, gpu_bytes)
+            out["cpu_baseline"] = cb
+            out["parity_check"] = {"first_gop_bytes": body, "identical_to_oracle": bool(identical)}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    enc.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,6 +36,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise M2VError("libm2v_mi355x.so is missing: run __graft_entry__.build() "
                            "(hipcc, gfx950); there is no CPU fallback")
+        # One process must hold ONE HIP runtime.  PyTorch-ROCm (used here only for device memory and
+        # streams) bundles its own libamdhip64; importing it first makes the loader resolve this
+        # library's libamdhip64.so.7 dependency to the copy torch already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         vp, sz, u32, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
         L.m2v_version.restype = ctypes.c_char_p

@@ -85,3 +85,59 @@ def degenerate(kind, W, H, nframes=2):
     else:
         raise ValueError(kind)
     return out
+
+
+def clip_torch(W, H, nframes, clip_index=0, device="cuda:0", scene_len=23):
+    """Same recipe as clip() generated with torch on `device` (fast enough for 90 x 1920x1152).
+
+    Not value-identical to clip(); used where the clip only has to be resident in HBM.
+    -> uint8 tensor [nframes, 3, H, W]
+    """
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(SEED0 + clip_index)
+    rng = np.random.default_rng(SEED0 + clip_index)
+    pad = 16
+    hh, ww = H + 2 * pad, W + 2 * pad
+    yy = torch.arange(hh, device=device, dtype=torch.float32)[:, None]
+    xx = torch.arange(ww, device=device, dtype=torch.float32)[None, :]
+    out = torch.empty((nframes, 3, H, W), dtype=torch.uint8, device=device)
+    base, pos, objs = None, np.zeros(2), []
+    for f in range(nframes):
+        if f % scene_len == 0:
+            base = []
+            for p in range(3):
+                t = torch.zeros((hh, ww), device=device)
+                for _ in range(4):
+                    fx, fy = rng.uniform(0.005, 0.08, 2)
+                    t += float(rng.uniform(10, 30)) * torch.sin(float(fx) * xx + float(fy) * yy + float(rng.uniform(0, 6.28)))
+                blocks = (torch.rand(((hh + 7) // 8, (ww + 7) // 8), device=device, generator=g) - 0.5) * 48
+                t += blocks.repeat_interleave(8, 0).repeat_interleave(8, 1)[:hh, :ww]
+                base.append(128 + t * (1.0 if p == 0 else 0.5))
+            pos = np.zeros(2)
+            objs = [dict(p=rng.uniform([0, 0], [H - 32, W - 32]), v=rng.uniform(-3, 3, 2), c=rng.uniform(30, 220, 3))
+                    for _ in range(4)]
+        else:
+            pos = np.clip(pos + rng.integers(-10, 11, 2) / 2.0, -pad + 1, pad - 2)
+        iy, ix = np.floor(pos).astype(int)
+        fy, fx = pos - np.floor(pos)
+        for p in range(3):
+            a = base[p][pad + iy:pad + iy + H + 1, pad + ix:pad + ix + W + 1]
+            img = a[:H, :W]
+            if fx:
+                img = (img + a[:H, 1:W + 1]) / 2
+            if fy:
+                img2 = a[1:H + 1, :W]
+                if fx:
+                    img2 = (img2 + a[1:H + 1, 1:W + 1]) / 2
+                img = (img + img2) / 2
+            img = img + torch.randint(-4, 5, (H, W), device=device, generator=g)
+            for o in objs:
+                oy, ox = int(o["p"][0]), int(o["p"][1])
+                img[oy:oy + 32, ox:ox + 32] = float(o["c"][p]) + torch.randint(-2, 3, (32, 32), device=device, generator=g)
+            if p == 0:
+                img[H // 2:H // 2 + 48, W // 4:W // 4 + 64] *= 0.05
+            out[f, p] = img.round().clamp(0, 255).to(torch.uint8)
+        for o in objs:
+            o["p"] = np.clip(o["p"] + o["v"], [0, 0], [H - 33, W - 33])
+    return out
