@@ -1,0 +1,80 @@
+"""The C-ABI library: loads, exports every symbol include/m2v_mi355x.h declares, validates
+parameters, and refuses to work without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import m2v_load
+
+M = m2v_load.load()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    M.build()
+    return M.lib()
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "m2v_mi355x.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(m2v_[a-z_]+)\s*\(", txt)))
+
+
+def test_exports_every_declared_symbol(L):
+    names = declared_functions()
+    assert len(names) >= 15 and set(M.EXPORTS) <= set(names)
+    for n in names:
+        assert hasattr(L, n), "missing export " + n
+
+
+def test_no_torch_or_hip_types_in_header():
+    txt = open(os.path.join(ROOT, "include", "m2v_mi355x.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    assert "#include <hip" not in code and "torch" not in code and "hipStream_t" not in code
+    assert 'extern "C"' in code
+
+
+def test_parameter_validation_and_no_cpu_fallback(L):
+    import torch
+    err = ctypes.c_int(0)
+    for bad in [(3, 6, 3, 2), (8, 6, 3, 2), (6, 3, 3, 2), (6, 6, 0, 2), (6, 6, 4, 2), (6, 6, 3, 0), (6, 6, 3, 5)]:
+        assert not L.m2v_create(*bad, 0, ctypes.byref(err)) and err.value == -1
+    if not torch.cuda.is_available():
+        assert not L.m2v_create(6, 6, 3, 2, 0, ctypes.byref(err)) and err.value == -2     # M2V_E_NODEVICE
+        with pytest.raises(M.M2VError):
+            M.Mpeg2Encoder(6, 6, 3, 2)
+    assert L.m2v_busy(None) == 0 and L.m2v_reset(None) == -1
+    assert b"m2v_mi355x" in L.m2v_version()
+
+
+def test_product_tables_match_oracle_tables(L):
+    from oracle import m2v_oracle_ctypes as orc
+    O = orc.lib()
+
+    def pair(fn, *a):
+        c, n = ctypes.c_int(), ctypes.c_int()
+        fn(*a, ctypes.byref(c), ctypes.byref(n))
+        return c.value, n.value
+    for i in range(8):
+        for j in range(8):
+            assert L.m2v_debug_table(0, i, j) == O.m2v_oracle_tab_dct(i, j)
+            assert L.m2v_debug_table(1, i, j) == O.m2v_oracle_tab_intra_w(i, j)
+            assert L.m2v_debug_table(2, i, j) == O.m2v_oracle_tab_zigzag(i, j)
+    for k in range(17):
+        c, n = pair(O.m2v_oracle_tab_motion, k)
+        assert L.m2v_debug_table(3, k, 0) == (n << 8) | c
+    for k in range(64):
+        c, n = pair(O.m2v_oracle_tab_cbp, k)
+        assert L.m2v_debug_table(4, k, 0) == (n << 8) | c
+    for ch in range(2):
+        for k in range(12):
+            c, n = pair(O.m2v_oracle_tab_dc, ch, k)
+            assert L.m2v_debug_table(5, ch, k) == (n << 16) | c
+    for run in range(32):
+        for lvl in range(1, 41):
+            c, n = pair(O.m2v_oracle_tab_ac, run, lvl)
+            assert L.m2v_debug_table(6, run, lvl) == ((n << 8) | c if n else 0)
