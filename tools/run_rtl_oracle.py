@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Cross-check against the REAL RTL wherever a Verilog simulator exists.
+
+    python tools/run_rtl_oracle.py [--rtl /path/to/mpeg2encoder.v] [--keep]
+
+For a few small seeded clips and parameter sets it (1) writes the clip as planar yuv444p, (2) writes a
+self-contained Verilog-2001 testbench (generated here, parameterised, same stimulus protocol as
+SIM/tb_mpeg2encoder.v: one beat per clock, stop pulse with i_en=0, o_data byte 0 first), (3) runs
+`iverilog -g2001` + `vvp -n` (SIM/tb_run_iverilog.bat:2-3), (4) compares the .m2v byte for byte with the
+CPU oracle and reports clocks/s.  Without iverilog/vvp or without the RTL file it prints
+"RTL oracle unavailable" and exits 0 (this is the case in the build image and on the GPU box).
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+TB = r"""
+`timescale 1ps/1ps
+module tb;
+localparam XL = %(XL)d, YL = %(YL)d, W = %(W)d, H = %(H)d, NF = %(NF)d, NBEATS = %(NBEATS)d;
+reg rstn = 1'b1, clk = 1'b0;
+always #10000 clk = ~clk;
+reg i_en = 0, i_stop = 0;
+reg [XL:0] xs16 = W/16;  reg [YL:0] ys16 = H/16;
+reg [7:0] Y0,Y1,Y2,Y3,U0,U1,U2,U3,V0,V1,V2,V3;
+wire busy, o_en, o_last;  wire [255:0] o_data;
+mpeg2encoder #(.XL(XL), .YL(YL), .VECTOR_LEVEL(%(VL)d), .Q_LEVEL(%(Q)d)) dut (
+  .rstn(rstn), .clk(clk), .i_xsize16(xs16), .i_ysize16(ys16), .i_pframes_count(8'd%(PF)d),
+  .i_en(i_en), .i_Y0(Y0), .i_Y1(Y1), .i_Y2(Y2), .i_Y3(Y3), .i_U0(U0), .i_U1(U1), .i_U2(U2), .i_U3(U3),
+  .i_V0(V0), .i_V1(V1), .i_V2(V2), .i_V3(V3), .i_sequence_stop(i_stop), .o_sequence_busy(busy),
+  .o_en(o_en), .o_last(o_last), .o_data(o_data));
+reg [7:0] mem [0:NF*W*H*3-1];
+integer fi, fo, k, f, p, b, clocks;
+initial begin
+  fi = $fopen("%(IN)s", "rb");  fo = $fopen("%(OUT)s", "wb");
+  for (k = 0; k < NF*W*H*3; k = k + 1) mem[k] = $fgetc(fi);
+  $fclose(fi);
+  repeat(4) @(posedge clk); rstn <= 1'b0; repeat(4) @(posedge clk); rstn <= 1'b1; @(posedge clk);
+  fork
+    begin
+      for (b = 0; b < NBEATS; b = b + 1) begin
+        f = b / (W*H/4);  p = (b %% (W*H/4)) * 4;
+        i_en <= 1'b1;
+        Y0 <= mem[f*W*H*3 + p];           Y1 <= mem[f*W*H*3 + p + 1];           Y2 <= mem[f*W*H*3 + p + 2];           Y3 <= mem[f*W*H*3 + p + 3];
+        U0 <= mem[f*W*H*3 + W*H + p];     U1 <= mem[f*W*H*3 + W*H + p + 1];     U2 <= mem[f*W*H*3 + W*H + p + 2];     U3 <= mem[f*W*H*3 + W*H + p + 3];
+        V0 <= mem[f*W*H*3 + 2*W*H + p];   V1 <= mem[f*W*H*3 + 2*W*H + p + 1];   V2 <= mem[f*W*H*3 + 2*W*H + p + 2];   V3 <= mem[f*W*H*3 + 2*W*H + p + 3];
+        @(posedge clk);
+        i_en <= 1'b0;
+      end
+      i_stop <= 1'b1; @(posedge clk); i_stop <= 1'b0; @(posedge clk);
+    end
+    begin
+      clocks = 0;
+      while (~busy) @(posedge clk);
+      while (busy) begin
+        if (o_en) for (k = 0; k < 32; k = k + 1) $fwrite(fo, "%%c", o_data[k*8 +: 8]);
+        clocks = clocks + 1;
+        @(posedge clk);
+      end
+    end
+  join
+  $fclose(fo);
+  $display("CLOCKS %%0d", clocks);
+  $finish;
+end
+endmodule
+"""
+
+CASES = [
+    # W, H, frames, pframes, XL, YL, VL, Q, stop_beats (None = all)
+    (64, 64, 1, 0, 4, 4, 1, 2, None),
+    (64, 64, 3, 2, 4, 4, 3, 2, None),
+    (96, 64, 5, 4, 5, 4, 3, 2, None),
+    (128, 96, 4, 3, 6, 6, 2, 3, None),
+    (96, 80, 4, 1, 6, 6, 1, 1, 3 * (96 * 80 // 4) + 77),
+    (128, 128, 9, 8, 7, 7, 3, 4, None),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rtl", default=os.environ.get("M2V_RTL", "/root/reference/RTL/mpeg2encoder.v"))
+    ap.add_argument("--keep", action="store_true")
+    args = ap.parse_args()
+    iv, vvp = shutil.which("iverilog"), shutil.which("vvp")
+    if not iv or not vvp or not os.path.exists(args.rtl):
+        print("RTL oracle unavailable (iverilog=%s vvp=%s rtl=%s): parity stays pinned by the oracle's own tests"
+              % (iv, vvp, os.path.exists(args.rtl)))
+        return 0
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    tmp = tempfile.mkdtemp(prefix="m2v_rtl_")
+    bad = 0
+    for ci, (W, H, nf, pf, XL, YL, VL, Q, stop) in enumerate(CASES):
+        clip = M.synth.clip(W, H, nf, clip_index=100 + ci, scene_len=3)
+        nbeats = nf * W * H // 4 if stop is None else stop
+        fin, fout, ftb = (os.path.join(tmp, "c%d.%s" % (ci, e)) for e in ("yuv", "m2v", "v"))
+        clip.tofile(fin)
+        open(ftb, "w").write(TB % dict(XL=XL, YL=YL, W=W, H=H, NF=nf, NBEATS=nbeats, VL=VL, Q=Q, PF=pf, IN=fin, OUT=fout))
+        sim = os.path.join(tmp, "c%d.out" % ci)
+        subprocess.check_call([iv, "-g2001", "-o", sim, ftb, args.rtl])
+        t0 = time.time()
+        log = subprocess.run([vvp, "-n", sim], capture_output=True, text=True).stdout
+        dt = time.time() - t0
+        clocks = [int(l.split()[1]) for l in log.splitlines() if l.startswith("CLOCKS")]
+        got = open(fout, "rb").read()
+        want = orc.encode(clip, W // 16, H // 16, pf, XL, YL, VL, Q, nbeats=nbeats)
+        ok = got == want
+        bad += not ok
+        print("case %d %dx%d x%d pf=%d VL=%d Q=%d: RTL %d bytes, oracle %d bytes -> %s   (%.1f s, %s clocks, %.4f MPixels/s)"
+              % (ci, W, H, nf, pf, VL, Q, len(got), len(want), "IDENTICAL" if ok else "DIFFERENT", dt,
+                 clocks[0] if clocks else "?", nbeats * 4 / dt * 1e-6))
+    if not args.keep:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
