@@ -2,16 +2,19 @@
 //
 // One wavefront per macroblock.  Kernels, in launch order for a chunk of frames:
 //
-//   k_mb<VL,P>      stages A..S of the RTL for one macroblock: 4:4:4->4:2:0, reference window
+//   k_mb<VL,P>      stages A..T of the RTL for one macroblock: 4:4:4->4:2:0, reference window
 //                   into LDS, (2YR+1)^2 full-pel SADs with v_qsad_pk_u16_u8, half-pel refine,
 //                   intra/inter decision, prediction, 6x 8x8 integer DCT, quantise, zig-zag,
-//                   dequantise, Chen-Wang IDCT, reconstruction            (RTL:1086-2468)
-//   k_vlc<false>    bit length of every macroblock layer (stage T, RTL:2718-2847)
-//   k_slice_scan    bit offset of each macroblock in its slice, byte size of each slice
+//                   dequantise, Chen-Wang IDCT, reconstruction, and the run/level VLC of every
+//                   coefficient: the macroblock's bits that do not depend on its left neighbour
+//                   leave as up to three word-aligned bit segments            (RTL:1086-2847)
+//   k_slice_scan    neighbour-dependent code lengths (motion vector deltas, DC differentials),
+//                   bit offset of each macroblock in its slice, byte size of each slice
 //   k_frame_scan    byte offset of every frame / slice in the stream (stage V alignment rules)
 //   k_zero          clears the stream bytes this chunk will occupy
 //   k_headers       sequence / GOP / picture headers, sequence end code (RTL:2590-2716)
-//   k_vlc<true>     VLC codes scattered to their final bit positions (stages T,U,V)
+//   k_assemble      slice header + macroblock header + DC codes + the stored segments, merged
+//                   into the stream at their final bit positions (stages T,U,V)
 //
 // All arithmetic is integer with the RTL's widths; see oracle/m2v_oracle.c for the plain-C
 // statement of the same semantics that the parity tests compare against.
@@ -64,40 +67,57 @@ __device__ uint16_t   d_cbp_code[64];
 __device__ uint16_t   d_dc_code[2][12];
 __device__ uint8_t    d_dc_len[2][12];
 __device__ uint16_t   d_ac_code[32 * 40];
+__constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for n < 25575 (tests/test_host_logic.py)
+
 
 // ----------------------------------------------------------------------------------------------
-// wave helpers (wave64)
+// wave helpers (wave64).  DPP row_shr 1,2,4,8 = inclusive scan inside each row of 16 lanes;
+// row_bcast:15 / row_bcast:31 carry the row totals across rows.  Lane 63 ends with the total.
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_sum(int v)
+#define M2V_DPP(old, src, ctrl, rmask, bound) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xF, (bound))
+
+__device__ __forceinline__ int wave_scan_incl(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += M2V_DPP(0, v, 0x111, 0xF, true);      // row_shr:1
+    v += M2V_DPP(0, v, 0x112, 0xF, true);      // row_shr:2
+    v += M2V_DPP(0, v, 0x114, 0xF, true);      // row_shr:4
+    v += M2V_DPP(0, v, 0x118, 0xF, true);      // row_shr:8
+    v += M2V_DPP(0, v, 0x142, 0xA, false);     // row_bcast:15 into rows 1 and 3
+    v += M2V_DPP(0, v, 0x143, 0xC, false);     // row_bcast:31 into rows 2 and 3
     return v;
 }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_scan_incl(v), 63); }
+
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
-        v = t < v ? t : v;
-    }
-    return v;
-}
-// inclusive prefix sum over the 64 lanes
-__device__ __forceinline__ int wave_scan_incl(int v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
+    int v = (int)x;
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x111, 0xF, false));
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x112, 0xF, false));
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x114, 0xF, false));
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x118, 0xF, false));
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x142, 0xA, false));
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x143, 0xC, false));
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ int mean2(int a, int b) { return (a + b + 1) >> 1; }                    // RTL:750-757
 __device__ __forceinline__ int mean4(int a, int b, int c, int d) { return (a + b + c + d + 1) >> 2; } // RTL:760-767
 __device__ __forceinline__ int iabs(int a) { return a < 0 ? -a : a; }
 __device__ __forceinline__ int sext(int v, int bits) { return (int)((uint32_t)v << (32 - bits)) >> (32 - bits); }
+
+// the same two means on four packed bytes
+__device__ __forceinline__ uint32_t avg2x4(uint32_t a, uint32_t b)           // (a+b+1)>>1 per byte
+{
+    return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu);
+}
+__device__ __forceinline__ uint32_t avg4x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)   // (a+b+c+d+1)>>2 per byte
+{
+    const uint32_t m = 0x00FF00FFu;
+    const uint32_t se = (a & m) + (b & m) + (c & m) + (d & m) + 0x00010001u;
+    const uint32_t so = ((a >> 8) & m) + ((b >> 8) & m) + ((c >> 8) & m) + ((d >> 8) & m) + 0x00010001u;
+    return ((se >> 2) & m) | (((so >> 2) & m) << 8);
+}
 
 // XCD-aware block remap: consecutive logical blocks land on the same XCD (shared L2 for the
 // overlapping reference windows of neighbouring macroblocks).  Bijective for any grid size.
@@ -200,38 +220,104 @@ __device__ __forceinline__ int find_min_in_10_values(const int v[10])
     return xi67 ? 6 + wi7 : 4 + wi5;
 }
 
-// half-pel grid sample Hg[2y+hy][2x+hx] from the 3x3 neighbourhood of T[y][x] (RTL:1746-1752)
-//   t[0..2] = rows y-1..y+1, q = column index of x inside the row arrays
-__device__ __forceinline__ int halfpel_sample(const int *t0, const int *t1, const int *t2, int q, int hy, int hx)
+
+// ----------------------------------------------------------------------------------------------
+// VLC helpers shared by k_mb (coefficients) and k_slice_scan / k_assemble (neighbour-dependent codes)
+// ----------------------------------------------------------------------------------------------
+constexpr int kSlotWords = 304;       // per-macroblock bit slot: 3 word-aligned segments, <= 9300 bits
+
+struct MbAux {                        // 16 bytes per macroblock next to the uint32 info word
+    uint32_t w0;                      // lenA | lenB << 16        (bits)
+    uint32_t w1;                      // lenC | dcV  << 16
+    uint32_t w2;                      // dcY00 | dcY11 << 16      (quantised DC levels, 16-bit two's complement)
+    uint32_t w3;                      // dcU
+};
+
+struct BitCode { uint32_t code, len; };
+
+__device__ __forceinline__ void lds_put(uint32_t *buf, uint32_t pos, uint32_t val, uint32_t len)
 {
-    const int a = t1[q];
-    if (hy == 0) {
-        if (hx == 0) return a;
-        return hx < 0 ? mean2(t1[q - 1], a) : mean2(a, t1[q + 1]);
+    if (!len) return;
+    const uint32_t w = pos >> 5, b = pos & 31u;
+    const unsigned long long v = (unsigned long long)val << (64u - len - b);
+    atomicOr(&buf[w], (uint32_t)(v >> 32));
+    const uint32_t lo = (uint32_t)v;
+    if (lo) atomicOr(&buf[w + 1], lo);
+}
+
+// dct_dc_size + dct_dc_differential (RTL:2808-2821), at most 10 + 11 bits
+__device__ __forceinline__ BitCode dc_code(int diff, int chroma)
+{
+    const int a = iabs(diff);
+    const int size = a ? 32 - __clz(a) : 0;
+    uint32_t bits = (uint32_t)diff & 0xFFFu;
+    if (diff < 0) bits = (bits + ((1u << size) - 1u)) & 0xFFFu;
+    const uint32_t sl = d_dc_len[chroma][size];
+    return BitCode{((uint32_t)d_dc_code[chroma][size] << size) | bits, sl + (uint32_t)size};
+}
+
+// motion_code + sign of the wrapped delta (RTL:2736-2748), at most 11 bits
+__device__ __forceinline__ BitCode mv_code(int mv, int prev)
+{
+    int d = mv - prev;
+    if (d > 15) d -= 32; else if (d < -16) d += 32;
+    const uint32_t e = d_motion_code[iabs(d)];
+    uint32_t code = e & 255u, len = e >> 8;
+    if (d != 0) { code = (code << 1) | (d < 0 ? 1u : 0u); len += 1; }
+    return BitCode{code, len};
+}
+
+// The parts of a macroblock that need the left neighbour (predictors reset at the start of a slice,
+// RTL:2713-2715): p1 = type [+ mvx + mvy | + DC of Y00], p2 = DC of U, p3 = DC of V.
+struct MbDep { BitCode p1, p2, p3; };
+
+__device__ __forceinline__ MbDep mb_dependent(uint32_t info, const MbAux &aux, bool has_left, uint32_t linfo,
+                                              const MbAux &laux, int i_frame)
+{
+    const int inter = info & 1, cbp = (info >> 1) & 63;
+    MbDep d{};
+    // macroblock_address_increment '1' + macroblock_type (RTL:2722-2731)
+    if (!inter && i_frame != 0) d.p1 = BitCode{0x23, 6};
+    else if (inter && cbp == 0) d.p1 = BitCode{0x09, 4};
+    else                        d.p1 = BitCode{0x03, 2};
+    if (inter) {
+        int pmvx = 0, pmvy = 0;                 // vectors carry over from an inter neighbour only (RTL:2769-2773)
+        if (has_left && (linfo & 1)) { pmvx = (int8_t)(linfo >> 8); pmvy = (int8_t)(linfo >> 16); }
+        const BitCode cx = mv_code((int8_t)(info >> 8), pmvx), cy = mv_code((int8_t)(info >> 16), pmvy);
+        d.p1.code = (((d.p1.code << cx.len) | cx.code) << cy.len) | cy.code;
+        d.p1.len += cx.len + cy.len;
+    } else {
+        int pY = 0, pU = 0, pV = 0;             // DC predictors: last Y tile / U / V of an intra neighbour, else 0 (RTL:2786-2792)
+        if (has_left && !(linfo & 1)) { pY = (int16_t)(laux.w2 >> 16); pU = (int16_t)laux.w3; pV = (int16_t)(laux.w1 >> 16); }
+        const BitCode c0 = dc_code((int16_t)aux.w2 - pY, 0);
+        d.p1.code = (d.p1.code << c0.len) | c0.code;
+        d.p1.len += c0.len;
+        d.p2 = dc_code((int16_t)aux.w3 - pU, 1);
+        d.p3 = dc_code((int16_t)(aux.w1 >> 16) - pV, 1);
     }
-    const int *o = hy < 0 ? t0 : t2;           // the other row
-    if (hx == 0) return mean2(o[q], a);
-    const int q2 = hx < 0 ? q - 1 : q + 1;
-    return mean4(o[q2], o[q], t1[q2], a);      // sum is order independent
+    return d;
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_mb: one wavefront = one macroblock, stages A..S
+// k_mb: one wavefront = one macroblock, stages A..T
 // ----------------------------------------------------------------------------------------------
 template <int VL, bool P>
 __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
-                                           Geom g, int16_t *__restrict__ coef, uint32_t *__restrict__ mbinfo)
+                                           Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
+                                           uint32_t *__restrict__ slots, int16_t *__restrict__ coef_dbg)
 {
     constexpr int UR = VL, YR = 2 * VL;
     constexpr int WROWS = 16 + 2 * YR;         // luma window rows -YR .. 16+YR-1 (RTL:1446)
     constexpr int CROWS = 8 + 2 * UR;          // chroma window rows -UR .. 8+UR-1 (RTL:1447)
 
-    __shared__ __attribute__((aligned(16))) uint32_t s_win[P ? WROWS * 8 : 1];       // luma window: 32 bytes/row = frame cols 16bx-8 .. 16bx+23
-    __shared__ __attribute__((aligned(16))) uint32_t s_cwin[2][P ? CROWS * 4 : 1];    // chroma windows: 16 bytes/row = cols 8bx-4 .. 8bx+11
-    __shared__ __attribute__((aligned(16))) uint32_t s_cur[64];                       // current luma, dword [row][4-px group]
-    __shared__ __attribute__((aligned(16))) uint8_t  s_pred[6][64];                   // prediction, later reconstruction, tile layout
-    __shared__ __attribute__((aligned(16))) int16_t  s_x[6][64];                      // residual, later dequantised coefficients
-    __shared__ __attribute__((aligned(16))) int32_t  s_t[6][64];                      // DCT phase 1, later IDCT row pass
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[P ? WROWS * 8 : 1];    // luma window: 32 bytes/row = frame cols 16bx-8 .. 16bx+23
+    __shared__ __attribute__((aligned(16))) uint32_t s_cwin[2][P ? CROWS * 4 : 1]; // chroma windows: 16 bytes/row = cols 8bx-4 .. 8bx+11
+    __shared__ __attribute__((aligned(16))) uint32_t s_cur[64];                   // current luma, dword [row][4-px group]
+    __shared__ __attribute__((aligned(16))) uint8_t  s_pred[6][64];               // prediction, later reconstruction, tile layout
+    __shared__ __attribute__((aligned(16))) int16_t  s_x[6][64];                  // residual, later dequantised coefficients
+    __shared__ __attribute__((aligned(16))) int32_t  s_t[6][64];                  // DCT phase 1, later IDCT row pass
+    __shared__ __attribute__((aligned(16))) int16_t  s_zig[6][64];                // quantised levels in zig-zag order
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[kSlotWords];          // VLC bit segments, MSB first
 
     const int lane = threadIdx.x;
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
@@ -242,6 +328,9 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
     const int W = g.W;
     const int r = lane >> 2, c4 = lane & 3;
 
+#pragma unroll
+    for (int k = lane; k < kSlotWords; k += 64) s_bits[k] = 0u;
+
     // ---- stages A..E: current macroblock; 4:4:4 -> 4:2:0 with two-stage rounding -------------
     // (RTL:1086-1089 horizontal mean2, RTL:1167-1170 vertical mean2 of the two means)
     const uint8_t *inY = job.in, *inU = inY + g.ysz, *inV = inU + g.ysz;
@@ -249,23 +338,22 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
     uint32_t cur4 = *(const uint32_t *)(inY + pix_off);
     uint32_t u4 = *(const uint32_t *)(inU + pix_off);
     uint32_t v4 = *(const uint32_t *)(inV + pix_off);
-    {
-        // beats after i_sequence_stop are black: Y=0, U=V=0x80 (RTL:1036-1056)
-        const uint32_t beat = pix_off >> 2;
-        if (beat >= job.valid_beats) { cur4 = 0u; u4 = 0x80808080u; v4 = 0x80808080u; }
+    if ((pix_off >> 2) >= job.valid_beats) {    // beats after i_sequence_stop are black (RTL:1036-1056)
+        cur4 = 0u; u4 = 0x80808080u; v4 = 0x80808080u;
     }
     s_cur[lane] = cur4;
-    int cu0, cu1, cv0, cv1;                     // this lane's two 4:2:0 chroma samples (even rows only)
+    int cu0, cu1, cv0, cv1;                     // this lane's two 4:2:0 chroma samples (used by even rows)
     {
         const uint32_t hu = (uint32_t)mean2(u4 & 255, (u4 >> 8) & 255) | ((uint32_t)mean2((u4 >> 16) & 255, u4 >> 24) << 8);
         const uint32_t hv = (uint32_t)mean2(v4 & 255, (v4 >> 8) & 255) | ((uint32_t)mean2((v4 >> 16) & 255, v4 >> 24) << 8);
-        const uint32_t hu_o = (uint32_t)__shfl_xor((int)hu, 4, 64);     // the other row of the pair
-        const uint32_t hv_o = (uint32_t)__shfl_xor((int)hv, 4, 64);
-        cu0 = mean2(hu & 255, hu_o & 255);  cu1 = mean2(hu >> 8, hu_o >> 8);
-        cv0 = mean2(hv & 255, hv_o & 255);  cv1 = mean2(hv >> 8, hv_o >> 8);
+        const uint32_t hu_p = (uint32_t)__shfl_xor((int)hu, 4, 64);     // the other row of the pair
+        const uint32_t hv_p = (uint32_t)__shfl_xor((int)hv, 4, 64);
+        cu0 = mean2(hu & 255, hu_p & 255);  cu1 = mean2(hu >> 8, hu_p >> 8);
+        cv0 = mean2(hv & 255, hv_p & 255);  cv1 = mean2(hv >> 8, hv_p >> 8);
     }
 
-    int inter = 0, mvx = 0, mvy = 0, hy = 0, hx = 0, fy = 0, fx = 0;
+    int inter = 0, mvx = 0, mvy = 0;
+    uint32_t pred4 = 0x80808080u;               // intra prediction (RTL:1894-1903)
 
     if constexpr (P) {
         // ---- stages X..Z: reference window of recon(f-1) into LDS (RTL:1350-1425, 1612-1629) --
@@ -294,6 +382,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
         // ---- full-pel search: (2YR+1)^2 SADs (RTL:1634-1715) ---------------------------------
         // lane = (dy, group of 4 consecutive dx); v_qsad_pk_u16_u8 slides the 4 current pixels
         // over 8 reference bytes and accumulates the 4 SADs as packed u16.
+        int fy = 0, fx = 0;
         {
             uint32_t key = 0xFFFFFFFFu;
             const int dyi = lane >> 2, gq = lane & 3;        // dy = dyi - YR, dx = 4*gq - 8 + j
@@ -330,85 +419,94 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
             }
         }
 
-        // ---- half-pel refinement + intra cost (RTL:1743-1816) ---------------------------------
-        // lane (r, c4) owns pixels (r, 4c4..4c4+3); T[y][x] = window[y+fy+YR][x+fx+8]
-        int t0[6], t1[6], t2[6];
+        // ---- half-pel refinement + intra cost (RTL:1743-1816), four pixels per lane, packed bytes ----
+        // T[y][x] = window[y+fy+YR][x+fx+8]; L/C/R = T[.][x-1 .. x+2], T[.][x .. x+3], T[.][x+1 .. x+4]
+        uint32_t L0, C0, R0, L1, C1, R1, L2, C2, R2;
         {
-            const uint8_t *wb = (const uint8_t *)s_win;
             int r0 = r - 1 + fy + YR, r1 = r + fy + YR, r2 = r + 1 + fy + YR;
-            r0 = r0 < 0 ? 0 : r0;                              // rows beyond the window are masked cases
+            r0 = r0 < 0 ? 0 : r0;                              // rows beyond the window belong to masked candidates
             r2 = r2 > WROWS - 1 ? WROWS - 1 : r2;
-            const int cb = 4 * c4 - 1 + fx + 8;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                t0[k] = wb[r0 * 32 + cb + k];
-                t1[k] = wb[r1 * 32 + cb + k];
-                t2[k] = wb[r2 * 32 + cb + k];
+            const int cb = 4 * c4 - 1 + fx + 8;                // 1 .. 25
+            const int wi = cb >> 2, wi2 = wi + 2 > 7 ? 7 : wi + 2;
+            const uint32_t sft = (uint32_t)cb & 3u;
+#define M2V_ROW3(ROW, L, C, R)                                                                  \
+            {                                                                                   \
+                const uint32_t a0 = s_win[(ROW) * 8 + wi], a1 = s_win[(ROW) * 8 + wi + 1], a2 = s_win[(ROW) * 8 + wi2]; \
+                const uint32_t lo = __builtin_amdgcn_alignbyte(a1, a0, sft);                    \
+                const uint32_t hi = __builtin_amdgcn_alignbyte(a2, a1, sft);                    \
+                L = lo;                                                                         \
+                C = __builtin_amdgcn_alignbyte(hi, lo, 1u);                                     \
+                R = __builtin_amdgcn_alignbyte(hi, lo, 2u);                                     \
             }
+            M2V_ROW3(r0, L0, C0, R0)
+            M2V_ROW3(r1, L1, C1, R1)
+            M2V_ROW3(r2, L2, C2, R2)
+#undef M2V_ROW3
         }
-        int sad9[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) sad9[k] = 0;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int c = (cur4 >> (8 * p)) & 255, q = p + 1;
-            const int a = t1[q], l = t1[q - 1], rt = t1[q + 1];
-            const int u = t0[q], ul = t0[q - 1], ur = t0[q + 1];
-            const int d = t2[q], dl = t2[q - 1], dr = t2[q + 1];
-            sad9[0] += iabs(c - mean4(ul, u, l, a));
-            sad9[1] += iabs(c - mean2(u, a));
-            sad9[2] += iabs(c - mean4(u, ur, a, rt));
-            sad9[3] += iabs(c - mean2(l, a));
-            sad9[4] += iabs(c - a);
-            sad9[5] += iabs(c - mean2(a, rt));
-            sad9[6] += iabs(c - mean4(l, a, dl, d));
-            sad9[7] += iabs(c - mean2(a, d));
-            sad9[8] += iabs(c - mean4(a, rt, d, dr));
-        }
+        uint32_t hp[9];                                         // the nine half-pel predictions (RTL:1746-1752)
+        hp[0] = avg4x4(L0, C0, L1, C1);  hp[1] = avg2x4(C0, C1);  hp[2] = avg4x4(C0, R0, C1, R1);
+        hp[3] = avg2x4(L1, C1);          hp[4] = C1;              hp[5] = avg2x4(C1, R1);
+        hp[6] = avg4x4(L1, C1, L2, C2);  hp[7] = avg2x4(C1, C2);  hp[8] = avg4x4(C1, R1, C2, R2);
         int v10[10];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int khy = k / 3 - 1, khx = k % 3 - 1;
-            const bool masked = ((bx == 0 || fx == -YR) && khx < 0) || ((bx == g.mbw - 1 || fx == YR) && khx > 0) ||
-                                ((by == 0 || fy == -YR) && khy < 0) || ((by == g.mbh - 1 || fy == YR) && khy > 0);   // RTL:1757-1760
-            const int s = wave_sum(sad9[k]);
-            v10[k] = (masked || s >= 4096) ? 4096 : s;         // {over, diff}: only "over" matters (RTL:1784-1785)
-        }
         {
+            uint32_t s[10];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s[k] = __builtin_amdgcn_sad_u8(cur4, hp[k], 0u);
+            s[9] = __builtin_amdgcn_sad_u8(cur4, 0u, 0u);       // pixel sum
+            int tot[10];
+#pragma unroll
+            for (int k = 0; k < 10; k += 2) {                   // two 16-bit sums per reduction (each total <= 65280)
+                const int t = wave_sum((int)(s[k] | (s[k + 1] << 16)));
+                tot[k] = t & 0xFFFF;
+                tot[k + 1] = (int)((uint32_t)t >> 16);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int khy = k / 3 - 1, khx = k % 3 - 1;
+                const bool masked = ((bx == 0 || fx == -YR) && khx < 0) || ((bx == g.mbw - 1 || fx == YR) && khx > 0) ||
+                                    ((by == 0 || fy == -YR) && khy < 0) || ((by == g.mbh - 1 || fy == YR) && khy > 0);   // RTL:1757-1760
+                v10[k] = (masked || tot[k] >= 4096) ? 4096 : tot[k];   // {over, diff}: only "over" matters (RTL:1784-1785)
+            }
             // "intra cost" accumulates on top of the pixel sum, 16-bit wrap (RTL:1744, 1774-1777, 1791)
-            const int S = wave_sum((int)__builtin_amdgcn_sad_u8(cur4, 0u, 0u));
-            const uint32_t m = ((uint32_t)S >> 8) & 255u;
+            const uint32_t S = (uint32_t)tot[9];
+            const uint32_t m = (S >> 8) & 255u;
             const int dev = wave_sum((int)__builtin_amdgcn_sad_u8(cur4, m * 0x01010101u, 0u));
-            const uint32_t S2 = ((uint32_t)S + (uint32_t)dev) & 0xFFFFu;
+            const uint32_t S2 = (S + (uint32_t)dev) & 0xFFFFu;
             v10[9] = (S2 >> 12) == 0 ? (int)S2 : 0xFFF;
         }
         const int idx = find_min_in_10_values(v10);
         inter = idx != 9;
-        if (inter) { hy = idx / 3 - 1; hx = idx % 3 - 1; }
+        int hy = 0, hx = 0;
+        if (inter) {
+            hy = idx / 3 - 1; hx = idx % 3 - 1;
+            pred4 = hp[0];
+#pragma unroll
+            for (int k = 1; k < 9; ++k) pred4 = idx == k ? hp[k] : pred4;
+        }
         mvy = 2 * fy + hy;                                      // RTL:1827-1828
         mvx = 2 * fx + hx;
+    }
 
-        // ---- prediction + residual (RTL:1891-1917, 1980-2014) ---------------------------------
+    // ---- prediction + residual into tile layout (RTL:1891-1917, 1980-2014) -----------------------
+    {
+        const int tile = ((r >> 3) << 1) | (c4 >> 1), ti = ((r & 7) << 3) | ((c4 & 1) << 2);
+        *(uint32_t *)&s_pred[tile][ti] = pred4;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int c = (cur4 >> (8 * p)) & 255;
-            const int pr = inter ? halfpel_sample(t0, t1, t2, p + 1, hy, hx) : 128;
-            const int x = 4 * c4 + p;
-            const int tile = ((r >> 3) << 1) | (x >> 3), ti = ((r & 7) << 3) | (x & 7);
-            s_pred[tile][ti] = (uint8_t)pr;
-            s_x[tile][ti] = (int16_t)(c - pr);
-        }
-        if (!(r & 1)) {
-            // chroma: integer part mv>>2 (floor), half flag = bit 1 of mv (RTL:1854-1887, 1904-1916)
-            const int yc = r >> 1;
+        for (int p = 0; p < 4; ++p)
+            s_x[tile][ti + p] = (int16_t)((int)((cur4 >> (8 * p)) & 255u) - (int)((pred4 >> (8 * p)) & 255u));
+    }
+    if (!(r & 1)) {
+        // chroma: integer part mv>>2 (floor), half flag = bit 1 of mv (RTL:1854-1887, 1904-1916)
+        const int yc = r >> 1;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int xc = 2 * c4 + e;
-                int pu = 128, pv = 128;
+        for (int e = 0; e < 2; ++e) {
+            const int xc = 2 * c4 + e;
+            int pu = 128, pv = 128;
+            if constexpr (P) {
                 if (inter) {
                     const int cyi = mvy >> 2, cxi = mvx >> 2, fyh = (mvy >> 1) & 1, fxh = (mvx >> 1) & 1;
-                    int row = yc + cyi + UR, col = xc + cxi + 4;
-                    int row1 = row + 1 > CROWS - 1 ? CROWS - 1 : row + 1;
+                    const int row = yc + cyi + UR, col = xc + cxi + 4;
+                    const int row1 = row + 1 > CROWS - 1 ? CROWS - 1 : row + 1;
                     const uint8_t *ub = (const uint8_t *)s_cwin[0], *vb = (const uint8_t *)s_cwin[1];
                     const int a_u = ub[row * 16 + col], b_u = ub[row * 16 + col + 1], c_u = ub[row1 * 16 + col], d_u = ub[row1 * 16 + col + 1];
                     const int a_v = vb[row * 16 + col], b_v = vb[row * 16 + col + 1], c_v = vb[row1 * 16 + col], d_v = vb[row1 * 16 + col + 1];
@@ -417,53 +515,44 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
                     else if (fyh)     { pu = mean2(a_u, c_u);           pv = mean2(a_v, c_v); }
                     else              { pu = a_u;                       pv = a_v; }
                 }
-                const int ti = (yc << 3) | xc;
-                s_pred[4][ti] = (uint8_t)pu;
-                s_pred[5][ti] = (uint8_t)pv;
-                s_x[4][ti] = (int16_t)((e ? cu1 : cu0) - pu);
-                s_x[5][ti] = (int16_t)((e ? cv1 : cv0) - pv);
             }
-        }
-    } else {
-        // I frame: every macroblock intra, prediction 0x80 (RTL:1820-1825, 1894-1903)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int c = (cur4 >> (8 * p)) & 255;
-            const int x = 4 * c4 + p;
-            const int tile = ((r >> 3) << 1) | (x >> 3), ti = ((r & 7) << 3) | (x & 7);
-            s_pred[tile][ti] = 128;
-            s_x[tile][ti] = (int16_t)(c - 128);
-        }
-        if (!(r & 1)) {
-            const int yc = r >> 1, ti = (yc << 3) | (2 * c4);
-            s_pred[4][ti] = 128; s_pred[4][ti + 1] = 128;
-            s_pred[5][ti] = 128; s_pred[5][ti + 1] = 128;
-            s_x[4][ti] = (int16_t)(cu0 - 128); s_x[4][ti + 1] = (int16_t)(cu1 - 128);
-            s_x[5][ti] = (int16_t)(cv0 - 128); s_x[5][ti + 1] = (int16_t)(cv1 - 128);
+            const int ti = (yc << 3) | xc;
+            s_pred[4][ti] = (uint8_t)pu;
+            s_pred[5][ti] = (uint8_t)pv;
+            s_x[4][ti] = (int16_t)((e ? cu1 : cu0) - pu);
+            s_x[5][ti] = (int16_t)((e ? cv1 : cv0) - pv);
         }
     }
     __syncthreads();
 
     // ---- stage G: 2-D forward DCT (RTL:2029-2062); lane = (i = lane>>3, j = lane&7) ------------
     const int di = lane >> 3, dj = lane & 7;
-    int bi[8], bj[8];
+    int bi[8];
+    typedef short short2_t __attribute__((ext_vector_type(2)));
+    short2_t bjp[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { bi[k] = c_dct[di * 8 + k]; bj[k] = c_dct[dj * 8 + k]; }
+    for (int k = 0; k < 8; ++k) bi[k] = c_dct[di * 8 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bjp[k] = short2_t{(short)c_dct[dj * 8 + 2 * k], (short)c_dct[dj * 8 + 2 * k + 1]};
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
-        int acc = 0;                                    // R1[r][j] = sum_k X[r][k] * DCTM[j][k]
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc += (int)s_x[t][di * 8 + k] * bj[k];
+        // R1[r][j] = sum_k X[r][k] * DCTM[j][k]: 8 int16 residuals = one 16-byte LDS read, 4 v_dot2
+        const uint4 xr = *(const uint4 *)&s_x[t][di * 8];
+        int acc = 0;
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, xr.x), bjp[0], acc, false);
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, xr.y), bjp[1], acc, false);
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, xr.z), bjp[2], acc, false);
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, xr.w), bjp[3], acc, false);
         s_t[t][lane] = acc;
     }
     __syncthreads();
 
     // ---- quantise (RTL:2065-2077), zig-zag + coded flags (RTL:2452-2468), dequantise (RTL:2129-2150)
     const int wq = c_intra_w[lane];
+    const uint32_t wrecip = c_intra_recip[lane];
     const int zz = c_zigzag[lane];
     const int Q = g.Q;
     const size_t mbidx = (size_t)fidx * g.mbs + mb;
-    int16_t *cout = coef + mbidx * 384;
     const bool need_rec = job.rec != nullptr;
     int cbp = 0;
 #pragma unroll
@@ -474,11 +563,12 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
         const int C = (acc >> 12) + ((acc >> 11) & 1);
         uint32_t a = (uint32_t)iabs(C) & 0xFFFFu;
         if (inter)          a = (a + 2u) >> (4 + Q);
-        else if (lane != 0) a = ((a + (((uint32_t)wq * ((3u << Q) + 2u)) >> 3)) >> Q) / (uint32_t)wq;
+        else if (lane != 0) a = (((a + (((uint32_t)wq * ((3u << Q) + 2u)) >> 3)) >> Q) * wrecip) >> 21;   // exact "/ W"
         else                a = (a >> 4) + ((a >> 3) & 1u);
         if (a > 2047u) a = 2047u;
         const int q = C < 0 ? -(int)a : (int)a;
-        cout[t * 64 + zz] = (int16_t)q;
+        s_zig[t][zz] = (int16_t)q;
+        if (coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
         const unsigned long long nzm = __ballot(q != 0);
         cbp = (cbp << 1) | ((!inter || nzm != 0ull) ? 1 : 0);
         if (need_rec) {
@@ -498,13 +588,86 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
             s_x[t][lane] = (int16_t)x;
         }
     }
-    if (lane == 0)
-        mbinfo[mbidx] = (uint32_t)inter | ((uint32_t)cbp << 1) | (((uint32_t)(inter ? mvx : 0) & 255u) << 8) |
-                        (((uint32_t)(inter ? mvy : 0) & 255u) << 16);
+    __syncthreads();
+
+    // ---- stage T, coefficient part: run/level VLC of the six tiles (RTL:2777-2847) -----------------
+    // lane = zig-zag index.  Bits that do not depend on the left neighbour go to three word-aligned
+    // segments: A = [cbp][all tiles] (inter) or [AC of Y00][Y01][Y10][Y11] (intra), B = AC of U, C = AC of V.
+    {
+        uint32_t pos = 0, lenA = 0, lenB = 0;
+        int dcs[6];
+        if (inter) {
+            const uint32_t e = d_cbp_code[cbp];
+            if (lane == 0) lds_put(s_bits, 0, e & 255u, e >> 8);
+            pos = e >> 8;
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int v = s_zig[t][lane];
+            const int v0 = __builtin_amdgcn_readlane(v, 0);
+            dcs[t] = v0;
+            if (!inter && t >= 4) {                         // segment boundary, word aligned
+                if (t == 4) lenA = pos; else lenB = pos - ((lenA + 31u) & ~31u);
+                pos = (pos + 31u) & ~31u;
+            }
+            const bool coded = (cbp >> (5 - t)) & 1;
+            if (coded) {
+                uint32_t dcl = 0;
+                if (!inter && t >= 1 && t <= 3) {           // DC of Y01/Y10/Y11 chains inside the macroblock (RTL:2784-2786)
+                    const BitCode c = dc_code(v0 - dcs[t - 1], 0);
+                    if (lane == 0) lds_put(s_bits, pos, c.code, c.len);
+                    dcl = c.len;
+                }
+                const bool nz = v != 0 && (inter || lane > 0);
+                const unsigned long long mask = __ballot(nz);
+                uint32_t code = 0, len = 0;
+                if (nz) {
+                    const unsigned long long below = mask & ((1ull << lane) - 1ull);
+                    const int run = below ? lane - (63 - __clzll((long long)below)) - 1 : (inter ? lane : lane - 1);
+                    const int a = iabs(v);
+                    if (inter && lane == 0 && a == 1) {     // first coefficient '1s' (RTL:2798-2802)
+                        code = 2u | (v < 0 ? 1u : 0u);
+                        len = 2;
+                    } else {
+                        uint32_t e = 0;
+                        if (run < 32 && a <= 40) e = d_ac_code[run * 40 + a - 1];
+                        if (e) {                             // run/level VLC + sign (RTL:2535-2540)
+                            code = ((e & 255u) << 1) | (v < 0 ? 1u : 0u);
+                            len = (e >> 8) + 1u;
+                        } else {                             // escape (RTL:2542-2543)
+                            code = (1u << 18) | ((uint32_t)run << 12) | ((uint32_t)v & 0xFFFu);
+                            len = 24;
+                        }
+                    }
+                }
+                const int incl = wave_scan_incl((int)len);
+                const uint32_t ac_total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+                if (nz) lds_put(s_bits, pos + dcl + (uint32_t)incl - len, code, len);
+                if (lane == 0) lds_put(s_bits, pos + dcl + ac_total, 2u, 2);      // end_of_block '10' (RTL:2835)
+                pos += dcl + ac_total + 2u;
+            }
+        }
+        uint32_t lenC = 0;
+        if (inter) lenA = pos;
+        else lenC = pos - ((lenA + 31u) & ~31u) - ((lenB + 31u) & ~31u);
+        __syncthreads();
+        const uint32_t nwords = (pos + 31u) >> 5;
+        uint32_t *slot = slots + mbidx * kSlotWords;
+        for (uint32_t k = lane; k < nwords; k += 64) slot[k] = s_bits[k];
+        if (lane == 0) {
+            mbinfo[mbidx] = (uint32_t)inter | ((uint32_t)cbp << 1) | (((uint32_t)(inter ? mvx : 0) & 255u) << 8) |
+                            (((uint32_t)(inter ? mvy : 0) & 255u) << 16);
+            MbAux aux;
+            aux.w0 = lenA | (lenB << 16);
+            aux.w1 = lenC | (((uint32_t)dcs[5] & 0xFFFFu) << 16);
+            aux.w2 = ((uint32_t)dcs[0] & 0xFFFFu) | (((uint32_t)dcs[3] & 0xFFFFu) << 16);
+            aux.w3 = (uint32_t)dcs[4] & 0xFFFFu;
+            mbaux[mbidx] = aux;
+        }
+    }
 
     // ---- stages H..R: Chen-Wang IDCT, reconstruction, store as next reference ------------------
     if (need_rec) {
-        __syncthreads();
         if (lane < 48) {                                // rows: lane = tile*8 + row (RTL:2159-2189)
             const int t = lane >> 3, row = lane & 7;
             int a[8], o[8];
@@ -544,165 +707,101 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_vlc: stage T macroblock layer, one wavefront per macroblock, lane = zig-zag index.
-// WRITE = false : bit length of the macroblock (+38-bit slice header for the first MB of a row)
-// WRITE = true  : codes assembled MSB-first in LDS, then merged into the stream at the final bit
+// k_slice_scan: one block per (frame, slice): total bit length of each macroblock (stored segments
+// + neighbour-dependent codes + 38-bit slice header on the first one), exclusive scan
 // ----------------------------------------------------------------------------------------------
-constexpr int kMbBitWords = 320;      // >= (38 + 33 + 6*(21 + 64*24 + 2) + 31) / 32 + 2
-
-__device__ __forceinline__ void lds_put(uint32_t *buf, uint32_t pos, uint32_t val, uint32_t len)
+__global__ __launch_bounds__(128) void k_slice_scan(const FrameJob *__restrict__ jobs, Geom g,
+                                                    const uint32_t *__restrict__ mbinfo, const MbAux *__restrict__ mbaux,
+                                                    uint32_t *__restrict__ mb_len, uint32_t *__restrict__ mb_bitoff,
+                                                    uint32_t *__restrict__ slice_bytes)
 {
-    if (!len) return;
-    const uint32_t w = pos >> 5, b = pos & 31u;
-    const unsigned long long v = (unsigned long long)val << (64u - len - b);
-    atomicOr(&buf[w], (uint32_t)(v >> 32));
-    const uint32_t lo = (uint32_t)v;
-    if (lo) atomicOr(&buf[w + 1], lo);
+    __shared__ uint32_t s[128];
+    const int tid = threadIdx.x;
+    const int f = blockIdx.x / g.mbh;
+    const size_t base = (size_t)blockIdx.x * g.mbw;        // blockIdx = frame * mbh + by
+    uint32_t len = 0;
+    if (tid < g.mbw) {
+        const size_t idx = base + tid;
+        const uint32_t info = mbinfo[idx];
+        const MbAux aux = mbaux[idx];
+        const bool has_left = tid > 0;
+        const uint32_t linfo = has_left ? mbinfo[idx - 1] : 0u;
+        const MbAux laux = has_left ? mbaux[idx - 1] : MbAux{0, 0, 0, 0};
+        const MbDep d = mb_dependent(info, aux, has_left, linfo, laux, jobs[f].i_frame);
+        len = (tid == 0 ? 38u : 0u) + d.p1.len + d.p2.len + d.p3.len + (aux.w0 & 0xFFFFu) + (aux.w0 >> 16) + (aux.w1 & 0xFFFFu);
+        mb_len[idx] = len;
+    }
+    s[tid] = len;
+    __syncthreads();
+    for (int o = 1; o < 128; o <<= 1) {
+        const uint32_t t = tid >= o ? s[tid - o] : 0u;
+        __syncthreads();
+        s[tid] += t;
+        __syncthreads();
+    }
+    if (tid < g.mbw) mb_bitoff[base + tid] = s[tid] - len;
+    if (tid == g.mbw - 1) slice_bytes[blockIdx.x] = (s[tid] + 7u) >> 3;   // next header aligns (RTL:2940-2943)
 }
 
-template <bool WRITE>
-__global__ __launch_bounds__(64) void k_vlc(const FrameJob *__restrict__ jobs, Geom g, int nframes,
-                                            const int16_t *__restrict__ coef, const uint32_t *__restrict__ mbinfo,
-                                            uint32_t *__restrict__ mb_len, const uint32_t *__restrict__ mb_bitoff,
-                                            const unsigned long long *__restrict__ slice_off,
-                                            uint32_t *__restrict__ out32, const StreamCtl *__restrict__ ctl)
+// ----------------------------------------------------------------------------------------------
+// k_assemble: one wavefront per macroblock: [slice header] p1 A p2 B p3 C, MSB first, assembled in
+// LDS and merged into the stream with a funnel shift; only the two boundary words use atomics
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_assemble(const FrameJob *__restrict__ jobs, Geom g, int nframes,
+                                                 const uint32_t *__restrict__ mbinfo, const MbAux *__restrict__ mbaux,
+                                                 const uint32_t *__restrict__ slots, const uint32_t *__restrict__ mb_len,
+                                                 const uint32_t *__restrict__ mb_bitoff,
+                                                 const unsigned long long *__restrict__ slice_off,
+                                                 uint32_t *__restrict__ out32, const StreamCtl *__restrict__ ctl)
 {
-    __shared__ uint32_t s_bits[WRITE ? kMbBitWords : 1];
+    __shared__ uint32_t s_bits[kSlotWords + 8];
     const int lane = threadIdx.x;
     const uint32_t blk = blockIdx.x;
     const int f = (int)(blk / (uint32_t)g.mbs), mb = (int)(blk % (uint32_t)g.mbs);
-    if (f >= nframes) return;
+    if (f >= nframes || ctl->overflow) return;
     const int by = mb / g.mbw, bx = mb - by * g.mbw;
     const size_t idx = (size_t)f * g.mbs + mb;
-    if (WRITE && ctl->overflow) return;
 
     const uint32_t info = mbinfo[idx];
-    const int inter = info & 1, cbp = (info >> 1) & 63;
-    const int mvx = (int8_t)(info >> 8), mvy = (int8_t)(info >> 16);
-    const int i_frame = jobs[f].i_frame;
-    const int16_t *cin = coef + idx * 384;
-
-    // predictors come from the left neighbour only; reset at the start of a slice (RTL:2713-2715)
-    int pmvx = 0, pmvy = 0, pdc[3] = {0, 0, 0};
-    if (bx > 0) {
-        const uint32_t li = mbinfo[idx - 1];
-        if (li & 1) {                           // inter: vectors carry over, DC predictors reset (RTL:2769, 2786-2792)
-            pmvx = (int8_t)(li >> 8);
-            pmvy = (int8_t)(li >> 16);
-        } else {                                // intra: DC of its last Y tile / U / V (RTL:2786-2792), vectors reset (RTL:2772)
-            pdc[0] = cin[-384 + 3 * 64];
-            pdc[1] = cin[-384 + 4 * 64];
-            pdc[2] = cin[-384 + 5 * 64];
-        }
-    }
-
-    uint32_t total = 0;
-    uint32_t nwords = 0;
-    if (WRITE) {
-        total = mb_len[idx];
-        nwords = (total + 31u) / 32u + 1u;
-        for (uint32_t k = lane; k < nwords; k += 64) s_bits[k] = 0u;
-        __syncthreads();
-    }
+    const MbAux aux = mbaux[idx];
+    const bool has_left = bx > 0;
+    const uint32_t linfo = has_left ? mbinfo[idx - 1] : 0u;
+    const MbAux laux = has_left ? mbaux[idx - 1] : MbAux{0, 0, 0, 0};
+    const MbDep d = mb_dependent(info, aux, has_left, linfo, laux, jobs[f].i_frame);
+    const uint32_t lenA = aux.w0 & 0xFFFFu, lenB = aux.w0 >> 16, lenC = aux.w1 & 0xFFFFu;
+    const uint32_t total = mb_len[idx];
+    const uint32_t nwords = (total + 31u) / 32u + 1u;
+    for (uint32_t k = lane; k < nwords; k += 64) s_bits[k] = 0u;
+    __syncthreads();
 
     uint32_t pos = 0;
-    // slice header: start code, slice_vertical_position, quantiser_scale_code, extra_bit_slice (RTL:2708-2710)
-    if (bx == 0) {
-        if (WRITE && lane == 0) {
+    if (bx == 0) {          // slice header: start code, slice_vertical_position, quantiser_scale_code, extra_bit_slice (RTL:2708-2710)
+        if (lane == 0) {
             lds_put(s_bits, 0, 0x000001u, 24);
             lds_put(s_bits, 24, ((uint32_t)(by + 1) << 6) | (2u << g.Q), 14);
         }
         pos = 38;
     }
-    // macroblock_address_increment '1' + macroblock_type (RTL:2722-2731)
-    {
-        uint32_t code, len;
-        if (!inter && i_frame != 0) { code = 0x23; len = 6; }
-        else if (inter && cbp == 0) { code = 0x09; len = 4; }
-        else                        { code = 0x03; len = 2; }
-        if (WRITE && lane == 0) lds_put(s_bits, pos, code, len);
-        pos += len;
-    }
-    if (inter) {                                // motion vectors then coded_block_pattern (RTL:2734-2767)
+    const uint32_t *slot = slots + idx * kSlotWords;
+    const uint32_t offB = (lenA + 31u) >> 5, offC = offB + ((lenB + 31u) >> 5);
+    // piece, segment, piece, segment, piece, segment
+    const uint32_t plen[3] = {d.p1.len, d.p2.len, d.p3.len}, pcode[3] = {d.p1.code, d.p2.code, d.p3.code};
+    const uint32_t slen[3] = {lenA, lenB, lenC}, soff[3] = {0u, offB, offC};
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            int d = c ? mvy - pmvy : mvx - pmvx;
-            if (d > 15) d -= 32; else if (d < -16) d += 32;
-            const int a = iabs(d);
-            const uint32_t e = d_motion_code[a];
-            uint32_t code = e & 255u, len = e >> 8;
-            if (d != 0) { code = (code << 1) | (d < 0 ? 1u : 0u); len += 1; }
-            if (WRITE && lane == 0) lds_put(s_bits, pos, code, len);
-            pos += len;
+    for (int sgm = 0; sgm < 3; ++sgm) {
+        if (lane == 0) lds_put(s_bits, pos, pcode[sgm], plen[sgm]);
+        pos += plen[sgm];
+        const uint32_t n = slen[sgm], nw = (n + 31u) >> 5;
+        for (uint32_t j = lane; j < nw; j += 64) {
+            const uint32_t w = slot[soff[sgm] + j];
+            const uint32_t valid = n - 32u * j < 32u ? n - 32u * j : 32u;
+            lds_put(s_bits, pos + 32u * j, w >> (32u - valid), valid);
         }
-        const uint32_t e = d_cbp_code[cbp];
-        if (WRITE && lane == 0) lds_put(s_bits, pos, e & 255u, e >> 8);
-        pos += e >> 8;
+        pos += n;
     }
-
-    // six tiles (RTL:2777-2847)
-#pragma unroll 1
-    for (int t = 0; t < 6; ++t) {
-        const int v = cin[t * 64 + lane];
-        const int v0 = __shfl(v, 0, 64);
-        const bool coded = (cbp >> (5 - t)) & 1;
-        const int comp = t < 4 ? 0 : t - 3;
-        const int diff = v0 - pdc[comp];
-        pdc[comp] = inter ? 0 : v0;             // updated for every tile, coded or not (RTL:2786-2792)
-        if (!coded) continue;
-
-        uint32_t dc_len = 0;
-        if (!inter) {                           // dct_dc_size + dct_dc_differential (RTL:2808-2821)
-            const int a = iabs(diff);
-            const int size = a ? 32 - __clz(a) : 0;
-            uint32_t bits = (uint32_t)diff & 0xFFFu;
-            if (diff < 0) bits = (bits + ((1u << size) - 1u)) & 0xFFFu;
-            const int ch = t < 4 ? 0 : 1;
-            const uint32_t sl = d_dc_len[ch][size];
-            if (WRITE && lane == 0) {
-                lds_put(s_bits, pos, d_dc_code[ch][size], sl);
-                lds_put(s_bits, pos + sl, bits, (uint32_t)size);
-            }
-            dc_len = sl + (uint32_t)size;
-        }
-        const bool nz = v != 0 && (inter || lane > 0);
-        const unsigned long long mask = __ballot(nz);
-        uint32_t code = 0, len = 0;
-        if (nz) {
-            const unsigned long long below = mask & ((1ull << lane) - 1ull);
-            const int run = below ? lane - (63 - __clzll((long long)below)) - 1 : (inter ? lane : lane - 1);
-            const int a = iabs(v);
-            if (inter && lane == 0 && a == 1) {             // first coefficient '1s' (RTL:2798-2802)
-                code = 2u | (v < 0 ? 1u : 0u);
-                len = 2;
-            } else {
-                uint32_t e = 0;
-                if (run < 32 && a <= 40) e = d_ac_code[run * 40 + a - 1];
-                if (e) {                                     // run/level VLC + sign (RTL:2535-2540)
-                    code = ((e & 255u) << 1) | (v < 0 ? 1u : 0u);
-                    len = (e >> 8) + 1u;
-                } else {                                     // escape (RTL:2542-2543)
-                    code = (1u << 18) | ((uint32_t)run << 12) | ((uint32_t)v & 0xFFFu);
-                    len = 24;
-                }
-            }
-        }
-        const int incl = wave_scan_incl((int)len, lane);
-        const uint32_t ac_total = (uint32_t)__shfl(incl, 63, 64);
-        if (WRITE) {
-            if (nz) lds_put(s_bits, pos + dc_len + (uint32_t)incl - len, code, len);
-            if (lane == 0) lds_put(s_bits, pos + dc_len + ac_total, 2u, 2);   // end_of_block '10' (RTL:2835)
-        }
-        pos += dc_len + ac_total + 2u;
-    }
-
-    if (!WRITE) {
-        if (lane == 0) mb_len[idx] = pos;
-        return;
-    }
+    __syncthreads();
 
     // merge into the stream: big-endian 32-bit words, atomics only on the two boundary words
-    __syncthreads();
     const unsigned long long q = (ctl->base_bytes + slice_off[(size_t)f * g.mbh + by]) * 8ull + mb_bitoff[idx];
     const uint32_t sh = (uint32_t)(q & 31ull);
     const unsigned long long w0 = q >> 5;
@@ -715,28 +814,6 @@ __global__ __launch_bounds__(64) void k_vlc(const FrameJob *__restrict__ jobs, G
         if (k == 0 || k == nout - 1) { if (be) atomicOr(&out32[w0 + k], be); }
         else out32[w0 + k] = be;
     }
-}
-
-// ----------------------------------------------------------------------------------------------
-// k_slice_scan: one block per (frame, slice): exclusive scan of the macroblock bit lengths
-// ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_slice_scan(Geom g, const uint32_t *__restrict__ mb_len,
-                                                    uint32_t *__restrict__ mb_bitoff, uint32_t *__restrict__ slice_bytes)
-{
-    __shared__ uint32_t s[128];
-    const int tid = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * g.mbw;        // blockIdx = frame * mbh + by
-    const uint32_t len = tid < g.mbw ? mb_len[base + tid] : 0u;
-    s[tid] = len;
-    __syncthreads();
-    for (int o = 1; o < 128; o <<= 1) {
-        const uint32_t t = tid >= o ? s[tid - o] : 0u;
-        __syncthreads();
-        s[tid] += t;
-        __syncthreads();
-    }
-    if (tid < g.mbw) mb_bitoff[base + tid] = s[tid] - len;
-    if (tid == g.mbw - 1) slice_bytes[blockIdx.x] = (s[tid] + 7u) >> 3;   // next header aligns (RTL:2940-2943)
 }
 
 // ----------------------------------------------------------------------------------------------

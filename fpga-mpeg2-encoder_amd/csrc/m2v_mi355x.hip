@@ -63,7 +63,7 @@ struct m2v_enc {
     // options
     size_t batch_frames = 96;
     bool profile = false;
-    bool keep_recon = false;      // debug: every frame keeps its own reconstruction buffer
+    bool keep_recon = false;      // debug: every frame keeps its own reconstruction buffer, levels are dumped
 
     // sequence state (RTL:1017-1022)
     enum State { IDLE, DURING, ENDED } state = IDLE;
@@ -87,7 +87,9 @@ struct m2v_enc {
     // device buffers
     DevBuf<uint8_t> d_in;                 // chunk input when it comes from the host
     DevBuf<uint8_t> d_out;                // chunk output when it goes to the host
-    DevBuf<int16_t> d_coef;
+    DevBuf<int16_t> d_coef;               // debug only: quantised levels
+    DevBuf<MbAux> d_mbaux;
+    DevBuf<uint32_t> d_slots;             // per-macroblock VLC bit segments (kSlotWords each)
     DevBuf<uint32_t> d_mbinfo, d_mblen, d_mboff, d_slice_bytes;
     DevBuf<unsigned long long> d_slice_off, d_frame_off;
     DevBuf<FrameJob> d_jobs;
@@ -168,6 +170,9 @@ void upload_tables(int device)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_dc_code), kDcSizeCode, sizeof kDcSizeCode));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_dc_len), kDcSizeLen, sizeof kDcSizeLen));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_ac_code), kAcCode, sizeof kAcCode));
+    uint32_t recip[64];
+    for (int i = 0; i < 64; ++i) recip[i] = ((1u << 21) + kIntraW[i] - 1u) / kIntraW[i];      // ceil(2^21 / W)
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_intra_recip), recip, sizeof recip));
     if (device >= 0 && device < 64) g_tables_loaded[device] = true;
 }
 
@@ -214,14 +219,15 @@ void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Ge
     if (count <= 0) return;
     const dim3 grid((unsigned)((size_t)count * g.mbs)), block(64);
     Timer t(e, s, P ? 0 : 1, (double)count * g.ysz);
+    int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
     if (P) {
         switch (e->VL) {
-            case 1: hipLaunchKernelGGL((k_mb<1, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_coef.p, e->d_mbinfo.p); break;
-            case 2: hipLaunchKernelGGL((k_mb<2, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_coef.p, e->d_mbinfo.p); break;
-            default: hipLaunchKernelGGL((k_mb<3, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_coef.p, e->d_mbinfo.p); break;
+            case 1: hipLaunchKernelGGL((k_mb<1, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots.p, dbg); break;
+            case 2: hipLaunchKernelGGL((k_mb<2, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots.p, dbg); break;
+            default: hipLaunchKernelGGL((k_mb<3, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots.p, dbg); break;
         }
     } else {
-        hipLaunchKernelGGL((k_mb<1, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_coef.p, e->d_mbinfo.p);
+        hipLaunchKernelGGL((k_mb<1, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots.p, dbg);
     }
     HIPCHK(hipGetLastError());
     t.stop();
@@ -327,7 +333,9 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
     const size_t nmb = nf * (size_t)g.mbs;
     e->d_jobs.ensure(nf);
     e->d_lists.ensure(lists.size());
-    e->d_coef.ensure(nmb * 384);
+    if (e->keep_recon) e->d_coef.ensure(nmb * 384);
+    e->d_mbaux.ensure(nmb);
+    e->d_slots.ensure(nmb * (size_t)kSlotWords);
     e->d_mbinfo.ensure(nmb);
     e->d_mblen.ensure(nmb);
     e->d_mboff.ensure(nmb);
@@ -358,20 +366,11 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
         launch_mb<true>(e, s, e->d_lists.p + steps[j].off_p, steps[j].n_p, g);
     }
 
-    // ---- entropy coding ----
-    const dim3 vgrid((unsigned)nmb), vblock(64);
-    {
-        Timer t(e, s, 2, (double)nf * g.ysz);
-        hipLaunchKernelGGL((k_vlc<false>), vgrid, vblock, 0, s, e->d_jobs.p, g, (int)nf, e->d_coef.p, e->d_mbinfo.p,
-                           e->d_mblen.p, (const uint32_t *)nullptr, (const unsigned long long *)nullptr,
-                           (uint32_t *)nullptr, e->d_ctl.p);
-        HIPCHK(hipGetLastError());
-        t.stop();
-    }
+    // ---- stream assembly ----
     {
         Timer t(e, s, 4, (double)nf * g.ysz);
-        hipLaunchKernelGGL(k_slice_scan, dim3((unsigned)(nf * g.mbh)), dim3(128), 0, s, g, e->d_mblen.p, e->d_mboff.p,
-                           e->d_slice_bytes.p);
+        hipLaunchKernelGGL(k_slice_scan, dim3((unsigned)(nf * g.mbh)), dim3(128), 0, s, e->d_jobs.p, g, e->d_mbinfo.p,
+                           e->d_mbaux.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_bytes.p);
         hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(1024), 0, s, e->d_jobs.p, g, (int)nf, first ? 1 : 0, last ? 1 : 0,
                            e->d_slice_bytes.p, e->d_slice_off.p, e->d_frame_off.p, e->d_ctl.p);
         hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, s, d_stream, e->d_ctl.p);
@@ -385,8 +384,9 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
     }
     {
         Timer t(e, s, 3, (double)nf * g.ysz);
-        hipLaunchKernelGGL((k_vlc<true>), vgrid, vblock, 0, s, e->d_jobs.p, g, (int)nf, e->d_coef.p, e->d_mbinfo.p,
-                           e->d_mblen.p, e->d_mboff.p, e->d_slice_off.p, (uint32_t *)d_stream, e->d_ctl.p);
+        hipLaunchKernelGGL(k_assemble, dim3((unsigned)nmb), dim3(64), 0, s, e->d_jobs.p, g, (int)nf, e->d_mbinfo.p,
+                           e->d_mbaux.p, e->d_slots.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_off.p, (uint32_t *)d_stream,
+                           e->d_ctl.p);
         HIPCHK(hipGetLastError());
         t.stop();
     }
@@ -567,7 +567,7 @@ void m2v_destroy(m2v_enc *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    e->d_in.release(); e->d_out.release(); e->d_coef.release(); e->d_mbinfo.release(); e->d_mblen.release();
+    e->d_in.release(); e->d_out.release(); e->d_coef.release(); e->d_mbaux.release(); e->d_slots.release(); e->d_mbinfo.release(); e->d_mblen.release();
     e->d_mboff.release(); e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
     e->d_jobs.release(); e->d_lists.release(); e->d_ctl.release();
     for (auto p : e->rec_pool) (void)hipFree(p);
@@ -780,7 +780,7 @@ static int debug_impl(m2v_enc *e, void *argp)
     size_t bytes = 0;
     switch (a->what) {
         case 0: src = e->d_mbinfo.p; bytes = nmb * 4; break;
-        case 1: src = e->d_coef.p; bytes = nmb * 768; break;
+        case 1: if (!e->keep_recon) return M2V_E_STATE; src = e->d_coef.p; bytes = nmb * 768; break;
         case 2: src = e->d_mblen.p; bytes = nmb * 4; break;
         case 3: {
             const size_t rb = e->rec_bytes;

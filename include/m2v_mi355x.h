@@ -105,7 +105,7 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value);
 
 /* Per-kernel statistics of the last m2v_encode_resident call with "profile" = 1.
  * kernel: 0 = macroblock kernel on P frames, 1 = macroblock kernel on I frames,
- * 2 = VLC length pass, 3 = VLC write pass, 4 = everything else.
+ * 2 = (unused), 3 = stream assembly (k_assemble), 4 = scans + headers.
  * Returns launches; *ms = summed duration, *units = luma pixels processed. */
 int m2v_kernel_stats(const m2v_enc *e, int kernel, double *ms, double *units);
 
