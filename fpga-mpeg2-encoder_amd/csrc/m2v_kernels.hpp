@@ -106,17 +106,16 @@ __device__ __forceinline__ int mean4(int a, int b, int c, int d) { return (a + b
 __device__ __forceinline__ int iabs(int a) { return a < 0 ? -a : a; }
 __device__ __forceinline__ int sext(int v, int bits) { return (int)((uint32_t)v << (32 - bits)) >> (32 - bits); }
 
-// the same two means on four packed bytes
+// the same two means on four packed bytes with v_lerp_u8: D.b = (S0.b + S1.b + (S2.b & 1)) >> 1
 __device__ __forceinline__ uint32_t avg2x4(uint32_t a, uint32_t b)           // (a+b+1)>>1 per byte
 {
-    return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu);
+    return __builtin_amdgcn_lerp(a, b, 0x01010101u);
 }
-__device__ __forceinline__ uint32_t avg4x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)   // (a+b+c+d+1)>>2 per byte
+// (a+b+c+d+1)>>2 per byte == (floor((a+b)/2) + floor((c+d)/2) + ((a^b)|(c^d))&1) >> 1, exhaustively
+// checked in tests/test_host_logic.py::test_mean4_lerp_identity
+__device__ __forceinline__ uint32_t avg4x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
-    const uint32_t m = 0x00FF00FFu;
-    const uint32_t se = (a & m) + (b & m) + (c & m) + (d & m) + 0x00010001u;
-    const uint32_t so = ((a >> 8) & m) + ((b >> 8) & m) + ((c >> 8) & m) + ((d >> 8) & m) + 0x00010001u;
-    return ((se >> 2) & m) | (((so >> 2) & m) << 8);
+    return __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(a, b, 0u), __builtin_amdgcn_lerp(c, d, 0u), (a ^ b) | (c ^ d));
 }
 
 // XCD-aware block remap: consecutive logical blocks land on the same XCD (shared L2 for the
@@ -136,17 +135,18 @@ __device__ __forceinline__ void idct_row(const int a[8], int r[8])
     int x0 = a[0], x1 = a[4], x2 = a[6], x3 = a[2], x4 = a[1], x5 = a[7], x6 = a[5], x7 = a[3], x8;
     x0 = (int)((uint32_t)x0 << 11) | 128;      // RTL:857-859
     x1 = (int)((uint32_t)x1 << 11);
-    x8 = kW7 * (x4 + x5);
-    x4 = x8 + (kW1 - kW7) * x4;
-    x5 = x8 - (kW1 + kW7) * x5;
-    x8 = kW3 * (x6 + x7);
-    x6 = x8 - (kW3 - kW5) * x6;
-    x7 = x8 - (kW3 + kW5) * x7;
+    // inputs are 13-bit coefficients: every product below fits the 24-bit multiplier
+    x8 = __mul24(kW7, x4 + x5);
+    x4 = x8 + __mul24(kW1 - kW7, x4);
+    x5 = x8 - __mul24(kW1 + kW7, x5);
+    x8 = __mul24(kW3, x6 + x7);
+    x6 = x8 - __mul24(kW3 - kW5, x6);
+    x7 = x8 - __mul24(kW3 + kW5, x7);
     x8 = x0 + x1;
     x0 = x0 - x1;
-    x1 = kW6 * (x3 + x2);
-    x2 = x1 - (kW2 + kW6) * x2;
-    x3 = x1 + (kW2 - kW6) * x3;
+    x1 = __mul24(kW6, x3 + x2);
+    x2 = x1 - __mul24(kW2 + kW6, x2);
+    x3 = x1 + __mul24(kW2 - kW6, x3);
     x1 = x4 + x6;
     x4 = x4 - x6;
     x6 = x5 + x7;
@@ -174,17 +174,18 @@ __device__ __forceinline__ void idct_col(const int a[8], int r[8])
     int x0 = a[0], x1 = a[4], x2 = a[6], x3 = a[2], x4 = a[1], x5 = a[7], x6 = a[5], x7 = a[3], x8;
     x0 = (int)((uint32_t)x0 << 8) + 8192;      // RTL:924-926
     x1 = (int)((uint32_t)x1 << 8);
-    x8 = kW7 * (x4 + x5) + 4;
-    x4 = (x8 + (kW1 - kW7) * x4) >> 3;
-    x5 = (x8 - (kW1 + kW7) * x5) >> 3;
-    x8 = kW3 * (x6 + x7) + 4;
-    x6 = (x8 - (kW3 - kW5) * x6) >> 3;
-    x7 = (x8 - (kW3 + kW5) * x7) >> 3;
+    // inputs are 18-bit row results: every product below fits the 24-bit multiplier
+    x8 = __mul24(kW7, x4 + x5) + 4;
+    x4 = (x8 + __mul24(kW1 - kW7, x4)) >> 3;
+    x5 = (x8 - __mul24(kW1 + kW7, x5)) >> 3;
+    x8 = __mul24(kW3, x6 + x7) + 4;
+    x6 = (x8 - __mul24(kW3 - kW5, x6)) >> 3;
+    x7 = (x8 - __mul24(kW3 + kW5, x7)) >> 3;
     x8 = x0 + x1;
     x0 = x0 - x1;
-    x1 = kW6 * (x3 + x2) + 4;
-    x2 = (x1 - (kW2 + kW6) * x2) >> 3;
-    x3 = (x1 + (kW2 - kW6) * x3) >> 3;
+    x1 = __mul24(kW6, x3 + x2) + 4;
+    x2 = (x1 - __mul24(kW2 + kW6, x2)) >> 3;
+    x3 = (x1 + __mul24(kW2 - kW6, x3)) >> 3;
     x1 = x4 + x6;
     x4 = x4 - x6;
     x6 = x5 + x7;
@@ -224,7 +225,7 @@ __device__ __forceinline__ int find_min_in_10_values(const int v[10])
 // ----------------------------------------------------------------------------------------------
 // VLC helpers shared by k_mb (coefficients) and k_slice_scan / k_assemble (neighbour-dependent codes)
 // ----------------------------------------------------------------------------------------------
-constexpr int kSlotWords = 304;       // per-macroblock bit slot: 3 word-aligned segments, <= 9300 bits
+constexpr int kSlotWords = 304;       // per-macroblock bit slot: 3 bit-contiguous segments, <= 9300 bits
 
 struct MbAux {                        // 16 bytes per macroblock next to the uint32 info word
     uint32_t w0;                      // lenA | lenB << 16        (bits)
@@ -310,14 +311,22 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
     constexpr int WROWS = 16 + 2 * YR;         // luma window rows -YR .. 16+YR-1 (RTL:1446)
     constexpr int CROWS = 8 + 2 * UR;          // chroma window rows -UR .. 8+UR-1 (RTL:1447)
 
-    __shared__ __attribute__((aligned(16))) uint32_t s_win[P ? WROWS * 8 : 1];    // luma window: 32 bytes/row = frame cols 16bx-8 .. 16bx+23
-    __shared__ __attribute__((aligned(16))) uint32_t s_cwin[2][P ? CROWS * 4 : 1]; // chroma windows: 16 bytes/row = cols 8bx-4 .. 8bx+11
-    __shared__ __attribute__((aligned(16))) uint32_t s_cur[64];                   // current luma, dword [row][4-px group]
-    __shared__ __attribute__((aligned(16))) uint8_t  s_pred[6][64];               // prediction, later reconstruction, tile layout
-    __shared__ __attribute__((aligned(16))) int16_t  s_x[6][64];                  // residual, later dequantised coefficients
-    __shared__ __attribute__((aligned(16))) int32_t  s_t[6][64];                  // DCT phase 1, later IDCT row pass
-    __shared__ __attribute__((aligned(16))) int16_t  s_zig[6][64];                // quantised levels in zig-zag order
-    __shared__ __attribute__((aligned(16))) uint32_t s_bits[kSlotWords];          // VLC bit segments, MSB first
+    // LDS map (bytes).  Region R1 holds the reference windows + current luma until the prediction is
+    // formed, then the VLC symbol list; the DCT/IDCT scratch doubles as the VLC bit buffer.
+    constexpr int kWinBytes = P ? WROWS * 32 : 0, kCwinBytes = P ? CROWS * 16 : 0;
+    constexpr int kR1 = (kWinBytes + 2 * kCwinBytes + 256) > 1600 ? (kWinBytes + 2 * kCwinBytes + 256) : 1600;
+    constexpr int kOffPred = kR1, kOffX = kOffPred + 384, kOffT = kOffX + 768, kOffZig = kOffT + 1536;
+    constexpr int kLdsBytes = kOffZig + 768;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+    uint32_t *const s_win = (uint32_t *)lds;                                   // luma window: 32 bytes/row = frame cols 16bx-8 .. 16bx+23
+    uint32_t (*const s_cwin)[CROWS * 4] = (uint32_t (*)[CROWS * 4])(lds + kWinBytes);   // chroma windows: 16 bytes/row = cols 8bx-4 .. 8bx+11
+    uint32_t *const s_cur = (uint32_t *)(lds + kWinBytes + 2 * kCwinBytes);    // current luma, dword [row][4-px group]
+    uint32_t *const s_sym = (uint32_t *)lds;                                   // VLC symbol list (<= 6 * 66), reuses R1
+    uint8_t (*const s_pred)[64] = (uint8_t (*)[64])(lds + kOffPred);           // prediction, later reconstruction, tile layout
+    int16_t (*const s_x)[64] = (int16_t (*)[64])(lds + kOffX);                 // residual, later dequantised coefficients
+    int32_t (*const s_t)[64] = (int32_t (*)[64])(lds + kOffT);                 // DCT phase 1, later IDCT row pass
+    uint32_t *const s_bits = (uint32_t *)(lds + kOffT);                        // VLC bit segments (<= 1216 bytes), reuses s_t
+    int16_t (*const s_zig)[64] = (int16_t (*)[64])(lds + kOffZig);             // quantised levels in zig-zag order
 
     const int lane = threadIdx.x;
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
@@ -327,9 +336,6 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
     const FrameJob job = jobs[fidx];
     const int W = g.W;
     const int r = lane >> 2, c4 = lane & 3;
-
-#pragma unroll
-    for (int k = lane; k < kSlotWords; k += 64) s_bits[k] = 0u;
 
     // ---- stages A..E: current macroblock; 4:4:4 -> 4:2:0 with two-stage rounding -------------
     // (RTL:1086-1089 horizontal mean2, RTL:1167-1170 vertical mean2 of the two means)
@@ -344,12 +350,13 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
     s_cur[lane] = cur4;
     int cu0, cu1, cv0, cv1;                     // this lane's two 4:2:0 chroma samples (used by even rows)
     {
-        const uint32_t hu = (uint32_t)mean2(u4 & 255, (u4 >> 8) & 255) | ((uint32_t)mean2((u4 >> 16) & 255, u4 >> 24) << 8);
-        const uint32_t hv = (uint32_t)mean2(v4 & 255, (v4 >> 8) & 255) | ((uint32_t)mean2((v4 >> 16) & 255, v4 >> 24) << 8);
+        const uint32_t hu = avg2x4(u4, u4 >> 8);          // bytes 0 and 2: horizontal means of the two pixel pairs
+        const uint32_t hv = avg2x4(v4, v4 >> 8);
         const uint32_t hu_p = (uint32_t)__shfl_xor((int)hu, 4, 64);     // the other row of the pair
         const uint32_t hv_p = (uint32_t)__shfl_xor((int)hv, 4, 64);
-        cu0 = mean2(hu & 255, hu_p & 255);  cu1 = mean2(hu >> 8, hu_p >> 8);
-        cv0 = mean2(hv & 255, hv_p & 255);  cv1 = mean2(hv >> 8, hv_p >> 8);
+        const uint32_t cu = avg2x4(hu, hu_p), cv = avg2x4(hv, hv_p);
+        cu0 = cu & 255;  cu1 = (cu >> 16) & 255;
+        cv0 = cv & 255;  cv1 = (cv >> 16) & 255;
     }
 
     int inter = 0, mvx = 0, mvy = 0;
@@ -496,32 +503,37 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
             s_x[tile][ti + p] = (int16_t)((int)((cur4 >> (8 * p)) & 255u) - (int)((pred4 >> (8 * p)) & 255u));
     }
     if (!(r & 1)) {
-        // chroma: integer part mv>>2 (floor), half flag = bit 1 of mv (RTL:1854-1887, 1904-1916)
-        const int yc = r >> 1;
+        // chroma: integer part mv>>2 (floor), half flag = bit 1 of mv (RTL:1854-1887, 1904-1916);
+        // this lane owns chroma pixels (yc, 2*c4) and (yc, 2*c4+1) of U and of V
+        const int yc = r >> 1, xc = 2 * c4;
+        uint32_t pu = 0x8080u, pv = 0x8080u;            // two packed prediction bytes per plane
+        if constexpr (P) {
+            if (inter) {
+                const int cyi = mvy >> 2, cxi = mvx >> 2, fyh = (mvy >> 1) & 1, fxh = (mvx >> 1) & 1;
+                const int row = yc + cyi + UR, col = xc + cxi + 4;         // col .. col+2 are needed, col <= 13
+                const int row1 = row + 1 > CROWS - 1 ? CROWS - 1 : row + 1;
+                const int wi = col >> 2, wi1 = wi + 1 > 3 ? 3 : wi + 1;
+                const uint32_t sft = (uint32_t)col & 3u;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int xc = 2 * c4 + e;
-            int pu = 128, pv = 128;
-            if constexpr (P) {
-                if (inter) {
-                    const int cyi = mvy >> 2, cxi = mvx >> 2, fyh = (mvy >> 1) & 1, fxh = (mvx >> 1) & 1;
-                    const int row = yc + cyi + UR, col = xc + cxi + 4;
-                    const int row1 = row + 1 > CROWS - 1 ? CROWS - 1 : row + 1;
-                    const uint8_t *ub = (const uint8_t *)s_cwin[0], *vb = (const uint8_t *)s_cwin[1];
-                    const int a_u = ub[row * 16 + col], b_u = ub[row * 16 + col + 1], c_u = ub[row1 * 16 + col], d_u = ub[row1 * 16 + col + 1];
-                    const int a_v = vb[row * 16 + col], b_v = vb[row * 16 + col + 1], c_v = vb[row1 * 16 + col], d_v = vb[row1 * 16 + col + 1];
-                    if (fyh && fxh)   { pu = mean4(a_u, b_u, c_u, d_u); pv = mean4(a_v, b_v, c_v, d_v); }
-                    else if (fxh)     { pu = mean2(a_u, b_u);           pv = mean2(a_v, b_v); }
-                    else if (fyh)     { pu = mean2(a_u, c_u);           pv = mean2(a_v, c_v); }
-                    else              { pu = a_u;                       pv = a_v; }
+                for (int pl = 0; pl < 2; ++pl) {
+                    const uint32_t *cw = s_cwin[pl];
+                    const uint32_t a = __builtin_amdgcn_alignbyte(cw[row * 4 + wi1], cw[row * 4 + wi], sft);      // T[row][col..col+3]
+                    const uint32_t c = __builtin_amdgcn_alignbyte(cw[row1 * 4 + wi1], cw[row1 * 4 + wi], sft);    // T[row+1][col..]
+                    const uint32_t b = a >> 8, d = c >> 8;
+                    uint32_t pr;
+                    if (fyh && fxh) pr = avg4x4(a, b, c, d);
+                    else if (fxh)   pr = avg2x4(a, b);
+                    else if (fyh)   pr = avg2x4(a, c);
+                    else            pr = a;
+                    if (pl == 0) pu = pr & 0xFFFFu; else pv = pr & 0xFFFFu;
                 }
             }
-            const int ti = (yc << 3) | xc;
-            s_pred[4][ti] = (uint8_t)pu;
-            s_pred[5][ti] = (uint8_t)pv;
-            s_x[4][ti] = (int16_t)((e ? cu1 : cu0) - pu);
-            s_x[5][ti] = (int16_t)((e ? cv1 : cv0) - pv);
         }
+        const int ti = (yc << 3) | xc;
+        *(uint16_t *)&s_pred[4][ti] = (uint16_t)pu;
+        *(uint16_t *)&s_pred[5][ti] = (uint16_t)pv;
+        s_x[4][ti] = (int16_t)(cu0 - (int)(pu & 255u));  s_x[4][ti + 1] = (int16_t)(cu1 - (int)(pu >> 8));
+        s_x[5][ti] = (int16_t)(cv0 - (int)(pv & 255u));  s_x[5][ti + 1] = (int16_t)(cv1 - (int)(pv >> 8));
     }
     __syncthreads();
 
@@ -555,101 +567,147 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
     const size_t mbidx = (size_t)fidx * g.mbs + mb;
     const bool need_rec = job.rec != nullptr;
     int cbp = 0;
+    if (inter) {
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        int acc = 0;                                    // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12
+        for (int t = 0; t < 6; ++t) {
+            int acc = 0;                                // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc += bi[k] * s_t[t][k * 8 + dj];
-        const int C = (acc >> 12) + ((acc >> 11) & 1);
-        uint32_t a = (uint32_t)iabs(C) & 0xFFFFu;
-        if (inter)          a = (a + 2u) >> (4 + Q);
-        else if (lane != 0) a = (((a + (((uint32_t)wq * ((3u << Q) + 2u)) >> 3)) >> Q) * wrecip) >> 21;   // exact "/ W"
-        else                a = (a >> 4) + ((a >> 3) & 1u);
-        if (a > 2047u) a = 2047u;
-        const int q = C < 0 ? -(int)a : (int)a;
-        s_zig[t][zz] = (int16_t)q;
-        if (coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
-        const unsigned long long nzm = __ballot(q != 0);
-        cbp = (cbp << 1) | ((!inter || nzm != 0ull) ? 1 : 0);
-        if (need_rec) {
-            int x;
-            if (inter) {
-                x = 2 * q;
+            for (int k = 0; k < 8; ++k) acc += __mul24(bi[k], s_t[t][k * 8 + dj]);   // |R1| < 2^18: v_mad_i32_i24
+            const int C = (acc >> 12) + ((acc >> 11) & 1);
+            uint32_t a = ((uint32_t)iabs(C) + 2u) >> (4 + Q);                       // RTL:2070
+            if (a > 2047u) a = 2047u;
+            const int q = C < 0 ? -(int)a : (int)a;
+            s_zig[t][zz] = (int16_t)q;
+            if (coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
+            cbp = (cbp << 1) | (__ballot(q != 0) != 0ull ? 1 : 0);
+            if (need_rec) {                             // RTL:2134-2137
+                int x = 2 * q;
                 x += (x < 0) ? -1 : (x > 0) ? 1 : 0;
                 x = (int)((uint32_t)x << Q);
-                x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
-            } else if (lane != 0) {
-                x = sext(q * wq, 17);                   // 17-bit temporary (RTL:2093, 2139)
-                x = Q >= 3 ? sext((int)((uint32_t)x << (Q - 3)), 17) : (x >> (3 - Q));
-                x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
-            } else {
-                x = 2 * q;
+                s_x[t][lane] = (int16_t)(x < -2047 ? -2047 : x > 2047 ? 2047 : x);
             }
-            s_x[t][lane] = (int16_t)x;
         }
+    } else {
+        const uint32_t qoff = ((uint32_t)wq * ((3u << Q) + 2u)) >> 3;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += __mul24(bi[k], s_t[t][k * 8 + dj]);
+            const int C = (acc >> 12) + ((acc >> 11) & 1);
+            uint32_t a = (uint32_t)iabs(C) & 0xFFFFu;
+            if (lane != 0) a = __umul24((a + qoff) >> Q, wrecip) >> 21;             // exact "/ W" (n < 2^14, recip < 2^19), RTL:2072
+            else           a = (a >> 4) + ((a >> 3) & 1u);                          // RTL:2074
+            if (a > 2047u) a = 2047u;
+            const int q = C < 0 ? -(int)a : (int)a;
+            s_zig[t][zz] = (int16_t)q;
+            if (coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
+            if (need_rec) {
+                int x;
+                if (lane != 0) {
+                    x = sext(__mul24(q, wq), 17);       // 17-bit temporary (RTL:2093, 2139)
+                    x = Q >= 3 ? sext((int)((uint32_t)x << (Q - 3)), 17) : (x >> (3 - Q));
+                    x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
+                } else {
+                    x = 2 * q;
+                }
+                s_x[t][lane] = (int16_t)x;
+            }
+        }
+        cbp = 63;                                       // intra: every tile is coded (RTL:2461)
     }
     __syncthreads();
 
     // ---- stage T, coefficient part: run/level VLC of the six tiles (RTL:2777-2847) -----------------
-    // lane = zig-zag index.  Bits that do not depend on the left neighbour go to three word-aligned
-    // segments: A = [cbp][all tiles] (inter) or [AC of Y00][Y01][Y10][Y11] (intra), B = AC of U, C = AC of V.
+    // Pass 1 (per tile, lane = zig-zag index): ballot the non-zero levels, rank them, and append
+    // {run, level} / raw-code symbols to one compact list.  Pass 2 (once per macroblock): table lookup,
+    // wave prefix sum of the code lengths, codes ORed MSB-first into the LDS bit buffer.
+    // Bits that need the left neighbour (motion vector deltas, DC of Y00 / U / V) are NOT produced here;
+    // the rest forms three bit-contiguous segments: A = [cbp][all tiles] (inter) or
+    // [AC of Y00][Y01][Y10][Y11] (intra), B = AC of U, C = AC of V.
     {
-        uint32_t pos = 0, lenA = 0, lenB = 0;
+        constexpr uint32_t SYM_RAW = 0x80000000u;          // raw: code[23:0], len[28:24]; else level[15:0], run[21:16]
+        uint32_t nsym = 0, idxB = 0, idxC = 0;
         int dcs[6];
         if (inter) {
             const uint32_t e = d_cbp_code[cbp];
-            if (lane == 0) lds_put(s_bits, 0, e & 255u, e >> 8);
-            pos = e >> 8;
+            if (lane == 0) s_sym[0] = SYM_RAW | ((e >> 8) << 24) | (e & 255u);
+            nsym = 1;
         }
+        const uint32_t lo_mask_l = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu;
+        const uint32_t hi_mask_l = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             const int v = s_zig[t][lane];
             const int v0 = __builtin_amdgcn_readlane(v, 0);
             dcs[t] = v0;
-            if (!inter && t >= 4) {                         // segment boundary, word aligned
-                if (t == 4) lenA = pos; else lenB = pos - ((lenA + 31u) & ~31u);
-                pos = (pos + 31u) & ~31u;
-            }
+            if (t == 4) idxB = nsym;
+            if (t == 5) idxC = nsym;
             const bool coded = (cbp >> (5 - t)) & 1;
             if (coded) {
-                uint32_t dcl = 0;
+                uint32_t hasdc = 0;
                 if (!inter && t >= 1 && t <= 3) {           // DC of Y01/Y10/Y11 chains inside the macroblock (RTL:2784-2786)
                     const BitCode c = dc_code(v0 - dcs[t - 1], 0);
-                    if (lane == 0) lds_put(s_bits, pos, c.code, c.len);
-                    dcl = c.len;
+                    if (lane == 0) s_sym[nsym] = SYM_RAW | (c.len << 24) | c.code;
+                    hasdc = 1;
                 }
                 const bool nz = v != 0 && (inter || lane > 0);
                 const unsigned long long mask = __ballot(nz);
-                uint32_t code = 0, len = 0;
+                const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+                const uint32_t nnz = (uint32_t)__popcll(mask);
                 if (nz) {
-                    const unsigned long long below = mask & ((1ull << lane) - 1ull);
-                    const int run = below ? lane - (63 - __clzll((long long)below)) - 1 : (inter ? lane : lane - 1);
-                    const int a = iabs(v);
-                    if (inter && lane == 0 && a == 1) {     // first coefficient '1s' (RTL:2798-2802)
-                        code = 2u | (v < 0 ? 1u : 0u);
-                        len = 2;
-                    } else {
-                        uint32_t e = 0;
-                        if (run < 32 && a <= 40) e = d_ac_code[run * 40 + a - 1];
-                        if (e) {                             // run/level VLC + sign (RTL:2535-2540)
-                            code = ((e & 255u) << 1) | (v < 0 ? 1u : 0u);
-                            len = (e >> 8) + 1u;
-                        } else {                             // escape (RTL:2542-2543)
-                            code = (1u << 18) | ((uint32_t)run << 12) | ((uint32_t)v & 0xFFFu);
-                            len = 24;
-                        }
-                    }
+                    const uint32_t blo = mlo & lo_mask_l, bhi = mhi & hi_mask_l;
+                    const uint32_t rank = (uint32_t)__popc(blo) + (uint32_t)__popc(bhi);
+                    // index of the previous non-zero level (or the position before the first AC slot)
+                    const int prev = bhi ? 63 - __clz(bhi) : blo ? 31 - __clz(blo) : (inter ? -1 : 0);
+                    const int run = lane - prev - 1;
+                    uint32_t sym;
+                    if (inter && lane == 0 && (v == 1 || v == -1)) sym = SYM_RAW | (2u << 24) | 2u | (v < 0 ? 1u : 0u);   // '1s' (RTL:2798-2802)
+                    else sym = ((uint32_t)run << 16) | ((uint32_t)v & 0xFFFFu);
+                    s_sym[nsym + hasdc + rank] = sym;
                 }
-                const int incl = wave_scan_incl((int)len);
-                const uint32_t ac_total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-                if (nz) lds_put(s_bits, pos + dcl + (uint32_t)incl - len, code, len);
-                if (lane == 0) lds_put(s_bits, pos + dcl + ac_total, 2u, 2);      // end_of_block '10' (RTL:2835)
-                pos += dcl + ac_total + 2u;
+                if (lane == 0) s_sym[nsym + hasdc + nnz] = SYM_RAW | (2u << 24) | 2u;      // end_of_block '10' (RTL:2835)
+                nsym += hasdc + nnz + 1u;
             }
         }
-        uint32_t lenC = 0;
+#pragma unroll
+        for (int k = lane; k < kSlotWords; k += 64) s_bits[k] = 0u;
+        __syncthreads();
+
+        uint32_t pos = 0, offB = 0, offC = 0;
+        for (uint32_t base = 0; base < nsym; base += 64) {
+            const uint32_t i = base + (uint32_t)lane;
+            uint32_t code = 0, len = 0;
+            if (i < nsym) {
+                const uint32_t sym = s_sym[i];
+                if (sym & SYM_RAW) {
+                    code = sym & 0xFFFFFFu;
+                    len = (sym >> 24) & 31u;
+                } else {
+                    const int v = (int16_t)(sym & 0xFFFFu);
+                    const int run = (int)(sym >> 16) & 63;
+                    const int a = iabs(v);
+                    uint32_t e = 0;
+                    if (run < 32 && a <= 40) e = d_ac_code[run * 40 + a - 1];
+                    if (e) {                                 // run/level VLC + sign (RTL:2535-2540)
+                        code = ((e & 255u) << 1) | (v < 0 ? 1u : 0u);
+                        len = (e >> 8) + 1u;
+                    } else {                                 // escape (RTL:2542-2543)
+                        code = (1u << 18) | ((uint32_t)run << 12) | ((uint32_t)v & 0xFFFu);
+                        len = 24;
+                    }
+                }
+            }
+            const int incl = wave_scan_incl((int)len);
+            const uint32_t excl = pos + (uint32_t)incl - len;
+            if (len) lds_put(s_bits, excl, code, len);
+            if (idxB >= base && idxB < base + 64) offB = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)(idxB - base));
+            if (idxC >= base && idxC < base + 64) offC = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)(idxC - base));
+            pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+        }
+        uint32_t lenA, lenB = 0, lenC = 0;
         if (inter) lenA = pos;
-        else lenC = pos - ((lenA + 31u) & ~31u) - ((lenB + 31u) & ~31u);
+        else { lenA = offB; lenB = offC - offB; lenC = pos - offC; }   // intra: tiles 4 and 5 always carry at least the EOB
         __syncthreads();
         const uint32_t nwords = (pos + 31u) >> 5;
         uint32_t *slot = slots + mbidx * kSlotWords;
@@ -668,6 +726,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
 
     // ---- stages H..R: Chen-Wang IDCT, reconstruction, store as next reference ------------------
     if (need_rec) {
+        __syncthreads();                                // s_t doubles as the bit buffer that was just copied out
         if (lane < 48) {                                // rows: lane = tile*8 + row (RTL:2159-2189)
             const int t = lane >> 3, row = lane & 7;
             int a[8], o[8];
@@ -783,17 +842,18 @@ __global__ __launch_bounds__(64) void k_assemble(const FrameJob *__restrict__ jo
         pos = 38;
     }
     const uint32_t *slot = slots + idx * kSlotWords;
-    const uint32_t offB = (lenA + 31u) >> 5, offC = offB + ((lenB + 31u) >> 5);
     // piece, segment, piece, segment, piece, segment
     const uint32_t plen[3] = {d.p1.len, d.p2.len, d.p3.len}, pcode[3] = {d.p1.code, d.p2.code, d.p3.code};
-    const uint32_t slen[3] = {lenA, lenB, lenC}, soff[3] = {0u, offB, offC};
+    const uint32_t slen[3] = {lenA, lenB, lenC}, soff[3] = {0u, lenA, lenA + lenB};
 #pragma unroll
     for (int sgm = 0; sgm < 3; ++sgm) {
         if (lane == 0) lds_put(s_bits, pos, pcode[sgm], plen[sgm]);
         pos += plen[sgm];
         const uint32_t n = slen[sgm], nw = (n + 31u) >> 5;
+        const uint32_t sw = soff[sgm] >> 5, sb = soff[sgm] & 31u;
         for (uint32_t j = lane; j < nw; j += 64) {
-            const uint32_t w = slot[soff[sgm] + j];
+            const uint32_t a0 = slot[sw + j], a1 = slot[sw + j + 1];      // slot has kSlotWords >= 292 + 2 words
+            const uint32_t w = sb ? ((a0 << sb) | (a1 >> (32u - sb))) : a0;
             const uint32_t valid = n - 32u * j < 32u ? n - 32u * j : 32u;
             lds_put(s_bits, pos + 32u * j, w >> (32u - valid), valid);
         }

@@ -40,3 +40,15 @@ def test_synth_is_deterministic_and_exercises_range():
     assert np.array_equal(a, b) and a.dtype == np.uint8 and a.shape == (4, 3, 64, 96)
     assert a.min() < 16 and a.max() > 200
     assert not np.array_equal(a, M.synth.clip(96, 64, 4, clip_index=6))
+
+
+def test_mean4_lerp_identity():
+    """k_mb computes the RTL's mean4 = (a+b+c+d+1)>>2 (RTL:760-767) on packed bytes as
+    lerp(floor_avg(a,b), floor_avg(c,d), round = (a^b)|(c^d)) with v_lerp_u8; exhaustive over all byte values
+    (the formula depends on (a,b) and (c,d) only through their sums)."""
+    a = np.arange(256, dtype=np.int64)
+    s1 = (a[:, None] + a[None, :]).reshape(-1)
+    combos = np.unique(np.stack([s1 >> 1, s1 & 1, s1], 1), axis=0)      # floor avg, parity (= (a^b)&1), sum
+    for p1, e1, t1 in combos:
+        lhs = (p1 + combos[:, 0] + (e1 | combos[:, 1])) >> 1
+        assert np.array_equal(lhs, (t1 + combos[:, 2] + 1) >> 2)
