@@ -97,6 +97,7 @@ struct m2v_enc {
     DevBuf<StreamCtl> d_ctl;
     std::vector<uint8_t *> rec_pool;      // reconstruction buffers (4:2:0 planar), each ysz + 2*csz
     size_t rec_bytes = 0;
+    size_t rec_pool_bytes = 0;            // allocation size of every buffer in rec_pool
     int persist_slot = -1;                // slot holding recon of the last encoded frame (GOP continues)
     StreamCtl *h_ctl = nullptr;           // pinned
     FrameJob *h_jobs = nullptr;           // pinned staging of the per-frame jobs
@@ -266,10 +267,16 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
     const bool need_any_rec = e->pframes > 0;
     std::vector<int> rec_slot(nf, -1);
     if (need_any_rec) {
+        if (e->rec_pool_bytes < e->rec_bytes) {       // geometry grew since the pool was allocated (new sequence)
+            if (e->persist_slot >= 0) throw HipError{hipErrorInvalidValue, "reference lost on geometry change"};
+            for (auto p : e->rec_pool) (void)hipFree(p);
+            e->rec_pool.clear();
+            e->rec_pool_bytes = e->rec_bytes;
+        }
         const size_t want = e->keep_recon ? nf + 1 : 2 * nseg + 1;
         while (e->rec_pool.size() < want) {
             uint8_t *p = nullptr;
-            HIPCHK(hipMalloc((void **)&p, e->rec_bytes));
+            HIPCHK(hipMalloc((void **)&p, e->rec_pool_bytes));
             e->rec_pool.push_back(p);
         }
         std::vector<int> free_slots;

@@ -1,0 +1,141 @@
+"""-m gpu: the port-level contract through the C-ABI (beats in, 32-byte words out), against the oracle.
+
+Mirrors what SIM/tb_mpeg2encoder.v exercises (three sequences back to back on one instance, TB:150) and the
+cases SURVEY.md 8(f1) lists: mid-frame stop / black fill, size clamp, pframes 0..255, bubbles."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    return m2v_load.load(), orc
+
+
+def beats_of(frame_block):
+    """[n,3,H,W] -> three flat arrays in beat order (raster, 4 px per beat)"""
+    f = np.ascontiguousarray(frame_block)
+    return f[:, 0].reshape(-1), f[:, 1].reshape(-1), f[:, 2].reshape(-1)
+
+
+def test_three_sequences_back_to_back(env):
+    """TB:150 - one encoder instance, three different videos, different sizes."""
+    M, orc = env
+    enc = M.Mpeg2Encoder(7, 6, 3, 2)
+    try:
+        for k, (W, H, n) in enumerate([(288, 208, 4), (640, 320, 3), (160, 704, 3)]):
+            clip = M.synth.clip(W, H, n, clip_index=20 + k)
+            want = orc.encode(clip, W // 16, H // 16, 23, 7, 6, 3, 2)
+            assert not enc.busy
+            got = enc.encode(clip, W // 16, H // 16, 23)
+            assert got == want, "sequence %d" % k
+            assert not enc.busy
+    finally:
+        enc.close()
+
+
+def test_irregular_beat_batches_and_stop_with_last(env):
+    """Bubbles (TB:233) = arbitrary beat batch sizes; stop raised together with the last beat (RTL:1082-1083)."""
+    M, orc = env
+    W, H, n, pf = 96, 64, 5, 2
+    clip = M.synth.clip(W, H, n, clip_index=30)
+    want = orc.encode(clip, 6, 4, pf, 6, 6, 3, 2)
+    y, u, v = (a.reshape(-1) for a in (clip[:, 0], clip[:, 1], clip[:, 2]))
+    # beats are per frame: frame f beat b -> pixels of frame f; build per-frame beat streams
+    enc = M.Mpeg2Encoder(6, 6, 3, 2)
+    try:
+        rng = np.random.default_rng(5)
+        bpf = W * H // 4
+        for f in range(n):
+            fy, fu, fv = clip[f, 0].reshape(-1), clip[f, 1].reshape(-1), clip[f, 2].reshape(-1)
+            b = 0
+            while b < bpf:
+                take = int(min(bpf - b, rng.integers(1, 700)))
+                last = f == n - 1 and b + take == bpf
+                enc.push_beats(6, 4, pf, fy[4 * b:4 * (b + take)], fu[4 * b:4 * (b + take)], fv[4 * b:4 * (b + take)],
+                               stop_with_last=last)
+                b += take
+        assert enc.busy
+        got = enc.pull_all()
+        assert got == want and not enc.busy
+    finally:
+        enc.close()
+
+
+@pytest.mark.parametrize("cut", [1, 333, 96 * 64 // 4 - 1])
+def test_stop_inside_a_frame(env, cut):
+    """i_sequence_stop mid-frame: the frame is completed with Y=0, U=V=0x80 (RTL:1036-1056)."""
+    M, orc = env
+    W, H = 96, 64
+    clip = M.synth.clip(W, H, 3, clip_index=31)
+    bpf = W * H // 4
+    nbeats = 2 * bpf + cut
+    want = orc.encode(clip, 6, 4, 2, 6, 6, 3, 2, nbeats=nbeats)
+    enc = M.Mpeg2Encoder(6, 6, 3, 2)
+    try:
+        got = enc.encode(clip, 6, 4, 2, nbeats=nbeats)
+        assert got == want
+        # beats pushed while the sequence is ending are dropped (RTL:1045-1058): push, stop, push again before pulling
+        enc.push_frames(6, 4, 2, clip[:1])
+        enc.sequence_stop()
+        enc.push_frames(6, 4, 2, clip[1:2])          # dropped
+        got2 = enc.pull_all()
+        assert got2 == orc.encode(clip[:1], 6, 4, 2, 6, 6, 3, 2)
+    finally:
+        enc.close()
+
+
+def test_chunk_boundary_inside_a_gop_streaming(env):
+    """Frames are encoded in chunks of batch_frames; a GOP that straddles chunks continues from the persisted
+    reconstruction, and the stream does not depend on the chunking."""
+    M, orc = env
+    W, H, n, pf = 128, 96, 11, 4
+    clip = M.synth.clip(W, H, n, clip_index=32)
+    want = orc.encode(clip, 8, 6, pf, 7, 7, 3, 2)
+    for bf in (1, 2, 3, 7, 64):
+        enc = M.Mpeg2Encoder(7, 7, 3, 2)
+        try:
+            enc.set_option("batch_frames", bf)
+            got = enc.encode(clip, 8, 6, pf)
+            assert got == want, "batch_frames=%d" % bf
+        finally:
+            enc.close()
+
+
+def test_size_clamp_and_pframes_255(env):
+    """Out-of-range sizes are clamped like RTL:985-991; i_pframes_count = 255 gives one I frame then only P."""
+    M, orc = env
+    enc = M.Mpeg2Encoder(4, 4, 1, 2)                       # max 256x256
+    try:
+        assert enc.geometry(20, 2) == (256, 64)            # 20 > 2^XL -> clamped; 2 < 4 -> clamped
+        clip = M.synth.clip(256, 64, 3, clip_index=33)
+        want = orc.encode(clip, 20, 2, 255, 4, 4, 1, 2)
+        assert enc.encode(clip, 20, 2, 255) == want
+        assert want.count(b"\x00\x00\x01\xb8") == 1
+    finally:
+        enc.close()
+
+
+def test_pull_granularity(env):
+    """m2v_pull hands out whole 32-byte words in order; `last` arrives with the final word only."""
+    M, orc = env
+    clip = M.synth.clip(64, 64, 2, clip_index=34)
+    want = orc.encode(clip, 4, 4, 1, 4, 4, 2, 3)
+    enc = M.Mpeg2Encoder(4, 4, 2, 3)
+    try:
+        enc.push_frames(4, 4, 1, clip)
+        enc.sequence_stop()
+        out, lasts = b"", []
+        while True:
+            b, last = enc.pull(100)                    # cap not a multiple of 32 -> 96 bytes at a time
+            assert len(b) % 32 == 0 and len(b) <= 96
+            out += b
+            lasts.append(last)
+            if last:
+                break
+        assert out == want and lasts.count(True) == 1
+    finally:
+        enc.close()
