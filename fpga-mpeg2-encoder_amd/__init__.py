@@ -12,6 +12,7 @@ import numpy as np
 
 from . import build as _build
 from . import synth  # noqa: F401  (seeded synthetic clips, numpy only)
+from . import parallel  # noqa: F401  (multi-GPU: independent sequences, macroblock-row strips)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libm2v_mi355x.so")
@@ -22,6 +23,7 @@ EXPORTS = [
     "m2v_version", "m2v_create", "m2v_destroy", "m2v_reset", "m2v_push_beats", "m2v_push_frames",
     "m2v_sequence_stop", "m2v_busy", "m2v_pull", "m2v_geometry", "m2v_encode_resident", "m2v_set_option",
     "m2v_kernel_stats", "m2v_debug_read", "m2v_last_error",
+    "m2v_strip_begin", "m2v_strip_info", "m2v_strip_step", "m2v_strip_halo_in", "m2v_strip_finish", "m2v_strip_assemble",
 ]
 
 
@@ -65,6 +67,12 @@ def lib():
         L.m2v_last_error.restype = ctypes.c_char_p
         L.m2v_last_error.argtypes = [vp]
         L.m2v_debug_table.argtypes = [ci, ci, ci]
+        L.m2v_strip_begin.argtypes = [vp, u32, u32, u32, vp, sz, ci, ci, vp]
+        L.m2v_strip_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(sz)]
+        L.m2v_strip_step.argtypes = [vp, ci, vp, vp]
+        L.m2v_strip_halo_in.argtypes = [vp, ci, vp, vp]
+        L.m2v_strip_finish.argtypes = [vp, vp, sz, vp]
+        L.m2v_strip_assemble.argtypes = [vp, u32, u32, u32, sz, ci, vp, vp, vp, sz, ctypes.POINTER(sz), vp]
         _lib = L
     return _lib
 
@@ -174,6 +182,35 @@ class Mpeg2Encoder:
         self._chk(self._L.m2v_encode_resident(self._h, xsize16, ysize16, pframes_count, d_frames_ptr, nframes,
                                               d_out_ptr, cap, ctypes.byref(n), stream), "m2v_encode_resident")
         return n.value
+
+    # ---- strip mode (config c5): see include/m2v_mi355x.h ----
+    def strip_begin(self, d_frames_ptr, nframes, xsize16, ysize16, pframes_count, row0, row1, stream=0):
+        self._chk(self._L.m2v_strip_begin(self._h, xsize16, ysize16, pframes_count, d_frames_ptr, nframes, row0, row1,
+                                          stream), "m2v_strip_begin")
+        steps, hb = ctypes.c_int(0), ctypes.c_size_t(0)
+        self._chk(self._L.m2v_strip_info(self._h, ctypes.byref(steps), ctypes.byref(hb)), "m2v_strip_info")
+        return steps.value, hb.value
+
+    def strip_step(self, j, send_up_ptr, send_down_ptr):
+        return self._chk(self._L.m2v_strip_step(self._h, j, send_up_ptr, send_down_ptr), "m2v_strip_step")
+
+    def strip_halo_in(self, j, from_up_ptr, from_down_ptr):
+        self._chk(self._L.m2v_strip_halo_in(self._h, j, from_up_ptr, from_down_ptr), "m2v_strip_halo_in")
+
+    def strip_finish(self, d_strip_ptr, cap, nframes):
+        off = np.zeros(nframes + 1, np.uint64)
+        self._chk(self._L.m2v_strip_finish(self._h, d_strip_ptr, cap, off.ctypes.data), "m2v_strip_finish")
+        return off
+
+    def strip_assemble(self, strip_ptrs, frame_offs, nframes, d_out_ptr, cap, xsize16, ysize16, pframes_count, stream=0):
+        n = len(strip_ptrs)
+        ptrs = (ctypes.c_void_p * n)(*strip_ptrs)
+        offs = [np.ascontiguousarray(o, np.uint64) for o in frame_offs]
+        optrs = (ctypes.c_void_p * n)(*[o.ctypes.data for o in offs])
+        out = ctypes.c_size_t(0)
+        self._chk(self._L.m2v_strip_assemble(self._h, xsize16, ysize16, pframes_count, nframes, n, ptrs, optrs, d_out_ptr,
+                                             cap, ctypes.byref(out), stream), "m2v_strip_assemble")
+        return out.value
 
     def kernel_stats(self, kernel):
         ms, units = ctypes.c_double(0), ctypes.c_double(0)

@@ -37,6 +37,8 @@ struct Geom {
     int mbs;         // mbw * mbh
     uint32_t ysz;    // W*H
     uint32_t csz;    // cw*ch
+    int row0, row1;  // macroblock rows this GPU encodes: [0, mbh) normally, a strip in multi-GPU strip mode
+    int strip;       // 1 = strip mode: the stream buffer holds only this strip's slices, no headers
 };
 
 struct FrameJob {           // one per frame of the chunk (device memory)
@@ -330,8 +332,9 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
 
     const int lane = threadIdx.x;
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
-    const int fidx = frame_list[blk / (uint32_t)g.mbs];
-    const int mb = (int)(blk % (uint32_t)g.mbs);
+    const uint32_t strip_mbs = (uint32_t)((g.row1 - g.row0) * g.mbw);
+    const int fidx = frame_list[blk / strip_mbs];
+    const int mb = g.row0 * g.mbw + (int)(blk % strip_mbs);
     const int by = mb / g.mbw, bx = mb - by * g.mbw;
     const FrameJob job = jobs[fidx];
     const int W = g.W;
@@ -776,8 +779,9 @@ __global__ __launch_bounds__(128) void k_slice_scan(const FrameJob *__restrict__
 {
     __shared__ uint32_t s[128];
     const int tid = threadIdx.x;
-    const int f = blockIdx.x / g.mbh;
-    const size_t base = (size_t)blockIdx.x * g.mbw;        // blockIdx = frame * mbh + by
+    const int rows = g.row1 - g.row0;
+    const int f = blockIdx.x / rows, by = g.row0 + (int)(blockIdx.x % rows);      // blockIdx = frame * rows + local row
+    const size_t base = ((size_t)f * g.mbh + by) * g.mbw;
     uint32_t len = 0;
     if (tid < g.mbw) {
         const size_t idx = base + tid;
@@ -799,7 +803,7 @@ __global__ __launch_bounds__(128) void k_slice_scan(const FrameJob *__restrict__
         __syncthreads();
     }
     if (tid < g.mbw) mb_bitoff[base + tid] = s[tid] - len;
-    if (tid == g.mbw - 1) slice_bytes[blockIdx.x] = (s[tid] + 7u) >> 3;   // next header aligns (RTL:2940-2943)
+    if (tid == g.mbw - 1) slice_bytes[(size_t)f * g.mbh + by] = (s[tid] + 7u) >> 3;   // next header aligns (RTL:2940-2943)
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -816,7 +820,8 @@ __global__ __launch_bounds__(64) void k_assemble(const FrameJob *__restrict__ jo
     __shared__ uint32_t s_bits[kSlotWords + 8];
     const int lane = threadIdx.x;
     const uint32_t blk = blockIdx.x;
-    const int f = (int)(blk / (uint32_t)g.mbs), mb = (int)(blk % (uint32_t)g.mbs);
+    const uint32_t strip_mbs = (uint32_t)((g.row1 - g.row0) * g.mbw);
+    const int f = (int)(blk / strip_mbs), mb = g.row0 * g.mbw + (int)(blk % strip_mbs);
     if (f >= nframes || ctl->overflow) return;
     const int by = mb / g.mbw, bx = mb - by * g.mbw;
     const size_t idx = (size_t)f * g.mbs + mb;
@@ -894,14 +899,15 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
 {
     const int tid = threadIdx.x;
     for (int f = tid; f < nframes; f += blockDim.x) {
-        unsigned long long s = frame_header_bytes(jobs[f].i_frame);
-        for (int y = 0; y < g.mbh; ++y) s += slice_bytes[(size_t)f * g.mbh + y];
+        unsigned long long s = g.strip ? 0ull : frame_header_bytes(jobs[f].i_frame);
+        for (int y = g.row0; y < g.row1; ++y) s += slice_bytes[(size_t)f * g.mbh + y];
         frame_off[f] = s;                                     // size for now
     }
     __syncthreads();
     if (tid == 0) {
         unsigned long long run = first ? kSeqHeaderBytes : 0ull;
         for (int f = 0; f < nframes; ++f) { const unsigned long long s = frame_off[f]; frame_off[f] = run; run += s; }
+        frame_off[nframes] = run;                             // one past the end (strip mode reads the sizes back)
         unsigned long long total = ctl->base_bytes + run;
         if (last) {
             total += 4;                                       // sequence_end_code (RTL:2621-2628)
@@ -913,8 +919,8 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
     }
     __syncthreads();
     for (int f = tid; f < nframes; f += blockDim.x) {
-        unsigned long long o = frame_off[f] + frame_header_bytes(jobs[f].i_frame);
-        for (int y = 0; y < g.mbh; ++y) {
+        unsigned long long o = frame_off[f] + (g.strip ? 0ull : frame_header_bytes(jobs[f].i_frame));
+        for (int y = g.row0; y < g.row1; ++y) {
             slice_off[(size_t)f * g.mbh + y] = o;
             o += slice_bytes[(size_t)f * g.mbh + y];
         }
@@ -1017,6 +1023,68 @@ __global__ void k_seq_end(uint8_t *out, const StreamCtl *ctl, const uint32_t *__
         e += slice_off[li] + slice_bytes[li];
     }
     out[e + 0] = 0x00; out[e + 1] = 0x00; out[e + 2] = 0x01; out[e + 3] = 0xB7;   // RTL:2625-2628
+}
+
+// ----------------------------------------------------------------------------------------------
+// strip mode (multi-GPU, config c5): rows of the reconstruction that the neighbouring strips need as
+// reference: YR luma + UR chroma rows (U and V) on each side (RTL:1446-1448 window geometry).
+// One block per (frame of the step, direction); packed layout per frame: [YR*W luma][UR*cw U][UR*cw V].
+// ----------------------------------------------------------------------------------------------
+__global__ void k_halo_pack(const FrameJob *__restrict__ jobs, const int *__restrict__ halo_list, Geom g, int YR, int UR,
+                            uint8_t *__restrict__ up, uint8_t *__restrict__ down)
+{
+    const int k = blockIdx.x, dir = blockIdx.y;               // dir 0: my top rows -> rank above; 1: my bottom rows -> rank below
+    uint8_t *dst = dir ? down : up;
+    if (!dst) return;
+    const uint8_t *rec = jobs[halo_list[k]].rec;
+    const uint32_t chunk = (uint32_t)(YR + UR) * (uint32_t)g.W;
+    dst += (size_t)k * chunk;
+    const int y0 = dir ? 16 * g.row1 - YR : 16 * g.row0, c0 = dir ? 8 * g.row1 - UR : 8 * g.row0;
+    const uint32_t nY = (uint32_t)YR * g.W, nC = (uint32_t)UR * g.cw;
+    for (uint32_t i = threadIdx.x; i < chunk; i += blockDim.x) {
+        uint8_t v;
+        if (i < nY) v = rec[(size_t)y0 * g.W + i];
+        else if (i < nY + nC) v = rec[g.ysz + (size_t)c0 * g.cw + (i - nY)];
+        else v = rec[g.ysz + g.csz + (size_t)c0 * g.cw + (i - nY - nC)];
+        dst[i] = v;
+    }
+}
+
+__global__ void k_halo_unpack(const FrameJob *__restrict__ jobs, const int *__restrict__ halo_list, Geom g, int YR, int UR,
+                              const uint8_t *__restrict__ from_up, const uint8_t *__restrict__ from_down)
+{
+    const int k = blockIdx.x, dir = blockIdx.y;               // dir 0: rows above my strip (from the rank above); 1: rows below
+    const uint8_t *src = dir ? from_down : from_up;
+    if (!src) return;
+    uint8_t *rec = jobs[halo_list[k]].rec;
+    const uint32_t chunk = (uint32_t)(YR + UR) * (uint32_t)g.W;
+    src += (size_t)k * chunk;
+    const int y0 = dir ? 16 * g.row1 : 16 * g.row0 - YR, c0 = dir ? 8 * g.row1 : 8 * g.row0 - UR;
+    const uint32_t nY = (uint32_t)YR * g.W, nC = (uint32_t)UR * g.cw;
+    for (uint32_t i = threadIdx.x; i < chunk; i += blockDim.x) {
+        const uint8_t v = src[i];
+        if (i < nY) rec[(size_t)y0 * g.W + i] = v;
+        else if (i < nY + nC) rec[g.ysz + (size_t)c0 * g.cw + (i - nY)] = v;
+        else rec[g.ysz + g.csz + (size_t)c0 * g.cw + (i - nY - nC)] = v;
+    }
+}
+
+// final assembly on the rank that owns the output: byte segments (slices of one strip of one frame) to their place
+struct CopySeg { const uint8_t *src; unsigned long long dst_off; unsigned long long len; };
+
+__global__ void k_copy_segments(const CopySeg *__restrict__ segs, uint8_t *__restrict__ out)
+{
+    const CopySeg sg = segs[blockIdx.x];
+    for (unsigned long long i = threadIdx.x; i < sg.len; i += blockDim.x) out[sg.dst_off + i] = sg.src[i];
+}
+
+// trailer: sequence_end_code + zero padding up to `total` (RTL:2621-2628, 2932-2937)
+__global__ void k_trailer(uint8_t *out, unsigned long long body_end, unsigned long long total)
+{
+    for (unsigned long long i = body_end + threadIdx.x; i < total; i += blockDim.x) {
+        const unsigned long long r = i - body_end;
+        out[i] = r == 2 ? 0x01 : r == 3 ? 0xB7 : 0x00;
+    }
 }
 
 }  // namespace m2v

@@ -108,6 +108,14 @@ struct m2v_enc {
     uint8_t *h_out = nullptr;             // pinned readback buffer
     size_t h_out_cap = 0;
 
+    // plan of the chunk being encoded (plan_chunk -> run_step* -> finish_chunk)
+    struct Step { int off_i, n_i, off_p, n_p, off_h, n_h; };
+    std::vector<Step> plan_steps;
+    size_t plan_nf = 0;
+    bool strip_active = false;            // between m2v_strip_begin and m2v_strip_finish
+    hipStream_t strip_stream = nullptr;
+    DevBuf<uint8_t> d_segs;               // CopySeg table of m2v_strip_assemble
+
     // debug bookkeeping of the last resident encode
     size_t dbg_frames = 0;
     std::vector<int> dbg_rec_slot;
@@ -155,6 +163,9 @@ Geom make_geom(const m2v_enc *e, uint32_t xs, uint32_t ys)
     g.mbs = g.mbw * g.mbh;
     g.ysz = (uint32_t)g.W * g.H;
     g.csz = (uint32_t)g.cw * g.ch;
+    g.row0 = 0;
+    g.row1 = g.mbh;
+    g.strip = 0;
     return g;
 }
 
@@ -218,7 +229,7 @@ template <bool P>
 void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g)
 {
     if (count <= 0) return;
-    const dim3 grid((unsigned)((size_t)count * g.mbs)), block(64);
+    const dim3 grid((unsigned)((size_t)count * (size_t)(g.row1 - g.row0) * g.mbw)), block(64);
     Timer t(e, s, P ? 0 : 1, (double)count * g.ysz);
     int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
     if (P) {
@@ -235,13 +246,13 @@ void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Ge
 }
 
 // ---------------------------------------------------------------------------------------------
-// encode one chunk of `nf` consecutive frames of the current sequence.
-//   d_frames : device pointer to nf planar 4:4:4 frames
-//   d_stream : device output buffer; ctl (device) carries base/total/cap across chunks
+// A chunk of `nf` consecutive frames of the current sequence is encoded in three parts:
+//   plan_chunk   per-frame jobs, GOP segments, reconstruction slots, launch lists, device buffers
+//   run_step(j)  macroblock kernel for the j-th frame of every GOP segment (frame f+1 needs recon(f))
+//   finish_chunk scans, headers, stream assembly into `d_stream` (ctl carries base/total/cap)
 // Everything is enqueued on `s`; nothing is synchronised here.
 // ---------------------------------------------------------------------------------------------
-void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool first, bool last,
-                  uint32_t last_valid_beats, uint8_t *d_stream)
+void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool last, uint32_t last_valid_beats)
 {
     const Geom &g = e->g;
     const size_t frame_bytes = (size_t)g.ysz * 3;
@@ -310,30 +321,32 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
         e->persist_slot = rec_slot[nf - 1];
     }
 
-    // ---- launch lists: step j = j-th frame of every segment; I and P frames in separate launches ----
+    // ---- launch lists: step j = j-th frame of every segment; I and P frames in separate launches;
+    //      halo list = frames of the step whose reconstruction is referenced later (strip mode) ----
     size_t maxlen = 0;
     for (size_t sg = 0; sg < nseg; ++sg) {
         const size_t a = seg_start[sg], b = sg + 1 < nseg ? (size_t)seg_start[sg + 1] : nf;
         maxlen = std::max(maxlen, b - a);
     }
     std::vector<int> lists;
-    struct Step { int off_i, n_i, off_p, n_p; };
-    std::vector<Step> steps(maxlen);
+    e->plan_steps.assign(maxlen, m2v_enc::Step{});
     for (size_t j = 0; j < maxlen; ++j) {
-        Step st{};
-        st.off_i = (int)lists.size();
-        for (size_t sg = 0; sg < nseg; ++sg) {
-            const size_t a = seg_start[sg], b = sg + 1 < nseg ? (size_t)seg_start[sg + 1] : nf;
-            if (a + j < b && jobs[a + j].i_frame == 0) lists.push_back((int)(a + j));
+        m2v_enc::Step st{};
+        for (int pass = 0; pass < 3; ++pass) {
+            const int off = (int)lists.size();
+            for (size_t sg = 0; sg < nseg; ++sg) {
+                const size_t a = seg_start[sg], b = sg + 1 < nseg ? (size_t)seg_start[sg + 1] : nf;
+                if (a + j >= b) continue;
+                const FrameJob &fj = jobs[a + j];
+                if ((pass == 0 && fj.i_frame == 0) || (pass == 1 && fj.i_frame != 0) || (pass == 2 && fj.rec != nullptr))
+                    lists.push_back((int)(a + j));
+            }
+            const int cnt = (int)lists.size() - off;
+            if (pass == 0) { st.off_i = off; st.n_i = cnt; }
+            else if (pass == 1) { st.off_p = off; st.n_p = cnt; }
+            else { st.off_h = off; st.n_h = cnt; }
         }
-        st.n_i = (int)lists.size() - st.off_i;
-        st.off_p = (int)lists.size();
-        for (size_t sg = 0; sg < nseg; ++sg) {
-            const size_t a = seg_start[sg], b = sg + 1 < nseg ? (size_t)seg_start[sg + 1] : nf;
-            if (a + j < b && jobs[a + j].i_frame != 0) lists.push_back((int)(a + j));
-        }
-        st.n_p = (int)lists.size() - st.off_p;
-        steps[j] = st;
+        e->plan_steps[j] = st;
     }
 
     // ---- device buffers ----
@@ -348,7 +361,7 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
     e->d_mboff.ensure(nmb);
     e->d_slice_bytes.ensure(nf * g.mbh);
     e->d_slice_off.ensure(nf * g.mbh);
-    e->d_frame_off.ensure(nf);
+    e->d_frame_off.ensure(nf + 1);
     // pinned staging: the caller synchronises the stream before the next chunk reuses it
     if (e->h_jobs_cap < nf) {
         if (e->h_jobs) (void)hipHostFree(e->h_jobs);
@@ -366,41 +379,57 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
     memcpy(e->h_lists, lists.data(), lists.size() * sizeof(int));
     HIPCHK(hipMemcpyAsync(e->d_jobs.p, e->h_jobs, nf * sizeof(FrameJob), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(e->d_lists.p, e->h_lists, lists.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    e->plan_nf = nf;
+    e->dbg_frames = nf;
+    e->dbg_rec_slot = rec_slot;
+}
 
-    // ---- macroblock kernel, step by step (frame f+1 of a GOP needs recon(f)) ----
-    for (size_t j = 0; j < maxlen; ++j) {
-        launch_mb<false>(e, s, e->d_lists.p + steps[j].off_i, steps[j].n_i, g);
-        launch_mb<true>(e, s, e->d_lists.p + steps[j].off_p, steps[j].n_p, g);
-    }
+void run_step(m2v_enc *e, hipStream_t s, size_t j)
+{
+    const m2v_enc::Step &st = e->plan_steps[j];
+    launch_mb<false>(e, s, e->d_lists.p + st.off_i, st.n_i, e->g);
+    launch_mb<true>(e, s, e->d_lists.p + st.off_p, st.n_p, e->g);
+}
 
-    // ---- stream assembly ----
+void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_stream)
+{
+    const Geom &g = e->g;
+    const size_t nf = e->plan_nf;
+    const size_t rows = (size_t)(g.row1 - g.row0);
     {
         Timer t(e, s, 4, (double)nf * g.ysz);
-        hipLaunchKernelGGL(k_slice_scan, dim3((unsigned)(nf * g.mbh)), dim3(128), 0, s, e->d_jobs.p, g, e->d_mbinfo.p,
+        hipLaunchKernelGGL(k_slice_scan, dim3((unsigned)(nf * rows)), dim3(128), 0, s, e->d_jobs.p, g, e->d_mbinfo.p,
                            e->d_mbaux.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_bytes.p);
         hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(1024), 0, s, e->d_jobs.p, g, (int)nf, first ? 1 : 0, last ? 1 : 0,
                            e->d_slice_bytes.p, e->d_slice_off.p, e->d_frame_off.p, e->d_ctl.p);
         hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, s, d_stream, e->d_ctl.p);
-        hipLaunchKernelGGL(k_headers, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, s, e->d_jobs.p, g, (int)nf,
-                           first ? 1 : 0, e->d_frame_off.p, d_stream, e->d_ctl.p);
-        if (last)
-            hipLaunchKernelGGL(k_seq_end, dim3(1), dim3(1), 0, s, d_stream, e->d_ctl.p, e->d_slice_bytes.p,
-                               e->d_slice_off.p, (int)nf, g.mbh);
+        if (!g.strip) {
+            hipLaunchKernelGGL(k_headers, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, s, e->d_jobs.p, g, (int)nf,
+                               first ? 1 : 0, e->d_frame_off.p, d_stream, e->d_ctl.p);
+            if (last)
+                hipLaunchKernelGGL(k_seq_end, dim3(1), dim3(1), 0, s, d_stream, e->d_ctl.p, e->d_slice_bytes.p,
+                                   e->d_slice_off.p, (int)nf, g.mbh);
+        }
         HIPCHK(hipGetLastError());
         t.stop();
     }
     {
         Timer t(e, s, 3, (double)nf * g.ysz);
-        hipLaunchKernelGGL(k_assemble, dim3((unsigned)nmb), dim3(64), 0, s, e->d_jobs.p, g, (int)nf, e->d_mbinfo.p,
-                           e->d_mbaux.p, e->d_slots.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_off.p, (uint32_t *)d_stream,
-                           e->d_ctl.p);
+        hipLaunchKernelGGL(k_assemble, dim3((unsigned)(nf * rows * g.mbw)), dim3(64), 0, s, e->d_jobs.p, g, (int)nf,
+                           e->d_mbinfo.p, e->d_mbaux.p, e->d_slots.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_off.p,
+                           (uint32_t *)d_stream, e->d_ctl.p);
         HIPCHK(hipGetLastError());
         t.stop();
     }
-
     e->frames_total += nf;
-    e->dbg_frames = nf;
-    e->dbg_rec_slot = rec_slot;
+}
+
+void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool first, bool last,
+                  uint32_t last_valid_beats, uint8_t *d_stream)
+{
+    plan_chunk(e, s, d_frames, nf, last, last_valid_beats);
+    for (size_t j = 0; j < e->plan_steps.size(); ++j) run_step(e, s, j);
+    finish_chunk(e, s, first, last, d_stream);
 }
 
 // advance the device-side stream cursor after a chunk: base = total
@@ -576,7 +605,7 @@ void m2v_destroy(m2v_enc *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     e->d_in.release(); e->d_out.release(); e->d_coef.release(); e->d_mbaux.release(); e->d_slots.release(); e->d_mbinfo.release(); e->d_mblen.release();
     e->d_mboff.release(); e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
-    e->d_jobs.release(); e->d_lists.release(); e->d_ctl.release();
+    e->d_jobs.release(); e->d_lists.release(); e->d_ctl.release(); e->d_segs.release();
     for (auto p : e->rec_pool) (void)hipFree(p);
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
@@ -753,6 +782,179 @@ int m2v_encode_resident(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t
     ResidentArgs a{xsize16, ysize16, pframes_count, (const uint8_t *)d_frames444, nframes, (uint8_t *)d_out, cap, out_bytes,
                    (hipStream_t)hip_stream};
     return guard(e, resident_impl, &a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// strip mode (BASELINE config c5): this handle encodes macroblock rows [row0,row1) of every frame
+// ---------------------------------------------------------------------------------------------
+struct StripBeginArgs { uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; int row0, row1; hipStream_t s; };
+
+static int strip_begin_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripBeginArgs *)argp;
+    if (e->state != m2v_enc::IDLE || e->strip_active) { e->set_err("m2v_strip_begin: encoder busy"); return M2V_E_STATE; }
+    Geom g = make_geom(e, a->xs, a->ys);
+    if (a->n == 0 || a->row0 < 0 || a->row1 > g.mbh || a->row0 >= a->row1) { e->set_err("m2v_strip_begin: bad rows / no frames"); return M2V_E_PARAM; }
+    g.row0 = a->row0; g.row1 = a->row1; g.strip = 1;
+    e->g = g;
+    e->pframes = a->pf & 0xFFu;
+    e->frames_total = 0;
+    e->persist_slot = -1;
+    for (auto &st : e->stats) st = KStat{};
+    e->strip_stream = a->s ? a->s : e->stream;
+    plan_chunk(e, e->strip_stream, a->d_in, a->n, true, g.ysz / 4);
+    e->strip_active = true;
+    return M2V_OK;
+}
+
+int m2v_strip_begin(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const void *d_frames444,
+                    size_t nframes, int row0, int row1, void *hip_stream)
+{
+    if (!e || !d_frames444) return M2V_E_PARAM;
+    StripBeginArgs a{xsize16, ysize16, pframes_count, (const uint8_t *)d_frames444, nframes, row0, row1, (hipStream_t)hip_stream};
+    return guard(e, strip_begin_impl, &a);
+}
+
+int m2v_strip_info(const m2v_enc *e, int *steps, size_t *halo_bytes_per_direction)
+{
+    if (!e || !e->strip_active) return M2V_E_STATE;
+    int mh = 0;
+    for (auto &st : e->plan_steps) mh = std::max(mh, st.n_h);
+    if (steps) *steps = (int)e->plan_steps.size();
+    if (halo_bytes_per_direction) *halo_bytes_per_direction = (size_t)mh * (size_t)(3 * e->VL) * (size_t)e->g.W;   // (YR + UR) * W per frame
+    return M2V_OK;
+}
+
+struct StripStepArgs { int j; uint8_t *up, *down; const uint8_t *from_up, *from_down; };
+
+static int strip_step_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripStepArgs *)argp;
+    if (!e->strip_active || a->j < 0 || a->j >= (int)e->plan_steps.size()) return M2V_E_STATE;
+    run_step(e, e->strip_stream, (size_t)a->j);
+    const m2v_enc::Step &st = e->plan_steps[a->j];
+    if (st.n_h > 0 && (a->up || a->down)) {
+        hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)st.n_h, 2), dim3(256), 0, e->strip_stream, e->d_jobs.p,
+                           e->d_lists.p + st.off_h, e->g, 2 * e->VL, e->VL, e->g.row0 > 0 ? a->up : nullptr,
+                           e->g.row1 < e->g.mbh ? a->down : nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    return st.n_h;
+}
+
+int m2v_strip_step(m2v_enc *e, int step, void *d_send_up, void *d_send_down)
+{
+    if (!e) return M2V_E_PARAM;
+    StripStepArgs a{step, (uint8_t *)d_send_up, (uint8_t *)d_send_down, nullptr, nullptr};
+    return guard(e, strip_step_impl, &a);
+}
+
+static int strip_halo_in_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripStepArgs *)argp;
+    if (!e->strip_active || a->j < 0 || a->j >= (int)e->plan_steps.size()) return M2V_E_STATE;
+    const m2v_enc::Step &st = e->plan_steps[a->j];
+    if (st.n_h > 0 && (a->from_up || a->from_down)) {
+        hipLaunchKernelGGL(k_halo_unpack, dim3((unsigned)st.n_h, 2), dim3(256), 0, e->strip_stream, e->d_jobs.p,
+                           e->d_lists.p + st.off_h, e->g, 2 * e->VL, e->VL, e->g.row0 > 0 ? a->from_up : nullptr,
+                           e->g.row1 < e->g.mbh ? a->from_down : nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    return M2V_OK;
+}
+
+int m2v_strip_halo_in(m2v_enc *e, int step, const void *d_from_up, const void *d_from_down)
+{
+    if (!e) return M2V_E_PARAM;
+    StripStepArgs a{step, nullptr, nullptr, (const uint8_t *)d_from_up, (const uint8_t *)d_from_down};
+    return guard(e, strip_halo_in_impl, &a);
+}
+
+struct StripFinishArgs { uint8_t *d_strip; size_t cap; unsigned long long *frame_off; };
+
+static int strip_finish_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripFinishArgs *)argp;
+    if (!e->strip_active) return M2V_E_STATE;
+    hipStream_t s = e->strip_stream;
+    const size_t nf = e->plan_nf;
+    ctl_init(e, s, a->cap);
+    finish_chunk(e, s, false, false, a->d_strip);
+    HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(a->frame_off, e->d_frame_off.p, (nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    collect_timers(e);
+    e->strip_active = false;
+    Geom full = e->g; full.row0 = 0; full.row1 = full.mbh; full.strip = 0;
+    e->g = full;
+    if (e->h_ctl->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
+    return M2V_OK;
+}
+
+int m2v_strip_finish(m2v_enc *e, void *d_strip, size_t cap, unsigned long long *frame_off)
+{
+    if (!e || !d_strip || !frame_off) return M2V_E_PARAM;
+    StripFinishArgs a{(uint8_t *)d_strip, cap, frame_off};
+    return guard(e, strip_finish_impl, &a);
+}
+
+struct StripAsmArgs { uint32_t xs, ys, pf; size_t n; int nranks; const void *const *strips; const unsigned long long *const *offs;
+                      uint8_t *d_out; size_t cap; size_t *bytes; hipStream_t s; };
+
+static int strip_assemble_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripAsmArgs *)argp;
+    if (e->strip_active || e->state != m2v_enc::IDLE) return M2V_E_STATE;
+    hipStream_t s = a->s ? a->s : e->stream;
+    const Geom g = make_geom(e, a->xs, a->ys);
+    const uint32_t gop = (a->pf & 0xFFu) + 1u;
+    const size_t nf = a->n;
+    // final layout: sequence headers, then per frame [GOP hdr] picture hdr, the strips top to bottom
+    std::vector<FrameJob> jobs(nf);
+    std::vector<unsigned long long> foff(nf + 1);
+    std::vector<CopySeg> segs;
+    unsigned long long pos = kSeqHeaderBytes;
+    for (size_t f = 0; f < nf; ++f) {
+        memset(&jobs[f], 0, sizeof(FrameJob));
+        jobs[f].i_frame = (int32_t)(f % gop);
+        jobs[f].n = (uint32_t)f;
+        foff[f] = pos;
+        pos += jobs[f].i_frame == 0 ? kGopHeaderBytes + 17u : 18u;
+        for (int r = 0; r < a->nranks; ++r) {
+            const unsigned long long len = a->offs[r][f + 1] - a->offs[r][f];
+            if (len) segs.push_back(CopySeg{(const uint8_t *)a->strips[r] + a->offs[r][f], pos, len});
+            pos += len;
+        }
+    }
+    foff[nf] = pos;
+    const unsigned long long total = ((pos + 4) / 32ull + 1ull) * 32ull;       // end code + final word rule (RTL:2932-2937)
+    if (total > a->cap) { e->set_err("output buffer too small"); return M2V_E_OVERFLOW; }
+    e->d_jobs.ensure(nf);
+    e->d_frame_off.ensure(nf + 1);
+    e->d_segs.ensure(segs.size() * sizeof(CopySeg) + 16);
+    ctl_init(e, s, a->cap);
+    HIPCHK(hipMemcpy(e->d_jobs.p, jobs.data(), nf * sizeof(FrameJob), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_frame_off.p, foff.data(), (nf + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    if (!segs.empty()) HIPCHK(hipMemcpy(e->d_segs.p, segs.data(), segs.size() * sizeof(CopySeg), hipMemcpyHostToDevice));
+    if (!segs.empty())
+        hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)segs.size()), dim3(256), 0, s, (const CopySeg *)e->d_segs.p, a->d_out);
+    hipLaunchKernelGGL(k_headers, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, s, e->d_jobs.p, g, (int)nf, 1,
+                       e->d_frame_off.p, a->d_out, e->d_ctl.p);
+    hipLaunchKernelGGL(k_trailer, dim3(1), dim3(256), 0, s, a->d_out, pos, total);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    if (a->bytes) *a->bytes = (size_t)total;
+    return M2V_OK;
+}
+
+int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, size_t nframes, int nranks,
+                       const void *const *d_strips, const unsigned long long *const *frame_off, void *d_out, size_t cap,
+                       size_t *out_bytes, void *hip_stream)
+{
+    if (!e || !d_strips || !frame_off || !d_out || nranks < 1 || nframes == 0) return M2V_E_PARAM;
+    StripAsmArgs a{xsize16, ysize16, pframes_count, nframes, nranks, d_strips, frame_off, (uint8_t *)d_out, cap, out_bytes,
+                   (hipStream_t)hip_stream};
+    return guard(e, strip_assemble_impl, &a);
 }
 
 int m2v_set_option(m2v_enc *e, const char *name, long long value)

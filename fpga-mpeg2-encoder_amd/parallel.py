@@ -1,0 +1,137 @@
+"""Multi-GPU orchestration, one process per GPU over torch.distributed (backend "nccl" = RCCL on ROCm).
+
+Two ways the path shards:
+
+* independent sequences (BASELINE config c4): `sequence_for_rank` — no data-path collective at all;
+* macroblock-row strips of ONE sequence (config c5): `encode_strips` — slices are byte-aligned and reset all
+  predictors (RTL/mpeg2encoder.v:2704-2715), so a strip needs from its neighbours only the +-2*VECTOR_LEVEL luma
+  and +-VECTOR_LEVEL chroma rows of the previous reconstruction next to the boundary (window geometry
+  RTL:1446-1448): one point-to-point send/recv pair per neighbour per GOP step (xGMI is point-to-point; there is
+  nothing to all-reduce), then one size all-gather + one gather of the strips' slice bytes to the output rank.
+
+`encode_strips` is written against a small engine interface so that the exchange logic is testable on CPU with the
+gloo backend (tests/test_parallel_gloo.py) and the kernels on one GPU with emulated ranks (tests/test_gpu_strips.py).
+"""
+import numpy as np
+
+
+def partition_rows(mbh, world):
+    """Contiguous macroblock-row strips, sizes differing by at most one row; the first `mbh % world` ranks get the
+    extra row.  Ranks beyond mbh (more GPUs than rows) are not supported."""
+    if world < 1 or world > mbh:
+        raise ValueError("cannot cut %d macroblock rows into %d strips" % (mbh, world))
+    base, rem = divmod(mbh, world)
+    rows, start = [], 0
+    for r in range(world):
+        cnt = base + (1 if r < rem else 0)
+        rows.append((start, start + cnt))
+        start += cnt
+    return rows
+
+
+def sequence_for_rank(nseq, rank, world):
+    """Config c4: which of `nseq` independent sequences this rank encodes (round robin)."""
+    return list(range(rank, nseq, world))
+
+
+class GpuStripEngine:
+    """One strip of one sequence on this process's GPU, through the C-ABI strip entry points."""
+
+    def __init__(self, enc, clip, xsize16, ysize16, pframes_count, device, stream=None):
+        import torch
+        self.torch = torch
+        # The kernels and the RCCL point-to-point ops must be ordered on ONE stream.  torch's default stream has the
+        # handle 0, which the C-ABI reads as "the handle's own stream", so a dedicated torch stream is used and
+        # encode_strips() runs under it (torch.distributed enqueues / synchronises against the current stream).
+        self.tstream = stream if stream is not None else torch.cuda.Stream(device=torch.device(device))
+        self.tstream.wait_stream(torch.cuda.current_stream(torch.device(device)))    # the clip was produced there
+        self.enc, self.clip, self.device, self.stream = enc, clip, device, self.tstream.cuda_stream
+        self.xs, self.ys, self.pf = xsize16, ysize16, pframes_count
+        self.nframes = int(clip.shape[0])
+        self.W, self.H = enc.geometry(xsize16, ysize16)
+        self.mbh = self.H // 16
+
+    def stream_ctx(self):
+        return self.torch.cuda.stream(self.tstream)
+
+    def begin(self, row0, row1):
+        self.steps, self.halo_bytes = self.enc.strip_begin(self.clip.data_ptr(), self.nframes, self.xs, self.ys, self.pf,
+                                                           row0, row1, self.stream)
+        self.rows = row1 - row0
+        return self.steps, self.halo_bytes
+
+    def alloc(self, nbytes):
+        return self.torch.empty(max(nbytes, 1), dtype=self.torch.uint8, device=self.device)
+
+    def step(self, j, send_up, send_down):
+        n = self.enc.strip_step(j, send_up.data_ptr(), send_down.data_ptr())
+        return n * (self.halo_bytes // max(1, self._max_halo_frames()))
+
+    def _max_halo_frames(self):
+        chunk = 3 * self.enc.params[2] * self.W
+        return self.halo_bytes // chunk if chunk else 1
+
+    def halo_in(self, j, from_up, from_down):
+        self.enc.strip_halo_in(j, from_up.data_ptr() if from_up is not None else None,
+                               from_down.data_ptr() if from_down is not None else None)
+
+    def finish(self):
+        cap = self.nframes * (self.rows * (self.W // 16) * 1216 + self.rows * 8 + 64) + 256
+        self.strip = self.torch.empty(cap, dtype=self.torch.uint8, device=self.device)
+        off = self.enc.strip_finish(self.strip.data_ptr(), cap, self.nframes)
+        return self.strip[:int(off[-1])], off.astype(np.int64)
+
+    def assemble(self, strips, offs):
+        total = 64 + sum(int(o[-1]) for o in offs) + self.nframes * 32 + 64
+        out = self.torch.empty(total, dtype=self.torch.uint8, device=self.device)
+        n = self.enc.strip_assemble([s.data_ptr() for s in strips], [np.asarray(o, np.uint64) for o in offs], self.nframes,
+                                    out.data_ptr(), total, self.xs, self.ys, self.pf, self.stream)
+        return out[:n]
+
+
+def encode_strips(engine, rank, world, dist=None, dst=0):
+    """Encode one sequence as `world` macroblock-row strips.  Returns the stream (engine tensor) on rank `dst`, None
+    elsewhere.  `dist` = torch.distributed (initialised) or None for world == 1."""
+    ctx = engine.stream_ctx() if hasattr(engine, "stream_ctx") else None
+    if ctx is None:
+        return _encode_strips(engine, rank, world, dist, dst)
+    with ctx:
+        return _encode_strips(engine, rank, world, dist, dst)
+
+
+def _encode_strips(engine, rank, world, dist, dst):
+    import torch
+    rows = partition_rows(engine.mbh, world)
+    row0, row1 = rows[rank]
+    steps, halo_bytes = engine.begin(row0, row1)
+    send_up, send_down = engine.alloc(halo_bytes), engine.alloc(halo_bytes)
+    recv_up, recv_down = engine.alloc(halo_bytes), engine.alloc(halo_bytes)
+    for j in range(steps):
+        nbytes = engine.step(j, send_up, send_down)
+        if nbytes and world > 1:
+            ops = []
+            if rank > 0:                       # my top rows go up; the rows above my strip come down from rank-1
+                ops.append(dist.P2POp(dist.isend, send_up[:nbytes], rank - 1))
+                ops.append(dist.P2POp(dist.irecv, recv_up[:nbytes], rank - 1))
+            if rank < world - 1:
+                ops.append(dist.P2POp(dist.isend, send_down[:nbytes], rank + 1))
+                ops.append(dist.P2POp(dist.irecv, recv_down[:nbytes], rank + 1))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if nbytes:
+            engine.halo_in(j, recv_up if rank > 0 else None, recv_down if rank < world - 1 else None)
+    strip, off = engine.finish()
+    if world == 1:
+        return engine.assemble([strip], [off])
+    # sizes to everyone (tiny), strips to the output rank (padded to the longest)
+    off_t = torch.as_tensor(off, dtype=torch.int64, device=strip.device)
+    all_off = [torch.empty_like(off_t) for _ in range(world)]
+    dist.all_gather(all_off, off_t)
+    maxlen = max(int(o[-1]) for o in all_off)
+    padded = engine.alloc(maxlen)
+    padded[:strip.numel()] = strip
+    gathered = [engine.alloc(maxlen) for _ in range(world)] if rank == dst else None
+    dist.gather(padded[:maxlen], gathered, dst=dst)
+    if rank != dst:
+        return None
+    return engine.assemble([gathered[r][:int(all_off[r][-1])] for r in range(world)], [o.cpu().numpy() for o in all_off])

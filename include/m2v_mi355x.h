@@ -99,6 +99,40 @@ int m2v_encode_resident(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t
                         const void *d_frames444, size_t nframes, void *d_out, size_t cap,
                         size_t *out_bytes, void *hip_stream);
 
+/*
+ * Strip mode (BASELINE config c5; no RTL counterpart — the RTL has one reference BRAM): several
+ * handles, one per GPU, each encode the macroblock rows [row0,row1) of EVERY frame of one sequence.
+ * Slices are byte-aligned and reset all predictors (RTL:2704-2715), so strips only interact through
+ * the +-2*VECTOR_LEVEL luma / +-VECTOR_LEVEL chroma rows of the previous reconstruction next to
+ * the strip boundary (window geometry RTL:1446-1448).  The caller moves those rows between GPUs
+ * (RCCL send/recv over xGMI in fpga-mpeg2-encoder_amd/parallel.py) between the steps:
+ *
+ *   m2v_strip_begin(...)                         plan the whole sequence as one chunk
+ *   m2v_strip_info(&steps, &halo_bytes)          steps = frames per GOP in the chunk
+ *   for j in 0..steps-1:
+ *       n = m2v_strip_step(j, send_up, send_down) macroblock kernel for the j-th frame of every GOP, then
+ *                                                packs this strip's top / bottom rows of the n frames that are
+ *                                                referenced later: n * 3*VECTOR_LEVEL*W bytes per direction
+ *       <exchange: send_up -> rank-1's from_down, send_down -> rank+1's from_up>
+ *       m2v_strip_halo_in(j, from_up, from_down) neighbour rows into the reconstruction buffers
+ *   m2v_strip_finish(d_strip, cap, frame_off)    this strip's slices of every frame, contiguous;
+ *                                                frame_off[f]..frame_off[f+1] = bytes of frame f (nframes+1 entries)
+ *   m2v_strip_assemble(...)                      on the rank that owns the output: headers + strips
+ *                                                of all ranks -> the final stream
+ * Everything is enqueued on the stream given to m2v_strip_begin (NULL = the handle's own stream).
+ * Buffers are device pointers except frame_off (host).
+ */
+int m2v_strip_begin(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
+                    const void *d_frames444, size_t nframes, int row0, int row1, void *hip_stream);
+int m2v_strip_info(const m2v_enc *e, int *steps, size_t *halo_bytes_per_direction);
+int m2v_strip_step(m2v_enc *e, int step, void *d_send_up, void *d_send_down);
+int m2v_strip_halo_in(m2v_enc *e, int step, const void *d_from_up, const void *d_from_down);
+int m2v_strip_finish(m2v_enc *e, void *d_strip, size_t cap, unsigned long long *frame_off);
+int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
+                       size_t nframes, int nranks, const void *const *d_strips,
+                       const unsigned long long *const *frame_off, void *d_out, size_t cap,
+                       size_t *out_bytes, void *hip_stream);
+
 /* Options: "batch_frames" (frames buffered before the GPU is kicked, default 96),
  * "profile" (1 = time the per-kernel launches with HIP events). */
 int m2v_set_option(m2v_enc *e, const char *name, long long value);

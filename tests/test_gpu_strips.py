@@ -1,0 +1,62 @@
+"""-m gpu: strip mode (config c5) on ONE GPU with emulated ranks: N encoder handles, each owning a strip of
+macroblock rows; the halo "exchange" is a device copy.  The assembled stream must equal the oracle's."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world,W,H,pf,VL", [(2, 128, 96, 4, 3), (3, 96, 160, 2, 2), (4, 160, 128, 3, 1), (8, 64, 128, 1, 3)])
+def test_strips_equal_single_encoder(world, W, H, pf, VL):
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    n = 2 * (pf + 1) + 1
+    clip = M.synth.clip(W, H, n, clip_index=50 + world)
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, 2)
+    d_clip = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
+    encs = [M.Mpeg2Encoder(7, 7, VL, 2) for _ in range(world)]
+    try:
+        shared = torch.cuda.Stream()                       # the emulated ranks share one stream: the "exchange" is a plain copy
+        engines = [M.parallel.GpuStripEngine(e, d_clip, W // 16, H // 16, pf, "cuda:0", stream=shared) for e in encs]
+        rows = M.parallel.partition_rows(H // 16, world)
+        info = [eng.begin(*rows[r]) for r, eng in enumerate(engines)]
+        steps, hb = info[0]
+        assert all(i == info[0] for i in info)
+        torch.cuda.synchronize()
+        up = [eng.alloc(hb) for eng in engines]
+        down = [eng.alloc(hb) for eng in engines]
+        for j in range(steps):
+            nb = [eng.step(j, up[r], down[r]) for r, eng in enumerate(engines)]
+            assert len(set(nb)) == 1
+            if nb[0]:
+                for r, eng in enumerate(engines):       # rank r receives rank r-1's bottom rows and rank r+1's top rows
+                    eng.halo_in(j, down[r - 1] if r > 0 else None, up[r + 1] if r < world - 1 else None)
+        outs = [eng.finish() for eng in engines]
+        stream = engines[0].assemble([o[0] for o in outs], [o[1] for o in outs])
+        torch.cuda.synchronize()
+        got = stream.cpu().numpy().tobytes()
+        assert got == want
+    finally:
+        for e in encs:
+            e.close()
+
+
+def test_encode_strips_world1_equals_resident():
+    """parallel.encode_strips with one rank (no exchange) == m2v_encode_resident == oracle."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    clip = M.synth.clip(160, 96, 7, clip_index=60)
+    want = orc.encode(clip, 10, 6, 2, 7, 7, 3, 2)
+    d_clip = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
+    enc = M.Mpeg2Encoder(7, 7, 3, 2)
+    try:
+        eng = M.parallel.GpuStripEngine(enc, d_clip, 10, 6, 2, "cuda:0")
+        out = M.parallel.encode_strips(eng, 0, 1)
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == want
+    finally:
+        enc.close()
