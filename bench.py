@@ -44,6 +44,49 @@ def cpu_baseline(frames_np, gpu_stream_bytes):
                        % (n, n - 1, dt)), identical, body
 
 
+def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
+    """Config c5: one 2048x2048 (XL=YL=7) I+P sequence, 128 macroblock rows cut into `world` strips; the +-6 luma /
+    +-3 chroma reference rows cross xGMI once per GOP step (fpga-mpeg2-encoder_amd/parallel.py)."""
+    Ws = Hs = 2048
+    nframes = args.gops * (PFRAMES + 1)
+    clip = M.synth.clip_torch(Ws, Hs, nframes, clip_index=0, device=dev)        # every rank holds the same clip
+    enc = M.Mpeg2Encoder(7, 7, VL, Q, device=local_rank)
+    eng = M.parallel.GpuStripEngine(enc, clip, 128, 128, PFRAMES, dev)
+    out = None
+    for _ in range(args.warmup):
+        out = M.parallel.encode_strips(eng, rank, world, dist)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = M.parallel.encode_strips(eng, rank, world, dist)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        px = nframes * Ws * Hs
+        print(json.dumps({
+            "metric": "MPixels/s encoded, 2048x2048 I+P, macroblock-row strips", "value": round(args.steps * px / dt * 1e-6, 2),
+            "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "c5: ONE 2048x2048 yuv444p sequence, %d GOPs of 1 I + %d P, VECTOR_LEVEL=3 Q_LEVEL=2, "
+                                   "%d strips of macroblock rows, halo = 9 rows x 2048 B per frame per direction"
+                                   % (args.gops, PFRAMES, world), "frames": nframes,
+                       "stream_bytes": int(out.numel()) if out is not None else None}}))
+        sys.stdout.flush()
+    enc.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +94,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gops", type=int, default=GOPS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["sequences", "strips"], default="sequences",
+                    help="sequences (default): config c3 / c4, one 1920x1152 sequence per GPU, no collective; "
+                         "strips: config c5, ONE 2048x2048 sequence cut into macroblock-row strips, RCCL halo exchange")
     args = ap.parse_args()
 
     import torch
@@ -72,6 +118,8 @@ def main():
     torch.cuda.set_device(local_rank)
 
     M.build()
+    if args.mode == "strips":
+        return bench_strips(args, M, torch, dist, rank, local_rank, world, dev)
     nframes = args.gops * (PFRAMES + 1)
     clip = M.synth.clip_torch(W, H, nframes, clip_index=rank, device=dev)       # resident in HBM
     cap = nframes * W * H * 3 // 2
