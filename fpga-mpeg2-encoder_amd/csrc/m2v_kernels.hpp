@@ -228,6 +228,7 @@ __device__ __forceinline__ int find_min_in_10_values(const int v[10])
 // VLC helpers shared by k_mb (coefficients) and k_slice_scan / k_assemble (neighbour-dependent codes)
 // ----------------------------------------------------------------------------------------------
 constexpr int kSlotWords = 304;       // per-macroblock bit slot: 3 bit-contiguous segments, <= 9300 bits
+constexpr int kSmallSlotWords = 32;   // macroblocks of <= 1024 stored bits (nearly all) use a compact 128-byte slot instead
 
 struct MbAux {                        // 16 bytes per macroblock next to the uint32 info word
     uint32_t w0;                      // lenA | lenB << 16        (bits)
@@ -273,6 +274,7 @@ __device__ __forceinline__ BitCode mv_code(int mv, int prev)
 // The parts of a macroblock that need the left neighbour (predictors reset at the start of a slice,
 // RTL:2713-2715): p1 = type [+ mvx + mvy | + DC of Y00], p2 = DC of U, p3 = DC of V.
 struct MbDep { BitCode p1, p2, p3; };
+struct MbDepRec { uint32_t c1, c2, c3, lens; };   // the three codes + l1 | l2 << 8 | l3 << 16, written by k_slice_scan
 
 __device__ __forceinline__ MbDep mb_dependent(uint32_t info, const MbAux &aux, bool has_left, uint32_t linfo,
                                               const MbAux &laux, int i_frame)
@@ -307,7 +309,8 @@ __device__ __forceinline__ MbDep mb_dependent(uint32_t info, const MbAux &aux, b
 template <int VL, bool P>
 __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
                                            Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
-                                           uint32_t *__restrict__ slots, int16_t *__restrict__ coef_dbg)
+                                           uint32_t *__restrict__ slots_small, uint32_t *__restrict__ slots,
+                                           int16_t *__restrict__ coef_dbg)
 {
     constexpr int UR = VL, YR = 2 * VL;
     constexpr int WROWS = 16 + 2 * YR;         // luma window rows -YR .. 16+YR-1 (RTL:1446)
@@ -713,8 +716,12 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
         else { lenA = offB; lenB = offC - offB; lenC = pos - offC; }   // intra: tiles 4 and 5 always carry at least the EOB
         __syncthreads();
         const uint32_t nwords = (pos + 31u) >> 5;
-        uint32_t *slot = slots + mbidx * kSlotWords;
-        for (uint32_t k = lane; k < nwords; k += 64) slot[k] = s_bits[k];
+        if (nwords <= (uint32_t)kSmallSlotWords) {          // the common case: one 128-byte line
+            if (lane < kSmallSlotWords) slots_small[mbidx * kSmallSlotWords + lane] = s_bits[lane];
+        } else {
+            uint32_t *slot = slots + mbidx * kSlotWords;
+            for (uint32_t k = lane; k < nwords; k += 64) slot[k] = s_bits[k];
+        }
         if (lane == 0) {
             mbinfo[mbidx] = (uint32_t)inter | ((uint32_t)cbp << 1) | (((uint32_t)(inter ? mvx : 0) & 255u) << 8) |
                             (((uint32_t)(inter ? mvy : 0) & 255u) << 16);
@@ -775,7 +782,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
 __global__ __launch_bounds__(128) void k_slice_scan(const FrameJob *__restrict__ jobs, Geom g,
                                                     const uint32_t *__restrict__ mbinfo, const MbAux *__restrict__ mbaux,
                                                     uint32_t *__restrict__ mb_len, uint32_t *__restrict__ mb_bitoff,
-                                                    uint32_t *__restrict__ slice_bytes)
+                                                    uint32_t *__restrict__ slice_bytes, MbDepRec *__restrict__ mbdep)
 {
     __shared__ uint32_t s[128];
     const int tid = threadIdx.x;
@@ -793,6 +800,7 @@ __global__ __launch_bounds__(128) void k_slice_scan(const FrameJob *__restrict__
         const MbDep d = mb_dependent(info, aux, has_left, linfo, laux, jobs[f].i_frame);
         len = (tid == 0 ? 38u : 0u) + d.p1.len + d.p2.len + d.p3.len + (aux.w0 & 0xFFFFu) + (aux.w0 >> 16) + (aux.w1 & 0xFFFFu);
         mb_len[idx] = len;
+        mbdep[idx] = MbDepRec{d.p1.code, d.p2.code, d.p3.code, d.p1.len | (d.p2.len << 8) | (d.p3.len << 16)};
     }
     s[tid] = len;
     __syncthreads();
@@ -807,39 +815,98 @@ __global__ __launch_bounds__(128) void k_slice_scan(const FrameJob *__restrict__
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_assemble: one wavefront per macroblock: [slice header] p1 A p2 B p3 C, MSB first, assembled in
-// LDS and merged into the stream with a funnel shift; only the two boundary words use atomics
+// k_assemble: one wavefront per macroblock: [slice header] p1 A p2 B p3 C, MSB first, merged into the stream
+// at its final bit position; only the two boundary words of a macroblock use atomics.
+// Common case (<= 1024 stored bits, compact slot): lane k builds stream word k directly in registers from the
+// pieces that overlap it - no LDS, no barrier.  Rare large macroblocks take the LDS path.
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_assemble(const FrameJob *__restrict__ jobs, Geom g, int nframes,
-                                                 const uint32_t *__restrict__ mbinfo, const MbAux *__restrict__ mbaux,
-                                                 const uint32_t *__restrict__ slots, const uint32_t *__restrict__ mb_len,
-                                                 const uint32_t *__restrict__ mb_bitoff,
+// bits of a left-aligned 32-bit code `c32` (length l) placed at bit offset `o`, seen through the window [r0, r0+32)
+__device__ __forceinline__ uint32_t window_code(uint32_t c32, int l, int o, int r0)
+{
+    const int rel = o - r0;
+    if (l == 0 || rel >= 32 || rel + l <= 0) return 0u;
+    return rel >= 0 ? (c32 >> rel) : (c32 << (-rel));
+}
+
+constexpr int kAsmWaves = 4;          // macroblocks (wavefronts) per k_assemble workgroup
+
+__global__ __launch_bounds__(64 * kAsmWaves) void k_assemble(const FrameJob *__restrict__ jobs, Geom g, int nframes,
+                                                 const MbAux *__restrict__ mbaux, const MbDepRec *__restrict__ mbdep,
+                                                 const uint32_t *__restrict__ slots_small, const uint32_t *__restrict__ slots,
+                                                 const uint32_t *__restrict__ mb_len, const uint32_t *__restrict__ mb_bitoff,
                                                  const unsigned long long *__restrict__ slice_off,
                                                  uint32_t *__restrict__ out32, const StreamCtl *__restrict__ ctl)
 {
-    __shared__ uint32_t s_bits[kSlotWords + 8];
-    const int lane = threadIdx.x;
-    const uint32_t blk = blockIdx.x;
+    __shared__ uint32_t s_bits_all[kAsmWaves][kSlotWords + 8];   // only large macroblocks use it; one region per wavefront
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *const s_bits = s_bits_all[wv];
+    const uint32_t blk = blockIdx.x * kAsmWaves + wv;
     const uint32_t strip_mbs = (uint32_t)((g.row1 - g.row0) * g.mbw);
     const int f = (int)(blk / strip_mbs), mb = g.row0 * g.mbw + (int)(blk % strip_mbs);
-    if (f >= nframes || ctl->overflow) return;
+    if (f >= nframes) return;
     const int by = mb / g.mbw, bx = mb - by * g.mbw;
     const size_t idx = (size_t)f * g.mbs + mb;
 
-    const uint32_t info = mbinfo[idx];
+    // every load is independent of the others: issue them all, then wait once (the kernel is latency bound)
+    const uint32_t spec = lane < kSmallSlotWords ? slots_small[idx * kSmallSlotWords + lane] : 0u;
     const MbAux aux = mbaux[idx];
-    const bool has_left = bx > 0;
-    const uint32_t linfo = has_left ? mbinfo[idx - 1] : 0u;
-    const MbAux laux = has_left ? mbaux[idx - 1] : MbAux{0, 0, 0, 0};
-    const MbDep d = mb_dependent(info, aux, has_left, linfo, laux, jobs[f].i_frame);
-    const uint32_t lenA = aux.w0 & 0xFFFFu, lenB = aux.w0 >> 16, lenC = aux.w1 & 0xFFFFu;
+    const MbDepRec dep = mbdep[idx];
     const uint32_t total = mb_len[idx];
+    const unsigned long long q = (ctl->base_bytes + slice_off[(size_t)f * g.mbh + by]) * 8ull + mb_bitoff[idx];
+    if (ctl->overflow) return;
+
+    const uint32_t lenA = aux.w0 & 0xFFFFu, lenB = aux.w0 >> 16, lenC = aux.w1 & 0xFFFFu;
+    const int l1 = (int)(dep.lens & 255u), l2 = (int)((dep.lens >> 8) & 255u), l3 = (int)((dep.lens >> 16) & 255u);
+    const int hdr = bx == 0 ? 38 : 0;            // slice header: start code, slice_vertical_position, quantiser_scale_code, extra_bit_slice (RTL:2708-2710)
+    const uint32_t sh = (uint32_t)(q & 31ull);
+    const unsigned long long w0 = q >> 5;
+    const uint32_t nout = (sh + total + 31u) / 32u;
+    const bool small = ((lenA + lenB + lenC + 31u) >> 5) <= (uint32_t)kSmallSlotWords;
+
+    if (small) {
+        // piece offsets relative to the first bit of the macroblock
+        const int o1 = hdr, oA = o1 + l1, o2 = oA + (int)lenA, oB = o2 + l2, o3 = oB + (int)lenB, oC = o3 + l3;
+        const int r0 = 32 * lane - (int)sh;                    // this lane's stream word as a window in those coordinates
+        uint32_t word = 0;
+        if (hdr) {
+            word |= window_code(0x000001u << 8, 24, 0, r0);
+            word |= window_code((((uint32_t)(by + 1) << 6) | (2u << g.Q)) << 18, 14, 24, r0);
+        }
+        word |= window_code(l1 ? dep.c1 << (32 - l1) : 0u, l1, o1, r0);
+        word |= window_code(l2 ? dep.c2 << (32 - l2) : 0u, l2, o2, r0);
+        word |= window_code(l3 ? dep.c3 << (32 - l3) : 0u, l3, o3, r0);
+        const int segoff[3] = {oA, oB, oC}, seglen[3] = {(int)lenA, (int)lenB, (int)lenC};
+        const int segsrc[3] = {0, (int)lenA, (int)(lenA + lenB)};
+#pragma unroll
+        for (int sgm = 0; sgm < 3; ++sgm) {
+            const int n = seglen[sgm], t = r0 - segoff[sgm];   // window start in segment coordinates
+            const int tt = t < 0 ? 0 : t;
+            int src = segsrc[sgm] + tt;
+            src = src > 1023 ? 1023 : src;                      // keeps the cross-lane index in range for lanes with no overlap
+            const uint32_t a0 = (uint32_t)__shfl((int)spec, src >> 5, 64);
+            const uint32_t a1 = (uint32_t)__shfl((int)spec, (src >> 5) + 1 > 31 ? 31 : (src >> 5) + 1, 64);
+            const uint32_t sb = (uint32_t)src & 31u;
+            uint32_t w = sb ? ((a0 << sb) | (a1 >> (32u - sb))) : a0;
+            const int valid = n - tt;                           // bits of the segment left from tt on
+            if (n > 0 && t > -32 && valid > 0) {
+                if (valid < 32) w &= ~0u << (32 - valid);
+                word |= t < 0 ? (w >> (-t)) : w;
+            }
+        }
+        if ((uint32_t)lane < nout) {
+            const uint32_t be = __builtin_bswap32(word);
+            if (lane == 0 || (uint32_t)lane == nout - 1) { if (be) atomicOr(&out32[w0 + lane], be); }
+            else out32[w0 + lane] = be;
+        }
+        return;
+    }
+
+    // ---- large macroblock: assemble in LDS, then merge with a funnel shift ----
     const uint32_t nwords = (total + 31u) / 32u + 1u;
     for (uint32_t k = lane; k < nwords; k += 64) s_bits[k] = 0u;
-    __syncthreads();
-
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // one wavefront owns this LDS region: program order suffices
     uint32_t pos = 0;
-    if (bx == 0) {          // slice header: start code, slice_vertical_position, quantiser_scale_code, extra_bit_slice (RTL:2708-2710)
+    if (bx == 0) {
         if (lane == 0) {
             lds_put(s_bits, 0, 0x000001u, 24);
             lds_put(s_bits, 24, ((uint32_t)(by + 1) << 6) | (2u << g.Q), 14);
@@ -847,8 +914,7 @@ __global__ __launch_bounds__(64) void k_assemble(const FrameJob *__restrict__ jo
         pos = 38;
     }
     const uint32_t *slot = slots + idx * kSlotWords;
-    // piece, segment, piece, segment, piece, segment
-    const uint32_t plen[3] = {d.p1.len, d.p2.len, d.p3.len}, pcode[3] = {d.p1.code, d.p2.code, d.p3.code};
+    const uint32_t plen[3] = {(uint32_t)l1, (uint32_t)l2, (uint32_t)l3}, pcode[3] = {dep.c1, dep.c2, dep.c3};
     const uint32_t slen[3] = {lenA, lenB, lenC}, soff[3] = {0u, lenA, lenA + lenB};
 #pragma unroll
     for (int sgm = 0; sgm < 3; ++sgm) {
@@ -864,13 +930,7 @@ __global__ __launch_bounds__(64) void k_assemble(const FrameJob *__restrict__ jo
         }
         pos += n;
     }
-    __syncthreads();
-
-    // merge into the stream: big-endian 32-bit words, atomics only on the two boundary words
-    const unsigned long long q = (ctl->base_bytes + slice_off[(size_t)f * g.mbh + by]) * 8ull + mb_bitoff[idx];
-    const uint32_t sh = (uint32_t)(q & 31ull);
-    const unsigned long long w0 = q >> 5;
-    const uint32_t nout = (sh + total + 31u) / 32u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     for (uint32_t k = lane; k < nout; k += 64) {
         const uint32_t hi = k ? s_bits[k - 1] : 0u;
         const uint32_t lo = k < nwords ? s_bits[k] : 0u;

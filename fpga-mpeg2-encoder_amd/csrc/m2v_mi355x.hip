@@ -89,7 +89,9 @@ struct m2v_enc {
     DevBuf<uint8_t> d_out;                // chunk output when it goes to the host
     DevBuf<int16_t> d_coef;               // debug only: quantised levels
     DevBuf<MbAux> d_mbaux;
-    DevBuf<uint32_t> d_slots;             // per-macroblock VLC bit segments (kSlotWords each)
+    DevBuf<MbDepRec> d_mbdep;             // neighbour-dependent codes of every macroblock (k_slice_scan -> k_assemble)
+    DevBuf<uint32_t> d_slots;             // per-macroblock VLC bit segments (kSlotWords each), used on overflow only
+    DevBuf<uint32_t> d_slots_small;       // compact 128-byte slots (kSmallSlotWords each): the common case
     DevBuf<uint32_t> d_mbinfo, d_mblen, d_mboff, d_slice_bytes;
     DevBuf<unsigned long long> d_slice_off, d_frame_off;
     DevBuf<FrameJob> d_jobs;
@@ -234,12 +236,12 @@ void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Ge
     int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
     if (P) {
         switch (e->VL) {
-            case 1: hipLaunchKernelGGL((k_mb<1, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots.p, dbg); break;
-            case 2: hipLaunchKernelGGL((k_mb<2, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots.p, dbg); break;
-            default: hipLaunchKernelGGL((k_mb<3, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots.p, dbg); break;
+            case 1: hipLaunchKernelGGL((k_mb<1, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
+            case 2: hipLaunchKernelGGL((k_mb<2, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
+            default: hipLaunchKernelGGL((k_mb<3, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
         }
     } else {
-        hipLaunchKernelGGL((k_mb<1, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots.p, dbg);
+        hipLaunchKernelGGL((k_mb<1, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg);
     }
     HIPCHK(hipGetLastError());
     t.stop();
@@ -355,7 +357,9 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
     e->d_lists.ensure(lists.size());
     if (e->keep_recon) e->d_coef.ensure(nmb * 384);
     e->d_mbaux.ensure(nmb);
+    e->d_mbdep.ensure(nmb);
     e->d_slots.ensure(nmb * (size_t)kSlotWords);
+    e->d_slots_small.ensure(nmb * (size_t)kSmallSlotWords);
     e->d_mbinfo.ensure(nmb);
     e->d_mblen.ensure(nmb);
     e->d_mboff.ensure(nmb);
@@ -399,7 +403,7 @@ void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_s
     {
         Timer t(e, s, 4, (double)nf * g.ysz);
         hipLaunchKernelGGL(k_slice_scan, dim3((unsigned)(nf * rows)), dim3(128), 0, s, e->d_jobs.p, g, e->d_mbinfo.p,
-                           e->d_mbaux.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_bytes.p);
+                           e->d_mbaux.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_bytes.p, e->d_mbdep.p);
         hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(1024), 0, s, e->d_jobs.p, g, (int)nf, first ? 1 : 0, last ? 1 : 0,
                            e->d_slice_bytes.p, e->d_slice_off.p, e->d_frame_off.p, e->d_ctl.p);
         hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, s, d_stream, e->d_ctl.p);
@@ -415,8 +419,8 @@ void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_s
     }
     {
         Timer t(e, s, 3, (double)nf * g.ysz);
-        hipLaunchKernelGGL(k_assemble, dim3((unsigned)(nf * rows * g.mbw)), dim3(64), 0, s, e->d_jobs.p, g, (int)nf,
-                           e->d_mbinfo.p, e->d_mbaux.p, e->d_slots.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_off.p,
+        hipLaunchKernelGGL(k_assemble, dim3((unsigned)((nf * rows * g.mbw + kAsmWaves - 1) / kAsmWaves)), dim3(64 * kAsmWaves), 0, s, e->d_jobs.p, g, (int)nf,
+                           e->d_mbaux.p, e->d_mbdep.p, e->d_slots_small.p, e->d_slots.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_off.p,
                            (uint32_t *)d_stream, e->d_ctl.p);
         HIPCHK(hipGetLastError());
         t.stop();
@@ -603,7 +607,7 @@ void m2v_destroy(m2v_enc *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    e->d_in.release(); e->d_out.release(); e->d_coef.release(); e->d_mbaux.release(); e->d_slots.release(); e->d_mbinfo.release(); e->d_mblen.release();
+    e->d_in.release(); e->d_out.release(); e->d_coef.release(); e->d_mbaux.release(); e->d_mbdep.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
     e->d_mboff.release(); e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
     e->d_jobs.release(); e->d_lists.release(); e->d_ctl.release(); e->d_segs.release();
     for (auto p : e->rec_pool) (void)hipFree(p);
