@@ -188,10 +188,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_mb<3,true> (P-frame macroblock kernel)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (PMC passes of an earlier run of this same command)"
+                                           if traffic is not None else None,
                          "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                          "algorithmic_bytes_per_launch": round(alg_bytes / max(launches, 1))},
-            "kernel_ms_per_step": {"k_mb_P": round(ms, 3), "k_mb_I": round(msi, 3), "k_vlc_len": round(ms2, 3),
-                                   "k_vlc_write": round(ms3, 3), "scan_headers": round(ms4, 3)},
+            "kernel_ms_per_step": {"k_mb_P": round(ms, 3), "k_mb_I": round(msi, 3), "k_assemble": round(ms3, 3),
+                                   "scans_headers": round(ms4, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             gop0 = clip[:PFRAMES + 1].cpu().numpy()
