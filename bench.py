@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gops", type=int, default=GOPS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ablate", type=int, default=0, help="profiling aid: skip kernel phases (output invalid), see Geom::ablate")
     ap.add_argument("--mode", choices=["sequences", "strips"], default="sequences",
                     help="sequences (default): config c3 / c4, one 1920x1152 sequence per GPU, no collective; "
                          "strips: config c5, ONE 2048x2048 sequence cut into macroblock-row strips, RCCL halo exchange")
@@ -126,6 +127,8 @@ def main():
     d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
     enc = M.Mpeg2Encoder(XL, YL, VL, Q, device=local_rank)
     enc.set_option("batch_frames", nframes)
+    if args.ablate:
+        enc.set_option("ablate", args.ablate)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():

@@ -39,6 +39,8 @@ struct Geom {
     uint32_t csz;    // cw*ch
     int row0, row1;  // macroblock rows this GPU encodes: [0, mbh) normally, a strip in multi-GPU strip mode
     int strip;       // 1 = strip mode: the stream buffer holds only this strip's slices, no headers
+    int ablate;      // profiling aid (option "ablate", default 0 = everything on; results are INVALID otherwise):
+                     // bit0 skip full-pel search, bit1 skip half-pel SADs, bit2 skip VLC, bit3 skip IDCT/recon, bit4 skip DCT/quant
 };
 
 struct FrameJob {           // one per frame of the chunk (device memory)
@@ -306,11 +308,18 @@ __device__ __forceinline__ MbDep mb_dependent(uint32_t info, const MbAux &aux, b
 // ----------------------------------------------------------------------------------------------
 // k_mb: one wavefront = one macroblock, stages A..T
 // ----------------------------------------------------------------------------------------------
+constexpr int kMbWaves = 1;           // macroblocks (independent wavefronts) per k_mb workgroup; 4 measured 16 % slower
+
+// One wavefront per workgroup: __syncthreads() lowers to "s_waitcnt lgkmcnt(0); wave barrier" (no s_barrier), which is
+// exactly the LDS write -> read ordering the phases need.  (A seq_cst wavefront fence also waits for vmcnt and costs 14 %.)
+#define M2V_WAVE_SYNC() __syncthreads()
+static_assert(kMbWaves == 1, "k_mb synchronises with __syncthreads(): its wavefronts must not share a workgroup");
+
 template <int VL, bool P>
-__global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
+__global__ __launch_bounds__(64 * kMbWaves) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
                                            Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
                                            uint32_t *__restrict__ slots_small, uint32_t *__restrict__ slots,
-                                           int16_t *__restrict__ coef_dbg)
+                                           int16_t *__restrict__ coef_dbg, uint32_t nblk)
 {
     constexpr int UR = VL, YR = 2 * VL;
     constexpr int WROWS = 16 + 2 * YR;         // luma window rows -YR .. 16+YR-1 (RTL:1446)
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
     constexpr int kR1 = (kWinBytes + 2 * kCwinBytes + 256) > 1600 ? (kWinBytes + 2 * kCwinBytes + 256) : 1600;
     constexpr int kOffPred = kR1, kOffX = kOffPred + 384, kOffT = kOffX + 768, kOffZig = kOffT + 1536;
     constexpr int kLdsBytes = kOffZig + 768;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];   // static base: every DS access uses an immediate offset
     uint32_t *const s_win = (uint32_t *)lds;                                   // luma window: 32 bytes/row = frame cols 16bx-8 .. 16bx+23
     uint32_t (*const s_cwin)[CROWS * 4] = (uint32_t (*)[CROWS * 4])(lds + kWinBytes);   // chroma windows: 16 bytes/row = cols 8bx-4 .. 8bx+11
     uint32_t *const s_cur = (uint32_t *)(lds + kWinBytes + 2 * kCwinBytes);    // current luma, dword [row][4-px group]
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
     const int lane = threadIdx.x;
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t strip_mbs = (uint32_t)((g.row1 - g.row0) * g.mbw);
+    (void)nblk;
     const int fidx = frame_list[blk / strip_mbs];
     const int mb = g.row0 * g.mbw + (int)(blk % strip_mbs);
     const int by = mb / g.mbw, bx = mb - by * g.mbw;
@@ -390,7 +400,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
             s_cwin[0][lane] = vu;
             s_cwin[1][lane] = vv;
         }
-        __syncthreads();
+        M2V_WAVE_SYNC();
 
         // ---- full-pel search: (2YR+1)^2 SADs (RTL:1634-1715) ---------------------------------
         // lane = (dy, group of 4 consecutive dx); v_qsad_pk_u16_u8 slides the 4 current pixels
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
         {
             uint32_t key = 0xFFFFFFFFu;
             const int dyi = lane >> 2, gq = lane & 3;        // dy = dyi - YR, dx = 4*gq - 8 + j
-            if (dyi <= 2 * YR) {
+            if (dyi <= 2 * YR && !(g.ablate & 1)) {
                 unsigned long long acc = 0;
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) {
@@ -460,8 +470,8 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
         hp[0] = avg4x4(L0, C0, L1, C1);  hp[1] = avg2x4(C0, C1);  hp[2] = avg4x4(C0, R0, C1, R1);
         hp[3] = avg2x4(L1, C1);          hp[4] = C1;              hp[5] = avg2x4(C1, R1);
         hp[6] = avg4x4(L1, C1, L2, C2);  hp[7] = avg2x4(C1, C2);  hp[8] = avg4x4(C1, R1, C2, R2);
-        int v10[10];
-        {
+        int v10[10] = {4096, 4096, 4096, 4096, 0, 4096, 4096, 4096, 4096, 4095};
+        if (!(g.ablate & 2)) {
             uint32_t s[10];
 #pragma unroll
             for (int k = 0; k < 9; ++k) s[k] = __builtin_amdgcn_sad_u8(cur4, hp[k], 0u);
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
         s_x[4][ti] = (int16_t)(cu0 - (int)(pu & 255u));  s_x[4][ti + 1] = (int16_t)(cu1 - (int)(pu >> 8));
         s_x[5][ti] = (int16_t)(cv0 - (int)(pv & 255u));  s_x[5][ti + 1] = (int16_t)(cv1 - (int)(pv >> 8));
     }
-    __syncthreads();
+    M2V_WAVE_SYNC();
 
     // ---- stage G: 2-D forward DCT (RTL:2029-2062); lane = (i = lane>>3, j = lane&7) ------------
     const int di = lane >> 3, dj = lane & 7;
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
         acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, xr.w), bjp[3], acc, false);
         s_t[t][lane] = acc;
     }
-    __syncthreads();
+    M2V_WAVE_SYNC();
 
     // ---- quantise (RTL:2065-2077), zig-zag + coded flags (RTL:2452-2468), dequantise (RTL:2129-2150)
     const int wq = c_intra_w[lane];
@@ -571,9 +581,12 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
     const int zz = c_zigzag[lane];
     const int Q = g.Q;
     const size_t mbidx = (size_t)fidx * g.mbs + mb;
-    const bool need_rec = job.rec != nullptr;
+    const bool need_rec = job.rec != nullptr && !(g.ablate & 8);
     int cbp = 0;
-    if (inter) {
+    if (g.ablate & 16) {
+        for (int t = 0; t < 6; ++t) s_zig[t][lane] = 0;
+        cbp = inter ? 0 : 63;
+    } else if (inter) {
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             int acc = 0;                                // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12
@@ -622,7 +635,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
         }
         cbp = 63;                                       // intra: every tile is coded (RTL:2461)
     }
-    __syncthreads();
+    M2V_WAVE_SYNC();
 
     // ---- stage T, coefficient part: run/level VLC of the six tiles (RTL:2777-2847) -----------------
     // Pass 1 (per tile, lane = zig-zag index): ballot the non-zero levels, rank them, and append
@@ -647,6 +660,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
             const int v = s_zig[t][lane];
             const int v0 = __builtin_amdgcn_readlane(v, 0);
             dcs[t] = v0;
+            if (g.ablate & 4) continue;
             if (t == 4) idxB = nsym;
             if (t == 5) idxC = nsym;
             const bool coded = (cbp >> (5 - t)) & 1;
@@ -678,7 +692,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
         }
 #pragma unroll
         for (int k = lane; k < kSlotWords; k += 64) s_bits[k] = 0u;
-        __syncthreads();
+        M2V_WAVE_SYNC();
 
         uint32_t pos = 0, offB = 0, offC = 0;
         for (uint32_t base = 0; base < nsym; base += 64) {
@@ -714,7 +728,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
         uint32_t lenA, lenB = 0, lenC = 0;
         if (inter) lenA = pos;
         else { lenA = offB; lenB = offC - offB; lenC = pos - offC; }   // intra: tiles 4 and 5 always carry at least the EOB
-        __syncthreads();
+        M2V_WAVE_SYNC();
         const uint32_t nwords = (pos + 31u) >> 5;
         if (nwords <= (uint32_t)kSmallSlotWords) {          // the common case: one 128-byte line
             if (lane < kSmallSlotWords) slots_small[mbidx * kSmallSlotWords + lane] = s_bits[lane];
@@ -736,7 +750,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
 
     // ---- stages H..R: Chen-Wang IDCT, reconstruction, store as next reference ------------------
     if (need_rec) {
-        __syncthreads();                                // s_t doubles as the bit buffer that was just copied out
+        M2V_WAVE_SYNC();                                // s_t doubles as the bit buffer that was just copied out
         if (lane < 48) {                                // rows: lane = tile*8 + row (RTL:2159-2189)
             const int t = lane >> 3, row = lane & 7;
             int a[8], o[8];
@@ -746,7 +760,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
 #pragma unroll
             for (int k = 0; k < 8; ++k) s_t[t][row * 8 + k] = o[k];
         }
-        __syncthreads();
+        M2V_WAVE_SYNC();
         if (lane < 48) {                                // columns: lane = tile*8 + col (RTL:2238-2279)
             const int t = lane >> 3, col = lane & 7;
             int a[8], o[8];
@@ -759,7 +773,7 @@ __global__ __launch_bounds__(64) void k_mb(const FrameJob *__restrict__ jobs, co
                 s_pred[t][k * 8 + col] = (uint8_t)(v > 255 ? 255 : v < 0 ? 0 : v);
             }
         }
-        __syncthreads();
+        M2V_WAVE_SYNC();
         uint8_t *recY = job.rec, *recU = recY + g.ysz, *recV = recU + g.csz;
         {
             const int tile = ((r >> 3) << 1) | (c4 >> 1);

@@ -63,6 +63,7 @@ struct m2v_enc {
     // options
     size_t batch_frames = 96;
     bool profile = false;
+    int ablate = 0;               // profiling aid, see Geom::ablate
     bool keep_recon = false;      // debug: every frame keeps its own reconstruction buffer, levels are dumped
 
     // sequence state (RTL:1017-1022)
@@ -168,6 +169,7 @@ Geom make_geom(const m2v_enc *e, uint32_t xs, uint32_t ys)
     g.row0 = 0;
     g.row1 = g.mbh;
     g.strip = 0;
+    g.ablate = e->ablate;
     return g;
 }
 
@@ -231,17 +233,18 @@ template <bool P>
 void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g)
 {
     if (count <= 0) return;
-    const dim3 grid((unsigned)((size_t)count * (size_t)(g.row1 - g.row0) * g.mbw)), block(64);
+    const uint32_t nblk = (uint32_t)((size_t)count * (size_t)(g.row1 - g.row0) * g.mbw);      // macroblocks = wavefronts
+    const dim3 grid((nblk + kMbWaves - 1) / kMbWaves), block(64 * kMbWaves);
     Timer t(e, s, P ? 0 : 1, (double)count * g.ysz);
     int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
     if (P) {
         switch (e->VL) {
-            case 1: hipLaunchKernelGGL((k_mb<1, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
-            case 2: hipLaunchKernelGGL((k_mb<2, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
-            default: hipLaunchKernelGGL((k_mb<3, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
+            case 1: hipLaunchKernelGGL((k_mb<1, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg, nblk); break;
+            case 2: hipLaunchKernelGGL((k_mb<2, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg, nblk); break;
+            default: hipLaunchKernelGGL((k_mb<3, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg, nblk); break;
         }
     } else {
-        hipLaunchKernelGGL((k_mb<1, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg);
+        hipLaunchKernelGGL((k_mb<1, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg, nblk);
     }
     HIPCHK(hipGetLastError());
     t.stop();
@@ -971,6 +974,7 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
     }
     if (!strcmp(name, "profile")) { e->profile = value != 0; return M2V_OK; }
     if (!strcmp(name, "keep_recon")) { e->keep_recon = value != 0; return M2V_OK; }
+    if (!strcmp(name, "ablate")) { e->ablate = (int)value; return M2V_OK; }   // profiling aid: output is invalid when != 0
     return M2V_E_PARAM;
 }
 
