@@ -316,7 +316,7 @@ constexpr int kMbWaves = 1;           // macroblocks (independent wavefronts) pe
 static_assert(kMbWaves == 1, "k_mb synchronises with __syncthreads(): its wavefronts must not share a workgroup");
 
 template <int VL, bool P>
-__global__ __launch_bounds__(64 * kMbWaves) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
+__global__ __launch_bounds__(64 * kMbWaves, 8) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
                                            Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
                                            uint32_t *__restrict__ slots_small, uint32_t *__restrict__ slots,
                                            int16_t *__restrict__ coef_dbg, uint32_t nblk)
@@ -355,11 +355,37 @@ __global__ __launch_bounds__(64 * kMbWaves) void k_mb(const FrameJob *__restrict
 
     // ---- stages A..E: current macroblock; 4:4:4 -> 4:2:0 with two-stage rounding -------------
     // (RTL:1086-1089 horizontal mean2, RTL:1167-1170 vertical mean2 of the two means)
+    // Every global load of the macroblock (3 current rows, 4 window row groups, 2 chroma windows) is issued
+    // back to back through explicit global-address-space pointers and waited for once: the wavefront pays ONE
+    // memory round trip.  Window samples outside the frame can never be selected (RTL:1642-1645), so their
+    // addresses are clamped into the frame instead of being branched around.
+    typedef const __attribute__((address_space(1))) uint32_t *gld32;
     const uint8_t *inY = job.in, *inU = inY + g.ysz, *inV = inU + g.ysz;
     const uint32_t pix_off = (uint32_t)(16 * by + r) * (uint32_t)W + (uint32_t)(16 * bx + 4 * c4);
-    uint32_t cur4 = *(const uint32_t *)(inY + pix_off);
-    uint32_t u4 = *(const uint32_t *)(inU + pix_off);
-    uint32_t v4 = *(const uint32_t *)(inV + pix_off);
+    uint32_t cur4 = *(gld32)(inY + pix_off);
+    uint32_t u4 = *(gld32)(inU + pix_off);
+    uint32_t v4 = *(gld32)(inV + pix_off);
+    uint32_t wv[P ? (WROWS * 8 + 63) / 64 : 1], wcu = 0, wcv = 0;
+    if constexpr (P) {
+        const uint8_t *refY = job.ref, *refU = refY + g.ysz, *refV = refU + g.csz;
+#pragma unroll
+        for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass) {
+            const int i = pass * 64 + lane, row = i >> 3, k = i & 7;
+            int yy = 16 * by - YR + row, xx = 16 * bx - 8 + 4 * k;
+            yy = yy < 0 ? 0 : yy > g.H - 1 ? g.H - 1 : yy;
+            xx = xx < 0 ? 0 : xx > W - 4 ? W - 4 : xx;
+            wv[pass] = *(gld32)(refY + ((uint32_t)yy * (uint32_t)W + (uint32_t)xx));   // 32-bit offset from a uniform base
+        }
+        {
+            const int cl = lane < CROWS * 4 ? lane : CROWS * 4 - 1, row = cl >> 2, k = cl & 3;
+            int yy = 8 * by - UR + row, xx = 8 * bx - 4 + 4 * k;
+            yy = yy < 0 ? 0 : yy > g.ch - 1 ? g.ch - 1 : yy;
+            xx = xx < 0 ? 0 : xx > g.cw - 4 ? g.cw - 4 : xx;
+            const uint32_t coff = (uint32_t)yy * (uint32_t)g.cw + (uint32_t)xx;
+            wcu = *(gld32)(refU + coff);
+            wcv = *(gld32)(refV + coff);
+        }
+    }
     if ((pix_off >> 2) >= job.valid_beats) {    // beats after i_sequence_stop are black (RTL:1036-1056)
         cur4 = 0u; u4 = 0x80808080u; v4 = 0x80808080u;
     }
@@ -380,25 +406,12 @@ __global__ __launch_bounds__(64 * kMbWaves) void k_mb(const FrameJob *__restrict
 
     if constexpr (P) {
         // ---- stages X..Z: reference window of recon(f-1) into LDS (RTL:1350-1425, 1612-1629) --
-        const uint8_t *refY = job.ref, *refU = refY + g.ysz, *refV = refU + g.csz;
 #pragma unroll
-        for (int i = lane; i < WROWS * 8; i += 64) {
-            const int row = i >> 3, k = i & 7;
-            const int yy = 16 * by - YR + row, xx = 16 * bx - 8 + 4 * k;
-            uint32_t v = 0;                    // outside the frame: never selectable (RTL:1642-1645)
-            if (yy >= 0 && yy < g.H && xx >= 0 && xx < W) v = *(const uint32_t *)(refY + (uint32_t)yy * W + xx);
-            s_win[i] = v;
-        }
+        for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass)
+            if ((pass + 1) * 64 <= WROWS * 8 || lane < WROWS * 8 - pass * 64) s_win[pass * 64 + lane] = wv[pass];
         if (lane < CROWS * 4) {
-            const int row = lane >> 2, k = lane & 3;
-            const int yy = 8 * by - UR + row, xx = 8 * bx - 4 + 4 * k;
-            uint32_t vu = 0, vv = 0;
-            if (yy >= 0 && yy < g.ch && xx >= 0 && xx < g.cw) {
-                vu = *(const uint32_t *)(refU + (uint32_t)yy * g.cw + xx);
-                vv = *(const uint32_t *)(refV + (uint32_t)yy * g.cw + xx);
-            }
-            s_cwin[0][lane] = vu;
-            s_cwin[1][lane] = vv;
+            s_cwin[0][lane] = wcu;
+            s_cwin[1][lane] = wcv;
         }
         M2V_WAVE_SYNC();
 
