@@ -448,15 +448,16 @@ __global__ void k_ctl_advance(StreamCtl *ctl)
 void ctl_init(m2v_enc *e, hipStream_t s, unsigned long long cap, unsigned long long prior = 0)
 {
     e->d_ctl.ensure(1);
-    if (!e->h_ctl) HIPCHK(hipHostMalloc((void **)&e->h_ctl, sizeof(StreamCtl)));
-    e->h_ctl->base_bytes = 0;
-    e->h_ctl->total_bytes = 0;
-    e->h_ctl->cap_bytes = cap & ~3ull;
-    e->h_ctl->prior_bytes = prior;
-    e->h_ctl->overflow = 0;
-    e->h_ctl->pad = 0;
-    HIPCHK(hipMemcpyAsync(e->d_ctl.p, e->h_ctl, sizeof(StreamCtl), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));     // h_ctl is reused for the read-back
+    if (!e->h_ctl) HIPCHK(hipHostMalloc((void **)&e->h_ctl, 2 * sizeof(StreamCtl)));   // [0] read-back, [1] initial values
+    StreamCtl *init = e->h_ctl + 1;
+    init->base_bytes = 0;
+    init->total_bytes = 0;
+    init->cap_bytes = cap & ~3ull;
+    init->prior_bytes = prior;
+    init->overflow = 0;
+    init->pad = 0;
+    // no synchronisation: the upload slot is only rewritten by the next call, after the caller's end-of-call sync
+    HIPCHK(hipMemcpyAsync(e->d_ctl.p, init, sizeof(StreamCtl), hipMemcpyHostToDevice, s));
 }
 
 // ---------------------------------------------------------------------------------------------
