@@ -64,12 +64,9 @@ class GpuStripEngine:
         return self.torch.empty(max(nbytes, 1), dtype=self.torch.uint8, device=self.device)
 
     def step(self, j, send_up, send_down):
+        """runs GOP step j; returns the bytes packed into each send buffer (frames referenced later x 3*VL*W)"""
         n = self.enc.strip_step(j, send_up.data_ptr(), send_down.data_ptr())
-        return n * (self.halo_bytes // max(1, self._max_halo_frames()))
-
-    def _max_halo_frames(self):
-        chunk = 3 * self.enc.params[2] * self.W
-        return self.halo_bytes // chunk if chunk else 1
+        return n * 3 * self.enc.params[2] * self.W
 
     def halo_in(self, j, from_up, from_down):
         self.enc.strip_halo_in(j, from_up.data_ptr() if from_up is not None else None,

@@ -1,8 +1,11 @@
-"""Quick GPU bring-up script: python tools_gpu_debug.py  (prints stage mismatches vs the oracle)."""
+"""Quick GPU bring-up script: python tools/gpu_debug.py  (prints stage mismatches vs the oracle)."""
+import os
 import sys
 import time
 
-sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gpu_util as G  # noqa: E402
 
 cases = [
