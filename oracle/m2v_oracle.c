@@ -201,7 +201,7 @@ void m2v_oracle_dequant(const int16_t q[64], int inter, int Q, int16_t d[64])
         for (int j = 0; j < 8; ++j) {
             int32_t t = q[i * 8 + j];
             if (inter) {
-                t = sext(t << 1, 17);                                   /* RTL:2134 */
+                t = sext(t * 2, 17);                                    /* RTL:2134 (x << 1) */
                 t = sext(t + (t < 0 ? -1 : t > 0 ? 1 : 0), 17);         /* RTL:2135 */
                 t = sext((int32_t)((uint32_t)t << Q), 17);              /* RTL:2136 */
                 t = t < -2047 ? -2047 : t > 2047 ? 2047 : t;            /* RTL:2137 */
@@ -211,7 +211,7 @@ void m2v_oracle_dequant(const int16_t q[64], int inter, int Q, int16_t d[64])
                 else        t = t >> (3 - Q);                           /* RTL:2143, arithmetic */
                 t = t < -2047 ? -2047 : t > 2047 ? 2047 : t;            /* RTL:2144 */
             } else {
-                t = sext(t << 1, 17);                                   /* RTL:2146 */
+                t = sext(t * 2, 17);                                    /* RTL:2146 (x << 1) */
             }
             d[i * 8 + j] = (int16_t)sext(t, 13);                        /* h_iquant is 13 bits */
         }

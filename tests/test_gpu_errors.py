@@ -1,0 +1,68 @@
+"""-m gpu: error behaviour of the C-ABI (codes of include/m2v_mi355x.h), reset, options."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_overflow_reset_and_options():
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    L = M.lib()
+    clip = M.synth.clip(96, 64, 4, clip_index=120)
+    want = orc.encode(clip, 6, 4, 3, 6, 6, 3, 2)
+    enc = M.Mpeg2Encoder(6, 6, 3, 2)
+    try:
+        d_in = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
+        small = torch.zeros(256, dtype=torch.uint8, device="cuda:0")
+        n = ctypes.c_size_t(0)
+        # output buffer too small: M2V_E_OVERFLOW, nothing written beyond the buffer, handle stays usable
+        r = L.m2v_encode_resident(enc._h, 6, 4, 3, d_in.data_ptr(), 4, small.data_ptr(), small.numel(), ctypes.byref(n), None)
+        assert r == -6 and b"too small" in L.m2v_last_error(enc._h)
+        big = torch.empty(1 << 20, dtype=torch.uint8, device="cuda:0")
+        nb = enc.encode_resident(d_in.data_ptr(), 4, big.data_ptr(), big.numel(), 6, 4, 3)
+        assert big[:nb].cpu().numpy().tobytes() == want
+        # busy handle refuses the resident entry; reset drops the sequence in flight (rstn, RTL:1028-1039)
+        enc.push_frames(6, 4, 3, clip[:2])
+        assert enc.busy
+        r = L.m2v_encode_resident(enc._h, 6, 4, 3, d_in.data_ptr(), 4, big.data_ptr(), big.numel(), ctypes.byref(n), None)
+        assert r == -4
+        assert L.m2v_reset(enc._h) == 0 and not enc.busy
+        assert enc.pull() == (b"", False)
+        assert enc.encode(clip, 6, 4, 3) == want                       # a fresh sequence after the reset
+        # options
+        assert L.m2v_set_option(enc._h, b"batch_frames", 0) == -1
+        assert L.m2v_set_option(enc._h, b"no_such_option", 1) == -1
+        assert L.m2v_set_option(enc._h, b"batch_frames", 2) == 0
+        assert enc.encode(clip, 6, 4, 3) == want
+        # zero frames: the sequence never starts (stop while idle does nothing, RTL:1090)
+        assert enc.encode_resident(d_in.data_ptr(), 0, big.data_ptr(), big.numel(), 6, 4, 3) == 0
+        enc.sequence_stop()
+        assert not enc.busy
+    finally:
+        enc.close()
+
+
+def test_two_handles_are_independent():
+    """config c4 in one process: two encoder instances interleaved on one GPU do not disturb each other."""
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    a, b = M.Mpeg2Encoder(6, 6, 3, 2), M.Mpeg2Encoder(5, 5, 1, 4)
+    try:
+        ca, cb = M.synth.clip(128, 96, 5, clip_index=121), M.synth.clip(64, 64, 6, clip_index=122)
+        for k in range(5):
+            a.push_frames(8, 6, 2, ca[k:k + 1])
+            b.push_frames(4, 4, 4, cb[k:k + 1])
+        b.push_frames(4, 4, 4, cb[5:6])
+        a.sequence_stop()
+        b.sequence_stop()
+        assert a.pull_all() == orc.encode(ca, 8, 6, 2, 6, 6, 3, 2)
+        assert b.pull_all() == orc.encode(cb, 4, 4, 4, 5, 5, 1, 4)
+    finally:
+        a.close()
+        b.close()
