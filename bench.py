@@ -107,16 +107,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # Test hook for 1-GPU boxes only: M2V_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and M2V_DIST_BACKEND=gloo replaces
+    # RCCL (which refuses two ranks on one device) for the barrier / max-over-ranks.  Never set by the driver.
+    if os.environ.get("M2V_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("M2V_DIST_BACKEND", "nccl")
     dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     dev = "cuda:%d" % local_rank
-    torch.cuda.set_device(local_rank)
 
     M.build()
     if args.mode == "strips":
@@ -150,7 +154,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -184,7 +188,8 @@ def main():
             "scaling": "weak", "vs_baseline": round(value / FPGA_MPIXELS, 3), "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "c3: 1920x1152 yuv444p, %d closed GOPs of 1 I + %d P frames (%d frames), "
-                                   "VECTOR_LEVEL=3 Q_LEVEL=2 XL=YL=7, one sequence per GPU" % (args.gops, PFRAMES, nframes),
+                                   "VECTOR_LEVEL=3 Q_LEVEL=2 XL=YL=7, one independent sequence per GPU (c4 for N > 1), "
+                                   "no data-path collective" % (args.gops, PFRAMES, nframes),
                        "frames": nframes, "stream_bytes": int(nbytes),
                        "bits_per_pixel": round(nbytes * 8 / pixels_per_step, 4),
                        "baseline": "FPGA Kintex-7 268 MPixels/s (README.md:22)"},
