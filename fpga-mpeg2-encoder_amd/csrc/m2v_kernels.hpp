@@ -308,18 +308,16 @@ __device__ __forceinline__ MbDep mb_dependent(uint32_t info, const MbAux &aux, b
 // ----------------------------------------------------------------------------------------------
 // k_mb: one wavefront = one macroblock, stages A..T
 // ----------------------------------------------------------------------------------------------
-constexpr int kMbWaves = 1;           // macroblocks (independent wavefronts) per k_mb workgroup; 4 measured 16 % slower
-
 // One wavefront per workgroup: __syncthreads() lowers to "s_waitcnt lgkmcnt(0); wave barrier" (no s_barrier), which is
-// exactly the LDS write -> read ordering the phases need.  (A seq_cst wavefront fence also waits for vmcnt and costs 14 %.)
+// exactly the LDS write -> read ordering the phases need, and the static LDS base keeps every DS offset an immediate.
+// (Measured alternatives: 4 wavefronts per workgroup with per-wave LDS regions -16 %, a seq_cst wavefront fence -14 %.)
 #define M2V_WAVE_SYNC() __syncthreads()
-static_assert(kMbWaves == 1, "k_mb synchronises with __syncthreads(): its wavefronts must not share a workgroup");
 
 template <int VL, bool P>
-__global__ __launch_bounds__(64 * kMbWaves, 8) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
+__global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
                                            Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
                                            uint32_t *__restrict__ slots_small, uint32_t *__restrict__ slots,
-                                           int16_t *__restrict__ coef_dbg, uint32_t nblk)
+                                           int16_t *__restrict__ coef_dbg)
 {
     constexpr int UR = VL, YR = 2 * VL;
     constexpr int WROWS = 16 + 2 * YR;         // luma window rows -YR .. 16+YR-1 (RTL:1446)
@@ -345,7 +343,6 @@ __global__ __launch_bounds__(64 * kMbWaves, 8) void k_mb(const FrameJob *__restr
     const int lane = threadIdx.x;
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t strip_mbs = (uint32_t)((g.row1 - g.row0) * g.mbw);
-    (void)nblk;
     const int fidx = frame_list[blk / strip_mbs];
     const int mb = g.row0 * g.mbw + (int)(blk % strip_mbs);
     const int by = mb / g.mbw, bx = mb - by * g.mbw;

@@ -233,18 +233,17 @@ template <bool P>
 void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g)
 {
     if (count <= 0) return;
-    const uint32_t nblk = (uint32_t)((size_t)count * (size_t)(g.row1 - g.row0) * g.mbw);      // macroblocks = wavefronts
-    const dim3 grid((nblk + kMbWaves - 1) / kMbWaves), block(64 * kMbWaves);
+    const dim3 grid((unsigned)((size_t)count * (size_t)(g.row1 - g.row0) * g.mbw)), block(64);      // one wavefront per macroblock
     Timer t(e, s, P ? 0 : 1, (double)count * g.ysz);
     int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
     if (P) {
         switch (e->VL) {
-            case 1: hipLaunchKernelGGL((k_mb<1, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg, nblk); break;
-            case 2: hipLaunchKernelGGL((k_mb<2, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg, nblk); break;
-            default: hipLaunchKernelGGL((k_mb<3, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg, nblk); break;
+            case 1: hipLaunchKernelGGL((k_mb<1, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
+            case 2: hipLaunchKernelGGL((k_mb<2, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
+            default: hipLaunchKernelGGL((k_mb<3, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
         }
     } else {
-        hipLaunchKernelGGL((k_mb<1, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg, nblk);
+        hipLaunchKernelGGL((k_mb<1, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg);
     }
     HIPCHK(hipGetLastError());
     t.stop();
