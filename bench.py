@@ -122,7 +122,10 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
     dev = "cuda:%d" % local_rank
 
-    M.build()
+    if rank == 0 or world == 1:
+        M.build()                              # one rank compiles (if the library is stale at all); the others wait
+    if dist is not None:
+        dist.barrier()
     if args.mode == "strips":
         return bench_strips(args, M, torch, dist, rank, local_rank, world, dev)
     nframes = args.gops * (PFRAMES + 1)

@@ -28,17 +28,29 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "m2v_mi355x.h")]
     if force or _stale(LIB, deps):
-        cmd = [hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB, os.path.join(CSRC, "m2v_mi355x.hip")]
+        tmp = "%s.%d.tmp" % (LIB, os.getpid())            # atomic replace: concurrent ranks never see a half-written library
+        cmd = [hipcc()] + HIPCC_FLAGS + ["-shared", "-o", tmp, os.path.join(CSRC, "m2v_mi355x.hip")]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     tb_src = os.path.join(CSRC, "m2v_tb.cpp")
     if os.path.exists(tb_src) and (force or _stale(TB, [tb_src, LIB])):
-        cmd = [hipcc(), "-O2", "-std=c++17", "-o", TB, tb_src, "-L" + HERE, "-lm2v_mi355x",
+        tmp = "%s.%d.tmp" % (TB, os.getpid())
+        cmd = [hipcc(), "-O2", "-std=c++17", "-o", tmp, tb_src, "-L" + HERE, "-lm2v_mi355x",
                "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, TB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return LIB
 
 
