@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <vector>
@@ -73,10 +74,31 @@ struct m2v_enc {
     size_t frames_total = 0;      // frames of this sequence handed to the GPU so far
     bool first_chunk = true;
 
-    // host staging of incoming beats: planar 4:4:4 frames in pinned memory
-    uint8_t *h_in = nullptr;
-    size_t h_in_cap = 0;          // frames
-    size_t buffered = 0;          // complete frames waiting
+    // Host staging, double buffered: while the GPU works on the chunk submitted from one stage the caller
+    // fills the other one.  Each stage owns everything the host and the device touch asynchronously:
+    // the pinned frames, the pinned launch plan, the control read-back, the chunk's stream buffer.
+    struct HostStage {
+        uint8_t *h_in = nullptr;              // pinned planar 4:4:4 frames of the chunk being filled
+        size_t h_in_cap = 0;                  // bytes
+        StreamCtl *h_ctl = nullptr;           // pinned: [0] read-back, [1] initial values
+        FrameJob *h_jobs = nullptr;           // pinned staging of the per-frame jobs
+        size_t h_jobs_cap = 0;
+        int *h_lists = nullptr;               // pinned staging of the launch lists
+        size_t h_lists_cap = 0;
+        uint8_t *h_out = nullptr;             // pinned read-back buffer
+        size_t h_out_cap = 0;
+        DevBuf<uint8_t> d_out;                // chunk output when it goes to the host
+        hipEvent_t ev_ctl = nullptr, ev_out = nullptr;
+        int stage = 0;                        // 0 free, 1 encode submitted, 2 stream read-back submitted
+        bool last = false;
+        size_t bytes = 0;
+    } hs[2];
+    int cur = 0;                  // stage being filled by m2v_push_*
+    HostStage &st() { return hs[cur]; }
+    std::deque<int> pending;      // submitted stages, oldest first
+    bool async = true;            // option "async": 0 = every chunk is completed before m2v_push_* returns
+    hipStream_t copy_stream = nullptr;   // stream read-back, concurrent with the next chunk's kernels
+    size_t buffered = 0;          // complete frames waiting in st().h_in
     size_t beat_pos = 0;          // beats received of the frame in progress
     uint32_t last_frame_valid_beats = 0;   // for a black-filled last frame
 
@@ -87,7 +109,6 @@ struct m2v_enc {
 
     // device buffers
     DevBuf<uint8_t> d_in;                 // chunk input when it comes from the host
-    DevBuf<uint8_t> d_out;                // chunk output when it goes to the host
     DevBuf<int16_t> d_coef;               // debug only: quantised levels
     DevBuf<MbAux> d_mbaux;
     DevBuf<MbDepRec> d_mbdep;             // neighbour-dependent codes of every macroblock (k_slice_scan -> k_assemble)
@@ -102,14 +123,7 @@ struct m2v_enc {
     size_t rec_bytes = 0;
     size_t rec_pool_bytes = 0;            // allocation size of every buffer in rec_pool
     int persist_slot = -1;                // slot holding recon of the last encoded frame (GOP continues)
-    StreamCtl *h_ctl = nullptr;           // pinned
-    FrameJob *h_jobs = nullptr;           // pinned staging of the per-frame jobs
-    size_t h_jobs_cap = 0;
-    int *h_lists = nullptr;               // pinned staging of the launch lists
-    size_t h_lists_cap = 0;
     unsigned long long stream_bytes = 0;  // bytes of the current sequence already moved to the FIFO
-    uint8_t *h_out = nullptr;             // pinned readback buffer
-    size_t h_out_cap = 0;
 
     // plan of the chunk being encoded (plan_chunk -> run_step* -> finish_chunk)
     struct Step { int off_i, n_i, off_p, n_p, off_h, n_h; };
@@ -369,22 +383,22 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
     e->d_slice_off.ensure(nf * g.mbh);
     e->d_frame_off.ensure(nf + 1);
     // pinned staging: the caller synchronises the stream before the next chunk reuses it
-    if (e->h_jobs_cap < nf) {
-        if (e->h_jobs) (void)hipHostFree(e->h_jobs);
-        e->h_jobs = nullptr; e->h_jobs_cap = 0;
-        HIPCHK(hipHostMalloc((void **)&e->h_jobs, nf * sizeof(FrameJob)));
-        e->h_jobs_cap = nf;
+    if (e->st().h_jobs_cap < nf) {
+        if (e->st().h_jobs) (void)hipHostFree(e->st().h_jobs);
+        e->st().h_jobs = nullptr; e->st().h_jobs_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&e->st().h_jobs, nf * sizeof(FrameJob)));
+        e->st().h_jobs_cap = nf;
     }
-    if (e->h_lists_cap < lists.size()) {
-        if (e->h_lists) (void)hipHostFree(e->h_lists);
-        e->h_lists = nullptr; e->h_lists_cap = 0;
-        HIPCHK(hipHostMalloc((void **)&e->h_lists, lists.size() * sizeof(int)));
-        e->h_lists_cap = lists.size();
+    if (e->st().h_lists_cap < lists.size()) {
+        if (e->st().h_lists) (void)hipHostFree(e->st().h_lists);
+        e->st().h_lists = nullptr; e->st().h_lists_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&e->st().h_lists, lists.size() * sizeof(int)));
+        e->st().h_lists_cap = lists.size();
     }
-    memcpy(e->h_jobs, jobs.data(), nf * sizeof(FrameJob));
-    memcpy(e->h_lists, lists.data(), lists.size() * sizeof(int));
-    HIPCHK(hipMemcpyAsync(e->d_jobs.p, e->h_jobs, nf * sizeof(FrameJob), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(e->d_lists.p, e->h_lists, lists.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    memcpy(e->st().h_jobs, jobs.data(), nf * sizeof(FrameJob));
+    memcpy(e->st().h_lists, lists.data(), lists.size() * sizeof(int));
+    HIPCHK(hipMemcpyAsync(e->d_jobs.p, e->st().h_jobs, nf * sizeof(FrameJob), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->d_lists.p, e->st().h_lists, lists.size() * sizeof(int), hipMemcpyHostToDevice, s));
     e->plan_nf = nf;
     e->dbg_frames = nf;
     e->dbg_rec_slot = rec_slot;
@@ -447,8 +461,8 @@ __global__ void k_ctl_advance(StreamCtl *ctl)
 void ctl_init(m2v_enc *e, hipStream_t s, unsigned long long cap, unsigned long long prior = 0)
 {
     e->d_ctl.ensure(1);
-    if (!e->h_ctl) HIPCHK(hipHostMalloc((void **)&e->h_ctl, 2 * sizeof(StreamCtl)));   // [0] read-back, [1] initial values
-    StreamCtl *init = e->h_ctl + 1;
+    if (!e->st().h_ctl) HIPCHK(hipHostMalloc((void **)&e->st().h_ctl, 2 * sizeof(StreamCtl)));   // [0] read-back, [1] initial values
+    StreamCtl *init = e->st().h_ctl + 1;
     init->base_bytes = 0;
     init->total_bytes = 0;
     init->cap_bytes = cap & ~3ull;
@@ -460,8 +474,82 @@ void ctl_init(m2v_enc *e, hipStream_t s, unsigned long long cap, unsigned long l
 }
 
 // ---------------------------------------------------------------------------------------------
-// host-input path: flush the buffered frames through the GPU and append the bytes to the FIFO
+// host-input path: the buffered frames go through the GPU chunk by chunk; a chunk's bytes reach the FIFO
+// when its read-back completes.  Two host stages alternate so that the caller's next beats are copied
+// into pinned memory while the previous chunk is uploaded, encoded and read back.
 // ---------------------------------------------------------------------------------------------
+// start of a chunk on the port path: the bytes of the sequence that precede this chunk are the previous
+// chunk's prior + total (they are still in *ctl: one stream, in order); only the padding rule needs them
+__global__ void k_ctl_chain(StreamCtl *ctl, unsigned long long cap, int first)
+{
+    const unsigned long long prior = first ? 0ull : ctl->prior_bytes + ctl->total_bytes;
+    ctl->base_bytes = 0;
+    ctl->total_bytes = 0;
+    ctl->cap_bytes = cap & ~3ull;
+    ctl->prior_bytes = prior;
+    ctl->overflow = 0;
+    ctl->pad = 0;
+}
+
+void ensure_staging(m2v_enc *e)
+{
+    m2v_enc::HostStage &h = e->st();
+    const size_t want = e->batch_frames * (size_t)e->g.ysz * 3;
+    if (!h.h_ctl) HIPCHK(hipHostMalloc((void **)&h.h_ctl, 2 * sizeof(StreamCtl)));
+    if (!h.ev_ctl) HIPCHK(hipEventCreateWithFlags(&h.ev_ctl, hipEventDisableTiming));
+    if (!h.ev_out) HIPCHK(hipEventCreateWithFlags(&h.ev_out, hipEventDisableTiming));
+    if (h.h_in && h.h_in_cap >= want) return;
+    if (h.h_in) (void)hipHostFree(h.h_in);
+    h.h_in = nullptr;
+    h.h_in_cap = 0;
+    HIPCHK(hipHostMalloc((void **)&h.h_in, want));
+    h.h_in_cap = want;
+}
+
+// wait for (block) or poll an event; false = not reached yet
+bool event_reached(hipEvent_t ev, bool block)
+{
+    if (block) { HIPCHK(hipEventSynchronize(ev)); return true; }
+    const hipError_t r = hipEventQuery(ev);
+    if (r == hipErrorNotReady) return false;
+    HIPCHK(r);
+    return true;
+}
+
+// Move submitted chunks forward, oldest first.  block = wait for every step; until >= 0 = return as soon
+// as that stage is free again.
+void progress(m2v_enc *e, bool block, int until = -1)
+{
+    while (!e->pending.empty()) {
+        const int idx = e->pending.front();
+        m2v_enc::HostStage &h = e->hs[idx];
+        if (h.stage == 1) {
+            if (!event_reached(h.ev_ctl, block)) return;
+            if (h.h_ctl->overflow) throw HipError{hipErrorOutOfMemory, "stream larger than the worst-case bound"};
+            h.bytes = (size_t)h.h_ctl->total_bytes;
+            if (h.bytes > h.h_out_cap) {
+                if (h.h_out) (void)hipHostFree(h.h_out);
+                h.h_out = nullptr;
+                h.h_out_cap = 0;
+                HIPCHK(hipHostMalloc((void **)&h.h_out, h.bytes + 4096));
+                h.h_out_cap = h.bytes + 4096;
+            }
+            // the kernels that wrote d_out are complete (ev_ctl follows them): no cross-stream wait needed
+            HIPCHK(hipMemcpyAsync(h.h_out, h.d_out.p, h.bytes, hipMemcpyDeviceToHost, e->copy_stream));
+            HIPCHK(hipEventRecord(h.ev_out, e->copy_stream));
+            h.stage = 2;
+        }
+        if (!event_reached(h.ev_out, block)) return;
+        e->fifo.insert(e->fifo.end(), h.h_out, h.h_out + h.bytes);
+        e->stream_bytes += h.bytes;
+        if (h.last) e->end_pending = true;
+        h.stage = 0;
+        e->pending.pop_front();
+        if (idx == until) break;
+    }
+    if (e->pending.empty()) collect_timers(e);
+}
+
 void flush_buffered(m2v_enc *e, bool last)
 {
     const size_t nf = e->buffered;
@@ -471,6 +559,7 @@ void flush_buffered(m2v_enc *e, bool last)
     hipStream_t s = e->stream;
     if (nf == 0) {
         // stop arrived exactly on a frame boundary after an earlier flush: only the end code is owed
+        progress(e, true);
         static const uint8_t endc[4] = {0x00, 0x00, 0x01, 0xB7};          // RTL:2625-2628
         e->fifo.insert(e->fifo.end(), endc, endc + 4);
         e->stream_bytes += 4;
@@ -480,43 +569,32 @@ void flush_buffered(m2v_enc *e, bool last)
         e->end_pending = true;
         return;
     }
-    e->d_in.ensure(nf * frame_bytes);
-    HIPCHK(hipMemcpyAsync(e->d_in.p, e->h_in, nf * frame_bytes, hipMemcpyHostToDevice, s));
+    m2v_enc::HostStage &h = e->st();
+    e->d_in.ensure(nf * frame_bytes);       // one buffer: the upload of chunk k+1 queues behind the kernels of chunk k
+    HIPCHK(hipMemcpyAsync(e->d_in.p, h.h_in, nf * frame_bytes, hipMemcpyHostToDevice, s));
     // worst case ~1.2 KB per macroblock; typical streams are ~100x smaller
     const size_t cap = nf * ((size_t)g.mbs * 1216 + (size_t)g.mbh * 8 + 64) + 256;
-    e->d_out.ensure(cap);
-    ctl_init(e, s, cap, e->stream_bytes);
-    encode_chunk(e, s, e->d_in.p, nf, e->first_chunk, last, e->last_frame_valid_beats, e->d_out.p);
-    HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    collect_timers(e);
-    if (e->h_ctl->overflow) throw HipError{hipErrorOutOfMemory, "stream larger than the worst-case bound"};
-    const size_t bytes = (size_t)e->h_ctl->total_bytes;
-    if (bytes > e->h_out_cap) {
-        if (e->h_out) (void)hipHostFree(e->h_out);
-        e->h_out = nullptr;
-        e->h_out_cap = 0;
-        HIPCHK(hipHostMalloc((void **)&e->h_out, bytes + 4096));
-        e->h_out_cap = bytes + 4096;
-    }
-    HIPCHK(hipMemcpyAsync(e->h_out, e->d_out.p, bytes, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    e->fifo.insert(e->fifo.end(), e->h_out, e->h_out + bytes);
-    e->stream_bytes += bytes;
-    if (last) e->end_pending = true;
+    h.d_out.ensure(cap);
+    e->d_ctl.ensure(1);
+    hipLaunchKernelGGL(k_ctl_chain, dim3(1), dim3(1), 0, s, e->d_ctl.p, (unsigned long long)cap, e->first_chunk ? 1 : 0);
+    encode_chunk(e, s, e->d_in.p, nf, e->first_chunk, last, e->last_frame_valid_beats, h.d_out.p);
+    HIPCHK(hipMemcpyAsync(h.h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(h.ev_ctl, s));
+    h.stage = 1;
+    h.last = last;
+    e->pending.push_back(e->cur);
     e->buffered = 0;
     e->first_chunk = false;
-}
-
-void ensure_staging(m2v_enc *e)
-{
-    const size_t frame_bytes = (size_t)e->g.ysz * 3;
-    const size_t want = e->batch_frames;
-    if (e->h_in && e->h_in_cap >= want * frame_bytes) return;
-    if (e->h_in) (void)hipHostFree(e->h_in);
-    e->h_in = nullptr;
-    HIPCHK(hipHostMalloc((void **)&e->h_in, want * frame_bytes));
-    e->h_in_cap = want * frame_bytes;
+    if (!e->async || e->profile || last) {
+        // profile: the HIP-event timers of a chunk are read before the next one is queued
+        // last:    the caller pulls next; nothing is left to overlap with
+        progress(e, true);
+        return;
+    }
+    e->cur ^= 1;
+    if (e->st().stage != 0) progress(e, true, e->cur);     // the other stage must be free before it is refilled
+    ensure_staging(e);
+    progress(e, false);
 }
 
 void start_sequence(m2v_enc *e, uint32_t xs, uint32_t ys, uint32_t pf)
@@ -545,7 +623,7 @@ void do_stop(m2v_enc *e)
     const uint32_t bpf = g.ysz / 4;
     if (e->beat_pos != 0) {
         // black-fill the frame in progress (RTL:1036-1056)
-        uint8_t *f = e->h_in + e->buffered * (size_t)g.ysz * 3;
+        uint8_t *f = e->st().h_in + e->buffered * (size_t)g.ysz * 3;
         const size_t done = e->beat_pos * 4;
         memset(f + done, 0x00, g.ysz - done);
         memset(f + g.ysz + done, 0x80, g.ysz - done);
@@ -594,6 +672,7 @@ m2v_enc *m2v_create(int XL, int YL, int VECTOR_LEVEL, int Q_LEVEL, int device, i
     try {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
         upload_tables(device);
         HIPCHK(hipDeviceSynchronize());
     } catch (const HipError &h) {
@@ -610,23 +689,34 @@ void m2v_destroy(m2v_enc *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    e->d_in.release(); e->d_out.release(); e->d_coef.release(); e->d_mbaux.release(); e->d_mbdep.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
+    if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+    e->d_in.release(); e->d_coef.release(); e->d_mbaux.release(); e->d_mbdep.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
     e->d_mboff.release(); e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
     e->d_jobs.release(); e->d_lists.release(); e->d_ctl.release(); e->d_segs.release();
     for (auto p : e->rec_pool) (void)hipFree(p);
-    if (e->h_in) (void)hipHostFree(e->h_in);
-    if (e->h_out) (void)hipHostFree(e->h_out);
-    if (e->h_ctl) (void)hipHostFree(e->h_ctl);
-    if (e->h_jobs) (void)hipHostFree(e->h_jobs);
-    if (e->h_lists) (void)hipHostFree(e->h_lists);
+    for (auto &h : e->hs) {
+        h.d_out.release();
+        if (h.h_in) (void)hipHostFree(h.h_in);
+        if (h.h_out) (void)hipHostFree(h.h_out);
+        if (h.h_ctl) (void)hipHostFree(h.h_ctl);
+        if (h.h_jobs) (void)hipHostFree(h.h_jobs);
+        if (h.h_lists) (void)hipHostFree(h.h_lists);
+        if (h.ev_ctl) (void)hipEventDestroy(h.ev_ctl);
+        if (h.ev_out) (void)hipEventDestroy(h.ev_out);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     delete e;
 }
 
 int m2v_reset(m2v_enc *e)
 {
     if (!e) return M2V_E_PARAM;
+    (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+    for (auto &h : e->hs) h.stage = 0;
+    e->pending.clear();
     e->state = m2v_enc::IDLE;
     e->buffered = 0; e->beat_pos = 0; e->frames_total = 0; e->persist_slot = -1;
     e->fifo.clear(); e->fifo_rd = 0; e->end_pending = false;
@@ -657,7 +747,7 @@ static int push_beats_impl(m2v_enc *e, void *argp)
     const Geom &g = e->g;
     const size_t bpf = g.ysz / 4;
     while (i < a->n) {
-        uint8_t *f = e->h_in + e->buffered * (size_t)g.ysz * 3;
+        uint8_t *f = e->st().h_in + e->buffered * (size_t)g.ysz * 3;
         const size_t take = std::min(a->n - i, bpf - e->beat_pos);
         memcpy(f + e->beat_pos * 4, a->y + i * 4, take * 4);    // raster order: beat b = pixels 4b..4b+3
         memcpy(f + g.ysz + e->beat_pos * 4, a->u + i * 4, take * 4);
@@ -671,6 +761,7 @@ static int push_beats_impl(m2v_enc *e, void *argp)
         }
     }
     if (a->stop) do_stop(e);
+    else progress(e, false);
     return M2V_OK;
 }
 
@@ -696,10 +787,11 @@ static int push_frames_impl(m2v_enc *e, void *argp)
         return M2V_E_STATE;
     }
     for (size_t k = 0; k < a->n; ++k) {
-        memcpy(e->h_in + e->buffered * fb, a->frames + k * fb, fb);
+        memcpy(e->st().h_in + e->buffered * fb, a->frames + k * fb, fb);
         e->buffered++;
         if (e->buffered == e->batch_frames) flush_buffered(e, false);
     }
+    progress(e, false);
     return M2V_OK;
 }
 
@@ -725,10 +817,21 @@ int m2v_sequence_stop(m2v_enc *e)
 
 int m2v_busy(const m2v_enc *e) { return e && e->state != m2v_enc::IDLE; }
 
+static int pull_progress_impl(m2v_enc *e, void *)
+{
+    // chunks still in flight: take what is complete; once the sequence has been stopped wait for the rest
+    progress(e, e->state == m2v_enc::ENDED);
+    return M2V_OK;
+}
+
 long long m2v_pull(m2v_enc *e, uint8_t *dst, size_t cap, int *last)
 {
     if (!e || (!dst && cap)) return M2V_E_PARAM;
     if (last) *last = 0;
+    if (!e->pending.empty()) {
+        const int r = guard(e, pull_progress_impl, nullptr);
+        if (r < 0) return r;
+    }
     const size_t avail = e->fifo.size() - e->fifo_rd;
     // only whole 32-byte words leave; the residue waits for more data or for the end of the sequence
     size_t n = std::min(avail, cap) & ~(size_t)31;
@@ -774,11 +877,11 @@ static int resident_impl(m2v_enc *e, void *argp)
         hipLaunchKernelGGL(k_ctl_advance, dim3(1), dim3(1), 0, s, e->d_ctl.p);
         if (!last) HIPCHK(hipStreamSynchronize(s));    // the per-chunk work buffers are reused
     }
-    HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     collect_timers(e);
-    if (e->h_ctl->overflow) { e->set_err("output buffer too small"); return M2V_E_OVERFLOW; }
-    if (a->bytes) *a->bytes = (size_t)e->h_ctl->total_bytes;
+    if (e->st().h_ctl->overflow) { e->set_err("output buffer too small"); return M2V_E_OVERFLOW; }
+    if (a->bytes) *a->bytes = (size_t)e->st().h_ctl->total_bytes;
     return M2V_OK;
 }
 
@@ -887,14 +990,14 @@ static int strip_finish_impl(m2v_enc *e, void *argp)
     const size_t nf = e->plan_nf;
     ctl_init(e, s, a->cap);
     finish_chunk(e, s, false, false, a->d_strip);
-    HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipMemcpy(a->frame_off, e->d_frame_off.p, (nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     collect_timers(e);
     e->strip_active = false;
     Geom full = e->g; full.row0 = 0; full.row1 = full.mbh; full.strip = 0;
     e->g = full;
-    if (e->h_ctl->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
+    if (e->st().h_ctl->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
     return M2V_OK;
 }
 
@@ -973,6 +1076,7 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
         return M2V_OK;
     }
     if (!strcmp(name, "profile")) { e->profile = value != 0; return M2V_OK; }
+    if (!strcmp(name, "async")) { e->async = value != 0; return M2V_OK; }
     if (!strcmp(name, "keep_recon")) { e->keep_recon = value != 0; return M2V_OK; }
     if (!strcmp(name, "ablate")) { e->ablate = (int)value; return M2V_OK; }   // profiling aid: output is invalid when != 0
     return M2V_E_PARAM;

@@ -80,8 +80,9 @@ int m2v_busy(const m2v_enc *e);
  * Stream output: `o_en` / `o_data[255:0]` / `o_last` (RTL:35-37, 2961-2994).  Copies up to
  * cap/32 whole 32-byte words, byte 0 = o_data[7:0], in stream order; returns the byte count.
  * *last (optional) is set to 1 when the returned data ends with the o_last word; the encoder is
- * idle again after that.  Encoding work is flushed as needed (GPU work is batched by GOP and may
- * run ahead of the caller).
+ * idle again after that.  GPU work is batched in chunks of "batch_frames" frames and runs asynchronously:
+ * before the stop, m2v_pull returns the words of the chunks that are complete (possibly none) without
+ * waiting; after the stop it waits for the rest.
  */
 long long m2v_pull(m2v_enc *e, uint8_t *dst, size_t cap, int *last);
 
@@ -134,7 +135,10 @@ int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t 
                        size_t *out_bytes, void *hip_stream);
 
 /* Options: "batch_frames" (frames buffered before the GPU is kicked, default 96),
- * "profile" (1 = time the per-kernel launches with HIP events). */
+ * "profile" (1 = time the per-kernel launches with HIP events),
+ * "async" (default 1: the port path keeps two chunks in flight - while one chunk is uploaded, encoded and
+ * read back, m2v_push_* fills the pinned staging of the next one; 0 = a chunk is complete when the push
+ * that filled it returns.  The bytes are the same either way). */
 int m2v_set_option(m2v_enc *e, const char *name, long long value);
 
 /* Per-kernel statistics of the last m2v_encode_resident call with "profile" = 1.

@@ -139,3 +139,51 @@ def test_pull_granularity(env):
         assert out == want and lasts.count(True) == 1
     finally:
         enc.close()
+
+
+@pytest.mark.parametrize("use_async", [1, 0])
+def test_double_buffered_chunks_with_interleaved_pulls(env, use_async):
+    """The port path keeps up to two chunks in flight (option "async"); pulling while frames are still being
+    pushed returns whatever is complete, in stream order, and the bytes do not depend on the overlap."""
+    M, orc = env
+    W, H, n, pf = 192, 128, 23, 5
+    clip = M.synth.clip(W, H, n, clip_index=36)
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, 2, 2)
+    enc = M.Mpeg2Encoder(7, 7, 2, 2)
+    try:
+        enc.set_option("batch_frames", 4)
+        enc.set_option("async", use_async)
+        out = b""
+        early = 0
+        for k in range(0, n, 3):                                   # pushes that do not line up with the chunks
+            enc.push_frames(W // 16, H // 16, pf, clip[k:k + 3])
+            b, last = enc.pull(1 << 20)
+            assert not last and len(b) % 32 == 0
+            early += len(b)
+            out += b
+        assert enc.busy
+        enc.sequence_stop()
+        while True:
+            b, last = enc.pull(4096)
+            out += b
+            if last:
+                break
+        assert out == want
+        assert not enc.busy
+        if not use_async:
+            assert early > 0                                       # synchronous chunks are complete when push returns
+        # the same handle, next sequence, beat interface across the stage flip
+        y, u, v = beats_of(clip[:9])
+        want2 = orc.encode(clip[:9], W // 16, H // 16, 2, 7, 7, 2, 2)
+        step = 4 * 1237
+        for o in range(0, y.size, step):
+            enc.push_beats(W // 16, H // 16, 2, y[o:o + step], u[o:o + step], v[o:o + step], stop_with_last=(o + step >= y.size))
+        got2 = b""
+        while True:
+            b, last = enc.pull(1 << 16)
+            got2 += b
+            if last:
+                break
+        assert got2 == want2
+    finally:
+        enc.close()
