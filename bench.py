@@ -44,6 +44,38 @@ def cpu_baseline(frames_np, gpu_stream_bytes):
                        % (n, n - 1, dt)), identical, body
 
 
+def cpu_baseline_all_cores(frames_np):
+    """SURVEY.md 8(d) baseline (2), 'all cores, one GOP per thread': closed GOPs are independent, so a CPU encoder
+    scales by giving every core its own GOP.  Every thread encodes the same GOP here (ctypes drops the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import m2v_oracle_ctypes as orc
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    n = frames_np.shape[0]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        outs = list(ex.map(lambda _: len(orc.encode(frames_np, XS16, YS16, PFRAMES, XL, YL, VL, Q)), range(threads)))
+    dt = time.perf_counter() - t0
+    assert len(set(outs)) == 1
+    return dict(value=round(threads * n * W * H / dt * 1e-6, 3), unit="MPixels/s", cores=threads, kind="port",
+                sample="%d threads, each one GOP (%d frames) of the benchmark clip, %.1f s" % (threads, n, dt))
+
+
+def hbm_copy_rate(torch, dev):
+    """Achievable HBM bandwidth of this device with a plain device-to-device copy (read + write bytes), GB/s."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 10 * 2.0 * n / (e0.elapsed_time(e1) * 1e-3) * 1e-9
+
+
 def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
     """Config c5: one 2048x2048 (XL=YL=7) I+P sequence, 128 macroblock rows cut into `world` strips; the +-6 luma /
     +-3 chroma reference rows cross xGMI once per GOP step (fpga-mpeg2-encoder_amd/parallel.py)."""
@@ -53,7 +85,7 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
     enc = M.Mpeg2Encoder(7, 7, VL, Q, device=local_rank)
     eng = M.parallel.GpuStripEngine(enc, clip, 128, 128, PFRAMES, dev)
     out = None
-    for _ in range(args.warmup):
+    for _ in range((20 if args.prewarm > 0 else 0) + args.warmup):     # fixed count: every rank takes part in the halo exchange
         out = M.parallel.encode_strips(eng, rank, world, dist)
     torch.cuda.synchronize()
     if dist is not None:
@@ -90,10 +122,13 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gops", type=int, default=GOPS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm", type=float, default=1.5,
+                    help="seconds of untimed encoder steps BEFORE the W warmup steps: a step is ~2 ms, far shorter than the "
+                         "GPU's clock ramp out of its idle state (sclk 312 MHz), so a cold start would time the ramp")
     ap.add_argument("--ablate", type=int, default=0, help="profiling aid: skip kernel phases (output invalid), see Geom::ablate")
     ap.add_argument("--mode", choices=["sequences", "strips"], default="sequences",
                     help="sequences (default): config c3 / c4, one 1920x1152 sequence per GPU, no collective; "
@@ -141,6 +176,9 @@ def main():
     def step():
         return enc.encode_resident(clip.data_ptr(), nframes, d_out.data_ptr(), cap, XS16, YS16, PFRAMES, stream)
 
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm:      # wake the device: not counted, not timed
+        step()
     for _ in range(args.warmup):
         nbytes = step()
     enc.set_option("profile", 1)       # HIP events around every kernel launch, on the launch stream
@@ -211,6 +249,10 @@ def main():
             gpu_bytes = d_out[:nbytes].cpu().numpy().tobytes()
             cb, identical, body = cpu_baseline(gop0, gpu_bytes)
             out["cpu_baseline"] = cb
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(gop0)
+            copy = hbm_copy_rate(torch, dev)
+            out["roofline"]["hbm_copy_measured"] = round(copy, 1)
+            out["roofline"]["frac_of_measured_copy"] = round(achieved / copy, 5) if copy > 0 else None
             out["parity_check"] = {"first_gop_bytes": body, "identical_to_oracle": bool(identical)}
         print(json.dumps(out))
         sys.stdout.flush()

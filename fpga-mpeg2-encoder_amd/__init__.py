@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libm2v_mi355x.so")
 _lib = None
 
 EXPORTS = [
-    "m2v_version", "m2v_create", "m2v_destroy", "m2v_reset", "m2v_push_beats", "m2v_push_frames",
+    "m2v_version", "m2v_create", "m2v_destroy", "m2v_reset", "m2v_push_beats", "m2v_push_packed", "m2v_push_frames",
     "m2v_sequence_stop", "m2v_busy", "m2v_pull", "m2v_geometry", "m2v_encode_resident", "m2v_set_option",
     "m2v_kernel_stats", "m2v_debug_read", "m2v_last_error",
     "m2v_strip_begin", "m2v_strip_info", "m2v_strip_step", "m2v_strip_halo_in", "m2v_strip_finish", "m2v_strip_assemble",
@@ -53,6 +53,7 @@ def lib():
         L.m2v_destroy.argtypes = [vp]
         L.m2v_reset.argtypes = [vp]
         L.m2v_push_beats.argtypes = [vp, u32, u32, u32, vp, vp, vp, sz, ci]
+        L.m2v_push_packed.argtypes = [vp, u32, u32, u32, vp, sz, ci, ci]
         L.m2v_push_frames.argtypes = [vp, u32, u32, u32, vp, sz]
         L.m2v_sequence_stop.argtypes = [vp]
         L.m2v_busy.argtypes = [vp]
@@ -129,6 +130,16 @@ class Mpeg2Encoder:
         assert y4.size == u4.size == v4.size and y4.size % 4 == 0
         self._chk(self._L.m2v_push_beats(self._h, xsize16, ysize16, pframes_count, y4.ctypes.data, u4.ctypes.data,
                                          v4.ctypes.data, y4.size // 4, int(bool(stop_with_last))), "m2v_push_beats")
+
+    PACKED = {"yuv24": (0, 3), "uyv24": (1, 3), "yuvx32": (2, 4), "ayuv32": (3, 4)}
+
+    def push_packed(self, xsize16, ysize16, pframes_count, pixels, layout="yuv24", stop_with_last=False):
+        """pixels: packed 4:4:4 samples in raster order ([..., bytes_per_pixel] uint8), a multiple of 4 pixels."""
+        code, bpp = self.PACKED[layout]
+        p = np.ascontiguousarray(pixels, np.uint8).reshape(-1)
+        assert p.size % (4 * bpp) == 0
+        self._chk(self._L.m2v_push_packed(self._h, xsize16, ysize16, pframes_count, p.ctypes.data, p.size // (4 * bpp),
+                                          code, int(bool(stop_with_last))), "m2v_push_packed")
 
     def push_frames(self, xsize16, ysize16, pframes_count, frames444):
         W, H = self.geometry(xsize16, ysize16)

@@ -839,10 +839,14 @@ __global__ __launch_bounds__(128) void k_slice_scan(const FrameJob *__restrict__
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_assemble: one wavefront per macroblock: [slice header] p1 A p2 B p3 C, MSB first, merged into the stream
-// at its final bit position; only the two boundary words of a macroblock use atomics.
-// Common case (<= 1024 stored bits, compact slot): lane k builds stream word k directly in registers from the
-// pieces that overlap it - no LDS, no barrier.  Rare large macroblocks take the LDS path.
+// k_assemble: one workgroup per slice, one LANE per 32-bit word of the stream (gather).  A slice is
+// [slice header] then per macroblock p1 A p2 B p3 C, MSB first.  The per-macroblock piece table of the slice
+// (bit offsets from k_slice_scan, the neighbour-dependent codes, the segment lengths) is staged in LDS once;
+// each lane then finds the macroblock that holds the first bit of its word (binary search), walks the
+// macroblocks that overlap the word (1-2 typically) and ORs in the overlapping bits of every piece, reading
+// the stored segments straight from the slot the macroblock kernel wrote (compact or overflow slot - same
+// code).  Slices are byte aligned, not word aligned: only the first and the last word of a slice can be
+// shared with a neighbour (previous slice, headers) and use atomics; everything else is a plain store.
 // ----------------------------------------------------------------------------------------------
 // bits of a left-aligned 32-bit code `c32` (length l) placed at bit offset `o`, seen through the window [r0, r0+32)
 __device__ __forceinline__ uint32_t window_code(uint32_t c32, int l, int o, int r0)
@@ -852,114 +856,86 @@ __device__ __forceinline__ uint32_t window_code(uint32_t c32, int l, int o, int 
     return rel >= 0 ? (c32 >> rel) : (c32 << (-rel));
 }
 
-constexpr int kAsmWaves = 4;          // macroblocks (wavefronts) per k_assemble workgroup
+constexpr int kAsmThreads = 256;
 
-__global__ __launch_bounds__(64 * kAsmWaves) void k_assemble(const FrameJob *__restrict__ jobs, Geom g, int nframes,
+__global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__restrict__ jobs, Geom g, int nframes,
                                                  const MbAux *__restrict__ mbaux, const MbDepRec *__restrict__ mbdep,
                                                  const uint32_t *__restrict__ slots_small, const uint32_t *__restrict__ slots,
                                                  const uint32_t *__restrict__ mb_len, const uint32_t *__restrict__ mb_bitoff,
                                                  const unsigned long long *__restrict__ slice_off,
                                                  uint32_t *__restrict__ out32, const StreamCtl *__restrict__ ctl)
 {
-    __shared__ uint32_t s_bits_all[kAsmWaves][kSlotWords + 8];   // only large macroblocks use it; one region per wavefront
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t *const s_bits = s_bits_all[wv];
-    const uint32_t blk = blockIdx.x * kAsmWaves + wv;
-    const uint32_t strip_mbs = (uint32_t)((g.row1 - g.row0) * g.mbw);
-    const int f = (int)(blk / strip_mbs), mb = g.row0 * g.mbw + (int)(blk % strip_mbs);
+    __shared__ uint32_t s_off[129];                       // bit offset of every macroblock in the slice, [mbw] = slice bits
+    __shared__ uint32_t s_c1[128], s_c2[128], s_c3[128];  // neighbour-dependent codes
+    __shared__ uint32_t s_lens[128];                      // l1 | l2 << 8 | l3 << 16
+    __shared__ uint32_t s_lab[128], s_lc[128];            // lenA | lenB << 16, lenC
+    const int tid = threadIdx.x;
+    const int rows = g.row1 - g.row0;
+    const int f = blockIdx.x / rows, by = g.row0 + (int)(blockIdx.x % rows);
     if (f >= nframes) return;
-    const int by = mb / g.mbw, bx = mb - by * g.mbw;
-    const size_t idx = (size_t)f * g.mbs + mb;
-
-    // every load is independent of the others: issue them all, then wait once (the kernel is latency bound)
-    const uint32_t spec = lane < kSmallSlotWords ? slots_small[idx * kSmallSlotWords + lane] : 0u;
-    const MbAux aux = mbaux[idx];
-    const MbDepRec dep = mbdep[idx];
-    const uint32_t total = mb_len[idx];
-    const unsigned long long q = (ctl->base_bytes + slice_off[(size_t)f * g.mbh + by]) * 8ull + mb_bitoff[idx];
-    if (ctl->overflow) return;
-
-    const uint32_t lenA = aux.w0 & 0xFFFFu, lenB = aux.w0 >> 16, lenC = aux.w1 & 0xFFFFu;
-    const int l1 = (int)(dep.lens & 255u), l2 = (int)((dep.lens >> 8) & 255u), l3 = (int)((dep.lens >> 16) & 255u);
-    const int hdr = bx == 0 ? 38 : 0;            // slice header: start code, slice_vertical_position, quantiser_scale_code, extra_bit_slice (RTL:2708-2710)
-    const uint32_t sh = (uint32_t)(q & 31ull);
+    const size_t base = ((size_t)f * g.mbh + by) * g.mbw;
+    if (tid < g.mbw) {
+        const MbAux aux = mbaux[base + tid];
+        const MbDepRec dep = mbdep[base + tid];
+        const uint32_t off = mb_bitoff[base + tid];
+        s_off[tid] = off;
+        if (tid == g.mbw - 1) s_off[g.mbw] = off + mb_len[base + tid];
+        s_c1[tid] = dep.c1; s_c2[tid] = dep.c2; s_c3[tid] = dep.c3; s_lens[tid] = dep.lens;
+        s_lab[tid] = aux.w0; s_lc[tid] = aux.w1 & 0xFFFFu;
+    }
+    const unsigned long long q = (ctl->base_bytes + slice_off[(size_t)f * g.mbh + by]) * 8ull;
+    const bool overflow = ctl->overflow != 0;
+    __syncthreads();
+    if (overflow) return;
+    const int sh = (int)(q & 31ull);
     const unsigned long long w0 = q >> 5;
-    const uint32_t nout = (sh + total + 31u) / 32u;
-    const bool small = ((lenA + lenB + lenC + 31u) >> 5) <= (uint32_t)kSmallSlotWords;
+    const uint32_t total = s_off[g.mbw];
+    const uint32_t nout = ((uint32_t)sh + total + 31u) / 32u;
 
-    if (small) {
-        // piece offsets relative to the first bit of the macroblock
-        const int o1 = hdr, oA = o1 + l1, o2 = oA + (int)lenA, oB = o2 + l2, o3 = oB + (int)lenB, oC = o3 + l3;
-        const int r0 = 32 * lane - (int)sh;                    // this lane's stream word as a window in those coordinates
-        uint32_t word = 0;
-        if (hdr) {
-            word |= window_code(0x000001u << 8, 24, 0, r0);
-            word |= window_code((((uint32_t)(by + 1) << 6) | (2u << g.Q)) << 18, 14, 24, r0);
+    for (uint32_t k = tid; k < nout; k += kAsmThreads) {
+        const int r0 = 32 * (int)k - sh;                  // this word as a window in slice bit coordinates
+        const uint32_t p = r0 < 0 ? 0u : (uint32_t)r0;
+        int lo = 0, hi = g.mbw - 1;                       // largest m with s_off[m] <= p
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= p) lo = mid; else hi = mid - 1;
         }
-        word |= window_code(l1 ? dep.c1 << (32 - l1) : 0u, l1, o1, r0);
-        word |= window_code(l2 ? dep.c2 << (32 - l2) : 0u, l2, o2, r0);
-        word |= window_code(l3 ? dep.c3 << (32 - l3) : 0u, l3, o3, r0);
-        const int segoff[3] = {oA, oB, oC}, seglen[3] = {(int)lenA, (int)lenB, (int)lenC};
-        const int segsrc[3] = {0, (int)lenA, (int)(lenA + lenB)};
+        uint32_t word = 0;
+        for (int m = lo; m < g.mbw && (int)s_off[m] < r0 + 32; ++m) {
+            const int r = r0 - (int)s_off[m];             // window start relative to the first bit of macroblock m
+            const uint32_t lens = s_lens[m], lab = s_lab[m];
+            const int l1 = (int)(lens & 255u), l2 = (int)((lens >> 8) & 255u), l3 = (int)((lens >> 16) & 255u);
+            const int lenA = (int)(lab & 0xFFFFu), lenB = (int)(lab >> 16), lenC = (int)s_lc[m];
+            int o1 = 0;
+            if (m == 0) {
+                // slice header: start code, slice_vertical_position, quantiser_scale_code, extra_bit_slice (RTL:2708-2710)
+                word |= window_code(0x000001u << 8, 24, 0, r);
+                word |= window_code((((uint32_t)(by + 1) << 6) | (2u << g.Q)) << 18, 14, 24, r);
+                o1 = 38;
+            }
+            const int oA = o1 + l1, o2 = oA + lenA, oB = o2 + l2, o3 = oB + lenB, oC = o3 + l3;
+            word |= window_code(l1 ? s_c1[m] << (32 - l1) : 0u, l1, o1, r);
+            word |= window_code(l2 ? s_c2[m] << (32 - l2) : 0u, l2, o2, r);
+            word |= window_code(l3 ? s_c3[m] << (32 - l3) : 0u, l3, o3, r);
+            const bool small = ((uint32_t)(lenA + lenB + lenC + 31) >> 5) <= (uint32_t)kSmallSlotWords;
+            const uint32_t *slot = small ? slots_small + (base + m) * kSmallSlotWords : slots + (base + m) * kSlotWords;
+            const int segoff[3] = {oA, oB, oC}, seglen[3] = {lenA, lenB, lenC}, segsrc[3] = {0, lenA, lenA + lenB};
 #pragma unroll
-        for (int sgm = 0; sgm < 3; ++sgm) {
-            const int n = seglen[sgm], t = r0 - segoff[sgm];   // window start in segment coordinates
-            const int tt = t < 0 ? 0 : t;
-            int src = segsrc[sgm] + tt;
-            src = src > 1023 ? 1023 : src;                      // keeps the cross-lane index in range for lanes with no overlap
-            const uint32_t a0 = (uint32_t)__shfl((int)spec, src >> 5, 64);
-            const uint32_t a1 = (uint32_t)__shfl((int)spec, (src >> 5) + 1 > 31 ? 31 : (src >> 5) + 1, 64);
-            const uint32_t sb = (uint32_t)src & 31u;
-            uint32_t w = sb ? ((a0 << sb) | (a1 >> (32u - sb))) : a0;
-            const int valid = n - tt;                           // bits of the segment left from tt on
-            if (n > 0 && t > -32 && valid > 0) {
-                if (valid < 32) w &= ~0u << (32 - valid);
-                word |= t < 0 ? (w >> (-t)) : w;
+            for (int sgm = 0; sgm < 3; ++sgm) {
+                const int n = seglen[sgm], t = r - segoff[sgm];           // window start in segment coordinates
+                const int tt = t < 0 ? 0 : t;
+                const int valid = n - tt;                                 // bits of the segment left from tt on
+                if (t > -32 && valid > 0) {
+                    const int src = segsrc[sgm] + tt;
+                    const uint32_t a0 = slot[src >> 5], a1 = slot[(src >> 5) + 1];   // +1: slots are padded by one word
+                    const uint32_t sb = (uint32_t)src & 31u;
+                    uint32_t w = sb ? ((a0 << sb) | (a1 >> (32u - sb))) : a0;
+                    if (valid < 32) w &= ~0u << (32 - valid);
+                    word |= t < 0 ? (w >> (-t)) : w;
+                }
             }
         }
-        if ((uint32_t)lane < nout) {
-            const uint32_t be = __builtin_bswap32(word);
-            if (lane == 0 || (uint32_t)lane == nout - 1) { if (be) atomicOr(&out32[w0 + lane], be); }
-            else out32[w0 + lane] = be;
-        }
-        return;
-    }
-
-    // ---- large macroblock: assemble in LDS, then merge with a funnel shift ----
-    const uint32_t nwords = (total + 31u) / 32u + 1u;
-    for (uint32_t k = lane; k < nwords; k += 64) s_bits[k] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // one wavefront owns this LDS region: program order suffices
-    uint32_t pos = 0;
-    if (bx == 0) {
-        if (lane == 0) {
-            lds_put(s_bits, 0, 0x000001u, 24);
-            lds_put(s_bits, 24, ((uint32_t)(by + 1) << 6) | (2u << g.Q), 14);
-        }
-        pos = 38;
-    }
-    const uint32_t *slot = slots + idx * kSlotWords;
-    const uint32_t plen[3] = {(uint32_t)l1, (uint32_t)l2, (uint32_t)l3}, pcode[3] = {dep.c1, dep.c2, dep.c3};
-    const uint32_t slen[3] = {lenA, lenB, lenC}, soff[3] = {0u, lenA, lenA + lenB};
-#pragma unroll
-    for (int sgm = 0; sgm < 3; ++sgm) {
-        if (lane == 0) lds_put(s_bits, pos, pcode[sgm], plen[sgm]);
-        pos += plen[sgm];
-        const uint32_t n = slen[sgm], nw = (n + 31u) >> 5;
-        const uint32_t sw = soff[sgm] >> 5, sb = soff[sgm] & 31u;
-        for (uint32_t j = lane; j < nw; j += 64) {
-            const uint32_t a0 = slot[sw + j], a1 = slot[sw + j + 1];      // slot has kSlotWords >= 292 + 2 words
-            const uint32_t w = sb ? ((a0 << sb) | (a1 >> (32u - sb))) : a0;
-            const uint32_t valid = n - 32u * j < 32u ? n - 32u * j : 32u;
-            lds_put(s_bits, pos + 32u * j, w >> (32u - valid), valid);
-        }
-        pos += n;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    for (uint32_t k = lane; k < nout; k += 64) {
-        const uint32_t hi = k ? s_bits[k - 1] : 0u;
-        const uint32_t lo = k < nwords ? s_bits[k] : 0u;
-        const uint32_t val = sh ? ((hi << (32u - sh)) | (lo >> sh)) : lo;
-        const uint32_t be = __builtin_bswap32(val);
+        const uint32_t be = __builtin_bswap32(word);
         if (k == 0 || k == nout - 1) { if (be) atomicOr(&out32[w0 + k], be); }
         else out32[w0 + k] = be;
     }

@@ -374,8 +374,8 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
     if (e->keep_recon) e->d_coef.ensure(nmb * 384);
     e->d_mbaux.ensure(nmb);
     e->d_mbdep.ensure(nmb);
-    e->d_slots.ensure(nmb * (size_t)kSlotWords);
-    e->d_slots_small.ensure(nmb * (size_t)kSmallSlotWords);
+    e->d_slots.ensure(nmb * (size_t)kSlotWords + 8);
+    e->d_slots_small.ensure(nmb * (size_t)kSmallSlotWords + 8);      // k_assemble reads one word past a segment's last word
     e->d_mbinfo.ensure(nmb);
     e->d_mblen.ensure(nmb);
     e->d_mboff.ensure(nmb);
@@ -435,7 +435,7 @@ void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_s
     }
     {
         Timer t(e, s, 3, (double)nf * g.ysz);
-        hipLaunchKernelGGL(k_assemble, dim3((unsigned)((nf * rows * g.mbw + kAsmWaves - 1) / kAsmWaves)), dim3(64 * kAsmWaves), 0, s, e->d_jobs.p, g, (int)nf,
+        hipLaunchKernelGGL(k_assemble, dim3((unsigned)(nf * rows)), dim3(kAsmThreads), 0, s, e->d_jobs.p, g, (int)nf,
                            e->d_mbaux.p, e->d_mbdep.p, e->d_slots_small.p, e->d_slots.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_off.p,
                            (uint32_t *)d_stream, e->d_ctl.p);
         HIPCHK(hipGetLastError());
@@ -771,6 +771,42 @@ int m2v_push_beats(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pfra
     if (!e || (nbeats && (!y4 || !u4 || !v4))) return M2V_E_PARAM;
     PushBeatsArgs a{xsize16, ysize16, pframes_count, y4, u4, v4, nbeats, stop_with_last};
     return guard(e, push_beats_impl, &a);
+}
+
+// Packed 4:4:4 sources (capture cards, SDI/HDMI receivers hand out interleaved samples): the same beats, the
+// twelve port bytes of a beat simply arrive interleaved instead of on three arrays.
+int m2v_push_packed(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const uint8_t *pixels,
+                    size_t nbeats, int layout, int stop_with_last)
+{
+    if (!e || (nbeats && !pixels)) return M2V_E_PARAM;
+    int stride, oy, ou, ov;
+    switch (layout) {
+    case M2V_PACKED_YUV24: stride = 3; oy = 0; ou = 1; ov = 2; break;
+    case M2V_PACKED_UYV24: stride = 3; oy = 1; ou = 0; ov = 2; break;
+    case M2V_PACKED_YUVX32: stride = 4; oy = 0; ou = 1; ov = 2; break;
+    case M2V_PACKED_AYUV32: stride = 4; oy = 1; ou = 2; ov = 3; break;
+    default: e->set_err("m2v_push_packed: unknown layout %d", layout); return M2V_E_PARAM;
+    }
+    constexpr size_t kBlock = 4096;                     // beats per de-interleave block (48 KB of planar data: stays in L1/L2)
+    uint8_t y[kBlock * 4], u[kBlock * 4], v[kBlock * 4];
+    if (nbeats == 0) {
+        PushBeatsArgs a{xsize16, ysize16, pframes_count, y, u, v, 0, stop_with_last};
+        return guard(e, push_beats_impl, &a);
+    }
+    for (size_t done = 0; done < nbeats;) {
+        const size_t nb = std::min(kBlock, nbeats - done);
+        const uint8_t *src = pixels + done * 4 * (size_t)stride;
+        for (size_t i = 0; i < nb * 4; ++i) {
+            y[i] = src[i * stride + oy];
+            u[i] = src[i * stride + ou];
+            v[i] = src[i * stride + ov];
+        }
+        done += nb;
+        PushBeatsArgs a{xsize16, ysize16, pframes_count, y, u, v, nb, (stop_with_last && done == nbeats) ? 1 : 0};
+        const int r = guard(e, push_beats_impl, &a);
+        if (r < 0) return r;
+    }
+    return M2V_OK;
 }
 
 struct PushFramesArgs { uint32_t xs, ys, pf; const uint8_t *frames; size_t n; };

@@ -62,6 +62,20 @@ int m2v_push_beats(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pfra
                    int stop_with_last);
 
 /*
+ * The same beats from a packed 4:4:4 source: `pixels` holds nbeats*4 pixels in raster order, each pixel
+ * `layout` bytes wide (the twelve port bytes i_Y0..3/i_U0..3/i_V0..3 of RTL:25-28, interleaved the way
+ * capture hardware delivers them).  Everything else as m2v_push_beats.
+ */
+enum {
+    M2V_PACKED_YUV24  = 0,   /* Y U V            3 bytes per pixel */
+    M2V_PACKED_UYV24  = 1,   /* U Y V            3 bytes per pixel */
+    M2V_PACKED_YUVX32 = 2,   /* Y U V x          4 bytes per pixel, 4th ignored */
+    M2V_PACKED_AYUV32 = 3    /* A Y U V          4 bytes per pixel, 1st ignored */
+};
+int m2v_push_packed(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
+                    const uint8_t *pixels, size_t nbeats, int layout, int stop_with_last);
+
+/*
  * Convenience = nframes * W*H/4 beats from planar frames laid out like the testbench's files
  * (Y plane, U plane, V plane per frame, each W*H bytes; SIM/tb_mpeg2encoder.v:210-234).
  * W,H are the CLAMPED sizes (m2v_geometry).

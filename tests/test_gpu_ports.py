@@ -187,3 +187,25 @@ def test_double_buffered_chunks_with_interleaved_pulls(env, use_async):
         assert got2 == want2
     finally:
         enc.close()
+
+
+@pytest.mark.parametrize("layout", ["yuv24", "uyv24", "yuvx32", "ayuv32"])
+def test_packed_444_layouts(env, layout):
+    """m2v_push_packed: the beats of RTL:25-28 delivered as interleaved samples; same stream as the planar beats."""
+    M, orc = env
+    W, H, n, pf = 80, 64, 5, 2
+    clip = M.synth.clip(W, H, n, clip_index=37)                     # [n,3,H,W]
+    want = orc.encode(clip, W // 16, H // 16, pf, 6, 6, 2, 2)
+    y, u, v = clip[:, 0], clip[:, 1], clip[:, 2]
+    pad = np.full_like(y, 0xA5)
+    order = {"yuv24": (y, u, v), "uyv24": (u, y, v), "yuvx32": (y, u, v, pad), "ayuv32": (pad, y, u, v)}[layout]
+    packed = np.stack(order, axis=-1).reshape(-1)                   # raster order, interleaved per pixel
+    bpp = len(order)
+    enc = M.Mpeg2Encoder(6, 6, 2, 2)
+    try:
+        cut = 4 * bpp * 5003                                        # pushes that do not line up with frames or blocks
+        for o in range(0, packed.size, cut):
+            enc.push_packed(W // 16, H // 16, pf, packed[o:o + cut], layout, stop_with_last=(o + cut >= packed.size))
+        assert enc.pull_all() == want
+    finally:
+        enc.close()
