@@ -189,11 +189,17 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    timeline = [] if os.environ.get("M2V_BENCH_TIMELINE") == "1" else None      # diagnostics: per-step wall times to stderr
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nbytes = step()
+        if timeline is not None:
+            timeline.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    if timeline:
+        d = [b - a for a, b in zip([t0] + timeline[:-1], timeline)]
+        sys.stderr.write("timeline ms: " + " ".join("%.2f" % (x * 1e3) for x in d) + "\n")
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

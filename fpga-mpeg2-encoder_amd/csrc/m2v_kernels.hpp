@@ -952,23 +952,51 @@ __device__ __forceinline__ uint32_t frame_header_bytes(int i_frame)
     return (i_frame == 0 ? kGopHeaderBytes + 17u : 18u);     // RTL:2670-2682
 }
 
+// One block; thread t owns K consecutive (frame, slice) items, an item = a slice preceded by its frame's
+// headers when it is the first slice of the frame: local sums -> block scan -> offsets.
 __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict__ jobs, Geom g, int nframes, int first, int last,
                                                      const uint32_t *__restrict__ slice_bytes,
                                                      unsigned long long *__restrict__ slice_off,
                                                      unsigned long long *__restrict__ frame_off, StreamCtl *ctl)
 {
+    __shared__ unsigned long long s_sum[1024];
     const int tid = threadIdx.x;
-    for (int f = tid; f < nframes; f += blockDim.x) {
-        unsigned long long s = g.strip ? 0ull : frame_header_bytes(jobs[f].i_frame);
-        for (int y = g.row0; y < g.row1; ++y) s += slice_bytes[(size_t)f * g.mbh + y];
-        frame_off[f] = s;                                     // size for now
+    const int rows = g.row1 - g.row0;
+    const int S = nframes * rows;
+    const int K = (S + 1023) / 1024;
+    const int i0 = tid * K, i1 = i0 + K < S ? i0 + K : S;
+    auto header_bytes = [&](int f) -> unsigned long long {     // bytes in front of the first slice of frame f
+        if (g.strip) return 0ull;
+        return (unsigned long long)frame_header_bytes(jobs[f].i_frame) + (first && f == 0 ? kSeqHeaderBytes : 0u);
+    };
+    unsigned long long sum = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int f = i / rows, r = i - f * rows;
+        sum += slice_bytes[(size_t)f * g.mbh + g.row0 + r];
+        if (r == 0) sum += header_bytes(f);
     }
+    s_sum[tid] = sum;
     __syncthreads();
-    if (tid == 0) {
-        unsigned long long run = first ? kSeqHeaderBytes : 0ull;
-        for (int f = 0; f < nframes; ++f) { const unsigned long long s = frame_off[f]; frame_off[f] = run; run += s; }
-        frame_off[nframes] = run;                             // one past the end (strip mode reads the sizes back)
-        unsigned long long total = ctl->base_bytes + run;
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned long long t = tid >= o ? s_sum[tid - o] : 0ull;
+        __syncthreads();
+        s_sum[tid] += t;
+        __syncthreads();
+    }
+    unsigned long long run = s_sum[tid] - sum;
+    for (int i = i0; i < i1; ++i) {
+        const int f = i / rows, r = i - f * rows;
+        if (r == 0) {
+            frame_off[f] = run + (!g.strip && first && f == 0 ? kSeqHeaderBytes : 0u);   // the frame's own headers start here
+            run += header_bytes(f);
+        }
+        slice_off[(size_t)f * g.mbh + g.row0 + r] = run;
+        run += slice_bytes[(size_t)f * g.mbh + g.row0 + r];
+    }
+    if (tid == 1023) {
+        const unsigned long long all_frames = s_sum[1023];
+        frame_off[nframes] = all_frames;                      // one past the end (strip mode reads the sizes back)
+        unsigned long long total = ctl->base_bytes + all_frames;
         if (last) {
             total += 4;                                       // sequence_end_code (RTL:2621-2628)
             const unsigned long long all = ctl->prior_bytes + total;
@@ -976,14 +1004,6 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
         }
         ctl->total_bytes = total;
         ctl->overflow = total > ctl->cap_bytes ? 1u : 0u;
-    }
-    __syncthreads();
-    for (int f = tid; f < nframes; f += blockDim.x) {
-        unsigned long long o = frame_off[f] + (g.strip ? 0ull : frame_header_bytes(jobs[f].i_frame));
-        for (int y = g.row0; y < g.row1; ++y) {
-            slice_off[(size_t)f * g.mbh + y] = o;
-            o += slice_bytes[(size_t)f * g.mbh + y];
-        }
     }
 }
 

@@ -140,6 +140,10 @@ struct m2v_enc {
     // profiling
     KStat stats[5];
     std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> ev_pool;      // timing events, reused from step to step
+    size_t ev_used = 0;
+    hipEvent_t chain_ev = nullptr;        // stop event of the previous timer while nothing else was enqueued after it
+    hipStream_t chain_stream = nullptr;
 
     void set_err(const char *fmt, ...)
     {
@@ -209,21 +213,37 @@ void upload_tables(int device)
 // ---------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------
+// HIP-event timers of option "profile": events come from a pool that lives as long as the handle, and a timer
+// that starts right where the previous one stopped (same stream, nothing enqueued in between) reuses that
+// event, so a step of n back-to-back launches costs n + 1 event records and no create / destroy.
+hipEvent_t pool_event(m2v_enc *e)
+{
+    if (e->ev_used == e->ev_pool.size()) {
+        hipEvent_t ev = nullptr;
+        HIPCHK(hipEventCreate(&ev));
+        e->ev_pool.push_back(ev);
+    }
+    return e->ev_pool[e->ev_used++];
+}
+
 struct Timer {
     m2v_enc *e; hipStream_t s; int kernel; double units; hipEvent_t a = nullptr, b = nullptr;
     Timer(m2v_enc *e_, hipStream_t s_, int k, double u) : e(e_), s(s_), kernel(k), units(u)
     {
         if (e->profile) {
-            HIPCHK(hipEventCreate(&a));
-            HIPCHK(hipEventCreate(&b));
-            HIPCHK(hipEventRecord(a, s));
+            if (e->chain_ev && e->chain_stream == s) a = e->chain_ev;
+            else { a = pool_event(e); HIPCHK(hipEventRecord(a, s)); }
+            e->chain_ev = nullptr;
         }
     }
     void stop()
     {
         if (e->profile) {
+            b = pool_event(e);
             HIPCHK(hipEventRecord(b, s));
             e->timed.push_back(TimedLaunch{a, b, kernel, units});
+            e->chain_ev = b;
+            e->chain_stream = s;
         }
     }
 };
@@ -237,10 +257,10 @@ void collect_timers(m2v_enc *e)
             e->stats[t.kernel].ms += ms;
             e->stats[t.kernel].units += t.units;
         }
-        (void)hipEventDestroy(t.a);
-        (void)hipEventDestroy(t.b);
     }
     e->timed.clear();
+    e->ev_used = 0;
+    e->chain_ev = nullptr;
 }
 
 template <bool P>
@@ -272,6 +292,7 @@ void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Ge
 // ---------------------------------------------------------------------------------------------
 void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool last, uint32_t last_valid_beats)
 {
+    e->chain_ev = nullptr;                  // copies are enqueued below: the next timer records its own start event
     const Geom &g = e->g;
     const size_t frame_bytes = (size_t)g.ysz * 3;
     const uint32_t bpf = g.ysz / 4;
@@ -694,6 +715,7 @@ void m2v_destroy(m2v_enc *e)
     e->d_mboff.release(); e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
     e->d_jobs.release(); e->d_lists.release(); e->d_ctl.release(); e->d_segs.release();
     for (auto p : e->rec_pool) (void)hipFree(p);
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto &h : e->hs) {
         h.d_out.release();
         if (h.h_in) (void)hipHostFree(h.h_in);
@@ -911,6 +933,7 @@ static int resident_impl(m2v_enc *e, void *argp)
         const bool first = k == 0, last = k + nf == a->n;
         encode_chunk(e, s, a->d_in + k * fb, nf, first, last, g.ysz / 4, a->d_out);
         hipLaunchKernelGGL(k_ctl_advance, dim3(1), dim3(1), 0, s, e->d_ctl.p);
+        e->chain_ev = nullptr;
         if (!last) HIPCHK(hipStreamSynchronize(s));    // the per-chunk work buffers are reused
     }
     HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
@@ -980,6 +1003,7 @@ static int strip_step_impl(m2v_enc *e, void *argp)
     run_step(e, e->strip_stream, (size_t)a->j);
     const m2v_enc::Step &st = e->plan_steps[a->j];
     if (st.n_h > 0 && (a->up || a->down)) {
+        e->chain_ev = nullptr;
         hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)st.n_h, 2), dim3(256), 0, e->strip_stream, e->d_jobs.p,
                            e->d_lists.p + st.off_h, e->g, 2 * e->VL, e->VL, e->g.row0 > 0 ? a->up : nullptr,
                            e->g.row1 < e->g.mbh ? a->down : nullptr);
@@ -1001,6 +1025,7 @@ static int strip_halo_in_impl(m2v_enc *e, void *argp)
     if (!e->strip_active || a->j < 0 || a->j >= (int)e->plan_steps.size()) return M2V_E_STATE;
     const m2v_enc::Step &st = e->plan_steps[a->j];
     if (st.n_h > 0 && (a->from_up || a->from_down)) {
+        e->chain_ev = nullptr;
         hipLaunchKernelGGL(k_halo_unpack, dim3((unsigned)st.n_h, 2), dim3(256), 0, e->strip_stream, e->d_jobs.p,
                            e->d_lists.p + st.off_h, e->g, 2 * e->VL, e->VL, e->g.row0 > 0 ? a->from_up : nullptr,
                            e->g.row1 < e->g.mbh ? a->from_down : nullptr);
