@@ -96,6 +96,8 @@ struct m2v_enc {
     int cur = 0;                  // stage being filled by m2v_push_*
     HostStage &st() { return hs[cur]; }
     std::deque<int> pending;      // submitted stages, oldest first
+    bool split_streams = false;   // experiment, see encode_chunk
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool async = true;            // option "async": 0 = every chunk is completed before m2v_push_* returns
     hipStream_t copy_stream = nullptr;   // stream read-back, concurrent with the next chunk's kernels
     size_t buffered = 0;          // complete frames waiting in st().h_in
@@ -126,7 +128,7 @@ struct m2v_enc {
     unsigned long long stream_bytes = 0;  // bytes of the current sequence already moved to the FIFO
 
     // plan of the chunk being encoded (plan_chunk -> run_step* -> finish_chunk)
-    struct Step { int off_i, n_i, off_p, n_p, off_h, n_h; };
+    struct Step { int off_i, n_i, off_p, n_p, off_h, n_h, half_i, half_p; };   // half_*: entries of the first half of the segments
     std::vector<Step> plan_steps;
     size_t plan_nf = 0;
     bool strip_active = false;            // between m2v_strip_begin and m2v_strip_finish
@@ -373,16 +375,19 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
         m2v_enc::Step st{};
         for (int pass = 0; pass < 3; ++pass) {
             const int off = (int)lists.size();
+            int lower = 0;                                  // entries that belong to the first half of the segments
             for (size_t sg = 0; sg < nseg; ++sg) {
                 const size_t a = seg_start[sg], b = sg + 1 < nseg ? (size_t)seg_start[sg + 1] : nf;
                 if (a + j >= b) continue;
                 const FrameJob &fj = jobs[a + j];
-                if ((pass == 0 && fj.i_frame == 0) || (pass == 1 && fj.i_frame != 0) || (pass == 2 && fj.rec != nullptr))
+                if ((pass == 0 && fj.i_frame == 0) || (pass == 1 && fj.i_frame != 0) || (pass == 2 && fj.rec != nullptr)) {
                     lists.push_back((int)(a + j));
+                    if (sg < nseg / 2) ++lower;
+                }
             }
             const int cnt = (int)lists.size() - off;
-            if (pass == 0) { st.off_i = off; st.n_i = cnt; }
-            else if (pass == 1) { st.off_p = off; st.n_p = cnt; }
+            if (pass == 0) { st.off_i = off; st.n_i = cnt; st.half_i = lower; }
+            else if (pass == 1) { st.off_p = off; st.n_p = cnt; st.half_p = lower; }
             else { st.off_h = off; st.n_h = cnt; }
         }
         e->plan_steps[j] = st;
@@ -469,7 +474,26 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
                   uint32_t last_valid_beats, uint8_t *d_stream)
 {
     plan_chunk(e, s, d_frames, nf, last, last_valid_beats);
-    for (size_t j = 0; j < e->plan_steps.size(); ++j) run_step(e, s, j);
+    if (e->split_streams && !e->profile && e->plan_steps.size() > 1) {
+        // EXPERIMENT: the GOP segments of the chunk as two independent halves on two streams, so that the tail of one
+        // half's launch (partially filled GPU) overlaps with the other half's next launch
+        if (!e->ev_fork) { HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); }
+        hipStream_t s2 = e->copy_stream;
+        HIPCHK(hipEventRecord(e->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(s2, e->ev_fork, 0));
+        for (size_t j = 0; j < e->plan_steps.size(); ++j) {
+            const m2v_enc::Step &st = e->plan_steps[j];
+            const int ia = st.half_i, pa = st.half_p;     // a segment stays on its stream: its frames depend on each other
+            launch_mb<false>(e, s, e->d_lists.p + st.off_i, ia, e->g);
+            launch_mb<true>(e, s, e->d_lists.p + st.off_p, pa, e->g);
+            launch_mb<false>(e, s2, e->d_lists.p + st.off_i + ia, st.n_i - ia, e->g);
+            launch_mb<true>(e, s2, e->d_lists.p + st.off_p + pa, st.n_p - pa, e->g);
+        }
+        HIPCHK(hipEventRecord(e->ev_join, s2));
+        HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
+    } else {
+        for (size_t j = 0; j < e->plan_steps.size(); ++j) run_step(e, s, j);
+    }
     finish_chunk(e, s, first, last, d_stream);
 }
 
@@ -1138,6 +1162,7 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
     }
     if (!strcmp(name, "profile")) { e->profile = value != 0; return M2V_OK; }
     if (!strcmp(name, "async")) { e->async = value != 0; return M2V_OK; }
+    if (!strcmp(name, "split_streams")) { e->split_streams = value != 0; return M2V_OK; }
     if (!strcmp(name, "keep_recon")) { e->keep_recon = value != 0; return M2V_OK; }
     if (!strcmp(name, "ablate")) { e->ablate = (int)value; return M2V_OK; }   // profiling aid: output is invalid when != 0
     return M2V_E_PARAM;

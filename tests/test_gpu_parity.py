@@ -56,3 +56,20 @@ def test_multi_gop_and_chunking(G):
     for bf in (96, 4, 5, 1):
         got = G.resident_encode(f, 6, 4, 3, XL=6, YL=6, batch_frames=bf)
         assert got == want, "batch_frames=%d" % bf
+
+
+def test_split_streams_option(G):
+    """Option "split_streams": the GOP segments of a chunk run as two independent halves on two HIP streams (fills the
+    tail of every launch).  Same bytes, resident and port path, odd and even GOP counts."""
+    from oracle import m2v_oracle_ctypes as orc
+    for n, pf in ((15, 2), (12, 3), (3, 4)):
+        f = G.M.synth.clip(112, 80, n, clip_index=11)
+        want = orc.encode(f, 7, 5, pf, XL=6, YL=6)
+        enc = G.M.Mpeg2Encoder(6, 6, 3, 2, device=0)
+        try:
+            enc.set_option("split_streams", 1)
+            assert G.resident_encode(f, 7, 5, pf, XL=6, YL=6, enc=enc) == want
+            enc.set_option("batch_frames", 7)
+            assert enc.encode(f, 7, 5, pf) == want
+        finally:
+            enc.close()

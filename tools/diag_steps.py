@@ -40,12 +40,14 @@ t_launch = (time.perf_counter() - t0) / 2000
 torch.cuda.synchronize()
 print("host: python 2M-iteration loop %.0f ms, ctypes call %.2f us, launch %.1f us, launch+sync round trip %.1f us, load %s"
       % (t_py * 1e3, t_api * 1e6, t_launch * 1e6, t_rt * 1e6, open("/proc/loadavg").read().split()[:3]))
-for profile in (0, 1, 0):
-    enc.set_option("profile", profile)
+import os
+for profile in (0, 1, 0, 2, 0, 2):
+    enc.set_option("split_streams", 1 if profile == 2 else 0)
+    enc.set_option("profile", 1 if profile == 1 else 0)
     torch.cuda.synchronize()
     rows = []
     t_start = time.perf_counter()
-    for blk in range(16):
+    for blk in range(6):
         ts = []
         for _ in range(50):
             t0 = time.perf_counter()
