@@ -314,41 +314,31 @@ __device__ __forceinline__ MbDep mb_dependent(uint32_t info, const MbAux &aux, b
 #define M2V_WAVE_SYNC() __syncthreads()
 
 typedef __attribute__((address_space(3))) uint32_t LdsU32;
+struct QsadRow { unsigned long long w01, w12, w23, w34; };    // the four overlapping 8-byte reference operands of one window row
 
-// two LDS dword pairs (w1,w2) and (w3,w4) of window row RR (8 dwords per row) into aligned register pairs; no wait
+// full-pel search, rows RR..15 of the macroblock.  The operands of row RR were issued one row earlier into `p`; this
+// step issues row RR + 1 into `q`, waits until only those four reads are outstanding (LDS returns in order), then
+// runs the four v_qsad of row RR.  ae / ao: LDS byte addresses of this lane's even / odd pairs in window row dy.
 template <int RR, int WS>
-__device__ __forceinline__ void lds_issue_odd_pairs(uint32_t wbase, unsigned long long &p12, unsigned long long &p34)
-{
-    asm volatile("ds_read2_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read2_b32 %1, %2 offset0:%5 offset1:%6"
-                 : "=&v"(p12), "=&v"(p34)
-                 : "v"(wbase), "n"(RR * WS + 1), "n"(RR * WS + 2), "n"(RR * WS + 3), "n"(RR * WS + 4));
-}
-
-// full-pel search, rows RR..15 of the macroblock: the odd pairs of row RR are in (p12, p34) once the wait retires;
-// the next row's are issued into (q12, q34) before this row's four v_qsad
-template <int RR, int WS>
-__device__ __forceinline__ void search_rows(const uint32_t *wlane, const uint32_t *s_cur, uint32_t wbase, unsigned long long &acc,
-                                            unsigned long long &p12, unsigned long long &p34,
-                                            unsigned long long &q12, unsigned long long &q34)
+__device__ __forceinline__ void search_rows(const uint32_t *s_cur, uint32_t ae, uint32_t ao, unsigned long long &acc,
+                                            QsadRow &p, QsadRow &q)
 {
     if constexpr (RR < 16) {
         if constexpr (RR + 1 < 16) {
-            // LDS returns in order: once at most the two reads issued here are outstanding, this row's pairs have landed
-            asm volatile("ds_read2_b32 %0, %4 offset0:%5 offset1:%6\n\tds_read2_b32 %1, %4 offset0:%7 offset1:%8\n\t"
-                         "s_waitcnt lgkmcnt(2)"
-                         : "=&v"(q12), "=&v"(q34), "+v"(p12), "+v"(p34)
-                         : "v"(wbase), "n"((RR + 1) * WS + 1), "n"((RR + 1) * WS + 2), "n"((RR + 1) * WS + 3), "n"((RR + 1) * WS + 4));
+            asm volatile("ds_read_b64 %0, %8 offset:%10\n\tds_read_b64 %1, %9 offset:%10\n\t"
+                         "ds_read_b64 %2, %8 offset:%11\n\tds_read_b64 %3, %9 offset:%11\n\t"
+                         "s_waitcnt lgkmcnt(4)"
+                         : "=&v"(q.w01), "=&v"(q.w12), "=&v"(q.w23), "=&v"(q.w34),
+                           "+v"(p.w01), "+v"(p.w12), "+v"(p.w23), "+v"(p.w34)
+                         : "v"(ae), "v"(ao), "n"((RR + 1) * WS * 4), "n"((RR + 1) * WS * 4 + 8));
         } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p12), "+v"(p34));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p.w01), "+v"(p.w12), "+v"(p.w23), "+v"(p.w34));
         }
-        const uint32_t *wrow = wlane + RR * WS;
-        const unsigned long long w01 = ((unsigned long long)wrow[1] << 32) | wrow[0];
-        const unsigned long long w23 = ((unsigned long long)wrow[3] << 32) | wrow[2];
-        acc = __builtin_amdgcn_qsad_pk_u16_u8(w01, s_cur[RR * 4 + 0], acc);
-        acc = __builtin_amdgcn_qsad_pk_u16_u8(p12, s_cur[RR * 4 + 1], acc);
-        acc = __builtin_amdgcn_qsad_pk_u16_u8(w23, s_cur[RR * 4 + 2], acc);
-        acc = __builtin_amdgcn_qsad_pk_u16_u8(p34, s_cur[RR * 4 + 3], acc);
-        search_rows<RR + 1, WS>(wlane, s_cur, wbase, acc, q12, q34, p12, p34);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w01, s_cur[RR * 4 + 0], acc);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w12, s_cur[RR * 4 + 1], acc);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w23, s_cur[RR * 4 + 2], acc);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w34, s_cur[RR * 4 + 3], acc);
+        search_rows<RR + 1, WS>(s_cur, ae, ao, acc, q, p);
     }
 }
 
@@ -365,20 +355,28 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // LDS map (bytes).  Region R1 holds the reference windows + current luma until the prediction is
     // formed, then the VLC symbol list; the DCT/IDCT scratch doubles as the VLC bit buffer.
     // The luma window rows are 8 dwords of data on a stride of kWS = 12 dwords: the search lanes (dy, 4-dx group) and the
-    // half-pel lanes (row, 4-px group) then fall on 32 different banks (stride 8 is 2-way conflicted: rows r and r+4 share
-    // banks).  The window sits LAST in R1 and runs over into the prediction / residual regions, which are first written
-    // after its last read (one wavefront: LDS operations execute in program order), so the padding costs no LDS.
+    // half-pel lanes (row, 4-px group) then fall on different banks (stride 8 is 2-way conflicted: rows r and r+4 share
+    // banks).  It is stored twice, the second copy shifted by one dword (B[j] = A[j+1]): v_qsad takes its 8 reference
+    // bytes from an even-aligned register pair and the four pairs of a row overlap ((w0,w1) (w1,w2) (w2,w3) (w3,w4)), so
+    // every lane reads two of them from the copy where they are 8-byte aligned and two from the other one - four
+    // ds_read_b64 per row (2 LDS cycles each), no register shuffling.  B starts 32 banks (mod 64) after A, which keeps
+    // the 32 lanes of a ds_read_b64 group on 64 different banks.  Both copies sit LAST in R1 and run over into the
+    // prediction / residual / transform regions, which are first written after the window's last read (one wavefront:
+    // LDS operations execute in program order), so neither the padding nor the copy costs LDS.
     constexpr int kWS = 12;
     constexpr int kWinBytes = P ? WROWS * kWS * 4 : 0, kCwinBytes = P ? CROWS * 16 : 0;
     constexpr int kOffWin = 2 * kCwinBytes + 256;
+    constexpr int kWinBGap = ((kWinBytes / 4 - 32 + 63) / 64) * 64 + 32;       // dwords from A to B: >= window, = 32 mod 64
+    constexpr int kOffWinB = kOffWin + kWinBGap * 4;
     constexpr int kR1 = 1600;
-    static_assert(kOffWin + kWinBytes <= 1600 + 384 + 768, "the luma window may only run over s_pred and s_x");
+    static_assert(!P || (kOffWin % 8 == 0 && kOffWinB + kWinBytes <= 1600 + 384 + 768 + 1536), "window copies may run over s_pred, s_x, s_t only");
     constexpr int kOffPred = kR1, kOffX = kOffPred + 384, kOffT = kOffX + 768, kOffZig = kOffT + 1536;
     constexpr int kLdsBytes = kOffZig + 768;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];   // static base: every DS access uses an immediate offset
     uint32_t (*const s_cwin)[CROWS * 4] = (uint32_t (*)[CROWS * 4])lds;       // chroma windows: 16 bytes/row = cols 8bx-4 .. 8bx+11
     uint32_t *const s_cur = (uint32_t *)(lds + 2 * kCwinBytes);                // current luma, dword [row][4-px group]
     uint32_t *const s_win = (uint32_t *)(lds + kOffWin);                       // luma window: row stride kWS dwords, 32 bytes = frame cols 16bx-8 .. 16bx+23
+    uint32_t *const s_winb = (uint32_t *)(lds + kOffWinB);                     // the same, one dword to the left
     uint32_t *const s_sym = (uint32_t *)lds;                                   // VLC symbol list (<= 6 * 66), reuses R1
     uint8_t (*const s_pred)[64] = (uint8_t (*)[64])(lds + kOffPred);           // prediction, later reconstruction, tile layout
     int16_t (*const s_x)[64] = (int16_t (*)[64])(lds + kOffX);                 // residual, later dequantised coefficients
@@ -451,7 +449,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         // ---- stages X..Z: reference window of recon(f-1) into LDS (RTL:1350-1425, 1612-1629) --
 #pragma unroll
         for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass)
-            if ((pass + 1) * 64 <= WROWS * 8 || lane < WROWS * 8 - pass * 64) s_win[(pass * 8 + (lane >> 3)) * kWS + (lane & 7)] = wv[pass];
+            if ((pass + 1) * 64 <= WROWS * 8 || lane < WROWS * 8 - pass * 64) {
+                s_win[(pass * 8 + (lane >> 3)) * kWS + (lane & 7)] = wv[pass];
+                s_winb[(pass * 8 + (lane >> 3)) * kWS + (lane & 7) - 1] = wv[pass];     // column 0 lands in padding
+            }
         if (lane < CROWS * 4) {
             s_cwin[0][lane] = wcu;
             s_cwin[1][lane] = wcv;
@@ -466,13 +467,18 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             uint32_t key = 0xFFFFFFFFu;
             const int dyi = lane >> 2, gq = lane & 3;        // dy = dyi - YR, dx = 4*gq - 8 + j
             if (dyi <= 2 * YR && !(g.ablate & 1)) {
-                // v_qsad needs its 8 reference bytes in an even-aligned register pair; the four pairs of a row overlap
-                // ((w0,w1) (w1,w2) (w2,w3) (w3,w4)), so the odd ones are loaded a second time straight into their own
-                // pair (ds_read2_b32, hand-issued one row ahead) instead of being rebuilt with three v_mov per row.
-                const uint32_t wbase = (uint32_t)(uintptr_t)(LdsU32 *)&s_win[dyi * kWS + gq];
-                unsigned long long acc = 0, pa12, pa34, pb12 = 0, pb34 = 0;
-                lds_issue_odd_pairs<0, kWS>(wbase, pa12, pa34);
-                search_rows<0, kWS>(s_win + dyi * kWS + gq, s_cur, wbase, acc, pa12, pa34, pb12, pb34);
+                // the pairs (w0,w1) (w2,w3) start at dword gq, the pairs (w1,w2) (w3,w4) at gq + 1: one of the two is even
+                // in copy A, the other one in copy B (which holds dword j + 1 at index j)
+                const uint32_t *const pe = (gq & 1) ? s_winb + dyi * kWS + gq - 1 : s_win + dyi * kWS + gq;
+                const uint32_t *const po = (gq & 1) ? s_win + dyi * kWS + gq + 1 : s_winb + dyi * kWS + gq;
+                // hand-issued ds_read_b64, one row ahead (left to itself the compiler fuses them into ds_read2_b64,
+                // which runs at half the LDS rate - MI355X_MICROARCH.md, LDS table)
+                const uint32_t ae = (uint32_t)(uintptr_t)(LdsU32 *)pe, ao = (uint32_t)(uintptr_t)(LdsU32 *)po;
+                unsigned long long acc = 0;
+                QsadRow ra, rb{};
+                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %5 offset:8"
+                             : "=&v"(ra.w01), "=&v"(ra.w12), "=&v"(ra.w23), "=&v"(ra.w34) : "v"(ae), "v"(ao));
+                search_rows<0, kWS>(s_cur, ae, ao, acc, ra, rb);
                 const int dy = dyi - YR;
                 const bool rowok = !((by == 0 && dy < 0) || (by == g.mbh - 1 && dy > 0));   // RTL:1644-1645
 #pragma unroll
