@@ -15,7 +15,8 @@ from . import synth  # noqa: F401  (seeded synthetic clips, numpy only)
 from . import parallel  # noqa: F401  (multi-GPU: independent sequences, macroblock-row strips)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libm2v_mi355x.so")
+# M2V_LIB: development hook for same-box A/B timing of two builds (tools/ab.sh); never set otherwise
+LIB_PATH = os.environ.get("M2V_LIB") or os.path.join(_HERE, "libm2v_mi355x.so")
 
 _lib = None
 

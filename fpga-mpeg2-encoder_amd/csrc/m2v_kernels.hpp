@@ -41,7 +41,17 @@ struct Geom {
     int strip;       // 1 = strip mode: the stream buffer holds only this strip's slices, no headers
     int ablate;      // profiling aid (option "ablate", default 0 = everything on; results are INVALID otherwise):
                      // bit0 skip full-pel search, bit1 skip half-pel SADs, bit2 skip VLC, bit3 skip IDCT/recon, bit4 skip DCT/quant
+    uint32_t strip_mbs;      // (row1 - row0) * mbw
+    uint32_t magic_strip;    // floor(2^32 / strip_mbs), floor(2^32 / mbw): wave-uniform divisions on the scalar unit
+    uint32_t magic_mbw;      // (geom_finish() fills the three after any change of the rows)
 };
+
+inline void geom_finish(Geom &g)
+{
+    g.strip_mbs = (uint32_t)((g.row1 - g.row0) * g.mbw);
+    g.magic_strip = g.strip_mbs > 1 ? (uint32_t)(0x100000000ull / g.strip_mbs) : 0xFFFFFFFFu;
+    g.magic_mbw = g.mbw > 1 ? (uint32_t)(0x100000000ull / (uint32_t)g.mbw) : 0xFFFFFFFFu;
+}
 
 struct FrameJob {           // one per frame of the chunk (device memory)
     const uint8_t *in;      // 4:4:4 planar frame: Y, U, V planes of W*H bytes
@@ -129,6 +139,15 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
     const uint32_t xcd = b & 7u, q = n >> 3, r = n & 7u;
     const uint32_t start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
     return start + (b >> 3);
+}
+
+// n / d for a wave-uniform n with M = floor(2^32 / d) (0xFFFFFFFF for d = 1): the estimate mulhi(n, M) is the
+// quotient or one less, so a single correction makes it exact; s_mul_hi_u32 + a few SALU instead of the ~12 VALU
+// instructions of the float-reciprocal sequence the compiler emits for a 32-bit division
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t M)
+{
+    const uint32_t q = __umulhi(n, M);
+    return n - q * d >= d ? q + 1u : q;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -386,10 +405,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 
     const int lane = threadIdx.x;
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t strip_mbs = (uint32_t)((g.row1 - g.row0) * g.mbw);
-    const int fidx = frame_list[blk / strip_mbs];
-    const int mb = g.row0 * g.mbw + (int)(blk % strip_mbs);
-    const int by = mb / g.mbw, bx = mb - by * g.mbw;
+    const uint32_t li = udiv_magic(blk, g.strip_mbs, g.magic_strip);           // which frame of the launch list
+    const int fidx = frame_list[li];
+    const int mb = g.row0 * g.mbw + (int)(blk - li * g.strip_mbs);
+    const int by = (int)udiv_magic((uint32_t)mb, (uint32_t)g.mbw, g.magic_mbw), bx = mb - by * g.mbw;
     const FrameJob job = jobs[fidx];
     const int W = g.W;
     const int r = lane >> 2, c4 = lane & 3;
@@ -402,7 +421,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // addresses are clamped into the frame instead of being branched around.
     typedef const __attribute__((address_space(1))) uint32_t *gld32;
     const uint8_t *inY = job.in, *inU = inY + g.ysz, *inV = inU + g.ysz;
-    const uint32_t pix_off = (uint32_t)(16 * by + r) * (uint32_t)W + (uint32_t)(16 * bx + 4 * c4);
+    const uint32_t pix_off = __umul24((uint32_t)(16 * by + r), (uint32_t)W) + (uint32_t)(16 * bx + 4 * c4);   // rows, W < 2^12
     uint32_t cur4 = *(gld32)(inY + pix_off);
     uint32_t u4 = *(gld32)(inU + pix_off);
     uint32_t v4 = *(gld32)(inV + pix_off);
@@ -415,14 +434,14 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             int yy = 16 * by - YR + row, xx = 16 * bx - 8 + 4 * k;
             yy = yy < 0 ? 0 : yy > g.H - 1 ? g.H - 1 : yy;
             xx = xx < 0 ? 0 : xx > W - 4 ? W - 4 : xx;
-            wv[pass] = *(gld32)(refY + ((uint32_t)yy * (uint32_t)W + (uint32_t)xx));   // 32-bit offset from a uniform base
+            wv[pass] = *(gld32)(refY + (__umul24((uint32_t)yy, (uint32_t)W) + (uint32_t)xx));   // 32-bit offset from a uniform base
         }
         {
             const int cl = lane < CROWS * 4 ? lane : CROWS * 4 - 1, row = cl >> 2, k = cl & 3;
             int yy = 8 * by - UR + row, xx = 8 * bx - 4 + 4 * k;
             yy = yy < 0 ? 0 : yy > g.ch - 1 ? g.ch - 1 : yy;
             xx = xx < 0 ? 0 : xx > g.cw - 4 ? g.cw - 4 : xx;
-            const uint32_t coff = (uint32_t)yy * (uint32_t)g.cw + (uint32_t)xx;
+            const uint32_t coff = __umul24((uint32_t)yy, (uint32_t)g.cw) + (uint32_t)xx;
             wcu = *(gld32)(refU + coff);
             wcv = *(gld32)(refV + coff);
         }
@@ -513,7 +532,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             const uint32_t sft = (uint32_t)cb & 3u;
 #define M2V_ROW3(ROW, L, C, R)                                                                  \
             {                                                                                   \
-                const uint32_t a0 = s_win[(ROW) * kWS + wi], a1 = s_win[(ROW) * kWS + wi + 1], a2 = s_win[(ROW) * kWS + wi2]; \
+                const uint32_t a0 = s_win[__mul24((ROW), kWS) + wi], a1 = s_win[__mul24((ROW), kWS) + wi + 1], a2 = s_win[__mul24((ROW), kWS) + wi2]; \
                 const uint32_t lo = __builtin_amdgcn_alignbyte(a1, a0, sft);                    \
                 const uint32_t hi = __builtin_amdgcn_alignbyte(a2, a1, sft);                    \
                 L = lo;                                                                         \
@@ -666,7 +685,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             }
         }
     } else {
-        const uint32_t qoff = ((uint32_t)wq * ((3u << Q) + 2u)) >> 3;
+        const uint32_t qoff = __umul24((uint32_t)wq, (3u << Q) + 2u) >> 3;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             int acc = 0;

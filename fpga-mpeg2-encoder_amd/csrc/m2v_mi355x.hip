@@ -190,6 +190,7 @@ Geom make_geom(const m2v_enc *e, uint32_t xs, uint32_t ys)
     g.row1 = g.mbh;
     g.strip = 0;
     g.ablate = e->ablate;
+    geom_finish(g);
     return g;
 }
 
@@ -989,6 +990,7 @@ static int strip_begin_impl(m2v_enc *e, void *argp)
     Geom g = make_geom(e, a->xs, a->ys);
     if (a->n == 0 || a->row0 < 0 || a->row1 > g.mbh || a->row0 >= a->row1) { e->set_err("m2v_strip_begin: bad rows / no frames"); return M2V_E_PARAM; }
     g.row0 = a->row0; g.row1 = a->row1; g.strip = 1;
+    geom_finish(g);
     e->g = g;
     e->pframes = a->pf & 0xFFu;
     e->frames_total = 0;
@@ -1081,6 +1083,7 @@ static int strip_finish_impl(m2v_enc *e, void *argp)
     collect_timers(e);
     e->strip_active = false;
     Geom full = e->g; full.row0 = 0; full.row1 = full.mbh; full.strip = 0;
+    geom_finish(full);
     e->g = full;
     if (e->st().h_ctl->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
     return M2V_OK;
