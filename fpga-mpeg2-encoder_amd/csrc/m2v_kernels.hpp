@@ -74,6 +74,7 @@ struct StreamCtl {          // device-resident stream bookkeeping, carried acros
 
 // device copies of the tables
 __constant__ int8_t   c_dct[64];
+__constant__ uint32_t c_dct_pk[32];       // c_dct rows as packed int16 pairs: [j][k] = basis[j][2k] | basis[j][2k+1] << 16
 __constant__ uint8_t  c_intra_w[64];
 __constant__ uint8_t  c_zigzag[64];
 __device__ uint16_t   d_motion_code[17];
@@ -89,6 +90,14 @@ __constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for
 // row_bcast:15 / row_bcast:31 carry the row totals across rows.  Lane 63 ends with the total.
 // ----------------------------------------------------------------------------------------------
 #define M2V_DPP(old, src, ctrl, rmask, bound) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xF, (bound))
+
+// value of lane ^ 4: two DPP moves (row_shl:4 into banks 0 and 2, row_shr:4 into banks 1 and 3), no LDS crossbar
+__device__ __forceinline__ uint32_t lane_xor4(uint32_t v)
+{
+    int r = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);
+    r = __builtin_amdgcn_update_dpp(r, (int)v, 0x114, 0xF, 0xA, false);
+    return (uint32_t)r;
+}
 
 __device__ __forceinline__ int wave_scan_incl(int v)
 {
@@ -454,8 +463,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     {
         const uint32_t hu = avg2x4(u4, u4 >> 8);          // bytes 0 and 2: horizontal means of the two pixel pairs
         const uint32_t hv = avg2x4(v4, v4 >> 8);
-        const uint32_t hu_p = (uint32_t)__shfl_xor((int)hu, 4, 64);     // the other row of the pair
-        const uint32_t hv_p = (uint32_t)__shfl_xor((int)hv, 4, 64);
+        const uint32_t hu_p = lane_xor4(hu);                            // the other row of the pair
+        const uint32_t hv_p = lane_xor4(hv);
         const uint32_t cu = avg2x4(hu, hu_p), cv = avg2x4(hv, hv_p);
         cu0 = cu & 255;  cu1 = (cu >> 16) & 255;
         cv0 = cv & 255;  cv1 = (cv >> 16) & 255;
@@ -639,7 +648,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 #pragma unroll
     for (int k = 0; k < 8; ++k) bi[k] = c_dct[di * 8 + k];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bjp[k] = short2_t{(short)c_dct[dj * 8 + 2 * k], (short)c_dct[dj * 8 + 2 * k + 1]};
+    for (int k = 0; k < 4; ++k) bjp[k] = __builtin_bit_cast(short2_t, c_dct_pk[dj * 4 + k]);
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
         // R1[r][j] = sum_k X[r][k] * DCTM[j][k]: 8 int16 residuals = one 16-byte LDS read, 4 v_dot2
@@ -667,36 +676,38 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     } else if (inter) {
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            int acc = 0;                                // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12
+            int acc = 2048;                             // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc += __mul24(bi[k], s_t[t][k * 8 + dj]);   // |R1| < 2^18: v_mad_i32_i24
-            const int C = (acc >> 12) + ((acc >> 11) & 1);
-            uint32_t a = ((uint32_t)iabs(C) + 2u) >> (4 + Q);                       // RTL:2070
+            const int C = acc >> 12;
+            const int sg = C >> 31;                     // sign-magnitude from here on: 0 / -1
+            const uint32_t mag = (uint32_t)((C ^ sg) - sg);
+            uint32_t a = (mag + 2u) >> (4 + Q);                                      // RTL:2070
             if (a > 2047u) a = 2047u;
-            const int q = C < 0 ? -(int)a : (int)a;
+            const int q = (int)(a ^ (uint32_t)sg) - sg;
             s_zig[t][zz] = (int16_t)q;
             if (coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
-            cbp = (cbp << 1) | (__ballot(q != 0) != 0ull ? 1 : 0);
-            if (need_rec) {                             // RTL:2134-2137
-                int x = 2 * q;
-                x += (x < 0) ? -1 : (x > 0) ? 1 : 0;
-                x = (int)((uint32_t)x << Q);
-                s_x[t][lane] = (int16_t)(x < -2047 ? -2047 : x > 2047 ? 2047 : x);
+            cbp = (cbp << 1) | (__ballot(a != 0u) != 0ull ? 1 : 0);
+            if (need_rec) {                             // RTL:2134-2137: (2q + sign(q)) << Q, clamped to +-2047
+                uint32_t xa = (2u * a + (a != 0u ? 1u : 0u)) << Q;
+                if (xa > 2047u) xa = 2047u;
+                s_x[t][lane] = (int16_t)((int)(xa ^ (uint32_t)sg) - sg);
             }
         }
     } else {
         const uint32_t qoff = __umul24((uint32_t)wq, (3u << Q) + 2u) >> 3;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            int acc = 0;
+            int acc = 2048;
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc += __mul24(bi[k], s_t[t][k * 8 + dj]);
-            const int C = (acc >> 12) + ((acc >> 11) & 1);
-            uint32_t a = (uint32_t)iabs(C) & 0xFFFFu;
+            const int C = acc >> 12;
+            const int sg = C >> 31;
+            uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
             if (lane != 0) a = __umul24((a + qoff) >> Q, wrecip) >> 21;             // exact "/ W" (n < 2^14, recip < 2^19), RTL:2072
-            else           a = (a >> 4) + ((a >> 3) & 1u);                          // RTL:2074
+            else           a = (a + 8u) >> 4;                                       // (a >> 4) + bit 3, RTL:2074
             if (a > 2047u) a = 2047u;
-            const int q = C < 0 ? -(int)a : (int)a;
+            const int q = (int)(a ^ (uint32_t)sg) - sg;
             s_zig[t][zz] = (int16_t)q;
             if (coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
             if (need_rec) {

@@ -200,6 +200,11 @@ void upload_tables(int device)
 {
     if (device >= 0 && device < 64 && g_tables_loaded[device]) return;
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dct), kDctBasis, sizeof kDctBasis));
+    uint32_t dct_pk[32];
+    for (int j = 0; j < 8; ++j)
+        for (int k = 0; k < 4; ++k)
+            dct_pk[j * 4 + k] = (uint32_t)(uint16_t)(int16_t)kDctBasis[j * 8 + 2 * k] | ((uint32_t)(uint16_t)(int16_t)kDctBasis[j * 8 + 2 * k + 1] << 16);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dct_pk), dct_pk, sizeof dct_pk));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_intra_w), kIntraW, sizeof kIntraW));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_zigzag), kZigzagPos, sizeof kZigzagPos));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_motion_code), kMotionCode, sizeof kMotionCode));
