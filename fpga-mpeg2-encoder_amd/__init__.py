@@ -13,6 +13,7 @@ import numpy as np
 from . import build as _build
 from . import synth  # noqa: F401  (seeded synthetic clips, numpy only)
 from . import parallel  # noqa: F401  (multi-GPU: independent sequences, macroblock-row strips)
+from . import container  # noqa: F401  (CPU-side conveniences: stream scan, MPEG-PS / TS multiplexers)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # M2V_LIB: development hook for same-box A/B timing of two builds (tools/ab.sh); never set otherwise

@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libm2v_mi355x.so")
 TB = os.path.join(HERE, "m2v_tb")
+CONTAINER_LIB = os.path.join(HERE, "libm2v_container.so")      # CPU-only conveniences (include/m2v_container.h)
 SOURCES = ["m2v_mi355x.hip", "m2v_kernels.hpp", "m2v_tables.hpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -38,6 +39,7 @@ def build(force=False, verbose=False):
         finally:
             if os.path.exists(tmp):
                 os.remove(tmp)
+    build_container(force, verbose)
     tb_src = os.path.join(CSRC, "m2v_tb.cpp")
     if os.path.exists(tb_src) and (force or _stale(TB, [tb_src, LIB])):
         tmp = "%s.%d.tmp" % (TB, os.getpid())
@@ -52,6 +54,25 @@ def build(force=False, verbose=False):
             if os.path.exists(tmp):
                 os.remove(tmp)
     return LIB
+
+
+def build_container(force=False, verbose=False):
+    """libm2v_container.so: elementary-stream scan + PS/TS multiplexers, plain C++ (g++), no GPU involved."""
+    src = os.path.join(CSRC, "m2v_container.cpp")
+    hdr = os.path.join(HERE, "..", "include", "m2v_container.h")
+    if force or _stale(CONTAINER_LIB, [src, hdr]):
+        cxx = shutil.which("g++") or hipcc()
+        tmp = "%s.%d.tmp" % (CONTAINER_LIB, os.getpid())
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared", "-o", tmp, src]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, CONTAINER_LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    return CONTAINER_LIB
 
 
 if __name__ == "__main__":
