@@ -25,7 +25,7 @@ EXPORTS = [
     "m2v_version", "m2v_create", "m2v_destroy", "m2v_reset", "m2v_push_beats", "m2v_push_packed", "m2v_push_frames",
     "m2v_sequence_stop", "m2v_busy", "m2v_pull", "m2v_geometry", "m2v_encode_resident", "m2v_set_option",
     "m2v_kernel_stats", "m2v_debug_read", "m2v_last_error",
-    "m2v_strip_begin", "m2v_strip_info", "m2v_strip_step", "m2v_strip_halo_in", "m2v_strip_finish", "m2v_strip_assemble",
+    "m2v_strip_begin", "m2v_strip_info", "m2v_strip_step", "m2v_strip_step_edges", "m2v_strip_step_interior", "m2v_strip_halo_in", "m2v_strip_finish", "m2v_strip_assemble",
 ]
 
 
@@ -73,6 +73,8 @@ def lib():
         L.m2v_strip_begin.argtypes = [vp, u32, u32, u32, vp, sz, ci, ci, vp]
         L.m2v_strip_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(sz)]
         L.m2v_strip_step.argtypes = [vp, ci, vp, vp]
+        L.m2v_strip_step_edges.argtypes = [vp, ci, vp, vp]
+        L.m2v_strip_step_interior.argtypes = [vp, ci]
         L.m2v_strip_halo_in.argtypes = [vp, ci, vp, vp]
         L.m2v_strip_finish.argtypes = [vp, vp, sz, vp]
         L.m2v_strip_assemble.argtypes = [vp, u32, u32, u32, sz, ci, vp, vp, vp, sz, ctypes.POINTER(sz), vp]
@@ -206,6 +208,12 @@ class Mpeg2Encoder:
 
     def strip_step(self, j, send_up_ptr, send_down_ptr):
         return self._chk(self._L.m2v_strip_step(self._h, j, send_up_ptr, send_down_ptr), "m2v_strip_step")
+
+    def strip_step_edges(self, j, send_up_ptr, send_down_ptr):
+        return self._chk(self._L.m2v_strip_step_edges(self._h, j, send_up_ptr, send_down_ptr), "m2v_strip_step_edges")
+
+    def strip_step_interior(self, j):
+        self._chk(self._L.m2v_strip_step_interior(self._h, j), "m2v_strip_step_interior")
 
     def strip_halo_in(self, j, from_up_ptr, from_down_ptr):
         self._chk(self._L.m2v_strip_halo_in(self._h, j, from_up_ptr, from_down_ptr), "m2v_strip_halo_in")

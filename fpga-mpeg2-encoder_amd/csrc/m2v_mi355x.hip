@@ -443,6 +443,20 @@ void run_step(m2v_enc *e, hipStream_t s, size_t j)
     launch_mb<true>(e, s, e->d_lists.p + st.off_p, st.n_p, e->g);
 }
 
+// macroblock rows [r0, r1) of GOP step j only (strip mode: edge rows first, so that their halo is on its way to the
+// neighbours while the interior rows are encoded)
+void run_step_rows(m2v_enc *e, hipStream_t s, size_t j, int r0, int r1)
+{
+    if (r0 >= r1) return;
+    const m2v_enc::Step &st = e->plan_steps[j];
+    Geom gg = e->g;
+    gg.row0 = r0;
+    gg.row1 = r1;
+    geom_finish(gg);
+    launch_mb<false>(e, s, e->d_lists.p + st.off_i, st.n_i, gg);
+    launch_mb<true>(e, s, e->d_lists.p + st.off_p, st.n_p, gg);
+}
+
 void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_stream)
 {
     const Geom &g = e->g;
@@ -1025,14 +1039,23 @@ int m2v_strip_info(const m2v_enc *e, int *steps, size_t *halo_bytes_per_directio
     return M2V_OK;
 }
 
-struct StripStepArgs { int j; uint8_t *up, *down; const uint8_t *from_up, *from_down; };
+struct StripStepArgs { int j; uint8_t *up, *down; const uint8_t *from_up, *from_down; int part = 0; };   // part: 0 whole strip, 1 edge rows + halo pack, 2 interior rows
 
 static int strip_step_impl(m2v_enc *e, void *argp)
 {
     auto *a = (StripStepArgs *)argp;
     if (!e->strip_active || a->j < 0 || a->j >= (int)e->plan_steps.size()) return M2V_E_STATE;
-    run_step(e, e->strip_stream, (size_t)a->j);
     const m2v_enc::Step &st = e->plan_steps[a->j];
+    const int r0 = e->g.row0, r1 = e->g.row1;
+    if (a->part == 0) {
+        run_step(e, e->strip_stream, (size_t)a->j);
+    } else if (a->part == 1) {                              // the rows the neighbours need: first and last of the strip
+        run_step_rows(e, e->strip_stream, (size_t)a->j, r0, r0 + 1);
+        if (r1 - r0 >= 2) run_step_rows(e, e->strip_stream, (size_t)a->j, r1 - 1, r1);
+    } else {                                                // everything in between; no halo is packed here
+        run_step_rows(e, e->strip_stream, (size_t)a->j, r0 + 1, r1 - 1);
+        return st.n_h;
+    }
     if (st.n_h > 0 && (a->up || a->down)) {
         e->chain_ev = nullptr;
         hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)st.n_h, 2), dim3(256), 0, e->strip_stream, e->d_jobs.p,
@@ -1046,7 +1069,21 @@ static int strip_step_impl(m2v_enc *e, void *argp)
 int m2v_strip_step(m2v_enc *e, int step, void *d_send_up, void *d_send_down)
 {
     if (!e) return M2V_E_PARAM;
-    StripStepArgs a{step, (uint8_t *)d_send_up, (uint8_t *)d_send_down, nullptr, nullptr};
+    StripStepArgs a{step, (uint8_t *)d_send_up, (uint8_t *)d_send_down, nullptr, nullptr, 0};
+    return guard(e, strip_step_impl, &a);
+}
+
+int m2v_strip_step_edges(m2v_enc *e, int step, void *d_send_up, void *d_send_down)
+{
+    if (!e) return M2V_E_PARAM;
+    StripStepArgs a{step, (uint8_t *)d_send_up, (uint8_t *)d_send_down, nullptr, nullptr, 1};
+    return guard(e, strip_step_impl, &a);
+}
+
+int m2v_strip_step_interior(m2v_enc *e, int step)
+{
+    if (!e) return M2V_E_PARAM;
+    StripStepArgs a{step, nullptr, nullptr, nullptr, nullptr, 2};
     return guard(e, strip_step_impl, &a);
 }
 

@@ -68,6 +68,15 @@ class GpuStripEngine:
         n = self.enc.strip_step(j, send_up.data_ptr(), send_down.data_ptr())
         return n * 3 * self.enc.params[2] * self.W
 
+    def step_edges(self, j, send_up, send_down):
+        """first and last macroblock row of the strip for GOP step j + their halo packed; same return value as step()"""
+        n = self.enc.strip_step_edges(j, send_up.data_ptr(), send_down.data_ptr())
+        return n * 3 * self.enc.params[2] * self.W
+
+    def step_interior(self, j):
+        """the rows in between: enqueued behind the edges on the same stream, runs while the halo travels"""
+        self.enc.strip_step_interior(j)
+
     def halo_in(self, j, from_up, from_down):
         self.enc.strip_halo_in(j, from_up.data_ptr() if from_up is not None else None,
                                from_down.data_ptr() if from_down is not None else None)
@@ -103,8 +112,13 @@ def _encode_strips(engine, rank, world, dist, dst):
     steps, halo_bytes = engine.begin(row0, row1)
     send_up, send_down = engine.alloc(halo_bytes), engine.alloc(halo_bytes)
     recv_up, recv_down = engine.alloc(halo_bytes), engine.alloc(halo_bytes)
+    # An engine that can encode the strip's edge rows first lets the exchange overlap with the interior rows: the
+    # point-to-point ops are enqueued behind the edge kernels (RCCL orders against the current stream), the interior
+    # kernels are enqueued right after and run while the halo crosses xGMI; req.wait() then orders halo_in behind both.
+    split = hasattr(engine, "step_edges") and world > 1
     for j in range(steps):
-        nbytes = engine.step(j, send_up, send_down)
+        nbytes = engine.step_edges(j, send_up, send_down) if split else engine.step(j, send_up, send_down)
+        reqs = []
         if nbytes and world > 1:
             ops = []
             if rank > 0:                       # my top rows go up; the rows above my strip come down from rank-1
@@ -113,8 +127,11 @@ def _encode_strips(engine, rank, world, dist, dst):
             if rank < world - 1:
                 ops.append(dist.P2POp(dist.isend, send_down[:nbytes], rank + 1))
                 ops.append(dist.P2POp(dist.irecv, recv_down[:nbytes], rank + 1))
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            reqs = dist.batch_isend_irecv(ops)
+        if split:
+            engine.step_interior(j)
+        for req in reqs:
+            req.wait()
         if nbytes:
             engine.halo_in(j, recv_up if rank > 0 else None, recv_down if rank < world - 1 else None)
     strip, off = engine.finish()

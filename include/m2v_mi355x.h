@@ -125,7 +125,8 @@ int m2v_encode_resident(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t
  *   m2v_strip_begin(...)                         plan the whole sequence as one chunk
  *   m2v_strip_info(&steps, &halo_bytes)          steps = frames per GOP in the chunk
  *   for j in 0..steps-1:
- *       n = m2v_strip_step(j, send_up, send_down) macroblock kernel for the j-th frame of every GOP, then
+ *       n = m2v_strip_step(j, send_up, send_down) (or _edges / _interior around the exchange, see below)
+ *                                                macroblock kernel for the j-th frame of every GOP, then
  *                                                packs this strip's top / bottom rows of the n frames that are
  *                                                referenced later: n * 3*VECTOR_LEVEL*W bytes per direction
  *       <exchange: send_up -> rank-1's from_down, send_down -> rank+1's from_up>
@@ -141,6 +142,11 @@ int m2v_strip_begin(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pfr
                     const void *d_frames444, size_t nframes, int row0, int row1, void *hip_stream);
 int m2v_strip_info(const m2v_enc *e, int *steps, size_t *halo_bytes_per_direction);
 int m2v_strip_step(m2v_enc *e, int step, void *d_send_up, void *d_send_down);
+/* The same step in two parts, so that the exchange overlaps with compute: _edges encodes the first
+ * and the last macroblock row of the strip and packs their halo (same return value as m2v_strip_step); the caller
+ * starts the send/recv; _interior encodes the rows in between while the halo is in flight; then m2v_strip_halo_in. */
+int m2v_strip_step_edges(m2v_enc *e, int step, void *d_send_up, void *d_send_down);
+int m2v_strip_step_interior(m2v_enc *e, int step);
 int m2v_strip_halo_in(m2v_enc *e, int step, const void *d_from_up, const void *d_from_down);
 int m2v_strip_finish(m2v_enc *e, void *d_strip, size_t cap, unsigned long long *frame_off);
 int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,

@@ -6,8 +6,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("world,W,H,pf,VL", [(2, 128, 96, 4, 3), (3, 96, 160, 2, 2), (4, 160, 128, 3, 1), (8, 64, 128, 1, 3)])
-def test_strips_equal_single_encoder(world, W, H, pf, VL):
+def test_strips_equal_single_encoder(world, W, H, pf, VL, split):
+    """split: the step in two parts (edge rows + halo pack, then interior rows) as encode_strips() issues it around the
+    exchange; strips of 1, 2, 3 and 4 rows"""
     import torch
     import m2v_load
     from oracle import m2v_oracle_ctypes as orc
@@ -28,7 +31,12 @@ def test_strips_equal_single_encoder(world, W, H, pf, VL):
         up = [eng.alloc(hb) for eng in engines]
         down = [eng.alloc(hb) for eng in engines]
         for j in range(steps):
-            nb = [eng.step(j, up[r], down[r]) for r, eng in enumerate(engines)]
+            if split:
+                nb = [eng.step_edges(j, up[r], down[r]) for r, eng in enumerate(engines)]
+                for eng in engines:
+                    eng.step_interior(j)
+            else:
+                nb = [eng.step(j, up[r], down[r]) for r, eng in enumerate(engines)]
             assert len(set(nb)) == 1
             if nb[0]:
                 for r, eng in enumerate(engines):       # rank r receives rank r-1's bottom rows and rank r+1's top rows

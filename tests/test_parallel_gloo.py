@@ -53,6 +53,7 @@ class OracleStripEngine:
         return np.concatenate([Y[y0:y0 + YR].reshape(-1), U[yc0:yc0 + UR].reshape(-1), V[yc0:yc0 + UR].reshape(-1)])
 
     def begin(self, row0, row1):
+        self.phase = None
         self.row0, self.row1 = row0, row1
         self.chunk = 3 * self.VL * self.W
         steps = min(self.n, self.pf + 1)
@@ -71,7 +72,19 @@ class OracleStripEngine:
                     self._rows(f, 16 * self.row1 - YR, 8 * self.row1 - UR))
         return len(self._halo_frames(j)) * self.chunk
 
+    # the two-part step encode_strips() prefers (edge rows + halo first, interior rows while the halo travels);
+    # the order of the calls is part of the contract
+    def step_edges(self, j, send_up, send_down):
+        assert self.phase == ("interior", j - 1) or (j == 0 and self.phase is None), self.phase
+        self.phase = ("edges", j)
+        return self.step(j, send_up, send_down)
+
+    def step_interior(self, j):
+        assert self.phase == ("edges", j), self.phase
+        self.phase = ("interior", j)
+
     def halo_in(self, j, from_up, from_down):
+        assert self.phase == ("interior", j), "halo_in comes after the interior rows were queued"
         YR, UR = 2 * self.VL, self.VL
         for k, f in enumerate(self._halo_frames(j)):
             if from_up is not None:
