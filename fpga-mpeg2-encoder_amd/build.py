@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libm2v_mi355x.so")
 TB = os.path.join(HERE, "m2v_tb")
 CONTAINER_LIB = os.path.join(HERE, "libm2v_container.so")      # CPU-only conveniences (include/m2v_container.h)
 SOURCES = ["m2v_mi355x.hip", "m2v_kernels.hpp", "m2v_tables.hpp"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-Wall", "-Wno-unused-function"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc():

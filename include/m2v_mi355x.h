@@ -158,7 +158,11 @@ int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t 
  * "profile" (1 = time the per-kernel launches with HIP events),
  * "async" (default 1: the port path keeps two chunks in flight - while one chunk is uploaded, encoded and
  * read back, m2v_push_* fills the pinned staging of the next one; 0 = a chunk is complete when the push
- * that filled it returns.  The bytes are the same either way). */
+ * that filled it returns.  The bytes are the same either way),
+ * "copy_threads" (default 4: threads m2v_push_frames uses to copy large inputs into pinned memory),
+ * "split_streams" (default 0; 1 = the GOP segments of a chunk run as two independent halves on two HIP streams so
+ * that the partially filled tail of one launch overlaps with the other half's next launch: +4 % on 1920x1152,
+ * ignored while "profile" is on). */
 int m2v_set_option(m2v_enc *e, const char *name, long long value);
 
 /* Per-kernel statistics of the last m2v_encode_resident call with "profile" = 1.

@@ -16,10 +16,11 @@ import torch
 base = M.synth.clip_torch(W, H, 90, clip_index=0, device="cuda:0").cpu().numpy()
 clip = np.concatenate([base, base, base])            # 270 frames = 30 GOPs, 1.8 GB of host memory
 want = None
-for use_async, bf in ((0, 90), (1, 90), (1, 27), (0, 27)):
+for use_async, bf, threads in ((0, 90, 1), (1, 90, 1), (1, 90, 2), (1, 90, 4), (1, 90, 8), (1, 27, 4)):
     enc = M.Mpeg2Encoder(7, 7, 3, 2)
     enc.set_option("batch_frames", bf)
     enc.set_option("async", use_async)
+    enc.set_option("copy_threads", threads)
     best = 1e9
     for it in range(3):
         t0 = time.perf_counter()
@@ -36,6 +37,6 @@ for use_async, bf in ((0, 90), (1, 90), (1, 27), (0, 27)):
         if want is None:
             want = data
         assert data == want, "stream differs between modes"
-    print("async=%d batch_frames=%d: %d frames %dx%d host -> %d bytes, best of 3 %.1f ms = %.0f MPixels/s (input %.1f GB/s)"
-          % (use_async, bf, n, W, H, len(data), best * 1e3, n * W * H / best * 1e-6, n * W * H * 3 / best * 1e-9))
+    print("async=%d batch_frames=%d copy_threads=%d: %d frames %dx%d host -> %d bytes, best of 3 %.1f ms = %.0f MPixels/s (input %.1f GB/s)"
+          % (use_async, bf, threads, n, W, H, len(data), best * 1e3, n * W * H / best * 1e-6, n * W * H * 3 / best * 1e-9))
     enc.close()
