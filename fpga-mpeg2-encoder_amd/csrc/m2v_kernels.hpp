@@ -141,6 +141,24 @@ __device__ __forceinline__ uint32_t avg4x4(uint32_t a, uint32_t b, uint32_t c, u
     return __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(a, b, 0u), __builtin_amdgcn_lerp(c, d, 0u), (a ^ b) | (c ^ d));
 }
 
+// (a + b + c + d + 2) >> 2 per byte, the ISO/IEC 13818-2 7.6.4 rounding (option "conformant" only): with the floor
+// means s = (a+b)>>1, t = (c+d)>>1 and their lost bits la, lc the sum is 2s + 2t + la + lc, so the result is
+// (s + t + 1 + (la & lc)) >> 1 = lerp(s, t, 1) plus one where la & lc and s + t is even (checked exhaustively over
+// (s, t, la, lc) in tests/test_host_logic.py); the per-byte result is <= 255, so the packed add cannot carry
+__device__ __forceinline__ uint32_t avg4x4_iso(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint32_t s2 = __builtin_amdgcn_lerp(a, b, 0u), t2 = __builtin_amdgcn_lerp(c, d, 0u);
+    const uint32_t both = (a ^ b) & (c ^ d);
+    return __builtin_amdgcn_lerp(s2, t2, 0x01010101u) + (both & ~(s2 ^ t2) & 0x01010101u);
+}
+
+template <bool CONF>
+__device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    if constexpr (CONF) return avg4x4_iso(a, b, c, d);
+    else return avg4x4(a, b, c, d);
+}
+
 // XCD-aware block remap: consecutive logical blocks land on the same XCD (shared L2 for the
 // overlapping reference windows of neighbouring macroblocks).  Bijective for any grid size.
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
@@ -370,7 +388,13 @@ __device__ __forceinline__ void search_rows(const uint32_t *s_cur, uint32_t ae, 
     }
 }
 
-template <int VL, bool P>
+// CONF = option "conformant" (NOT the reference's behaviour): the reconstruction loop follows
+// ISO/IEC 13818-2 where the RTL deviates from it, so that a standard decoder reproduces the encoder's reference frames
+// exactly (no drift inside a GOP): four-sample average with +2, 4:2:0 chroma vector = mv / 2 toward zero, inverse
+// quantiser truncating toward zero with [-2048, 2047] saturation and mismatch control, blocks that are not coded are
+// not reconstructed.  The IDCT needs no change: for in-range coefficients its 18-bit row store never wraps and the
+// +-255 clip gives the same pixel after the final clip to 0..255.  Checked against the oracle's conformant mode.
+template <int VL, bool P, bool CONF = false>
 __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
                                            Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
                                            uint32_t *__restrict__ slots_small, uint32_t *__restrict__ slots,
@@ -554,9 +578,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 #undef M2V_ROW3
         }
         uint32_t hp[9];                                         // the nine half-pel predictions (RTL:1746-1752)
-        hp[0] = avg4x4(L0, C0, L1, C1);  hp[1] = avg2x4(C0, C1);  hp[2] = avg4x4(C0, R0, C1, R1);
+        hp[0] = avg4<CONF>(L0, C0, L1, C1);  hp[1] = avg2x4(C0, C1);  hp[2] = avg4<CONF>(C0, R0, C1, R1);
         hp[3] = avg2x4(L1, C1);          hp[4] = C1;              hp[5] = avg2x4(C1, R1);
-        hp[6] = avg4x4(L1, C1, L2, C2);  hp[7] = avg2x4(C1, C2);  hp[8] = avg4x4(C1, R1, C2, R2);
+        hp[6] = avg4<CONF>(L1, C1, L2, C2);  hp[7] = avg2x4(C1, C2);  hp[8] = avg4<CONF>(C1, R1, C2, R2);
         int v10[10] = {4096, 4096, 4096, 4096, 0, 4096, 4096, 4096, 4096, 4095};
         if (!(g.ablate & 2)) {
             uint32_t s[10];
@@ -612,7 +636,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         uint32_t pu = 0x8080u, pv = 0x8080u;            // two packed prediction bytes per plane
         if constexpr (P) {
             if (inter) {
-                const int cyi = mvy >> 2, cxi = mvx >> 2, fyh = (mvy >> 1) & 1, fxh = (mvx >> 1) & 1;
+                // chroma vector in chroma half samples: RTL floor; ISO 7.6.3.7 divides with truncation toward zero
+                const int cmy = CONF ? (mvy - (mvy >> 31)) >> 1 : mvy >> 1, cmx = CONF ? (mvx - (mvx >> 31)) >> 1 : mvx >> 1;
+                const int cyi = cmy >> 1, cxi = cmx >> 1, fyh = cmy & 1, fxh = cmx & 1;
                 const int row = yc + cyi + UR, col = xc + cxi + 4;         // col .. col+2 are needed, col <= 13
                 const int row1 = row + 1 > CROWS - 1 ? CROWS - 1 : row + 1;
                 const int wi = col >> 2, wi1 = wi + 1 > 3 ? 3 : wi + 1;
@@ -624,7 +650,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     const uint32_t c = __builtin_amdgcn_alignbyte(cw[row1 * 4 + wi1], cw[row1 * 4 + wi], sft);    // T[row+1][col..]
                     const uint32_t b = a >> 8, d = c >> 8;
                     uint32_t pr;
-                    if (fyh && fxh) pr = avg4x4(a, b, c, d);
+                    if (fyh && fxh) pr = avg4<CONF>(a, b, c, d);
                     else if (fxh)   pr = avg2x4(a, b);
                     else if (fyh)   pr = avg2x4(a, c);
                     else            pr = a;
@@ -690,8 +716,19 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             cbp = (cbp << 1) | (__ballot(a != 0u) != 0ull ? 1 : 0);
             if (need_rec) {                             // RTL:2134-2137: (2q + sign(q)) << Q, clamped to +-2047
                 uint32_t xa = (2u * a + (a != 0u ? 1u : 0u)) << Q;
-                if (xa > 2047u) xa = 2047u;
-                s_x[t][lane] = (int16_t)((int)(xa ^ (uint32_t)sg) - sg);
+                if constexpr (CONF) {
+                    // ISO 7.4.2.3 gives the same product; saturation to [-2048, 2047] (7.4.3), mismatch control (7.4.4);
+                    // a block without coefficients is not reconstructed at all
+                    int x = (int)(xa ^ (uint32_t)sg) - sg;
+                    x = x < -2048 ? -2048 : x > 2047 ? 2047 : x;
+                    const bool coded = __ballot(a != 0u) != 0ull;
+                    const bool even = (__popcll(__ballot(x & 1)) & 1) == 0;
+                    if (coded && even && lane == 63) x ^= 1;
+                    s_x[t][lane] = (int16_t)x;
+                } else {
+                    if (xa > 2047u) xa = 2047u;
+                    s_x[t][lane] = (int16_t)((int)(xa ^ (uint32_t)sg) - sg);
+                }
             }
         }
     } else {
@@ -712,7 +749,18 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             if (coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
             if (need_rec) {
                 int x;
-                if (lane != 0) {
+                if constexpr (CONF) {
+                    // ISO 7.4.2.3: (2 QF W quantiser_scale) / 32 with quantiser_scale = 2 << Q, truncating toward zero
+                    if (lane != 0) {
+                        const uint32_t m = (a * (uint32_t)wq) << Q;             // |QF| W (1 << Q): < 2^11 * 2^7 * 2^4
+                        x = (int)((m >> 3) ^ (uint32_t)sg) - sg;
+                        x = x < -2048 ? -2048 : x > 2047 ? 2047 : x;
+                    } else {
+                        x = 2 * q;
+                    }
+                    const bool even = (__popcll(__ballot(x & 1)) & 1) == 0;      // mismatch control (7.4.4)
+                    if (even && lane == 63) x ^= 1;
+                } else if (lane != 0) {
                     x = sext(__mul24(q, wq), 17);       // 17-bit temporary (RTL:2093, 2139)
                     x = Q >= 3 ? sext((int)((uint32_t)x << (Q - 3)), 17) : (x >> (3 - Q));
                     x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;

@@ -97,6 +97,7 @@ struct m2v_enc {
     int cur = 0;                  // stage being filled by m2v_push_*
     HostStage &st() { return hs[cur]; }
     std::deque<int> pending;      // submitted stages, oldest first
+    bool conformant = false;      // option "conformant": ISO reconstruction loop instead of the RTL's (NOT byte-identical to the reference)
     int copy_threads = 4;         // option "copy_threads": threads that copy m2v_push_frames input into pinned memory
     bool split_streams = false;   // see encode_chunk
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -280,15 +281,28 @@ void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Ge
     const dim3 grid((unsigned)((size_t)count * (size_t)(g.row1 - g.row0) * g.mbw)), block(64);      // one wavefront per macroblock
     Timer t(e, s, P ? 0 : 1, (double)count * g.ysz);
     int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
+#define M2V_LAUNCH_MB(VLV, PV, CV) \
+    hipLaunchKernelGGL((k_mb<VLV, PV, CV>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
+                       e->d_slots_small.p, e->d_slots.p, dbg)
     if (P) {
-        switch (e->VL) {
-            case 1: hipLaunchKernelGGL((k_mb<1, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
-            case 2: hipLaunchKernelGGL((k_mb<2, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
-            default: hipLaunchKernelGGL((k_mb<3, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg); break;
+        if (e->conformant) {
+            switch (e->VL) {
+                case 1: M2V_LAUNCH_MB(1, true, true); break;
+                case 2: M2V_LAUNCH_MB(2, true, true); break;
+                default: M2V_LAUNCH_MB(3, true, true); break;
+            }
+        } else {
+            switch (e->VL) {
+                case 1: M2V_LAUNCH_MB(1, true, false); break;
+                case 2: M2V_LAUNCH_MB(2, true, false); break;
+                default: M2V_LAUNCH_MB(3, true, false); break;
+            }
         }
     } else {
-        hipLaunchKernelGGL((k_mb<1, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, dbg);
+        if (e->conformant) M2V_LAUNCH_MB(1, false, true);
+        else M2V_LAUNCH_MB(1, false, false);
     }
+#undef M2V_LAUNCH_MB
     HIPCHK(hipGetLastError());
     t.stop();
 }
@@ -1233,6 +1247,11 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
     if (!strcmp(name, "profile")) { e->profile = value != 0; return M2V_OK; }
     if (!strcmp(name, "async")) { e->async = value != 0; return M2V_OK; }
     if (!strcmp(name, "split_streams")) { e->split_streams = value != 0; return M2V_OK; }
+    if (!strcmp(name, "conformant")) {
+        if (e->state != m2v_enc::IDLE) return M2V_E_PARAM;
+        e->conformant = value != 0;
+        return M2V_OK;
+    }
     if (!strcmp(name, "copy_threads")) { if (value < 1 || value > 64) return M2V_E_PARAM; e->copy_threads = (int)value; return M2V_OK; }
     if (!strcmp(name, "keep_recon")) { e->keep_recon = value != 0; return M2V_OK; }
     if (!strcmp(name, "ablate")) { e->ablate = (int)value; return M2V_OK; }   // profiling aid: output is invalid when != 0

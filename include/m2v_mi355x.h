@@ -162,7 +162,12 @@ int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t 
  * "copy_threads" (default 4: threads m2v_push_frames uses to copy large inputs into pinned memory),
  * "split_streams" (default 0; 1 = the GOP segments of a chunk run as two independent halves on two HIP streams so
  * that the partially filled tail of one launch overlaps with the other half's next launch: +4 % on 1920x1152,
- * ignored while "profile" is on). */
+ * ignored while "profile" is on),
+ * "conformant" (default 0 = the reference's arithmetic, byte-identical to the RTL.  1 = NOT the reference's
+ * behaviour: the reconstruction loop follows ISO/IEC 13818-2 where the RTL deviates from it - four-sample average
+ * rounded with +2, 4:2:0 chroma vector = mv / 2 toward zero, inverse quantiser truncating toward zero with
+ * [-2048, 2047] saturation and mismatch control - so that a standard decoder reproduces the encoder's reference
+ * frames exactly instead of drifting inside a GOP.  Only while idle). */
 int m2v_set_option(m2v_enc *e, const char *name, long long value);
 
 /* Per-kernel statistics of the last m2v_encode_resident call with "profile" = 1.

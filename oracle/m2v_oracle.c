@@ -81,7 +81,16 @@ size_t m2v_oracle_frame_count(const m2v_oracle_params *p, unsigned xsize16, unsi
  * small helpers (RTL:750-795)
  * ---------------------------------------------------------------------------------------- */
 static inline int mean2(int a, int b)                 { return (a + b + 1) >> 1; }      /* RTL:750-757 */
-static inline int mean4(int a, int b, int c, int d)   { return (a + b + c + d + 1) >> 2; } /* RTL:760-767: +1, not +2 */
+/* Optional standard-conformant reconstruction loop (NOT a mode of the reference, it pins the GPU
+ * path's option "conformant"): ISO/IEC 13818-2 where the RTL deviates from it - mean4 rounds with +2 (7.6.4), the
+ * 4:2:0 chroma vector is mv / 2 truncated toward zero (7.6.3.7), inverse quantisation truncates toward zero,
+ * saturates to [-2048, 2047] and applies mismatch control (7.4.2.3, 7.4.3, 7.4.4), the IDCT keeps its row pass in
+ * full width and saturates to [-256, 255] (Annex A).  Process-global, tests switch it serially. */
+static int g_conformant = 0;
+void m2v_oracle_set_conformant(int on) { g_conformant = on != 0; }
+int  m2v_oracle_get_conformant(void)   { return g_conformant; }
+
+static inline int mean4(int a, int b, int c, int d)   { return (a + b + c + d + (g_conformant ? 2 : 1)) >> 2; } /* RTL:760-767: +1, not +2 */
 static inline int absdiff(int a, int b)               { return a > b ? a - b : b - a; } /* RTL:770-775 */
 static inline int32_t sext(int32_t v, int bits)
 {
@@ -195,8 +204,27 @@ void m2v_oracle_quant(const int32_t c[64], int inter, int Q, int16_t q[64])
 /* ------------------------------------------------------------------------------------------
  * stage H: inverse quantiser (RTL:2129-2150), 17-bit signed temporary, no mismatch control
  * ---------------------------------------------------------------------------------------- */
+static void dequant_conformant(const int16_t q[64], int inter, int Q, int16_t d[64])
+{
+    const int qs = 2 << Q;                                  /* quantiser_scale: the slice header carries code 1 << Q, q_scale_type 0 */
+    int sum = 0;
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) {
+            const int32_t qf = q[i * 8 + j];
+            int32_t t;
+            if (inter)                 t = ((2 * qf + (qf > 0 ? 1 : qf < 0 ? -1 : 0)) * 16 * qs) / 32;   /* 7.4.2.3, k = sign */
+            else if (i != 0 || j != 0) t = (2 * qf * M2V_INTRA_W[i][j] * qs) / 32;                      /* k = 0; "/" truncates */
+            else                       t = 2 * qf;                                                      /* intra_dc_mult, 10 bit */
+            t = t < -2048 ? -2048 : t > 2047 ? 2047 : t;                                                /* 7.4.3 */
+            d[i * 8 + j] = (int16_t)t;
+            sum += t;
+        }
+    if ((sum & 1) == 0) d[63] ^= 1;                         /* 7.4.4: odd -> minus 1, even -> plus 1 = toggle the LSB */
+}
+
 void m2v_oracle_dequant(const int16_t q[64], int inter, int Q, int16_t d[64])
 {
+    if (g_conformant) { dequant_conformant(q, inter, Q, d); return; }
     for (int i = 0; i < 8; ++i)
         for (int j = 0; j < 8; ++j) {
             int32_t t = q[i * 8 + j];
@@ -225,6 +253,8 @@ void m2v_oracle_dequant(const int16_t q[64], int inter, int Q, int16_t d[64])
 static inline int32_t mul32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
 static inline int32_t add32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 static inline int32_t sub32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+
+static inline int32_t row_store(int32_t v) { return g_conformant ? v : sext(v, 18); }   /* RTL:886, 2170: 18-bit register */
 
 static void idct_row(const int16_t a[8], int32_t r[8])
 {
@@ -257,18 +287,19 @@ static void idct_row(const int16_t a[8], int32_t r[8])
     x2 = add32(mul32(181, add32(x4, x5)), 128) >> 8;
     x4 = add32(mul32(181, sub32(x4, x5)), 128) >> 8;
     /* step 4, RTL:897-904: >>>8 then stored in 18 bits */
-    r[0] = sext(add32(x7, x1) >> 8, 18);
-    r[1] = sext(add32(x3, x2) >> 8, 18);
-    r[2] = sext(add32(x0, x4) >> 8, 18);
-    r[3] = sext(add32(x8, x6) >> 8, 18);
-    r[4] = sext(sub32(x8, x6) >> 8, 18);
-    r[5] = sext(sub32(x0, x4) >> 8, 18);
-    r[6] = sext(sub32(x3, x2) >> 8, 18);
-    r[7] = sext(sub32(x7, x1) >> 8, 18);
+    r[0] = row_store(add32(x7, x1) >> 8);
+    r[1] = row_store(add32(x3, x2) >> 8);
+    r[2] = row_store(add32(x0, x4) >> 8);
+    r[3] = row_store(add32(x8, x6) >> 8);
+    r[4] = row_store(sub32(x8, x6) >> 8);
+    r[5] = row_store(sub32(x0, x4) >> 8);
+    r[6] = row_store(sub32(x3, x2) >> 8);
+    r[7] = row_store(sub32(x7, x1) >> 8);
 }
 
 static inline int clip255(int32_t v)                       /* RTL:778-783; the argument port is 28 bits */
 {
+    if (g_conformant) return v < -256 ? -256 : v > 255 ? 255 : v;      /* Annex A saturation */
     v = sext(v, 28);
     return v < -255 ? -255 : v > 255 ? 255 : v;
 }
@@ -471,8 +502,10 @@ static void motion_stage(const geom_t *g, const uint8_t cy[256], const planes_t 
 
     /* ---- chroma prediction (RTL:1854-1888 integer part mv>>>2, RTL:1904-1916 half flag = bit 1) ---- */
     const int cw = W / 2, ch = H / 2;
-    int cy_i = mvy >> 2, cx_i = mvx >> 2;               /* floor */
-    int fyh = (mvy >> 1) & 1, fxh = (mvx >> 1) & 1;
+    /* chroma vector in chroma half samples: RTL floor (mv >>> 1), ISO 7.6.3.7 truncation toward zero (mv / 2) */
+    const int cmvy = g_conformant ? mvy / 2 : mvy >> 1, cmvx = g_conformant ? mvx / 2 : mvx >> 1;
+    int cy_i = cmvy >> 1, cx_i = cmvx >> 1;             /* floor */
+    int fyh = cmvy & 1, fxh = cmvx & 1;
     for (int pl = 0; pl < 2; ++pl) {
         const uint8_t *rp = pl ? ref->V : ref->U;
         uint8_t *out = pl ? pv : pu;
@@ -737,8 +770,12 @@ static void encode_frame(const geom_t *g, size_t n, int i_frame, const planes_t 
                     }
                 cbp = (cbp << 1) | nz;
                 /* reconstruction loop (stages H..P) */
-                m2v_oracle_dequant(q, inter, g->Q, d);
-                m2v_oracle_idct(d, r);
+                if (g_conformant && inter && !nz) {
+                    memset(r, 0, sizeof r);                 /* a block that is not coded is not reconstructed (7.6.8): no mismatch toggle */
+                } else {
+                    m2v_oracle_dequant(q, inter, g->Q, d);
+                    m2v_oracle_idct(d, r);
+                }
                 for (int y = 0; y < 8; ++y)
                     for (int xx = 0; xx < 8; ++xx) {
                         int v = pp[(oy + y) * cs + ox + xx] + r[y * 8 + xx];   /* add_clip_0_255, RTL:786-795 */

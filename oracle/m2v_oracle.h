@@ -50,6 +50,13 @@ typedef struct m2v_oracle_dump {
     uint32_t *mb_bits;   /* [frames][mbs]          bits of the macroblock layer of each MB */
 } m2v_oracle_dump;
 
+/* NOT a reference mode: switches the reconstruction loop to ISO/IEC 13818-2 where the RTL deviates from it (+2
+ * rounding of the four-sample average, chroma vector = mv / 2 toward zero, truncating inverse quantiser with
+ * [-2048, 2047] saturation and mismatch control, full-width IDCT row pass, [-256, 255] saturation).  It exists
+ * to check the GPU path's option "conformant" (SURVEY.md 8(f4)).  Process-global; default off. */
+void m2v_oracle_set_conformant(int on);
+int  m2v_oracle_get_conformant(void);
+
 /* Size clamp of RTL/mpeg2encoder.v:985-991.  Returns 0, or -1 for bad params. */
 int m2v_oracle_geometry(const m2v_oracle_params *p, unsigned xsize16, unsigned ysize16,
                         int *width, int *height);

@@ -68,10 +68,11 @@ def geometry(xsize16, ysize16, XL=7, YL=7, VL=3, Q=2):
     return w.value, h.value
 
 
-def encode(frames444, xsize16, ysize16, pframes, XL=7, YL=7, VL=3, Q=2, nbeats=None, dump=False):
+def encode(frames444, xsize16, ysize16, pframes, XL=7, YL=7, VL=3, Q=2, nbeats=None, dump=False, conformant=False):
     """Encode a sequence.  `frames444`: uint8 array [nframes, 3, H, W] (or flat) in the CLAMPED geometry.
 
-    Returns bytes, or (bytes, dict of numpy dumps) when dump=True.
+    Returns bytes, or (bytes, dict of numpy dumps) when dump=True.  conformant=True is NOT the reference's behaviour:
+    ISO/IEC 13818-2 reconstruction loop, the checker of the GPU path's option "conformant" (see m2v_oracle.h).
     """
     p = Params(XL, YL, VL, Q)
     W, H = geometry(xsize16, ysize16, XL, YL, VL, Q)
@@ -95,8 +96,12 @@ def encode(frames444, xsize16, ysize16, pframes, XL=7, YL=7, VL=3, Q=2, nbeats=N
                     mb_bits=np.zeros((nframes, mbs), np.uint32))
         d = Dump(*[arrs[k].ctypes.data for k in ("mb_inter", "mb_mvx", "mb_mvy", "mb_cbp", "coef", "recon",
                                                   "yuv420", "mb_bits")])
-    n = lib().m2v_oracle_encode(ctypes.byref(p), xsize16, ysize16, pframes, f.ctypes.data, nbeats,
-                                out.ctypes.data, cap, ctypes.byref(d) if d is not None else None)
+    lib().m2v_oracle_set_conformant(1 if conformant else 0)
+    try:
+        n = lib().m2v_oracle_encode(ctypes.byref(p), xsize16, ysize16, pframes, f.ctypes.data, nbeats,
+                                    out.ctypes.data, cap, ctypes.byref(d) if d is not None else None)
+    finally:
+        lib().m2v_oracle_set_conformant(0)
     if n == ctypes.c_size_t(-1).value:
         raise ValueError("oracle rejected the parameters")
     if n > cap:

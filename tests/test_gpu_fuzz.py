@@ -66,5 +66,9 @@ def test_fuzz(seed):
         try:
             enc.set_option("batch_frames", bf)
             assert enc.encode(clip, W // 16, H // 16, pf, nbeats=nbeats) == want, tag + " (port interface)"
+            if case % 3 == 2:                                                          # the non-reference ISO reconstruction loop
+                enc.set_option("conformant", 1)
+                want_c = orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, Q, nbeats=nbeats, conformant=True)
+                assert enc.encode(clip, W // 16, H // 16, pf, nbeats=nbeats) == want_c, tag + " (conformant)"
         finally:
             enc.close()

@@ -73,3 +73,25 @@ def test_split_streams_option(G):
             assert enc.encode(f, 7, 5, pf) == want
         finally:
             enc.close()
+
+
+@pytest.mark.parametrize("VL,Q,pf", [(3, 2, 8), (2, 1, 3), (1, 4, 5), (3, 3, 0)])
+def test_conformant_option_matches_the_oracles_conformant_mode(G, VL, Q, pf):
+    """Option "conformant" (ISO reconstruction loop: +2 rounding, chroma vector toward zero, truncating inverse quantiser
+    with mismatch control) is NOT the reference's behaviour; it is checked against the oracle's own conformant mode,
+    which tests/test_conformant.py ties to a standard decoder.  The default mode is untouched (all other tests)."""
+    from oracle import m2v_oracle_ctypes as orc
+    f = G.M.synth.clip(144, 112, 11, clip_index=13, scene_len=6)
+    want = orc.encode(f, 9, 7, pf, XL=6, YL=6, VL=VL, Q=Q, conformant=True)
+    base = orc.encode(f, 9, 7, pf, XL=6, YL=6, VL=VL, Q=Q)
+    enc = G.M.Mpeg2Encoder(6, 6, VL, Q, device=0)
+    try:
+        enc.set_option("conformant", 1)
+        assert G.resident_encode(f, 9, 7, pf, XL=6, YL=6, VL=VL, Q=Q, enc=enc) == want
+        assert enc.encode(f, 9, 7, pf) == want
+        enc.set_option("conformant", 0)
+        assert G.resident_encode(f, 9, 7, pf, XL=6, YL=6, VL=VL, Q=Q, enc=enc) == base
+    finally:
+        enc.close()
+    if pf:
+        assert want != base
