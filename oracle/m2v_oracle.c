@@ -90,7 +90,7 @@ static int g_conformant = 0;
 void m2v_oracle_set_conformant(int on) { g_conformant = on != 0; }
 int  m2v_oracle_get_conformant(void)   { return g_conformant; }
 
-static inline int mean4(int a, int b, int c, int d)   { return (a + b + c + d + (g_conformant ? 2 : 1)) >> 2; } /* RTL:760-767: +1, not +2 */
+static inline int mean4(int a, int b, int c, int d, int r4) { return (a + b + c + d + r4) >> 2; } /* RTL:760-767: r4 = 1, not 2 (2 = ISO, conformant mode only) */
 static inline int absdiff(int a, int b)               { return a > b ? a - b : b - a; } /* RTL:770-775 */
 static inline int32_t sext(int32_t v, int bits)
 {
@@ -254,9 +254,9 @@ static inline int32_t mul32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a
 static inline int32_t add32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 static inline int32_t sub32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 
-static inline int32_t row_store(int32_t v) { return g_conformant ? v : sext(v, 18); }   /* RTL:886, 2170: 18-bit register */
+static inline int32_t row_store(int32_t v, int conf) { return conf ? v : sext(v, 18); }   /* RTL:886, 2170: 18-bit register */
 
-static void idct_row(const int16_t a[8], int32_t r[8])
+static void idct_row(const int16_t a[8], int32_t r[8], int conf)
 {
     int32_t x0 = a[0], x1 = a[4], x2 = a[6], x3 = a[2], x4 = a[1], x5 = a[7], x6 = a[5], x7 = a[3], x8;
     x0 = (int32_t)((uint32_t)x0 << 11);
@@ -287,24 +287,24 @@ static void idct_row(const int16_t a[8], int32_t r[8])
     x2 = add32(mul32(181, add32(x4, x5)), 128) >> 8;
     x4 = add32(mul32(181, sub32(x4, x5)), 128) >> 8;
     /* step 4, RTL:897-904: >>>8 then stored in 18 bits */
-    r[0] = row_store(add32(x7, x1) >> 8);
-    r[1] = row_store(add32(x3, x2) >> 8);
-    r[2] = row_store(add32(x0, x4) >> 8);
-    r[3] = row_store(add32(x8, x6) >> 8);
-    r[4] = row_store(sub32(x8, x6) >> 8);
-    r[5] = row_store(sub32(x0, x4) >> 8);
-    r[6] = row_store(sub32(x3, x2) >> 8);
-    r[7] = row_store(sub32(x7, x1) >> 8);
+    r[0] = row_store(add32(x7, x1) >> 8, conf);
+    r[1] = row_store(add32(x3, x2) >> 8, conf);
+    r[2] = row_store(add32(x0, x4) >> 8, conf);
+    r[3] = row_store(add32(x8, x6) >> 8, conf);
+    r[4] = row_store(sub32(x8, x6) >> 8, conf);
+    r[5] = row_store(sub32(x0, x4) >> 8, conf);
+    r[6] = row_store(sub32(x3, x2) >> 8, conf);
+    r[7] = row_store(sub32(x7, x1) >> 8, conf);
 }
 
-static inline int clip255(int32_t v)                       /* RTL:778-783; the argument port is 28 bits */
+static inline int clip255(int32_t v, int conf)             /* RTL:778-783; the argument port is 28 bits */
 {
-    if (g_conformant) return v < -256 ? -256 : v > 255 ? 255 : v;      /* Annex A saturation */
+    if (conf) return v < -256 ? -256 : v > 255 ? 255 : v;      /* Annex A saturation */
     v = sext(v, 28);
     return v < -255 ? -255 : v > 255 ? 255 : v;
 }
 
-static void idct_col(const int32_t a[8], int16_t r[8])
+static void idct_col(const int32_t a[8], int16_t r[8], int conf)
 {
     int32_t x0 = a[0], x1 = a[4], x2 = a[6], x3 = a[2], x4 = a[1], x5 = a[7], x6 = a[5], x7 = a[3], x8;
     x0 = (int32_t)((uint32_t)x0 << 8);
@@ -335,25 +335,26 @@ static void idct_col(const int32_t a[8], int16_t r[8])
     x2 = add32(mul32(181, add32(x4, x5)), 128) >> 8;
     x4 = add32(mul32(181, sub32(x4, x5)), 128) >> 8;
     /* step 4, RTL:963-970 */
-    r[0] = (int16_t)clip255(add32(x7, x1) >> 14);
-    r[1] = (int16_t)clip255(add32(x3, x2) >> 14);
-    r[2] = (int16_t)clip255(add32(x0, x4) >> 14);
-    r[3] = (int16_t)clip255(add32(x8, x6) >> 14);
-    r[4] = (int16_t)clip255(sub32(x8, x6) >> 14);
-    r[5] = (int16_t)clip255(sub32(x0, x4) >> 14);
-    r[6] = (int16_t)clip255(sub32(x3, x2) >> 14);
-    r[7] = (int16_t)clip255(sub32(x7, x1) >> 14);
+    r[0] = (int16_t)clip255(add32(x7, x1) >> 14, conf);
+    r[1] = (int16_t)clip255(add32(x3, x2) >> 14, conf);
+    r[2] = (int16_t)clip255(add32(x0, x4) >> 14, conf);
+    r[3] = (int16_t)clip255(add32(x8, x6) >> 14, conf);
+    r[4] = (int16_t)clip255(sub32(x8, x6) >> 14, conf);
+    r[5] = (int16_t)clip255(sub32(x0, x4) >> 14, conf);
+    r[6] = (int16_t)clip255(sub32(x3, x2) >> 14, conf);
+    r[7] = (int16_t)clip255(sub32(x7, x1) >> 14, conf);
 }
 
 void m2v_oracle_idct(const int16_t d[64], int16_t r[64])
 {
     int32_t rows[64];
-    for (int i = 0; i < 8; ++i) idct_row(d + 8 * i, rows + 8 * i);   /* stage J, RTL:2159-2189 */
+    const int conf = g_conformant;
+    for (int i = 0; i < 8; ++i) idct_row(d + 8 * i, rows + 8 * i, conf);   /* stage J, RTL:2159-2189 */
     for (int j = 0; j < 8; ++j) {                                    /* stages K/M, RTL:2238-2279 */
         int32_t col[8];
         int16_t out[8];
         for (int i = 0; i < 8; ++i) col[i] = rows[i * 8 + j];
-        idct_col(col, out);
+        idct_col(col, out, conf);
         for (int i = 0; i < 8; ++i) r[i * 8 + j] = out[i];
     }
 }
@@ -408,6 +409,7 @@ static void motion_stage(const geom_t *g, const uint8_t cy[256], const planes_t 
 {
     const int YR = g->YR, W = g->W, H = g->H;
     const int x0 = 16 * bx, y0 = 16 * by;
+    const int r4 = g_conformant ? 2 : 1;                  /* rounding of the four-sample mean: 1 = RTL:764 */
 
     /* ---- full-pel search (RTL:1634-1715) ---- */
     int have = 0, best = 0, fy = 0, fx = 0;
@@ -449,7 +451,7 @@ static void motion_stage(const geom_t *g, const uint8_t cy[256], const planes_t 
             if (!yo && !xo)      v = a;
             else if (!yo)        v = mean2(a, T[y + 1][x + 2]);
             else if (!xo)        v = mean2(a, T[y + 2][x + 1]);
-            else                 v = mean4(a, T[y + 1][x + 2], T[y + 2][x + 1], T[y + 2][x + 2]);
+            else                 v = mean4(a, T[y + 1][x + 2], T[y + 2][x + 1], T[y + 2][x + 2], r4);
             hg[i + 1][j + 1] = (uint8_t)v;
         }
 
@@ -515,7 +517,7 @@ static void motion_stage(const geom_t *g, const uint8_t cy[256], const planes_t 
                 int a = pix(rp, cw, cw, ch, yy, xx);
                 int v;
                 if (fyh && fxh) v = mean4(a, pix(rp, cw, cw, ch, yy, xx + 1), pix(rp, cw, cw, ch, yy + 1, xx),
-                                          pix(rp, cw, cw, ch, yy + 1, xx + 1));
+                                          pix(rp, cw, cw, ch, yy + 1, xx + 1), r4);
                 else if (fxh)   v = mean2(a, pix(rp, cw, cw, ch, yy, xx + 1));
                 else if (fyh)   v = mean2(a, pix(rp, cw, cw, ch, yy + 1, xx));
                 else            v = a;
