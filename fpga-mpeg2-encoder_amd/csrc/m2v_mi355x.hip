@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <new>
 #include <string>
 #include <thread>
@@ -747,6 +748,12 @@ int guard(m2v_enc *e, int (*fn)(m2v_enc *, void *), void *arg)
     } catch (const std::bad_alloc &) {
         e->set_err("host allocation failed");
         return M2V_E_NOMEM;
+    } catch (const std::exception &ex) {        // nothing may unwind through the C boundary (e.g. std::system_error from a copy thread)
+        e->set_err("%s", ex.what());
+        return M2V_E_HIP;
+    } catch (...) {
+        e->set_err("unknown failure");
+        return M2V_E_HIP;
     }
 }
 
