@@ -1,6 +1,8 @@
 // m2v_tb — file-to-file driver over the C-ABI; the counterpart of SIM/tb_mpeg2encoder.v.
 //
-//   m2v_tb [-XL n] [-YL n] [-VL n] [-Q n] [-p pframes] [-d device] [-bubbles]  in.yuv W H out.m2v  [in2.yuv W2 H2 out2.m2v ...]
+//   m2v_tb [-XL n] [-YL n] [-VL n] [-Q n] [-p pframes] [-d device] [-bubbles] [-conformant]  in.yuv W H out.m2v  [in2.yuv W2 H2 out2.m2v ...]
+//
+// -conformant switches the encoder's option "conformant" on (ISO reconstruction loop; NOT byte-identical to the RTL).
 //
 // Like the testbench it encodes the listed videos back to back on ONE encoder instance (TB:150:
 // "verify the module can end a sequence and start the next"), pushes only the complete frames of
@@ -17,10 +19,11 @@
 
 int main(int argc, char **argv)
 {
-    int XL = 7, YL = 6, VL = 3, Q = 2, pf = 23, dev = 0, bubbles = 0;
+    int XL = 7, YL = 6, VL = 3, Q = 2, pf = 23, dev = 0, bubbles = 0, conformant = 0;
     int i = 1;
     for (; i < argc && argv[i][0] == '-'; ++i) {
         if (!strcmp(argv[i], "-bubbles")) { bubbles = 1; continue; }
+        if (!strcmp(argv[i], "-conformant")) { conformant = 1; continue; }
         if (i + 1 >= argc) break;
         int v = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "-XL")) XL = v; else if (!strcmp(argv[i], "-YL")) YL = v;
@@ -36,6 +39,7 @@ int main(int argc, char **argv)
     int err = 0;
     m2v_enc *e = m2v_create(XL, YL, VL, Q, dev, &err);
     if (!e) { fprintf(stderr, "*** m2v_create failed (%d): an MI355X is required, there is no CPU fallback\n", err); return 1; }
+    if (conformant) m2v_set_option(e, "conformant", 1);
     int num_video = 0;
     for (; i + 3 < argc; i += 4) {
         ++num_video;
