@@ -790,8 +790,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             if (lane == 0) s_sym[0] = SYM_RAW | ((e >> 8) << 24) | (e & 255u);
             nsym = 1;
         }
-        const uint32_t lo_mask_l = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu;
-        const uint32_t hi_mask_l = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
+        // positions of the non-zero levels of the tile in rank order: the previous non-zero position of the level with
+        // rank k is s_pos[k - 1].  The region is the DCT scratch, free until the bit buffer is cleared below; one
+        // wavefront, LDS operations in program order: the read below sees every lane's write.
+        uint32_t *const s_pos = (uint32_t *)(lds + kOffT) + 1;       // s_pos[-1] exists (read by rank 0, value unused)
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             const int v = s_zig[t][lane];
@@ -812,11 +814,12 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 const unsigned long long mask = __ballot(nz);
                 const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
                 const uint32_t nnz = (uint32_t)__popcll(mask);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));   // non-zero levels in lower lanes
+                if (nz) s_pos[rank] = (uint32_t)lane;
                 if (nz) {
-                    const uint32_t blo = mlo & lo_mask_l, bhi = mhi & hi_mask_l;
-                    const uint32_t rank = (uint32_t)__popc(blo) + (uint32_t)__popc(bhi);
                     // index of the previous non-zero level (or the position before the first AC slot)
-                    const int prev = bhi ? 63 - __clz(bhi) : blo ? 31 - __clz(blo) : (inter ? -1 : 0);
+                    const int before = (int)s_pos[(int)rank - 1];
+                    const int prev = rank ? before : (inter ? -1 : 0);
                     const int run = lane - prev - 1;
                     uint32_t sym;
                     if (inter && lane == 0 && (v == 1 || v == -1)) sym = SYM_RAW | (2u << 24) | 2u | (v < 0 ? 1u : 0u);   // '1s' (RTL:2798-2802)
