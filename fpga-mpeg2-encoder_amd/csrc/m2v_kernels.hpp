@@ -830,9 +830,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     const int before = (int)s_pos[(int)rank - 1];
                     const int prev = rank ? before : (inter ? -1 : 0);
                     const int run = lane - prev - 1;
-                    uint32_t sym;
-                    if (inter && lane == 0 && (v == 1 || v == -1)) sym = SYM_RAW | (2u << 24) | 2u | (v < 0 ? 1u : 0u);   // '1s' (RTL:2798-2802)
-                    else sym = ((uint32_t)run << 16) | ((uint32_t)v & 0xFFFFu);
+                    uint32_t sym = ((uint32_t)run << 16) | ((uint32_t)v & 0xFFFFu);
+                    // first coefficient of a non-intra block with level +-1: '1s' (RTL:2798-2802); v0 is wave-uniform, so the
+                    // test is scalar and only lane 0 is touched
+                    if (inter && (v0 == 1 || v0 == -1) && lane == 0) sym = SYM_RAW | (2u << 24) | 2u | (v0 < 0 ? 1u : 0u);
                     s_sym[nsym + hasdc + rank] = sym;
                 }
                 if (lane == 0) s_sym[nsym + hasdc + nnz] = SYM_RAW | (2u << 24) | 2u;      // end_of_block '10' (RTL:2835)
