@@ -715,29 +715,27 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc = mad24(bi[k], s_t[t][k * 8 + dj], acc);   // |R1| < 2^18
             const int C = acc >> 12;
-            const int sg = C >> 31;                     // sign-magnitude from here on: 0 / -1
-            const uint32_t mag = (uint32_t)((C ^ sg) - sg);
-            uint32_t a = (mag + 2u) >> (4 + Q);                                      // RTL:2070
-            if (a > 2047u) a = 2047u;
-            const int q = (int)(a ^ (uint32_t)sg) - sg;
+            // RTL:2070: sign(C) * min((|C| + 2) >> s, 2047), s = 4 + Q, computed on the signed value: for C < 0 it is
+            // ceil((C - 2) / 2^s) = (C + 2^s - 3) >> s (identity checked over the 17-bit range in tests/test_host_logic.py)
+            const int sg = C >> 31;                     // 0 / -1
+            int q = (C + 2 + (sg & ((1 << (4 + Q)) - 5))) >> (4 + Q);
+            q = q < -2047 ? -2047 : q > 2047 ? 2047 : q;
             s_zig[t][zz] = (int16_t)q;
             if (coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
-            cbp = (cbp << 1) | (__ballot(a != 0u) != 0ull ? 1 : 0);
+            cbp = (cbp << 1) | (__ballot(q != 0) != 0ull ? 1 : 0);
             if (need_rec) {                             // RTL:2134-2137: (2q + sign(q)) << Q, clamped to +-2047
-                uint32_t xa = (2u * a + (a != 0u ? 1u : 0u)) << Q;
+                int x = (2 * q + (q != 0 ? (sg | 1) : 0)) << Q;
                 if constexpr (CONF) {
                     // ISO 7.4.2.3 gives the same product; saturation to [-2048, 2047] (7.4.3), mismatch control (7.4.4);
                     // a block without coefficients is not reconstructed at all
-                    int x = (int)(xa ^ (uint32_t)sg) - sg;
                     x = x < -2048 ? -2048 : x > 2047 ? 2047 : x;
-                    const bool coded = __ballot(a != 0u) != 0ull;
+                    const bool coded = __ballot(q != 0) != 0ull;
                     const bool even = (__popcll(__ballot(x & 1)) & 1) == 0;
                     if (coded && even && lane == 63) x ^= 1;
-                    s_x[t][lane] = (int16_t)x;
                 } else {
-                    if (xa > 2047u) xa = 2047u;
-                    s_x[t][lane] = (int16_t)((int)(xa ^ (uint32_t)sg) - sg);
+                    x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
                 }
+                s_x[t][lane] = (int16_t)x;
             }
         }
     } else {

@@ -52,3 +52,20 @@ def test_mean4_lerp_identity():
     for p1, e1, t1 in combos:
         lhs = (p1 + combos[:, 0] + (e1 | combos[:, 1])) >> 1
         assert np.array_equal(lhs, (t1 + combos[:, 2] + 1) >> 2)
+
+
+def test_signed_inter_quantiser_identity():
+    """csrc/m2v_kernels.hpp quantises non-intra coefficients on the signed value: sign(C)*min((|C|+2)>>s, 2047) (RTL:2070)
+    == clamp((C + 2 + (sg & (2^s - 5))) >> s) with sg = C >> 31, and the inverse quantiser's (2q + sign q) << Q
+    (RTL:2134-2137) == (2q + (q != 0 ? sg | 1 : 0)) << Q - over more than the 17-bit range of the DCT output."""
+    C = np.arange(-70000, 70001, dtype=np.int64)
+    sg = C >> 63
+    for Q in (1, 2, 3, 4):
+        s = 4 + Q
+        a = np.minimum((np.abs(C) + 2) >> s, 2047)
+        q_ref = np.where(C < 0, -a, a)
+        q_new = np.clip((C + 2 + (sg & ((1 << s) - 5))) >> s, -2047, 2047)
+        assert np.array_equal(q_ref, q_new)
+        x_ref = np.clip((2 * q_ref + np.sign(q_ref)) << Q, -2047, 2047)
+        x_new = np.clip((2 * q_new + np.where(q_new != 0, sg | 1, 0)) << Q, -2047, 2047)
+        assert np.array_equal(x_ref, x_new)
