@@ -542,20 +542,24 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 search_rows<0, kWS>(s_cur, ae, ao, acc, ra, rb);
                 const int dy = dyi - YR;
                 const bool rowok = !((by == 0 && dy < 0) || (by == g.mbh - 1 && dy > 0));   // RTL:1644-1645
+                // live dx range of this macroblock column (RTL:1642-1643), wave-uniform: one unsigned compare per candidate
+                const int lo = bx == 0 ? 0 : -YR, hi = bx == g.mbw - 1 ? 0 : YR;
+                const uint32_t span = (uint32_t)(hi - lo);
+                const int d0 = 4 * gq - 8 - lo;
+                // minimum SAD; among equals the largest dy, then the largest dx (RTL:1694-1710): key = sad << 8 | (255 - index),
+                // index = dy' << 4 | dx + 8.  A SAD >= 4096 kills a candidate (RTL:1669-1670): such keys are >= 1 << 20 and lose
+                // against every live one, so the test is made once on the reduced key instead of per candidate
+                const uint32_t cbase = 255u - (uint32_t)((dyi << 4) | (4 * gq));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int dx = 4 * gq - 8 + j;
                     const uint32_t sad = (uint32_t)(acc >> (16 * j)) & 0xFFFFu;
-                    const bool ok = rowok && dx >= -YR && dx <= YR && !(bx == 0 && dx < 0) &&
-                                    !(bx == g.mbw - 1 && dx > 0) &&                          // RTL:1642-1643
-                                    sad < 4096u;                                             // RTL:1669-1670
-                    // minimum SAD; among equals the largest dy, then the largest dx (RTL:1694-1710)
-                    const uint32_t k = (sad << 8) | (uint32_t)(255 - ((dyi << 4) | (dx + 8)));
+                    const uint32_t k = (sad << 8) | (cbase - (uint32_t)j);
+                    const bool ok = rowok && (uint32_t)(d0 + j) <= span;
                     if (ok && k < key) key = k;
                 }
             }
             key = wave_min_u32(key);
-            if (key != 0xFFFFFFFFu) {           // no live candidate: (0,0) (RTL:1695, 1707)
+            if (key < (4096u << 8)) {           // no live candidate: (0,0) (RTL:1695, 1707)
                 const int c = 255 - (int)(key & 255u);
                 fy = (c >> 4) - YR;
                 fx = (c & 15) - 8;
