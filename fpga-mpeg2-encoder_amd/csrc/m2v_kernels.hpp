@@ -470,15 +470,26 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     uint32_t wv[P ? (WROWS * 8 + 63) / 64 : 1], wcu = 0, wcv = 0;
     if constexpr (P) {
         const uint8_t *refY = job.ref, *refU = refY + g.ysz, *refV = refU + g.csz;
+        if (bx > 0 && bx < g.mbw - 1 && by > 0 && by < g.mbh - 1) {
+            // interior macroblock (wave-uniform test): the whole window lies inside the frame, no clamping, and the
+            // passes differ by a constant row offset
+            const uint32_t w0 = __umul24((uint32_t)(16 * by - YR + (lane >> 3)), (uint32_t)W) + (uint32_t)(16 * bx - 8 + 4 * (lane & 7));
 #pragma unroll
-        for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass) {
-            const int i = pass * 64 + lane, row = i >> 3, k = i & 7;
-            int yy = 16 * by - YR + row, xx = 16 * bx - 8 + 4 * k;
-            yy = yy < 0 ? 0 : yy > g.H - 1 ? g.H - 1 : yy;
-            xx = xx < 0 ? 0 : xx > W - 4 ? W - 4 : xx;
-            wv[pass] = *(gld32)(refY + (__umul24((uint32_t)yy, (uint32_t)W) + (uint32_t)xx));   // 32-bit offset from a uniform base
-        }
-        {
+            for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass)
+                wv[pass] = *(gld32)(refY + (w0 + (uint32_t)(pass * 8) * (uint32_t)W));
+            const int cl = lane < CROWS * 4 ? lane : CROWS * 4 - 1;
+            const uint32_t coff = __umul24((uint32_t)(8 * by - UR + (cl >> 2)), (uint32_t)g.cw) + (uint32_t)(8 * bx - 4 + 4 * (cl & 3));
+            wcu = *(gld32)(refU + coff);
+            wcv = *(gld32)(refV + coff);
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass) {
+                const int i = pass * 64 + lane, row = i >> 3, k = i & 7;
+                int yy = 16 * by - YR + row, xx = 16 * bx - 8 + 4 * k;
+                yy = yy < 0 ? 0 : yy > g.H - 1 ? g.H - 1 : yy;
+                xx = xx < 0 ? 0 : xx > W - 4 ? W - 4 : xx;
+                wv[pass] = *(gld32)(refY + (__umul24((uint32_t)yy, (uint32_t)W) + (uint32_t)xx));   // 32-bit offset from a uniform base
+            }
             const int cl = lane < CROWS * 4 ? lane : CROWS * 4 - 1, row = cl >> 2, k = cl & 3;
             int yy = 8 * by - UR + row, xx = 8 * bx - 4 + 4 * k;
             yy = yy < 0 ? 0 : yy > g.ch - 1 ? g.ch - 1 : yy;
@@ -488,8 +499,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             wcv = *(gld32)(refV + coff);
         }
     }
-    if ((pix_off >> 2) >= job.valid_beats) {    // beats after i_sequence_stop are black (RTL:1036-1056)
-        cur4 = 0u; u4 = 0x80808080u; v4 = 0x80808080u;
+    if (job.valid_beats < (g.ysz >> 2) && (pix_off >> 2) >= job.valid_beats) {    // beats after i_sequence_stop are black (RTL:1036-1056);
+        cur4 = 0u; u4 = 0x80808080u; v4 = 0x80808080u;                            // the first test is wave-uniform and almost always false
     }
     s_cur[lane] = cur4;
     int cu0, cu1, cv0, cv1;                     // this lane's two 4:2:0 chroma samples (used by even rows)
