@@ -255,14 +255,17 @@ __device__ __forceinline__ void idct_col(const int a[8], int r[8])
     x0 = x0 - x2;
     x2 = (181 * (x4 + x5) + 128) >> 8;
     x4 = (181 * (x4 - x5) + 128) >> 8;
-    r[0] = clip255((x7 + x1) >> 14);
-    r[1] = clip255((x3 + x2) >> 14);
-    r[2] = clip255((x0 + x4) >> 14);
-    r[3] = clip255((x8 + x6) >> 14);
-    r[4] = clip255((x8 - x6) >> 14);
-    r[5] = clip255((x0 - x4) >> 14);
-    r[6] = clip255((x3 - x2) >> 14);
-    r[7] = clip255((x7 - x1) >> 14);
+    // The RTL clips these to +-255 (RTL:778-783, 963-970) before add_clip_0_255 adds the prediction p in 0..255 and
+    // clips to 0..255 (RTL:786-795).  The first clip cannot change the final pixel: v > 255 gives 255 + p >= 255 -> 255
+    // either way, v < -255 gives -255 + p <= 0 -> 0 either way; so only the final clip is done (by the caller).
+    r[0] = (x7 + x1) >> 14;
+    r[1] = (x3 + x2) >> 14;
+    r[2] = (x0 + x4) >> 14;
+    r[3] = (x8 + x6) >> 14;
+    r[4] = (x8 - x6) >> 14;
+    r[5] = (x0 - x4) >> 14;
+    r[6] = (x3 - x2) >> 14;
+    r[7] = (x7 - x1) >> 14;
 }
 
 // 10-way argmin with the RTL's tree tie-breaks (RTL:804-840)
