@@ -10,11 +10,13 @@
 //                   leave as up to three word-aligned bit segments            (RTL:1086-2847)
 //   k_slice_scan    neighbour-dependent code lengths (motion vector deltas, DC differentials),
 //                   bit offset of each macroblock in its slice, byte size of each slice
-//   k_frame_scan    byte offset of every frame / slice in the stream (stage V alignment rules)
-//   k_zero          clears the stream bytes this chunk will occupy
-//   k_headers       sequence / GOP / picture headers, sequence end code (RTL:2590-2716)
-//   k_assemble      slice header + macroblock header + DC codes + the stored segments, merged
-//                   into the stream at their final bit positions (stages T,U,V)
+//   k_frame_scan    byte offset of every frame / slice in the stream (stage V alignment rules), stream
+//                   length; clears the boundary dwords of the slices and the padded tail
+//   k_assemble      one lane per 32-bit stream word: slice header + macroblock header + DC codes + the
+//                   stored segments gathered at their final bit positions (stages T,U,V); the
+//                   sequence / GOP / picture headers and the sequence end code (RTL:2590-2716)
+//                   travel with the first / last slice
+//   k_headers       the same headers as a kernel of its own (strip mode: m2v_strip_assemble)
 //
 // All arithmetic is integer with the RTL's widths; see oracle/m2v_oracle.c for the plain-C
 // statement of the same semantics that the parity tests compare against.
@@ -995,6 +997,73 @@ __global__ __launch_bounds__(128) void k_slice_scan(const FrameJob *__restrict__
 }
 
 // ----------------------------------------------------------------------------------------------
+// byte-aligned headers, written field by field by ONE thread (they are a few dozen bytes per frame)
+// ----------------------------------------------------------------------------------------------
+struct ByteWriter {
+    uint8_t *p;
+    uint32_t acc;
+    int nbits;
+    __device__ void put(uint32_t v, int len)
+    {
+        for (int i = len - 1; i >= 0; --i) {
+            acc = (acc << 1) | ((v >> i) & 1u);
+            if (++nbits == 8) { *p++ = (uint8_t)acc; acc = 0; nbits = 0; }
+        }
+    }
+    __device__ void align() { if (nbits) put(0, 8 - nbits); }
+};
+
+
+// [group_of_pictures_header] picture_header picture_coding_extension of one frame (RTL:2645-2698)
+__device__ inline void write_frame_headers(uint8_t *p, const FrameJob &job)
+{
+    ByteWriter w{p, 0u, 0};
+    if (job.i_frame == 0) {
+        // group_of_pictures_header, closed_gop = 1; time code of frame n at 24 fps (RTL:2645-2656, 2685-2698)
+        const uint32_t n = job.n;
+        const uint32_t hh = n / 86400u;
+        w.put(0x000001B8u, 32);
+        w.put(hh > 63u ? 63u : hh, 6);
+        w.put((n / 1440u) % 60u, 6);
+        w.put(1u, 1);
+        w.put((n / 24u) % 60u, 6);
+        w.put(n % 24u, 6);
+        w.put(2u, 2);
+        w.align();
+    }
+    // picture_header + picture_coding_extension (RTL:2670-2682)
+    w.put(0x00000100u, 32);
+    w.put((uint32_t)job.i_frame, 10);       // temporal_reference
+    if (job.i_frame == 0) { w.put(1u, 3); w.put(0u, 16); w.put(0u, 3); }
+    else                  { w.put(2u, 3); w.put(0u, 16); w.put(0u, 1); w.put(7u, 3); w.put(0u, 7); }
+    w.put(0x000001B5u, 32);
+    w.put(8u, 4);                           // picture coding extension
+    w.put(0x1111u, 16);                     // f_code[s][t] = 1
+    w.put(2u, 2);                           // intra_dc_precision 10 bit
+    w.put(3u, 2);                           // frame picture
+    w.put(1u, 1);                           // top_field_first
+    w.put(1u, 1);                           // frame_pred_frame_dct
+    w.put(0u, 8);
+    w.put(0u, 6);
+}
+
+// sequence_header + sequence_extension + sequence_display_extension (RTL:2598-2617)
+__device__ inline void write_sequence_headers(uint8_t *p, const Geom &g)
+{
+    ByteWriter w{p, 0u, 0};
+    w.put(0x000001B3u, 32);
+    w.put((uint32_t)g.W, 12); w.put((uint32_t)g.H, 12);
+    w.put(1u, 4); w.put(2u, 4); w.put(10000u, 18); w.put(1u, 1); w.put(0u, 10); w.put(0u, 3);
+    w.put(0x000001B5u, 32);
+    w.put(1u, 4); w.put(0x44u, 8); w.put(0u, 1); w.put(1u, 2); w.put(0u, 4); w.put(0u, 12); w.put(1u, 1);
+    w.put(0u, 8); w.put(0u, 8);
+    w.put(0x000001B5u, 32);
+    w.put(2u, 4); w.put(1u, 3); w.put(1u, 1); w.put(5u, 8); w.put(5u, 8); w.put(5u, 8);
+    w.put((uint32_t)g.W, 14); w.put(1u, 1); w.put((uint32_t)g.H, 14);
+    w.align();
+}
+
+// ----------------------------------------------------------------------------------------------
 // k_assemble: one workgroup per slice, one LANE per 32-bit word of the stream (gather).  A slice is
 // [slice header] then per macroblock p1 A p2 B p3 C, MSB first.  The per-macroblock piece table of the slice
 // (bit offsets from k_slice_scan, the neighbour-dependent codes, the segment lengths) is staged in LDS once;
@@ -1019,7 +1088,9 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
                                                  const uint32_t *__restrict__ slots_small, const uint32_t *__restrict__ slots,
                                                  const uint32_t *__restrict__ mb_len, const uint32_t *__restrict__ mb_bitoff,
                                                  const unsigned long long *__restrict__ slice_off,
-                                                 uint32_t *__restrict__ out32, const StreamCtl *__restrict__ ctl)
+                                                 uint32_t *__restrict__ out32, const StreamCtl *__restrict__ ctl,
+                                                 int first, int last, const unsigned long long *__restrict__ frame_off,
+                                                 const uint32_t *__restrict__ slice_bytes)
 {
     __shared__ uint32_t s_off[129];                       // bit offset of every macroblock in the slice, [mbw] = slice bits
     __shared__ uint32_t s_c1[128], s_c2[128], s_c3[128];  // neighbour-dependent codes
@@ -1095,6 +1166,20 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
         if (k == 0 || k == nout - 1) { if (be) atomicOr(&out32[w0 + k], be); }
         else out32[w0 + k] = be;
     }
+    // The frame's headers travel with its first slice and the sequence end code with the very last one: plain byte
+    // stores by one thread.  A header byte may share a dword with a slice's boundary word; that dword was cleared by
+    // k_frame_scan, the atomic OR above only adds the slice's own bits and the byte store only touches its byte.
+    if (!g.strip && tid == 0) {
+        uint8_t *const out8 = (uint8_t *)out32 + ctl->base_bytes;
+        if (by == g.row0) {
+            if (first && f == 0) write_sequence_headers(out8, g);
+            write_frame_headers(out8 + frame_off[f], jobs[f]);
+        }
+        if (last && f == nframes - 1 && by == g.row1 - 1) {
+            uint8_t *e = out8 + slice_off[(size_t)f * g.mbh + by] + slice_bytes[(size_t)f * g.mbh + by];
+            e[0] = 0x00; e[1] = 0x00; e[2] = 0x01; e[3] = 0xB7;       // sequence_end_code (RTL:2625-2628)
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1113,10 +1198,18 @@ __device__ __forceinline__ uint32_t frame_header_bytes(int i_frame)
 __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict__ jobs, Geom g, int nframes, int first, int last,
                                                      const uint32_t *__restrict__ slice_bytes,
                                                      unsigned long long *__restrict__ slice_off,
-                                                     unsigned long long *__restrict__ frame_off, StreamCtl *ctl)
+                                                     unsigned long long *__restrict__ frame_off, StreamCtl *ctl,
+                                                     int advance, uint32_t *__restrict__ out32)
 {
     __shared__ unsigned long long s_sum[1024];
+    __shared__ unsigned long long s_base;
     const int tid = threadIdx.x;
+    if (tid == 0) {
+        // advance = this chunk continues the stream of the previous one in the same buffer: base = previous total
+        unsigned long long b = ctl->base_bytes;
+        if (advance && !ctl->overflow) { b = ctl->total_bytes; ctl->base_bytes = b; }
+        s_base = b;
+    }
     const int rows = g.row1 - g.row0;
     const int S = nframes * rows;
     const int K = (S + 1023) / 1024;
@@ -1139,6 +1232,19 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
         s_sum[tid] += t;
         __syncthreads();
     }
+    // stream length and overflow: every thread derives them from the grand total (thread 1023 publishes them)
+    const unsigned long long base = s_base, all_frames = s_sum[1023];
+    unsigned long long total = base + all_frames;
+    if (last) {
+        total += 4;                                           // sequence_end_code (RTL:2621-2628)
+        const unsigned long long all = ctl->prior_bytes + total;
+        total = (all / 32ull + 1ull) * 32ull - ctl->prior_bytes;       // final word always leaves (RTL:2932-2937)
+    }
+    const bool ov = total > ctl->cap_bytes || ctl->overflow;
+    // k_assemble writes the inner dwords of a slice with plain stores and ORs its first and last dword into place (slices
+    // and headers are byte aligned, not dword aligned): only those boundary dwords have to be cleared beforehand, not
+    // the whole stream.  None of them can hold bytes of the previous chunk: at least a 17-byte picture header lies between
+    // `base` and the first slice.  The tail (end code + padding of the final 32-byte word) is cleared as a whole.
     unsigned long long run = s_sum[tid] - sum;
     for (int i = i0; i < i1; ++i) {
         const int f = i / rows, r = i - f * rows;
@@ -1146,119 +1252,35 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
             frame_off[f] = run + (!g.strip && first && f == 0 ? kSeqHeaderBytes : 0u);   // the frame's own headers start here
             run += header_bytes(f);
         }
+        const uint32_t sb = slice_bytes[(size_t)f * g.mbh + g.row0 + r];
         slice_off[(size_t)f * g.mbh + g.row0 + r] = run;
-        run += slice_bytes[(size_t)f * g.mbh + g.row0 + r];
+        if (!ov) {
+            out32[(base + run) >> 2] = 0u;
+            if (sb) out32[(base + run + sb - 1u) >> 2] = 0u;
+        }
+        run += sb;
     }
+    __syncthreads();                                          // every thread has read ctl->overflow / cap before they change
     if (tid == 1023) {
-        const unsigned long long all_frames = s_sum[1023];
         frame_off[nframes] = all_frames;                      // one past the end (strip mode reads the sizes back)
-        unsigned long long total = ctl->base_bytes + all_frames;
-        if (last) {
-            total += 4;                                       // sequence_end_code (RTL:2621-2628)
-            const unsigned long long all = ctl->prior_bytes + total;
-            total = (all / 32ull + 1ull) * 32ull - ctl->prior_bytes;   // final word always leaves (RTL:2932-2937)
-        }
         ctl->total_bytes = total;
-        ctl->overflow = total > ctl->cap_bytes ? 1u : 0u;
+        ctl->overflow = ov ? 1u : 0u;
+        if (!ov && last && !g.strip)
+            for (unsigned long long w = (base + all_frames) >> 2; w < (total + 3ull) >> 2; ++w) out32[w] = 0u;
     }
 }
 
-// clears [base_bytes rounded down to 4, total_bytes rounded up to 4) except bytes that belong to
-// the previous chunk (those below base_bytes are preserved)
-__global__ void k_zero(uint8_t *out, const StreamCtl *ctl)
-{
-    if (ctl->overflow) return;
-    const unsigned long long b = ctl->base_bytes, e = (ctl->total_bytes + 3ull) & ~3ull;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x * 4ull;
-    unsigned long long a = ((b + 3ull) & ~3ull) + ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 4ull;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (unsigned long long i = b; i < ((b + 3ull) & ~3ull) && i < e; ++i) out[i] = 0;
-    for (; a + 4ull <= e; a += stride) *(uint32_t *)(out + a) = 0u;
-}
-
 // ----------------------------------------------------------------------------------------------
-// k_headers: byte-aligned headers, one thread per frame (+ thread 0 for sequence header / end)
+// k_headers: byte-aligned headers, one thread per frame (+ thread 0 for the sequence headers).  Used by
+// m2v_strip_assemble; the single-GPU path writes the headers from k_assemble.
 // ----------------------------------------------------------------------------------------------
-struct ByteWriter {
-    uint8_t *p;
-    uint32_t acc;
-    int nbits;
-    __device__ void put(uint32_t v, int len)
-    {
-        for (int i = len - 1; i >= 0; --i) {
-            acc = (acc << 1) | ((v >> i) & 1u);
-            if (++nbits == 8) { *p++ = (uint8_t)acc; acc = 0; nbits = 0; }
-        }
-    }
-    __device__ void align() { if (nbits) put(0, 8 - nbits); }
-};
-
 __global__ void k_headers(const FrameJob *__restrict__ jobs, Geom g, int nframes, int first,
                           const unsigned long long *__restrict__ frame_off, uint8_t *out, const StreamCtl *ctl)
 {
     if (ctl->overflow) return;
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < nframes) {
-        ByteWriter w{out + ctl->base_bytes + frame_off[f], 0u, 0};
-        const FrameJob job = jobs[f];
-        if (job.i_frame == 0) {
-            // group_of_pictures_header, closed_gop = 1; time code of frame n at 24 fps (RTL:2645-2656, 2685-2698)
-            const uint32_t n = job.n;
-            const uint32_t hh = n / 86400u;
-            w.put(0x000001B8u, 32);
-            w.put(hh > 63u ? 63u : hh, 6);
-            w.put((n / 1440u) % 60u, 6);
-            w.put(1u, 1);
-            w.put((n / 24u) % 60u, 6);
-            w.put(n % 24u, 6);
-            w.put(2u, 2);
-            w.align();
-        }
-        // picture_header + picture_coding_extension (RTL:2670-2682)
-        w.put(0x00000100u, 32);
-        w.put((uint32_t)job.i_frame, 10);       // temporal_reference
-        if (job.i_frame == 0) { w.put(1u, 3); w.put(0u, 16); w.put(0u, 3); }
-        else                  { w.put(2u, 3); w.put(0u, 16); w.put(0u, 1); w.put(7u, 3); w.put(0u, 7); }
-        w.put(0x000001B5u, 32);
-        w.put(8u, 4);                           // picture coding extension
-        w.put(0x1111u, 16);                     // f_code[s][t] = 1
-        w.put(2u, 2);                           // intra_dc_precision 10 bit
-        w.put(3u, 2);                           // frame picture
-        w.put(1u, 1);                           // top_field_first
-        w.put(1u, 1);                           // frame_pred_frame_dct
-        w.put(0u, 8);
-        w.put(0u, 6);
-    }
-    if (f == 0) {
-        if (first) {
-            // sequence_header + sequence_extension + sequence_display_extension (RTL:2598-2617)
-            ByteWriter w{out + ctl->base_bytes, 0u, 0};
-            w.put(0x000001B3u, 32);
-            w.put((uint32_t)g.W, 12); w.put((uint32_t)g.H, 12);
-            w.put(1u, 4); w.put(2u, 4); w.put(10000u, 18); w.put(1u, 1); w.put(0u, 10); w.put(0u, 3);
-            w.put(0x000001B5u, 32);
-            w.put(1u, 4); w.put(0x44u, 8); w.put(0u, 1); w.put(1u, 2); w.put(0u, 4); w.put(0u, 12); w.put(1u, 1);
-            w.put(0u, 8); w.put(0u, 8);
-            w.put(0x000001B5u, 32);
-            w.put(2u, 4); w.put(1u, 3); w.put(1u, 1); w.put(5u, 8); w.put(5u, 8); w.put(5u, 8);
-            w.put((uint32_t)g.W, 14); w.put(1u, 1); w.put((uint32_t)g.H, 14);
-            w.align();
-        }
-    }
-}
-
-// sequence_end_code at the end of the last chunk's body (position = total before padding)
-__global__ void k_seq_end(uint8_t *out, const StreamCtl *ctl, const uint32_t *__restrict__ slice_bytes,
-                          const unsigned long long *__restrict__ slice_off, int nframes, int mbh)
-{
-    if (ctl->overflow) return;
-    // end of the body = offset of the last slice + its size
-    unsigned long long e = ctl->base_bytes;
-    if (nframes > 0) {
-        const size_t li = (size_t)(nframes - 1) * mbh + (mbh - 1);
-        e += slice_off[li] + slice_bytes[li];
-    }
-    out[e + 0] = 0x00; out[e + 1] = 0x00; out[e + 2] = 0x01; out[e + 3] = 0xB7;   // RTL:2625-2628
+    if (f < nframes) write_frame_headers(out + ctl->base_bytes + frame_off[f], jobs[f]);
+    if (f == 0 && first) write_sequence_headers(out + ctl->base_bytes, g);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -474,7 +474,7 @@ void run_step_rows(m2v_enc *e, hipStream_t s, size_t j, int r0, int r1)
     launch_mb<true>(e, s, e->d_lists.p + st.off_p, st.n_p, gg);
 }
 
-void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_stream)
+void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_stream, bool advance = false)
 {
     const Geom &g = e->g;
     const size_t nf = e->plan_nf;
@@ -483,24 +483,19 @@ void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_s
         Timer t(e, s, 4, (double)nf * g.ysz);
         hipLaunchKernelGGL(k_slice_scan, dim3((unsigned)(nf * rows)), dim3(128), 0, s, e->d_jobs.p, g, e->d_mbinfo.p,
                            e->d_mbaux.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_bytes.p, e->d_mbdep.p);
+        // offsets of every frame and slice, stream length, and the boundary dwords k_assemble ORs into cleared
         hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(1024), 0, s, e->d_jobs.p, g, (int)nf, first ? 1 : 0, last ? 1 : 0,
-                           e->d_slice_bytes.p, e->d_slice_off.p, e->d_frame_off.p, e->d_ctl.p);
-        hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, s, d_stream, e->d_ctl.p);
-        if (!g.strip) {
-            hipLaunchKernelGGL(k_headers, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, s, e->d_jobs.p, g, (int)nf,
-                               first ? 1 : 0, e->d_frame_off.p, d_stream, e->d_ctl.p);
-            if (last)
-                hipLaunchKernelGGL(k_seq_end, dim3(1), dim3(1), 0, s, d_stream, e->d_ctl.p, e->d_slice_bytes.p,
-                                   e->d_slice_off.p, (int)nf, g.mbh);
-        }
+                           e->d_slice_bytes.p, e->d_slice_off.p, e->d_frame_off.p, e->d_ctl.p, advance ? 1 : 0,
+                           (uint32_t *)d_stream);
         HIPCHK(hipGetLastError());
         t.stop();
     }
     {
+        // slices, and with them the headers and the sequence end code
         Timer t(e, s, 3, (double)nf * g.ysz);
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)(nf * rows)), dim3(kAsmThreads), 0, s, e->d_jobs.p, g, (int)nf,
                            e->d_mbaux.p, e->d_mbdep.p, e->d_slots_small.p, e->d_slots.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_off.p,
-                           (uint32_t *)d_stream, e->d_ctl.p);
+                           (uint32_t *)d_stream, e->d_ctl.p, first ? 1 : 0, last ? 1 : 0, e->d_frame_off.p, e->d_slice_bytes.p);
         HIPCHK(hipGetLastError());
         t.stop();
     }
@@ -508,7 +503,7 @@ void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_s
 }
 
 void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool first, bool last,
-                  uint32_t last_valid_beats, uint8_t *d_stream)
+                  uint32_t last_valid_beats, uint8_t *d_stream, bool advance = false)
 {
     plan_chunk(e, s, d_frames, nf, last, last_valid_beats);
     if (e->split_streams && !e->profile && e->plan_steps.size() > 1) {
@@ -531,13 +526,7 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
     } else {
         for (size_t j = 0; j < e->plan_steps.size(); ++j) run_step(e, s, j);
     }
-    finish_chunk(e, s, first, last, d_stream);
-}
-
-// advance the device-side stream cursor after a chunk: base = total
-__global__ void k_ctl_advance(StreamCtl *ctl)
-{
-    if (!ctl->overflow) ctl->base_bytes = ctl->total_bytes;
+    finish_chunk(e, s, first, last, d_stream, advance);
 }
 
 void ctl_init(m2v_enc *e, hipStream_t s, unsigned long long cap, unsigned long long prior = 0)
@@ -1021,9 +1010,7 @@ static int resident_impl(m2v_enc *e, void *argp)
     for (size_t k = 0; k < a->n; k += step) {
         const size_t nf = std::min(step, a->n - k);
         const bool first = k == 0, last = k + nf == a->n;
-        encode_chunk(e, s, a->d_in + k * fb, nf, first, last, g.ysz / 4, a->d_out);
-        hipLaunchKernelGGL(k_ctl_advance, dim3(1), dim3(1), 0, s, e->d_ctl.p);
-        e->chain_ev = nullptr;
+        encode_chunk(e, s, a->d_in + k * fb, nf, first, last, g.ysz / 4, a->d_out, /*advance=*/k > 0);
         if (!last) HIPCHK(hipStreamSynchronize(s));    // the per-chunk work buffers are reused
     }
     HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
