@@ -77,6 +77,7 @@ struct StreamCtl {          // device-resident stream bookkeeping, carried acros
 // device copies of the tables
 __constant__ int8_t   c_dct[64];
 __constant__ uint32_t c_dct_pk[32];       // c_dct rows as packed int16 pairs: [j][k] = basis[j][2k] | basis[j][2k+1] << 16
+__constant__ int32_t  c_dct32[64];        // c_dct widened: a lane loads its basis row as two 16-byte reads, no unpacking
 __constant__ uint8_t  c_intra_w[64];
 __constant__ uint8_t  c_zigzag[64];
 __device__ uint16_t   d_motion_code[17];
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     typedef short short2_t __attribute__((ext_vector_type(2)));
     short2_t bjp[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bi[k] = c_dct[di * 8 + k];
+    for (int k = 0; k < 8; ++k) bi[k] = c_dct32[di * 8 + k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) bjp[k] = __builtin_bit_cast(short2_t, c_dct_pk[dj * 4 + k]);
 #pragma unroll

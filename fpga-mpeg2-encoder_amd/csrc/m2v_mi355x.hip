@@ -209,6 +209,9 @@ void upload_tables(int device)
         for (int k = 0; k < 4; ++k)
             dct_pk[j * 4 + k] = (uint32_t)(uint16_t)(int16_t)kDctBasis[j * 8 + 2 * k] | ((uint32_t)(uint16_t)(int16_t)kDctBasis[j * 8 + 2 * k + 1] << 16);
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dct_pk), dct_pk, sizeof dct_pk));
+    int32_t dct32[64];
+    for (int i = 0; i < 64; ++i) dct32[i] = kDctBasis[i];
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dct32), dct32, sizeof dct32));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_intra_w), kIntraW, sizeof kIntraW));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_zigzag), kZigzagPos, sizeof kZigzagPos));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_motion_code), kMotionCode, sizeof kMotionCode));
