@@ -209,3 +209,30 @@ def test_packed_444_layouts(env, layout):
         assert enc.pull_all() == want
     finally:
         enc.close()
+
+
+def test_long_sequence_many_chunks_in_flight(env):
+    """1500 frames through the double-buffered port path in 30 chunks (FIFO compaction, stage reuse, the padding rule
+    against the whole-sequence byte count chained on the device), pulled in small pieces while pushing."""
+    M, orc = env
+    W, H, n, pf = 64, 64, 1500, 7
+    rng = np.random.default_rng(123)
+    base = M.synth.clip(W, H, 60, clip_index=38)
+    clip = base[rng.integers(0, 60, n)]                              # a long, jumpy sequence out of 60 distinct frames
+    want = orc.encode(clip, 4, 4, pf, 5, 5, 2, 3)
+    enc = M.Mpeg2Encoder(5, 5, 2, 3)
+    try:
+        enc.set_option("batch_frames", 50)
+        out = []
+        for k in range(0, n, 37):
+            enc.push_frames(4, 4, pf, clip[k:k + 37])
+            b, last = enc.pull(7 * 32)                               # drain slower than the encoder produces
+            assert not last
+            out.append(b)
+        enc.sequence_stop()
+        out.append(enc.pull_all())
+        got = b"".join(out)
+        assert len(got) == len(want) and got == want
+        assert not enc.busy
+    finally:
+        enc.close()
