@@ -247,6 +247,14 @@ def main():
                                            if traffic is not None else None,
                          "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                          "algorithmic_bytes_per_launch": round(alg_bytes / max(launches, 1))},
+            # secondary "operation roofline" of SURVEY.md 8(d): the search alone is (2*6+1)^2 + 9 = 178 byte absolute
+            # differences per luma pixel of a P frame; v_qsad / v_sad retire one per lane per clock
+            "op_roofline": {"bound": "valu-sad", "unit": "T byte-absdiff/s",
+                            "achieved": round(178.0 * px / (ms * 1e-3) * 1e-12, 2) if ms > 0 else 0.0,
+                            "peak": round(256 * 4 * 64 * 2.4e9 * 1e-12, 1),
+                            "frac": round(178.0 * px / (ms * 1e-3) / (256 * 4 * 64 * 2.4e9), 4) if ms > 0 else 0.0,
+                            "note": "256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz; the macroblock kernel is VALU-issue bound "
+                                    "(VALUBusy 100 %), the SADs are ~21 % of its VALU cycles at 66 % lane efficiency"},
             "kernel_ms_per_step": {"k_mb_P": round(ms, 3), "k_mb_I": round(msi, 3), "k_assemble": round(ms3, 3),
                                    "scans_headers": round(ms4, 3)},
         }
