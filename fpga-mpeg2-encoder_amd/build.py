@@ -41,9 +41,9 @@ def build(force=False, verbose=False):
                 os.remove(tmp)
     build_container(force, verbose)
     tb_src = os.path.join(CSRC, "m2v_tb.cpp")
-    if os.path.exists(tb_src) and (force or _stale(TB, [tb_src, LIB])):
+    if os.path.exists(tb_src) and (force or _stale(TB, [tb_src, LIB, CONTAINER_LIB])):
         tmp = "%s.%d.tmp" % (TB, os.getpid())
-        cmd = [hipcc(), "-O2", "-std=c++17", "-o", tmp, tb_src, "-L" + HERE, "-lm2v_mi355x",
+        cmd = [hipcc(), "-O2", "-std=c++17", "-o", tmp, tb_src, "-L" + HERE, "-lm2v_mi355x", "-lm2v_container",
                "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

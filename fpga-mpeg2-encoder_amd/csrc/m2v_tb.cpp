@@ -1,8 +1,11 @@
 // m2v_tb — file-to-file driver over the C-ABI; the counterpart of SIM/tb_mpeg2encoder.v.
 //
-//   m2v_tb [-XL n] [-YL n] [-VL n] [-Q n] [-p pframes] [-d device] [-bubbles] [-conformant]  in.yuv W H out.m2v  [in2.yuv W2 H2 out2.m2v ...]
+//   m2v_tb [-XL n] [-YL n] [-VL n] [-Q n] [-p pframes] [-d device] [-bubbles] [-conformant] [-ps] [-ts]
+//          in.yuv W H out.m2v  [in2.yuv W2 H2 out2.m2v ...]
 //
 // -conformant switches the encoder's option "conformant" on (ISO reconstruction loop; NOT byte-identical to the RTL).
+// -ps / -ts additionally write out.m2v.mpg / out.m2v.ts: the same elementary stream in an MPEG-2 program / transport
+// stream (include/m2v_container.h), so the result plays in an ordinary player.
 //
 // Like the testbench it encodes the listed videos back to back on ONE encoder instance (TB:150:
 // "verify the module can end a sequence and start the next"), pushes only the complete frames of
@@ -13,17 +16,21 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
+#include "../../include/m2v_container.h"
 #include "../../include/m2v_mi355x.h"
 
 int main(int argc, char **argv)
 {
-    int XL = 7, YL = 6, VL = 3, Q = 2, pf = 23, dev = 0, bubbles = 0, conformant = 0;
+    int XL = 7, YL = 6, VL = 3, Q = 2, pf = 23, dev = 0, bubbles = 0, conformant = 0, want_ps = 0, want_ts = 0;
     int i = 1;
     for (; i < argc && argv[i][0] == '-'; ++i) {
         if (!strcmp(argv[i], "-bubbles")) { bubbles = 1; continue; }
         if (!strcmp(argv[i], "-conformant")) { conformant = 1; continue; }
+        if (!strcmp(argv[i], "-ps")) { want_ps = 1; continue; }
+        if (!strcmp(argv[i], "-ts")) { want_ts = 1; continue; }
         if (i + 1 >= argc) break;
         int v = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "-XL")) XL = v; else if (!strcmp(argv[i], "-YL")) YL = v;
@@ -59,7 +66,7 @@ int main(int argc, char **argv)
             return 1;
         }
         const size_t fb = (size_t)xsize * ysize * 3;
-        std::vector<uint8_t> frame(fb), word(1 << 20);
+        std::vector<uint8_t> frame(fb), word(1 << 20), es;
         size_t frames = 0, bytes = 0;
         const auto t0 = std::chrono::steady_clock::now();
         auto drain = [&](bool until_last) {
@@ -67,7 +74,11 @@ int main(int argc, char **argv)
                 int last = 0;
                 long long n = m2v_pull(e, word.data(), word.size(), &last);
                 if (n < 0) { fprintf(stderr, "*** m2v_pull: %s\n", m2v_last_error(e)); exit(1); }
-                if (n) { fwrite(word.data(), 1, (size_t)n, fo); bytes += (size_t)n; }
+                if (n) {
+                    fwrite(word.data(), 1, (size_t)n, fo);
+                    bytes += (size_t)n;
+                    if (want_ps || want_ts) es.insert(es.end(), word.begin(), word.begin() + n);
+                }
                 if (last || (!until_last && n == 0)) break;
                 if (until_last && n == 0 && !m2v_busy(e)) break;
             }
@@ -98,6 +109,21 @@ int main(int argc, char **argv)
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         fclose(fi);
         fclose(fo);
+        for (int kind = 0; kind < 2; ++kind) {
+            if (!(kind ? want_ts : want_ps) || es.empty()) continue;
+            size_t need = 0;
+            int r = kind ? m2vc_mux_ts(es.data(), es.size(), nullptr, 0, &need) : m2vc_mux_ps(es.data(), es.size(), nullptr, 0, &need);
+            std::vector<uint8_t> mux(need);
+            if (r == 0) r = kind ? m2vc_mux_ts(es.data(), es.size(), mux.data(), mux.size(), &need)
+                                 : m2vc_mux_ps(es.data(), es.size(), mux.data(), mux.size(), &need);
+            if (r < 0) { fprintf(stderr, "*** multiplexer failed (%d)\n", r); return 1; }
+            const std::string name = std::string(out) + (kind ? ".ts" : ".mpg");
+            FILE *fm = fopen(name.c_str(), "wb");
+            if (!fm) { printf("*** couldn't open %s\n", name.c_str()); return 1; }
+            fwrite(mux.data(), 1, need, fm);
+            fclose(fm);
+            printf("  %s: %zu bytes\n", name.c_str(), need);
+        }
         printf("end of video %d: %zu frames -> %zu bytes, %.3f s, %.1f MPixels/s incl. file I/O and PCIe\n", num_video, frames,
                bytes, s, (double)frames * xsize * ysize / s * 1e-6);
     }

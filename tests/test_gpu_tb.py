@@ -48,3 +48,22 @@ def test_tb_rejects_bad_sizes(tmp_path):
     f.write_bytes(b"\x00" * 100)
     out = subprocess.run([tb, str(f), "72", "64", str(tmp_path / "x.m2v")], capture_output=True, text=True)
     assert out.returncode != 0 and "xsize=  72 is invalid" in out.stdout          # TB:189-194
+
+
+def test_tb_writes_program_and_transport_streams(tmp_path):
+    """-ps / -ts: the elementary stream wrapped by libm2v_container, identical to what the Python binding produces"""
+    import importlib
+    import m2v_load
+    M = m2v_load.load()
+    M.build()
+    C = importlib.import_module(M.__name__ + ".container")
+    tb = os.path.join(ROOT, "fpga-mpeg2-encoder_amd", "m2v_tb")
+    clip = M.synth.clip(160, 96, 7, clip_index=95)
+    fin = tmp_path / "v.yuv"
+    fin.write_bytes(clip.tobytes())
+    out = tmp_path / "v.m2v"
+    r = subprocess.run([tb, "-p", "3", "-ps", "-ts", str(fin), "160", "96", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    es = out.read_bytes()
+    assert (tmp_path / "v.m2v.mpg").read_bytes() == C.mux_ps(es)
+    assert (tmp_path / "v.m2v.ts").read_bytes() == C.mux_ts(es)
