@@ -167,7 +167,7 @@ def main():
     clip = M.synth.clip_torch(W, H, nframes, clip_index=rank, device=dev)       # resident in HBM
     cap = nframes * W * H * 3 // 2
     d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
-    enc = M.Mpeg2Encoder(XL, YL, VL, Q, device=local_rank)
+    enc = M.Mpeg2Encoder(XL, YL, VL, Q, device=local_rank, debug=bool(args.ablate))   # --ablate needs the -DM2V_DEBUG library
     enc.set_option("batch_frames", nframes)
     if args.ablate:
         enc.set_option("ablate", args.ablate)

@@ -14,17 +14,20 @@ from . import build as _build
 from . import synth  # noqa: F401  (seeded synthetic clips, numpy only)
 from . import parallel  # noqa: F401  (multi-GPU: independent sequences, macroblock-row strips)
 from . import container  # noqa: F401  (CPU-side conveniences: stream scan, MPEG-PS / TS multiplexers)
+from . import decoder  # noqa: F401  (analysis tool: MPEG-2 ES decoder written from ISO/IEC 13818-2, CPU, not on the encode path)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # M2V_LIB: development hook for same-box A/B timing of two builds (tools/ab.sh); never set otherwise
 LIB_PATH = os.environ.get("M2V_LIB") or os.path.join(_HERE, "libm2v_mi355x.so")
+# the -DM2V_DEBUG build (level dump, "keep_recon", "ablate"): stage-level parity tests and profiling scripts only
+LIB_DBG_PATH = os.environ.get("M2V_LIB_DBG") or os.path.join(_HERE, "libm2v_mi355x_dbg.so")
 
-_lib = None
+_libs = {}
 
 EXPORTS = [
     "m2v_version", "m2v_create", "m2v_destroy", "m2v_reset", "m2v_push_beats", "m2v_push_packed", "m2v_push_frames",
     "m2v_sequence_stop", "m2v_busy", "m2v_pull", "m2v_geometry", "m2v_encode_resident", "m2v_set_option",
-    "m2v_kernel_stats", "m2v_debug_read", "m2v_last_error",
+    "m2v_kernel_stats", "m2v_debug_read", "m2v_last_error", "m2v_debug_table",
     "m2v_strip_begin", "m2v_strip_info", "m2v_strip_step", "m2v_strip_step_edges", "m2v_strip_step_interior", "m2v_strip_halo_in", "m2v_strip_finish", "m2v_strip_assemble",
 ]
 
@@ -33,13 +36,14 @@ class M2VError(RuntimeError):
     pass
 
 
-def lib():
-    """The C-ABI shared library; raises if it has not been built (no silent fallback)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise M2VError("libm2v_mi355x.so is missing: run __graft_entry__.build() "
-                           "(hipcc, gfx950); there is no CPU fallback")
+def lib(debug=False):
+    """The C-ABI shared library; raises if it has not been built (no silent fallback).
+    debug=True: the -DM2V_DEBUG build of the same sources (tests and profiling only)."""
+    path = LIB_DBG_PATH if debug else LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise M2VError("%s is missing: run __graft_entry__.build() "
+                           "(hipcc, gfx950); there is no CPU fallback" % os.path.basename(path))
         # One process must hold ONE HIP runtime.  PyTorch-ROCm (used here only for device memory and
         # streams) bundles its own libamdhip64; importing it first makes the loader resolve this
         # library's libamdhip64.so.7 dependency to the copy torch already mapped.
@@ -47,7 +51,7 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         vp, sz, u32, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
         L.m2v_version.restype = ctypes.c_char_p
         L.m2v_create.restype = vp
@@ -78,8 +82,8 @@ def lib():
         L.m2v_strip_halo_in.argtypes = [vp, ci, vp, vp]
         L.m2v_strip_finish.argtypes = [vp, vp, sz, vp]
         L.m2v_strip_assemble.argtypes = [vp, u32, u32, u32, sz, ci, vp, vp, vp, sz, ctypes.POINTER(sz), vp]
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
 
 
 def build(force=False, verbose=False):
@@ -98,13 +102,14 @@ def clamp_geometry(xsize16, ysize16, XL=7, YL=7):
 class Mpeg2Encoder:
     """`mpeg2encoder #(XL, YL, VECTOR_LEVEL, Q_LEVEL)` on one MI355X (RTL/mpeg2encoder.v:10-38)."""
 
-    def __init__(self, XL=6, YL=6, VECTOR_LEVEL=3, Q_LEVEL=2, device=0):
+    def __init__(self, XL=6, YL=6, VECTOR_LEVEL=3, Q_LEVEL=2, device=0, debug=False):
         self.params = (XL, YL, VECTOR_LEVEL, Q_LEVEL)
         err = ctypes.c_int(0)
-        self._L = lib()
+        self._L = lib(debug)
         self._h = self._L.m2v_create(XL, YL, VECTOR_LEVEL, Q_LEVEL, device, ctypes.byref(err))
         if not self._h:
-            raise M2VError("m2v_create failed with code %d (parameters %r, device %d)" % (err.value, self.params, device))
+            raise M2VError("m2v_create failed with code %d (parameters %r, device %d): %s"
+                           % (err.value, self.params, device, self._L.m2v_last_error(None).decode()))
 
     def close(self):
         if getattr(self, "_h", None):

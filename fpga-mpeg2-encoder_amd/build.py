@@ -6,6 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libm2v_mi355x.so")
+LIB_DBG = os.path.join(HERE, "libm2v_mi355x_dbg.so")       # -DM2V_DEBUG: level dump, keep_recon, ablate (tests / profiling only)
 TB = os.path.join(HERE, "m2v_tb")
 CONTAINER_LIB = os.path.join(HERE, "libm2v_container.so")      # CPU-only conveniences (include/m2v_container.h)
 SOURCES = ["m2v_mi355x.hip", "m2v_kernels.hpp", "m2v_tables.hpp"]
@@ -28,17 +29,18 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "m2v_mi355x.h")]
-    if force or _stale(LIB, deps):
-        tmp = "%s.%d.tmp" % (LIB, os.getpid())            # atomic replace: concurrent ranks never see a half-written library
-        cmd = [hipcc()] + HIPCC_FLAGS + ["-shared", "-o", tmp, os.path.join(CSRC, "m2v_mi355x.hip")]
-        if verbose:
-            print(" ".join(cmd))
-        try:
-            subprocess.check_call(cmd)
-            os.replace(tmp, LIB)
-        finally:
-            if os.path.exists(tmp):
-                os.remove(tmp)
+    for target, extra in ((LIB, []), (LIB_DBG, ["-DM2V_DEBUG"])):
+        if force or _stale(target, deps):
+            tmp = "%s.%d.tmp" % (target, os.getpid())     # atomic replace: concurrent ranks never see a half-written library
+            cmd = [hipcc()] + HIPCC_FLAGS + extra + ["-shared", "-o", tmp, os.path.join(CSRC, "m2v_mi355x.hip")]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, target)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
     build_container(force, verbose)
     tb_src = os.path.join(CSRC, "m2v_tb.cpp")
     if os.path.exists(tb_src) and (force or _stale(TB, [tb_src, LIB, CONTAINER_LIB])):

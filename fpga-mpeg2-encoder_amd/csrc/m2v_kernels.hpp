@@ -28,6 +28,15 @@
 
 namespace m2v {
 
+// -DM2V_DEBUG builds libm2v_mi355x_dbg.so, the library the stage-level parity tests and the profiling scripts load:
+// it can dump the quantised levels, keep every frame's reconstruction (option "keep_recon") and skip kernel phases
+// (option "ablate").  The shipped library has none of that code in its kernels.
+#ifdef M2V_DEBUG
+constexpr bool kDebug = true;
+#else
+constexpr bool kDebug = false;
+#endif
+
 // ----------------------------------------------------------------------------------------------
 // shared host/device structures
 // ----------------------------------------------------------------------------------------------
@@ -41,7 +50,7 @@ struct Geom {
     uint32_t csz;    // cw*ch
     int row0, row1;  // macroblock rows this GPU encodes: [0, mbh) normally, a strip in multi-GPU strip mode
     int strip;       // 1 = strip mode: the stream buffer holds only this strip's slices, no headers
-    int ablate;      // profiling aid (option "ablate", default 0 = everything on; results are INVALID otherwise):
+    int ablate;      // M2V_DEBUG builds only: profiling aid (option "ablate", default 0 = everything on; results are INVALID otherwise):
                      // bit0 skip full-pel search, bit1 skip half-pel SADs, bit2 skip VLC, bit3 skip IDCT/recon, bit4 skip DCT/quant
     uint32_t strip_mbs;      // (row1 - row0) * mbw
     uint32_t magic_strip;    // floor(2^32 / strip_mbs), floor(2^32 / mbw): wave-uniform divisions on the scalar unit
@@ -544,7 +553,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         {
             uint32_t key = 0xFFFFFFFFu;
             const int dyi = lane >> 2, gq = lane & 3;        // dy = dyi - YR, dx = 4*gq - 8 + j
-            if (dyi <= 2 * YR && !(g.ablate & 1)) {
+            if (dyi <= 2 * YR && !(kDebug && (g.ablate & 1))) {
                 // the pairs (w0,w1) (w2,w3) start at dword gq, the pairs (w1,w2) (w3,w4) at gq + 1: one of the two is even
                 // in copy A, the other one in copy B (which holds dword j + 1 at index j)
                 const uint32_t *const pe = (gq & 1) ? s_winb + dyi * kWS + gq - 1 : s_win + dyi * kWS + gq;
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         hp[3] = avg2x4(L1, C1);          hp[4] = C1;              hp[5] = avg2x4(C1, R1);
         hp[6] = avg4<CONF>(L1, C1, L2, C2);  hp[7] = avg2x4(C1, C2);  hp[8] = avg4<CONF>(C1, R1, C2, R2);
         int v10[10] = {4096, 4096, 4096, 4096, 0, 4096, 4096, 4096, 4096, 4095};
-        if (!(g.ablate & 2)) {
+        if (!(kDebug && (g.ablate & 2))) {
             uint32_t s[10];
 #pragma unroll
             for (int k = 0; k < 9; ++k) s[k] = __builtin_amdgcn_sad_u8(cur4, hp[k], 0u);
@@ -724,9 +733,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     const int zz = c_zigzag[lane];
     const int Q = g.Q;
     const size_t mbidx = (size_t)fidx * g.mbs + mb;
-    const bool need_rec = job.rec != nullptr && !(g.ablate & 8);
+    const bool need_rec = job.rec != nullptr && !(kDebug && (g.ablate & 8));
     int cbp = 0;
-    if (g.ablate & 16) {
+    if (kDebug && (g.ablate & 16)) {
         for (int t = 0; t < 6; ++t) s_zig[t][lane] = 0;
         cbp = inter ? 0 : 63;
     } else if (inter) {
@@ -742,7 +751,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             int q = (C + 2 + (sg & ((1 << (4 + Q)) - 5))) >> (4 + Q);
             q = q < -2047 ? -2047 : q > 2047 ? 2047 : q;
             s_zig[t][zz] = (int16_t)q;
-            if (coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
+            if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
             cbp = (cbp << 1) | (__ballot(q != 0) != 0ull ? 1 : 0);
             if (need_rec) {                             // RTL:2134-2137: (2q + sign(q)) << Q, clamped to +-2047
                 int x = (2 * q + (q != 0 ? (sg | 1) : 0)) << Q;
@@ -774,7 +783,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             if (a > 2047u) a = 2047u;
             const int q = (int)(a ^ (uint32_t)sg) - sg;
             s_zig[t][zz] = (int16_t)q;
-            if (coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
+            if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
             if (need_rec) {
                 int x;
                 if constexpr (CONF) {
@@ -827,7 +836,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             const int v = s_zig[t][lane];
             const int v0 = __builtin_amdgcn_readlane(v, 0);
             dcs[t] = v0;
-            if (g.ablate & 4) continue;
+            if (kDebug && (g.ablate & 4)) continue;
             if (t == 4) idxB = nsym;
             if (t == 5) idxC = nsym;
             const bool coded = (cbp >> (5 - t)) & 1;

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <deque>
 #include <exception>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -51,6 +52,9 @@ struct DevBuf {
 };
 
 struct KStat { int launches = 0; double ms = 0, units = 0; };
+
+// why the last m2v_create on this thread failed: there is no handle yet to carry the text (m2v_last_error(NULL))
+thread_local std::string t_create_err;
 
 struct TimedLaunch { hipEvent_t a, b; int kernel; double units; };
 
@@ -198,11 +202,14 @@ Geom make_geom(const m2v_enc *e, uint32_t xs, uint32_t ys)
     return g;
 }
 
-bool g_tables_loaded[64] = {};
+// The constant tables live in each device's copy of the code object: uploaded once per device, whichever thread
+// creates the first handle there (config c4 creates 8 handles from 8 threads).  call_once leaves the flag unset when
+// the upload throws, so a later m2v_create retries.
+constexpr int kMaxDevices = 64;
+std::once_flag g_tables_once[kMaxDevices];
 
-void upload_tables(int device)
+void upload_tables_now()
 {
-    if (device >= 0 && device < 64 && g_tables_loaded[device]) return;
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dct), kDctBasis, sizeof kDctBasis));
     uint32_t dct_pk[32];
     for (int j = 0; j < 8; ++j)
@@ -222,7 +229,13 @@ void upload_tables(int device)
     uint32_t recip[64];
     for (int i = 0; i < 64; ++i) recip[i] = ((1u << 21) + kIntraW[i] - 1u) / kIntraW[i];      // ceil(2^21 / W)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_intra_recip), recip, sizeof recip));
-    if (device >= 0 && device < 64) g_tables_loaded[device] = true;
+    HIPCHK(hipDeviceSynchronize());         // the copies read stack arrays: complete before they go out of scope
+}
+
+void upload_tables(int device)
+{
+    if (device >= 0 && device < kMaxDevices) std::call_once(g_tables_once[device], upload_tables_now);
+    else upload_tables_now();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -756,17 +769,23 @@ int guard(m2v_enc *e, int (*fn)(m2v_enc *, void *), void *arg)
 // =============================================================================================
 extern "C" {
 
-const char *m2v_version(void) { return "m2v_mi355x 0.1 (gfx950, wave64, one wavefront per macroblock)"; }
+const char *m2v_version(void)
+{
+    return kDebug ? "m2v_mi355x 0.2-debug (gfx950, wave64, one wavefront per macroblock; M2V_DEBUG: level dump, keep_recon, ablate)"
+                  : "m2v_mi355x 0.2 (gfx950, wave64, one wavefront per macroblock)";
+}
 
 m2v_enc *m2v_create(int XL, int YL, int VECTOR_LEVEL, int Q_LEVEL, int device, int *err)
 {
-    auto fail = [&](int code) -> m2v_enc * { if (err) *err = code; return nullptr; };
+    auto fail = [&](int code, const std::string &why) -> m2v_enc * { t_create_err = why; if (err) *err = code; return nullptr; };
+    t_create_err.clear();
     if (XL < 4 || XL > 7 || YL < 4 || YL > 7 || VECTOR_LEVEL < 1 || VECTOR_LEVEL > 3 || Q_LEVEL < 1 || Q_LEVEL > 4)
-        return fail(M2V_E_PARAM);
+        return fail(M2V_E_PARAM, "m2v_create: XL, YL must be 4..7, VECTOR_LEVEL 1..3, Q_LEVEL 1..4 (RTL:11-14)");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return fail(M2V_E_NODEVICE);
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(M2V_E_NODEVICE, "m2v_create: no HIP device (there is no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(M2V_E_NODEVICE, "m2v_create: device ordinal out of range");
     m2v_enc *e = new (std::nothrow) m2v_enc();
-    if (!e) return fail(M2V_E_NOMEM);
+    if (!e) return fail(M2V_E_NOMEM, "m2v_create: host allocation failed");
     e->XL = XL; e->YL = YL; e->VL = VECTOR_LEVEL; e->Q = Q_LEVEL; e->device = device;
     try {
         HIPCHK(hipSetDevice(device));
@@ -775,9 +794,11 @@ m2v_enc *m2v_create(int XL, int YL, int VECTOR_LEVEL, int Q_LEVEL, int device, i
         upload_tables(device);
         HIPCHK(hipDeviceSynchronize());
     } catch (const HipError &h) {
-        fprintf(stderr, "m2v_create: %s: %s\n", h.what, hipGetErrorString(h.e));
+        const std::string why = std::string("m2v_create: ") + h.what + ": " + hipGetErrorString(h.e);
+        if (e->stream) (void)hipStreamDestroy(e->stream);
+        if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
         delete e;
-        return fail(M2V_E_HIP);
+        return fail(M2V_E_HIP, why);
     }
     if (err) *err = M2V_OK;
     return e;
@@ -815,11 +836,22 @@ int m2v_reset(m2v_enc *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+    if (e->strip_stream && e->strip_stream != e->stream) (void)hipStreamSynchronize(e->strip_stream);
     for (auto &h : e->hs) h.stage = 0;
     e->pending.clear();
     e->state = m2v_enc::IDLE;
     e->buffered = 0; e->beat_pos = 0; e->frames_total = 0; e->persist_slot = -1;
+    e->first_chunk = true; e->stream_bytes = 0; e->cur = 0;
     e->fifo.clear(); e->fifo_rd = 0; e->end_pending = false;
+    // a strip sequence abandoned between m2v_strip_begin and m2v_strip_finish: back to the full frame
+    e->strip_active = false;
+    e->strip_stream = nullptr;
+    e->plan_steps.clear();
+    e->plan_nf = 0;
+    e->g.row0 = 0; e->g.row1 = e->g.mbh; e->g.strip = 0;
+    geom_finish(e->g);
+    e->timed.clear(); e->ev_used = 0; e->chain_ev = nullptr;
+    e->err.clear();
     return M2V_OK;
 }
 
@@ -837,6 +869,7 @@ struct PushBeatsArgs { uint32_t xs, ys, pf; const uint8_t *y, *u, *v; size_t n; 
 static int push_beats_impl(m2v_enc *e, void *argp)
 {
     auto *a = (PushBeatsArgs *)argp;
+    if (e->strip_active) { e->set_err("m2v_push_*: a strip sequence is open (m2v_strip_finish or m2v_reset first)"); return M2V_E_STATE; }
     if (e->state == m2v_enc::ENDED) return M2V_OK;              // dropped while the sequence ends (RTL:1045-1058)
     size_t i = 0;
     if (a->n == 0) {
@@ -914,6 +947,7 @@ struct PushFramesArgs { uint32_t xs, ys, pf; const uint8_t *frames; size_t n; };
 static int push_frames_impl(m2v_enc *e, void *argp)
 {
     auto *a = (PushFramesArgs *)argp;
+    if (e->strip_active) { e->set_err("m2v_push_*: a strip sequence is open (m2v_strip_finish or m2v_reset first)"); return M2V_E_STATE; }
     if (e->state == m2v_enc::ENDED || a->n == 0) return M2V_OK;
     if (e->state == m2v_enc::IDLE) start_sequence(e, a->xs, a->ys, a->pf);
     const Geom &g = e->g;
@@ -995,7 +1029,7 @@ struct ResidentArgs { uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; uint8_
 static int resident_impl(m2v_enc *e, void *argp)
 {
     auto *a = (ResidentArgs *)argp;
-    if (e->state != m2v_enc::IDLE) { e->set_err("m2v_encode_resident: encoder busy"); return M2V_E_STATE; }
+    if (e->state != m2v_enc::IDLE || e->strip_active) { e->set_err("m2v_encode_resident: encoder busy"); return M2V_E_STATE; }
     if (a->n == 0) { if (a->bytes) *a->bytes = 0; return M2V_OK; }   // no beat: the sequence never starts
     hipStream_t s = a->s ? a->s : e->stream;
     e->g = make_geom(e, a->xs, a->ys);
@@ -1250,8 +1284,11 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
         return M2V_OK;
     }
     if (!strcmp(name, "copy_threads")) { if (value < 1 || value > 64) return M2V_E_PARAM; e->copy_threads = (int)value; return M2V_OK; }
-    if (!strcmp(name, "keep_recon")) { e->keep_recon = value != 0; return M2V_OK; }
-    if (!strcmp(name, "ablate")) { e->ablate = (int)value; return M2V_OK; }   // profiling aid: output is invalid when != 0
+    if (kDebug) {       // libm2v_mi355x_dbg.so only (-DM2V_DEBUG): the shipped library does not know these names
+        if (!strcmp(name, "keep_recon")) { e->keep_recon = value != 0; return M2V_OK; }
+        if (!strcmp(name, "ablate")) { e->ablate = (int)value; return M2V_OK; }   // profiling aid: output is invalid when != 0
+    }
+    e->set_err("m2v_set_option: unknown option '%s'", name);
     return M2V_E_PARAM;
 }
 
@@ -1303,9 +1340,9 @@ long long m2v_debug_read(m2v_enc *e, int what, void *dst, size_t cap)
     return r < 0 ? r : a.ret;
 }
 
-const char *m2v_last_error(const m2v_enc *e) { return e ? e->err.c_str() : "null handle"; }
+const char *m2v_last_error(const m2v_enc *e) { return e ? e->err.c_str() : t_create_err.c_str(); }
 
-/* table accessors (no GPU needed): tests/test_tables_product.py */
+/* table accessors (no GPU needed): tests/test_abi.py checks the product's tables against the oracle's */
 int m2v_debug_table(int which, int i, int j)
 {
     switch (which) {

@@ -10,11 +10,10 @@ reference frames, so the quirks can be switched on to reproduce the encoder's re
    * chroma vector = floor(mv / 2) instead of mv / 2 truncated toward zero       (RTL:1854-1916)
    * intra AC dequantisation floors negatives; no mismatch control               (RTL:2132-2148)
    * IDCT = Chen-Wang with an 18-bit row store and a +-255 output clip           (RTL:844-972)
-The VLC code tables are read from the oracle's accessors (they were checked entry by entry against the RTL);
-everything else here is written from the standard.  TEST INFRASTRUCTURE ONLY.
+Everything here, the VLC tables of Annex B included, is written from the standard: nothing is shared with the
+encoder, the oracle or the RTL.  It is an analysis tool (tools/m2v_stats.py: PSNR of a stream against its source) and
+the independent checker of the parity tests; it runs on the CPU and is not on the encode path.
 """
-import ctypes
-
 import numpy as np
 
 
@@ -73,34 +72,81 @@ def _vlc_decoder(entries):
     return dec
 
 
-def _tables():
-    from oracle import m2v_oracle_ctypes as orc
-    L = orc.lib()
+# ---------------------------------------------------------------------------------------------------------------
+# ISO/IEC 13818-2 Annex B, typed in from the standard's tables (NOT taken from the encoder, the oracle or the RTL:
+# tests/test_decoder_tables.py checks that the three agree entry by entry)
+# ---------------------------------------------------------------------------------------------------------------
+_B10_MOTION = """0:1 1:01 2:001 3:0001 4:000011 5:0000101 6:0000100 7:0000011 8:000001011 9:000001010 10:000001001
+11:0000010001 12:0000010000 13:0000001111 14:0000001110 15:0000001101 16:0000001100"""
 
-    def pair(fn, *a):
-        c, n = ctypes.c_int(), ctypes.c_int()
-        fn(*a, ctypes.byref(c), ctypes.byref(n))
-        return c.value, n.value
-    motion = [pair(L.m2v_oracle_tab_motion, k) + (k,) for k in range(17)]
-    cbp = [pair(L.m2v_oracle_tab_cbp, k) + (k,) for k in range(1, 64)]
-    dcy = [pair(L.m2v_oracle_tab_dc, 0, k) + (k,) for k in range(12)]
-    dcc = [pair(L.m2v_oracle_tab_dc, 1, k) + (k,) for k in range(12)]
-    ac = []
-    for run in range(32):
-        for lvl in range(1, 41):
-            c, n = pair(L.m2v_oracle_tab_ac, run, lvl)
-            if n and not (run == 0 and lvl == 1):
-                ac.append((c, n, (run, lvl)))
-    ac.append((0b10, 2, "EOB"))
-    ac.append((0b000001, 6, "ESC"))
+_B12_DC_LUMA = "0:100 1:00 2:01 3:101 4:110 5:1110 6:11110 7:111110 8:1111110 9:11111110 10:111111110 11:111111111"
+_B13_DC_CHROMA = "0:00 1:01 2:10 3:110 4:1110 5:11110 6:111110 7:1111110 8:11111110 9:111111110 10:1111111110 11:1111111111"
+
+_B9_CBP = """60:111 4:1101 8:1100 16:1011 32:1010 12:10011 48:10010 20:10001 40:10000 28:01111 44:01110 52:01101 56:01100
+1:01011 61:01010 2:01001 62:01000 24:001111 36:001110 3:001101 63:001100 5:0010111 9:0010110 17:0010101 33:0010100
+6:0010011 10:0010010 18:0010001 34:0010000 7:00011111 11:00011110 19:00011101 35:00011100 13:00011011 49:00011010
+21:00011001 41:00011000 14:00010111 50:00010110 22:00010101 42:00010100 15:00010011 51:00010010 23:00010001 43:00010000
+25:00001111 37:00001110 26:00001101 38:00001100 29:00001011 45:00001010 53:00001001 57:00001000 30:00000111 46:00000110
+54:00000101 58:00000100 31:000000111 47:000000110 55:000000101 59:000000100 27:000000011 39:000000010"""
+
+# Table B-14 (DCT coefficients table zero), "run,level:code" without the sign bit; (0,1) is listed in its
+# "not first coefficient" form '11' - the first-coefficient form '1s' is handled in the block loop
+_B14_AC = """0,1:11 1,1:011 0,2:0100 2,1:0101 0,3:00101 3,1:00111 4,1:00110 1,2:000110 5,1:000111 6,1:000101 7,1:000100
+0,4:0000110 2,2:0000100 8,1:0000111 9,1:0000101
+0,5:00100110 0,6:00100001 1,3:00100101 3,2:00100100 10,1:00100111 11,1:00100011 12,1:00100010 13,1:00100000
+0,7:0000001010 1,4:0000001100 2,3:0000001011 4,2:0000001111 5,2:0000001001 14,1:0000001110 15,1:0000001101 16,1:0000001000
+0,8:000000011101 0,9:000000011000 0,10:000000010011 0,11:000000010000 1,5:000000011011 2,4:000000010100 3,3:000000011100
+4,3:000000010010 6,2:000000011110 7,2:000000010101 8,2:000000010001 17,1:000000011111 18,1:000000011010 19,1:000000011001
+20,1:000000010111 21,1:000000010110
+0,12:0000000011010 0,13:0000000011001 0,14:0000000011000 0,15:0000000010111 1,6:0000000010110 1,7:0000000010101
+2,5:0000000010100 3,4:0000000010011 5,3:0000000010010 9,2:0000000010001 10,2:0000000010000 22,1:0000000011111
+23,1:0000000011110 24,1:0000000011101 25,1:0000000011100 26,1:0000000011011
+0,16:00000000011111 0,17:00000000011110 0,18:00000000011101 0,19:00000000011100 0,20:00000000011011 0,21:00000000011010
+0,22:00000000011001 0,23:00000000011000 0,24:00000000010111 0,25:00000000010110 0,26:00000000010101 0,27:00000000010100
+0,28:00000000010011 0,29:00000000010010 0,30:00000000010001 0,31:00000000010000
+0,32:000000000011000 0,33:000000000010111 0,34:000000000010110 0,35:000000000010101 0,36:000000000010100
+0,37:000000000010011 0,38:000000000010010 0,39:000000000010001 0,40:000000000010000 1,8:000000000011111
+1,9:000000000011110 1,10:000000000011101 1,11:000000000011100 1,12:000000000011011 1,13:000000000011010 1,14:000000000011001
+1,15:0000000000010011 1,16:0000000000010010 1,17:0000000000010001 1,18:0000000000010000 6,3:0000000000010100
+11,2:0000000000011010 12,2:0000000000011001 13,2:0000000000011000 14,2:0000000000010111 15,2:0000000000010110
+16,2:0000000000010101 27,1:0000000000011111 28,1:0000000000011110 29,1:0000000000011101 30,1:0000000000011100
+31,1:0000000000011011"""
+_B14_EOB, _B14_ESCAPE = "10", "000001"
+
+# 7.3 figure 7-2: zig-zag scan (alternate_scan = 0), scan position of raster [v][u]
+_ZIGZAG = [0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53,
+           10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63]
+# 6.3.11: default intra quantiser matrix, raster [v][u]
+_INTRA_W = [8, 16, 19, 22, 26, 27, 29, 34, 16, 16, 22, 24, 27, 29, 34, 37, 19, 22, 26, 27, 29, 34, 34, 38, 22, 22, 26, 27, 29, 34, 37, 40,
+            22, 26, 27, 29, 32, 35, 40, 48, 26, 27, 29, 32, 35, 40, 48, 58, 26, 27, 29, 34, 38, 46, 56, 69, 27, 29, 35, 38, 46, 56, 69, 83]
+
+
+def _parse(text, key=int):
+    """'sym:bits sym:bits ...' -> [(code, length, sym)]"""
+    out = []
+    for item in text.split():
+        sym, bits = item.split(":")
+        out.append((int(bits, 2), len(bits), key(sym)))
+    return out
+
+
+def iso_tables():
+    """The raw Annex B tables as lists of (code, length, symbol); used by tests/test_decoder_tables.py"""
+    ac = _parse(_B14_AC, key=lambda t: tuple(int(x) for x in t.split(",")))
+    return dict(motion=_parse(_B10_MOTION), cbp=_parse(_B9_CBP), dcy=_parse(_B12_DC_LUMA), dcc=_parse(_B13_DC_CHROMA), ac=ac,
+                zigzag=list(_ZIGZAG), intra_w=list(_INTRA_W))
+
+
+def _tables():
+    t = iso_tables()
+    ac = [e for e in t["ac"] if e[2] != (0, 1)]          # '11' is matched before the table look-up (see the block loop)
+    ac.append((int(_B14_EOB, 2), len(_B14_EOB), "EOB"))
+    ac.append((int(_B14_ESCAPE, 2), len(_B14_ESCAPE), "ESC"))
     zz = np.zeros(64, np.int64)                          # scan position -> raster index
-    W = np.zeros(64, np.int64)
-    for i in range(8):
-        for j in range(8):
-            zz[L.m2v_oracle_tab_zigzag(i, j)] = i * 8 + j
-            W[i * 8 + j] = L.m2v_oracle_tab_intra_w(i, j)
-    return dict(motion=_vlc_decoder(motion), cbp=_vlc_decoder(cbp), dcy=_vlc_decoder(dcy), dcc=_vlc_decoder(dcc),
-                ac=_vlc_decoder(ac), zz=zz, W=W)
+    for raster, pos in enumerate(_ZIGZAG):
+        zz[pos] = raster
+    return dict(motion=_vlc_decoder(t["motion"]), cbp=_vlc_decoder(t["cbp"]), dcy=_vlc_decoder(t["dcy"]),
+                dcc=_vlc_decoder(t["dcc"]), ac=_vlc_decoder(ac), zz=zz, W=np.array(_INTRA_W, np.int64))
 
 
 _T = None

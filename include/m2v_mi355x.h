@@ -178,7 +178,9 @@ int m2v_kernel_stats(const m2v_enc *e, int kernel, double *ms, double *units);
 
 /*
  * Stage-level introspection for the parity tests (not part of the port contract): copies an
- * intermediate of the last m2v_encode_resident call to host memory.
+ * intermediate of the last m2v_encode_resident call to host memory.  what = 1 and a complete what = 3 need the
+ * debug build of the library (libm2v_mi355x_dbg.so, compiled with -DM2V_DEBUG, option "keep_recon"); the shipped
+ * library carries no dump code in its kernels and answers M2V_E_STATE for what = 1.
  *   what: 0 = mb info  uint32 [frames][mbs]  (bit0 inter, bits1-6 cbp, bits8-15 mvx, bits16-23 mvy, two's complement)
  *         1 = levels   int16  [frames][mbs][6][64] (zig-zag order)
  *         2 = mb bits  uint32 [frames][mbs]
@@ -187,7 +189,16 @@ int m2v_kernel_stats(const m2v_enc *e, int kernel, double *ms, double *units);
  */
 long long m2v_debug_read(m2v_enc *e, int what, void *dst, size_t cap);
 
+/* Text of the last failure on this handle; with e == NULL, why the last m2v_create on the calling thread failed. */
 const char *m2v_last_error(const m2v_enc *e);
+
+/*
+ * The product's constant tables, readable without a GPU (tests/test_abi.py compares them with the oracle's and
+ * with the RTL's assign lines): which 0 = DCT basis [i][j] (RTL:2020-2027), 1 = intra quantiser matrix (RTL:2080-2087),
+ * 2 = zig-zag position (RTL:2439-2446), 3 = motion code i (len << 8 | code, RTL:2500-2519), 4 = coded block pattern i,
+ * 5 = DC size code (len << 16 | code) of component i, size j, 6 = run/level code of run i, level j (0 = escape).
+ */
+int m2v_debug_table(int which, int i, int j);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,8 @@ def resident_encode(frames, xs16, ys16, pframes, XL=7, YL=7, VL=3, Q=2, batch_fr
     import torch
     own = enc is None
     if own:
-        enc = M.Mpeg2Encoder(XL, YL, VL, Q, device=0)
+        # debug=True: the -DM2V_DEBUG build of the same sources (level dump, every frame's reconstruction kept)
+        enc = M.Mpeg2Encoder(XL, YL, VL, Q, device=0, debug=debug)
     try:
         if batch_frames:
             enc.set_option("batch_frames", batch_frames)

@@ -1,4 +1,4 @@
-"""The encoder's streams through an independent MPEG-2 decoder written from ISO/IEC 13818-2 (tests/m2v_decode.py):
+"""The encoder's streams through an independent MPEG-2 decoder written from ISO/IEC 13818-2 (fpga-mpeg2-encoder_amd/decoder.py):
 every bit must parse, the decoded modes/vectors must be the encoder's, and with the RTL's documented deviations
 switched on the decoder must reproduce the encoder's own reconstruction exactly."""
 import numpy as np
@@ -6,9 +6,9 @@ import pytest
 
 import m2v_load
 from oracle import m2v_oracle_ctypes as orc
-import m2v_decode as dec
 
 M = m2v_load.load()
+dec = M.decoder
 
 
 @pytest.mark.parametrize("W,H,n,pf,VL,Q,ci", [(64, 64, 3, 2, 3, 2, 80), (96, 64, 4, 3, 1, 1, 81), (64, 96, 3, 1, 2, 4, 82),

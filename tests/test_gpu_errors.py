@@ -66,3 +66,55 @@ def test_two_handles_are_independent():
     finally:
         a.close()
         b.close()
+
+
+def test_reset_in_the_middle_of_a_strip_sequence():
+    """m2v_reset between m2v_strip_begin and m2v_strip_finish: the handle is idle again, full-frame geometry, and the
+    other entry points refuse to run while the strip sequence is open"""
+    import ctypes
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    L = M.lib()
+    clip = M.synth.clip(96, 96, 4, clip_index=123)
+    want = orc.encode(clip, 6, 6, 3, 6, 6, 3, 2)
+    enc = M.Mpeg2Encoder(6, 6, 3, 2)
+    try:
+        d_in = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
+        big = torch.empty(1 << 20, dtype=torch.uint8, device="cuda:0")
+        steps, hb = enc.strip_begin(d_in.data_ptr(), 4, 6, 6, 3, 2, 4)
+        assert steps == 4 and hb > 0
+        enc.strip_step(0, 0, 0)
+        n = ctypes.c_size_t(0)
+        assert L.m2v_encode_resident(enc._h, 6, 6, 3, d_in.data_ptr(), 4, big.data_ptr(), big.numel(), ctypes.byref(n), None) == -4
+        assert L.m2v_push_frames(enc._h, 6, 6, 3, clip.ctypes.data, 1) == -4
+        assert L.m2v_strip_begin(enc._h, 6, 6, 3, d_in.data_ptr(), 4, 0, 2, None) == -4
+        assert L.m2v_reset(enc._h) == 0 and not enc.busy
+        nb = enc.encode_resident(d_in.data_ptr(), 4, big.data_ptr(), big.numel(), 6, 6, 3)      # whole frames again
+        assert big[:nb].cpu().numpy().tobytes() == want
+        assert enc.encode(clip, 6, 6, 3) == want
+        steps2, _ = enc.strip_begin(d_in.data_ptr(), 4, 6, 6, 3, 0, 6)                          # and strips work again
+        assert steps2 == 4
+        assert L.m2v_reset(enc._h) == 0
+    finally:
+        enc.close()
+
+
+def test_create_failure_reports_text_without_a_handle():
+    import ctypes
+    import m2v_load
+    M = m2v_load.load()
+    L = M.lib()
+    err = ctypes.c_int(0)
+    assert not L.m2v_create(9, 6, 3, 2, 0, ctypes.byref(err)) and err.value == -1
+    assert b"XL" in L.m2v_last_error(None)
+    assert not L.m2v_create(6, 6, 3, 2, 99, ctypes.byref(err)) and err.value == -2
+    assert b"device" in L.m2v_last_error(None)
+    # the shipped library has no profiling / dump switches
+    enc = M.Mpeg2Encoder(6, 6, 3, 2)
+    try:
+        assert L.m2v_set_option(enc._h, b"ablate", 1) == -1 and L.m2v_set_option(enc._h, b"keep_recon", 1) == -1
+        assert b"unknown option" in L.m2v_last_error(enc._h)
+    finally:
+        enc.close()

@@ -1,0 +1,59 @@
+"""-m gpu: the drop-in boundary from a plain C caller and through the independent decoder.
+
+* integration/port_caller.c (gcc, C99, only include/m2v_mi355x.h): the per-clock call sequence of the DPI-C shim
+  integration/mpeg2encoder_mi355x.sv - one beat per m2v_push_beats, one word per m2v_pull, stop pulse - must write the
+  oracle's bytes.
+* the HIP encoder's stream through the ISO/IEC 13818-2 decoder (fpga-mpeg2-encoder_amd/decoder.py,
+  which shares no table or code with the encoder): parses to the last bit, decoded picture close to the source, and
+  with the RTL's documented deviations switched on equal to the oracle's reconstruction."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("bubble", [0, 7])
+def test_plain_c_caller_drives_the_port_contract(tmp_path, bubble):
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    M.build()
+    libdir = os.path.join(ROOT, "fpga-mpeg2-encoder_amd")
+    exe = str(tmp_path / "port_caller")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "integration", "port_caller.c"), "-L" + libdir, "-lm2v_mi355x",
+           "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    W, H, n, pf = 160, 96, 7, 3
+    clip = M.synth.clip(W, H, n, clip_index=130)
+    (tmp_path / "in.yuv").write_bytes(clip.tobytes() + b"\x11" * 500)       # trailing partial frame is ignored (TB:220)
+    out = tmp_path / "out.m2v"
+    r = subprocess.run([exe, str(tmp_path / "in.yuv"), str(W), str(H), str(out), str(pf), "6", "5", "2", "3", str(bubble)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "last=1" in r.stdout
+    assert out.read_bytes() == orc.encode(clip, W // 16, H // 16, pf, 6, 5, 2, 3)
+
+
+@pytest.mark.parametrize("W,H,n,pf,VL,Q,ci", [(96, 64, 5, 4, 3, 2, 131), (64, 80, 4, 1, 1, 4, 132), (80, 64, 3, 0, 2, 1, 133)])
+def test_hip_stream_through_the_independent_decoder(W, H, n, pf, VL, Q, ci):
+    import gpu_util as G
+    from oracle import m2v_oracle_ctypes as orc
+    clip = G.M.synth.clip(W, H, n, clip_index=ci, scene_len=3)
+    es = G.resident_encode(clip, W // 16, H // 16, pf, 7, 7, VL, Q)
+    dec = G.M.decoder
+    out = dec.decode(es, quirks=True)                                    # asserts on every syntax rule it knows
+    assert (out.width, out.height) == (W, H) and len(out.frames) == n
+    _, d = orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, Q, dump=True)
+    for f in range(n):
+        assert out.pictures[f]["type"] == (1 if f % (pf + 1) == 0 else 2)
+        rec = np.concatenate([p.reshape(-1) for p in out.frames[f]])
+        assert np.array_equal(rec, d["recon"][f]), "decoded frame %d is not the encoder's reconstruction" % f
+        assert dec.psnr(out.frames[f][0], clip[f, 0]) > 28.0
+    iso = dec.decode(es, quirks=False)                                   # a standard decoder: parses, stays close
+    assert all(dec.psnr(iso.frames[f][0], clip[f, 0]) > 26.0 for f in range(n))

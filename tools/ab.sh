@@ -1,6 +1,7 @@
 #!/bin/sh
 # Same-box A/B of two builds of the library: box-to-box variation (+-1.5 %) is larger than most kernel tweaks.
-#   A = gpurun_out/ab/base.so  (a copy of an earlier build, made before editing)   B = the in-tree library
+#   A = ./ab_base.so at the repo root (a copy of an earlier build, made before editing: `cp fpga-mpeg2-encoder_amd/libm2v_mi355x.so ab_base.so`)
+#   B = the in-tree library
 # usage (on the GPU box): sh tools/ab.sh [rounds]
 N=${1:-3}
 for i in $(seq $N); do

@@ -44,9 +44,8 @@ def main():
             print("  %5d  %s  tref %3d  %8d bytes  %d slices%s" % (k, "IP"[p.coding_type - 1], p.temporal_reference, p.bytes,
                                                                 p.slices, "  GOP" if p.gop_start else ""))
     if args.yuv:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-        import m2v_decode
-        dec = m2v_decode.decode(es, quirks=True)           # the encoder's own reconstruction (see tests/m2v_decode.py)
+        m2v_decode = M.decoder
+        dec = m2v_decode.decode(es, quirks=True)           # the encoder's own reconstruction (see fpga-mpeg2-encoder_amd/decoder.py)
         W, H = info.width, info.height
         src = np.fromfile(args.yuv, np.uint8)
         n = min(src.size // (3 * W * H), len(dec.frames))
