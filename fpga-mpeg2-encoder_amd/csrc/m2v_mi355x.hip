@@ -93,8 +93,10 @@ struct m2v_enc {
         size_t h_lists_cap = 0;
         uint8_t *h_out = nullptr;             // pinned read-back buffer
         size_t h_out_cap = 0;
+        DevBuf<uint8_t> d_in;                 // the chunk's frames on the device: the upload of chunk k+1 (up_stream) runs
+                                              // while the kernels of chunk k read the other stage's buffer
         DevBuf<uint8_t> d_out;                // chunk output when it goes to the host
-        hipEvent_t ev_ctl = nullptr, ev_out = nullptr;
+        hipEvent_t ev_ctl = nullptr, ev_out = nullptr, ev_up = nullptr;
         int stage = 0;                        // 0 free, 1 encode submitted, 2 stream read-back submitted
         bool last = false;
         size_t bytes = 0;
@@ -104,8 +106,11 @@ struct m2v_enc {
     std::deque<int> pending;      // submitted stages, oldest first
     bool conformant = false;      // option "conformant": ISO reconstruction loop instead of the RTL's (NOT byte-identical to the reference)
     int copy_threads = 4;         // option "copy_threads": threads that copy m2v_push_frames input into pinned memory
-    bool split_streams = false;   // see encode_chunk
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int split_streams = 2;        // GOP segments of a chunk run as this many independent groups on as many streams (encode_chunk)
+    static constexpr int kMaxSplit = 8;
+    hipStream_t side[kMaxSplit - 1] = {};            // group 0 runs on the caller's stream
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSplit - 1] = {};
+    hipStream_t up_stream = nullptr;     // host -> device uploads of the port path
     bool async = true;            // option "async": 0 = every chunk is completed before m2v_push_* returns
     hipStream_t copy_stream = nullptr;   // stream read-back, concurrent with the next chunk's kernels
     size_t buffered = 0;          // complete frames waiting in st().h_in
@@ -118,7 +123,6 @@ struct m2v_enc {
     bool end_pending = false;     // the data in the FIFO ends with the o_last word
 
     // device buffers
-    DevBuf<uint8_t> d_in;                 // chunk input when it comes from the host
     DevBuf<int16_t> d_coef;               // debug only: quantised levels
     DevBuf<MbAux> d_mbaux;
     DevBuf<MbDepRec> d_mbdep;             // neighbour-dependent codes of every macroblock (k_slice_scan -> k_assemble)
@@ -136,7 +140,8 @@ struct m2v_enc {
     unsigned long long stream_bytes = 0;  // bytes of the current sequence already moved to the FIFO
 
     // plan of the chunk being encoded (plan_chunk -> run_step* -> finish_chunk)
-    struct Step { int off_i, n_i, off_p, n_p, off_h, n_h, half_i, half_p; };   // half_*: entries of the first half of the segments
+    struct Step { int off_i, n_i, off_p, n_p, off_h, n_h; int cut_i[kMaxSplit + 1], cut_p[kMaxSplit + 1]; };   // cut_*[k]: first list entry of segment group k
+    int plan_groups = 1;                  // groups the launch lists of the current plan are cut into
     std::vector<Step> plan_steps;
     size_t plan_nf = 0;
     bool strip_active = false;            // between m2v_strip_begin and m2v_strip_finish
@@ -410,23 +415,28 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
     }
     std::vector<int> lists;
     e->plan_steps.assign(maxlen, m2v_enc::Step{});
+    // segment group of a GOP segment (option "split_streams"): contiguous runs of segments, group g on stream g
+    const int groups = (int)std::max<size_t>(1, std::min<size_t>({(size_t)e->split_streams, nseg, (size_t)m2v_enc::kMaxSplit}));
+    e->plan_groups = groups;
+    auto group_of = [&](size_t sg) { return (int)(sg * (size_t)groups / nseg); };
     for (size_t j = 0; j < maxlen; ++j) {
         m2v_enc::Step st{};
         for (int pass = 0; pass < 3; ++pass) {
             const int off = (int)lists.size();
-            int lower = 0;                                  // entries that belong to the first half of the segments
+            int cut[m2v_enc::kMaxSplit + 1];
+            int gnext = 0;
             for (size_t sg = 0; sg < nseg; ++sg) {
                 const size_t a = seg_start[sg], b = sg + 1 < nseg ? (size_t)seg_start[sg + 1] : nf;
+                while (gnext <= group_of(sg)) cut[gnext++] = (int)lists.size() - off;      // the lists are in segment order
                 if (a + j >= b) continue;
                 const FrameJob &fj = jobs[a + j];
-                if ((pass == 0 && fj.i_frame == 0) || (pass == 1 && fj.i_frame != 0) || (pass == 2 && fj.rec != nullptr)) {
+                if ((pass == 0 && fj.i_frame == 0) || (pass == 1 && fj.i_frame != 0) || (pass == 2 && fj.rec != nullptr))
                     lists.push_back((int)(a + j));
-                    if (sg < nseg / 2) ++lower;
-                }
             }
             const int cnt = (int)lists.size() - off;
-            if (pass == 0) { st.off_i = off; st.n_i = cnt; st.half_i = lower; }
-            else if (pass == 1) { st.off_p = off; st.n_p = cnt; st.half_p = lower; }
+            while (gnext <= m2v_enc::kMaxSplit) cut[gnext++] = cnt;
+            if (pass == 0) { st.off_i = off; st.n_i = cnt; memcpy(st.cut_i, cut, sizeof cut); }
+            else if (pass == 1) { st.off_p = off; st.n_p = cnt; memcpy(st.cut_p, cut, sizeof cut); }
             else { st.off_h = off; st.n_h = cnt; }
         }
         e->plan_steps[j] = st;
@@ -522,23 +532,32 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
                   uint32_t last_valid_beats, uint8_t *d_stream, bool advance = false)
 {
     plan_chunk(e, s, d_frames, nf, last, last_valid_beats);
-    if (e->split_streams && !e->profile && e->plan_steps.size() > 1) {
-        // EXPERIMENT: the GOP segments of the chunk as two independent halves on two streams, so that the tail of one
-        // half's launch (partially filled GPU) overlaps with the other half's next launch
-        if (!e->ev_fork) { HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)); }
-        hipStream_t s2 = e->copy_stream;
+    if (e->plan_groups > 1 && !e->profile && e->plan_steps.size() > 1) {
+        // The GOP segments of the chunk as `plan_groups` independent groups, one stream each: a launch of 86 400
+        // wavefronts ends with a partially filled GPU (10.55 rounds of 8 192 wave slots) and the next step of the
+        // same GOPs cannot start before it has drained; the other groups' launches fill those slots.  A segment stays
+        // on its stream (its frames depend on each other), so plain stream order is all the synchronisation needed.
+        // Off while option "profile" times the launches with in-band events (one stream: unambiguous durations).
+        const int G = e->plan_groups;
+        if (!e->ev_fork) HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventRecord(e->ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(s2, e->ev_fork, 0));
+        for (int k = 1; k < G; ++k) {
+            if (!e->side[k - 1]) HIPCHK(hipStreamCreateWithFlags(&e->side[k - 1], hipStreamNonBlocking));
+            if (!e->ev_join[k - 1]) HIPCHK(hipEventCreateWithFlags(&e->ev_join[k - 1], hipEventDisableTiming));
+            HIPCHK(hipStreamWaitEvent(e->side[k - 1], e->ev_fork, 0));
+        }
         for (size_t j = 0; j < e->plan_steps.size(); ++j) {
             const m2v_enc::Step &st = e->plan_steps[j];
-            const int ia = st.half_i, pa = st.half_p;     // a segment stays on its stream: its frames depend on each other
-            launch_mb<false>(e, s, e->d_lists.p + st.off_i, ia, e->g);
-            launch_mb<true>(e, s, e->d_lists.p + st.off_p, pa, e->g);
-            launch_mb<false>(e, s2, e->d_lists.p + st.off_i + ia, st.n_i - ia, e->g);
-            launch_mb<true>(e, s2, e->d_lists.p + st.off_p + pa, st.n_p - pa, e->g);
+            for (int k = 0; k < G; ++k) {
+                hipStream_t sk = k == 0 ? s : e->side[k - 1];
+                launch_mb<false>(e, sk, e->d_lists.p + st.off_i + st.cut_i[k], st.cut_i[k + 1] - st.cut_i[k], e->g);
+                launch_mb<true>(e, sk, e->d_lists.p + st.off_p + st.cut_p[k], st.cut_p[k + 1] - st.cut_p[k], e->g);
+            }
         }
-        HIPCHK(hipEventRecord(e->ev_join, s2));
-        HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
+        for (int k = 1; k < G; ++k) {
+            HIPCHK(hipEventRecord(e->ev_join[k - 1], e->side[k - 1]));
+            HIPCHK(hipStreamWaitEvent(s, e->ev_join[k - 1], 0));
+        }
     } else {
         for (size_t j = 0; j < e->plan_steps.size(); ++j) run_step(e, s, j);
     }
@@ -604,6 +623,7 @@ void ensure_staging(m2v_enc *e)
     if (!h.h_ctl) HIPCHK(hipHostMalloc((void **)&h.h_ctl, 2 * sizeof(StreamCtl)));
     if (!h.ev_ctl) HIPCHK(hipEventCreateWithFlags(&h.ev_ctl, hipEventDisableTiming));
     if (!h.ev_out) HIPCHK(hipEventCreateWithFlags(&h.ev_out, hipEventDisableTiming));
+    if (!h.ev_up) HIPCHK(hipEventCreateWithFlags(&h.ev_up, hipEventDisableTiming));
     if (h.h_in && h.h_in_cap >= want) return;
     if (h.h_in) (void)hipHostFree(h.h_in);
     h.h_in = nullptr;
@@ -676,14 +696,18 @@ void flush_buffered(m2v_enc *e, bool last)
         return;
     }
     m2v_enc::HostStage &h = e->st();
-    e->d_in.ensure(nf * frame_bytes);       // one buffer: the upload of chunk k+1 queues behind the kernels of chunk k
-    HIPCHK(hipMemcpyAsync(e->d_in.p, h.h_in, nf * frame_bytes, hipMemcpyHostToDevice, s));
+    // the stage's own device buffer, filled on the upload stream: the copy of chunk k+1 crosses PCIe while the kernels
+    // of chunk k run (the stage is only refilled after its previous chunk has completed, see the end of this function)
+    h.d_in.ensure(nf * frame_bytes);
+    HIPCHK(hipMemcpyAsync(h.d_in.p, h.h_in, nf * frame_bytes, hipMemcpyHostToDevice, e->up_stream));
+    HIPCHK(hipEventRecord(h.ev_up, e->up_stream));
+    HIPCHK(hipStreamWaitEvent(s, h.ev_up, 0));
     // worst case ~1.2 KB per macroblock; typical streams are ~100x smaller
     const size_t cap = nf * ((size_t)g.mbs * 1216 + (size_t)g.mbh * 8 + 64) + 256;
     h.d_out.ensure(cap);
     e->d_ctl.ensure(1);
     hipLaunchKernelGGL(k_ctl_chain, dim3(1), dim3(1), 0, s, e->d_ctl.p, (unsigned long long)cap, e->first_chunk ? 1 : 0);
-    encode_chunk(e, s, e->d_in.p, nf, e->first_chunk, last, e->last_frame_valid_beats, h.d_out.p);
+    encode_chunk(e, s, h.d_in.p, nf, e->first_chunk, last, e->last_frame_valid_beats, h.d_out.p);
     HIPCHK(hipMemcpyAsync(h.h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(h.ev_ctl, s));
     h.stage = 1;
@@ -791,12 +815,14 @@ m2v_enc *m2v_create(int XL, int YL, int VECTOR_LEVEL, int Q_LEVEL, int device, i
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
         upload_tables(device);
         HIPCHK(hipDeviceSynchronize());
     } catch (const HipError &h) {
         const std::string why = std::string("m2v_create: ") + h.what + ": " + hipGetErrorString(h.e);
         if (e->stream) (void)hipStreamDestroy(e->stream);
         if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+        if (e->up_stream) (void)hipStreamDestroy(e->up_stream);
         delete e;
         return fail(M2V_E_HIP, why);
     }
@@ -810,13 +836,17 @@ void m2v_destroy(m2v_enc *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
-    e->d_in.release(); e->d_coef.release(); e->d_mbaux.release(); e->d_mbdep.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
+    if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
+    for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
+    e->d_coef.release(); e->d_mbaux.release(); e->d_mbdep.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
     e->d_mboff.release(); e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
     e->d_jobs.release(); e->d_lists.release(); e->d_ctl.release(); e->d_segs.release();
     for (auto p : e->rec_pool) (void)hipFree(p);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto &h : e->hs) {
         h.d_out.release();
+        h.d_in.release();
+        if (h.ev_up) (void)hipEventDestroy(h.ev_up);
         if (h.h_in) (void)hipHostFree(h.h_in);
         if (h.h_out) (void)hipHostFree(h.h_out);
         if (h.h_ctl) (void)hipHostFree(h.h_ctl);
@@ -825,8 +855,12 @@ void m2v_destroy(m2v_enc *e)
         if (h.ev_ctl) (void)hipEventDestroy(h.ev_ctl);
         if (h.ev_out) (void)hipEventDestroy(h.ev_out);
     }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (auto ev : e->ev_join) if (ev) (void)hipEventDestroy(ev);
+    for (auto sd : e->side) if (sd) (void)hipStreamDestroy(sd);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->up_stream) (void)hipStreamDestroy(e->up_stream);
     delete e;
 }
 
@@ -836,6 +870,8 @@ int m2v_reset(m2v_enc *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+    if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
+    for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
     if (e->strip_stream && e->strip_stream != e->stream) (void)hipStreamSynchronize(e->strip_stream);
     for (auto &h : e->hs) h.stage = 0;
     e->pending.clear();
@@ -1277,7 +1313,11 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
     }
     if (!strcmp(name, "profile")) { e->profile = value != 0; return M2V_OK; }
     if (!strcmp(name, "async")) { e->async = value != 0; return M2V_OK; }
-    if (!strcmp(name, "split_streams")) { e->split_streams = value != 0; return M2V_OK; }
+    if (!strcmp(name, "split_streams")) {
+        if (value < 0 || value > m2v_enc::kMaxSplit) return M2V_E_PARAM;
+        e->split_streams = value < 1 ? 1 : (int)value;      // 0 and 1 both mean one stream
+        return M2V_OK;
+    }
     if (!strcmp(name, "conformant")) {
         if (e->state != m2v_enc::IDLE) return M2V_E_PARAM;
         e->conformant = value != 0;

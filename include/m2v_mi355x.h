@@ -160,9 +160,9 @@ int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t 
  * read back, m2v_push_* fills the pinned staging of the next one; 0 = a chunk is complete when the push
  * that filled it returns.  The bytes are the same either way),
  * "copy_threads" (default 4: threads m2v_push_frames uses to copy large inputs into pinned memory),
- * "split_streams" (default 0; 1 = the GOP segments of a chunk run as two independent halves on two HIP streams so
- * that the partially filled tail of one launch overlaps with the other half's next launch: +4 % on 1920x1152,
- * ignored while "profile" is on),
+ * "split_streams" (default 2; 1..8 = the closed GOPs of a chunk are encoded as this many independent groups on as many
+ * HIP streams, so that the partially filled tail of one group's launch overlaps with another group's next launch;
+ * 1 = a single stream; ignored while "profile" is on, which times every launch with in-band events on one stream),
  * "conformant" (default 0 = the reference's arithmetic, byte-identical to the RTL.  1 = NOT the reference's
  * behaviour: the reconstruction loop follows ISO/IEC 13818-2 where the RTL deviates from it - four-sample average
  * rounded with +2, 4:2:0 chroma vector = mv / 2 toward zero, inverse quantiser truncating toward zero with

@@ -118,3 +118,46 @@ def test_create_failure_reports_text_without_a_handle():
         assert b"unknown option" in L.m2v_last_error(enc._h)
     finally:
         enc.close()
+
+
+def test_config_c4_eight_handles_from_eight_threads():
+    """BASELINE config c4 as far as one GPU can show it: 8 independent 1920x1152 sequences (one whole GOP of 1 I + 8 P
+    each, VECTOR_LEVEL 3, Q_LEVEL 2), every handle created, driven and destroyed by its own thread at the same time
+    (the first m2v_create on a device uploads the constant tables: once, whichever thread gets there first).
+    Every stream byte-identical to the oracle's."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    M.lib()
+    orc.build()
+    W, H, pf, n, T = 1920, 1152, 8, 9, 8
+    clips = [M.synth.clip_torch(W, H, n, clip_index=200 + t, device="cuda:0", scene_len=4 + t) for t in range(T)]
+    host = [c.cpu().numpy() for c in clips]
+    torch.cuda.synchronize()
+    gate = threading.Barrier(T)
+    got = [None] * T
+
+    def worker(t):
+        gate.wait()                                            # all eight m2v_create calls race
+        enc = M.Mpeg2Encoder(7, 7, 3, 2, device=0)
+        try:
+            d_out = torch.empty(n * W * H, dtype=torch.uint8, device="cuda:0")
+            for _ in range(2):                                 # twice: buffers are reused while the other handles run
+                nb = enc.encode_resident(clips[t].data_ptr(), n, d_out.data_ptr(), d_out.numel(), 120, 72, pf)
+            got[t] = d_out[:nb].cpu().numpy().tobytes()
+        finally:
+            enc.close()
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    with ThreadPoolExecutor(T) as ex:                          # the oracle drops the GIL: one GOP per core
+        want = list(ex.map(lambda c: orc.encode(c, 120, 72, pf, 7, 7, 3, 2), host))
+    for t in range(T):
+        assert got[t] is not None, "thread %d died" % t
+        assert got[t] == want[t], "sequence %d" % t

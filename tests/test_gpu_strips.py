@@ -6,19 +6,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("world,W,H,pf,VL", [(2, 128, 96, 4, 3), (3, 96, 160, 2, 2), (4, 160, 128, 3, 1), (8, 64, 128, 1, 3)])
-def test_strips_equal_single_encoder(world, W, H, pf, VL, split):
-    """split: the step in two parts (edge rows + halo pack, then interior rows) as encode_strips() issues it around the
-    exchange; strips of 1, 2, 3 and 4 rows"""
+def run_emulated_strips(M, d_clip, W, H, pf, VL, world, split):
+    """`world` encoder handles on ONE GPU, each owning a strip of macroblock rows; the halo "exchange" is a device copy.
+    Returns the assembled stream bytes."""
     import torch
-    import m2v_load
-    from oracle import m2v_oracle_ctypes as orc
-    M = m2v_load.load()
-    n = 2 * (pf + 1) + 1
-    clip = M.synth.clip(W, H, n, clip_index=50 + world)
-    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, 2)
-    d_clip = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
     encs = [M.Mpeg2Encoder(7, 7, VL, 2) for _ in range(world)]
     try:
         shared = torch.cuda.Stream()                       # the emulated ranks share one stream: the "exchange" is a plain copy
@@ -44,11 +35,47 @@ def test_strips_equal_single_encoder(world, W, H, pf, VL, split):
         outs = [eng.finish() for eng in engines]
         stream = engines[0].assemble([o[0] for o in outs], [o[1] for o in outs])
         torch.cuda.synchronize()
-        got = stream.cpu().numpy().tobytes()
-        assert got == want
+        return stream.cpu().numpy().tobytes()
     finally:
         for e in encs:
             e.close()
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("world,W,H,pf,VL", [(2, 128, 96, 4, 3), (3, 96, 160, 2, 2), (4, 160, 128, 3, 1), (8, 64, 128, 1, 3)])
+def test_strips_equal_single_encoder(world, W, H, pf, VL, split):
+    """split: the step in two parts (edge rows + halo pack, then interior rows) as encode_strips() issues it around the
+    exchange; strips of 1, 2, 3 and 4 rows"""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    n = 2 * (pf + 1) + 1
+    clip = M.synth.clip(W, H, n, clip_index=50 + world)
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, 2)
+    d_clip = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
+    assert run_emulated_strips(M, d_clip, W, H, pf, VL, world, split) == want
+
+
+def test_config_c5_full_size_8_strips_of_16_rows():
+    """BASELINE config c5 at its real size on one GPU: ONE 2048x2048 sequence (XL = YL = 7, 128 x 128 macroblocks), one
+    whole GOP of 1 I + 8 P frames, VECTOR_LEVEL 3, cut into 8 strips of 16 macroblock rows with the +-6 luma / +-3
+    chroma halo (9 rows x 2048 bytes per frame per direction), edge rows first as encode_strips() issues them.
+    Byte-identical to the oracle (about 5 s of CPU) and to the single-handle encode of the same clip."""
+    import torch
+    import m2v_load
+    import gpu_util as G
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    W = H = 2048
+    pf, n = 8, 9
+    d_clip = M.synth.clip_torch(W, H, n, clip_index=55, device="cuda:0", scene_len=5)      # a scene cut inside the GOP
+    clip = d_clip.cpu().numpy()
+    want = orc.encode(clip, 128, 128, pf, 7, 7, 3, 2)
+    got = run_emulated_strips(M, d_clip, W, H, pf, 3, 8, True)
+    assert len(got) == len(want)
+    assert got == want
+    assert G.resident_encode(clip, 128, 128, pf, 7, 7, 3, 2) == want
 
 
 def test_encode_strips_world1_equals_resident():

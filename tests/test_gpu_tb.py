@@ -67,3 +67,30 @@ def test_tb_writes_program_and_transport_streams(tmp_path):
     es = out.read_bytes()
     assert (tmp_path / "v.m2v.mpg").read_bytes() == C.mux_ps(es)
     assert (tmp_path / "v.m2v.ts").read_bytes() == C.mux_ts(es)
+
+
+def test_tb_testbench_geometries_config_c1(tmp_path):
+    """BASELINE config c1 / TB:150-152: the testbench's own three geometries, 288x208, 640x320 and 1440x704 (90 macroblocks
+    wide, the largest one XL = 7, YL = 6 is exercised with), back to back on one m2v_tb instance with the testbench's
+    defaults (pframes 23, VECTOR_LEVEL 3, Q_LEVEL 2), against the oracle's CLI."""
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    M.build()
+    orc.build()
+    tb = os.path.join(ROOT, "fpga-mpeg2-encoder_amd", "m2v_tb")
+    cli = os.path.join(ROOT, "oracle", "m2v_oracle_cli")
+    vids = [(288, 208, 3), (640, 320, 3), (1440, 704, 4)]
+    args = []
+    for k, (W, H, n) in enumerate(vids):
+        fin = tmp_path / ("v%d.yuv" % k)
+        fin.write_bytes(M.synth.clip(W, H, n, clip_index=96 + k, scene_len=3).tobytes())     # a scene cut: intra blocks in P frames
+        args += [str(fin), str(W), str(H), str(tmp_path / ("v%d.m2v" % k))]
+    out = subprocess.run([tb] + args, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for k, (W, H, n) in enumerate(vids):
+        ref = tmp_path / ("r%d.m2v" % k)
+        r = subprocess.run([cli, str(tmp_path / ("v%d.yuv" % k)), str(W), str(H), str(ref), "23", "7", "6", "3", "2"],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr
+        assert (tmp_path / ("v%d.m2v" % k)).read_bytes() == ref.read_bytes(), "video %dx%d" % (W, H)

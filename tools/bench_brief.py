@@ -9,5 +9,8 @@ if not line:
     print("no JSON line on stdin")
     sys.exit(1)
 d = json.loads(line[-1])
-print("MPixels/s", d["value"], "ms/step", d["ms_per_step"], d.get("kernel_ms_per_step"), d.get("parity_check"),
-      "roofline", d.get("roofline", {}).get("achieved"), d.get("roofline", {}).get("frac"))
+pc = d.get("parity_check") or {}
+print("MPixels/s", d["value"], "ms/step", d["ms_per_step"], "| profiled pass", (d.get("profiled_pass") or {}).get("value"),
+      d.get("kernel_ms_per_step"), "| parity", pc.get("identical_to_oracle"), pc.get("gops_compared"), pc.get("problems"),
+      "| roofline", d.get("roofline", {}).get("achieved"), d.get("roofline", {}).get("frac"),
+      "| e2e", (d.get("end_to_end") or {}).get("value"), (d.get("end_to_end") or {}).get("identical_to_resident_stream"))
