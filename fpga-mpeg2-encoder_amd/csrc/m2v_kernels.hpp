@@ -123,16 +123,47 @@ __device__ __forceinline__ int wave_scan_incl(int v)
 }
 __device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_scan_incl(v), 63); }
 
+// Sums of FOUR values over the wave for the price of less than two (gfx950 lane swaps): v_permlane32_swap exchanges the
+// upper half of one register with the lower half of another, so one add folds two registers' 64 partial sums into 32 + 32
+// lanes of a single register; v_permlane16_swap does the same for odd / even rows of 16.  After both levels each row of
+// 16 lanes holds one value's partial sums and a 4-step row scan finishes all four at once: 10 VALU instead of 24.
+// Totals: a -> lane 15, c -> lane 31, b -> lane 47, d -> lane 63 of the result.
+__device__ __forceinline__ int wave_sum4(int a, int b, int c, int d)
+{
+    const auto ab = __builtin_amdgcn_permlane32_swap(a, b, false, false);      // [a.lo b.lo], [a.hi b.hi]
+    const auto cd = __builtin_amdgcn_permlane32_swap(c, d, false, false);
+    const int x = (int)(ab[0] + ab[1]), y = (int)(cd[0] + cd[1]);              // rows: a a b b / c c d d
+    const auto xy = __builtin_amdgcn_permlane16_swap(x, y, false, false);      // [x0 y0 x2 y2], [x1 y1 x3 y3]
+    int v = (int)(xy[0] + xy[1]);                                              // rows: a c b d
+    v += M2V_DPP(0, v, 0x111, 0xF, true);
+    v += M2V_DPP(0, v, 0x112, 0xF, true);
+    v += M2V_DPP(0, v, 0x114, 0xF, true);
+    v += M2V_DPP(0, v, 0x118, 0xF, true);
+    return v;
+}
+
+// EXEC-masked lane mask of a predicate as the compare instruction leaves it (HIP's __ballot goes through a 0/1 select
+// and a second compare: two VALU instructions more per use)
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// 1 if any lane's predicate holds, on the scalar unit
+__device__ __forceinline__ uint32_t any_lane(bool p)
+{
+    const uint32_t n = (uint32_t)__builtin_popcountll(ballot(p));
+    return n < 1u ? n : 1u;
+}
+
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
 {
+    // old = ~0 is the identity of min: lanes without a source (and the rows a row_bcast skips) keep their value, and the
+    // compiler folds each move into ONE v_min_u32_dpp (with old = v it emits v_mov + v_mov_dpp + v_min: three)
     int v = (int)x;
-    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x111, 0xF, false));
-    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x112, 0xF, false));
-    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x114, 0xF, false));
-    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x118, 0xF, false));
-    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x142, 0xA, false));
-    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(v, v, 0x143, 0xC, false));
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(-1, v, 0x111, 0xF, false));
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(-1, v, 0x112, 0xF, false));
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(-1, v, 0x114, 0xF, false));
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(-1, v, 0x118, 0xF, false));
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(-1, v, 0x142, 0xA, false));
+    v = (int)umin32((uint32_t)v, (uint32_t)M2V_DPP(-1, v, 0x143, 0xC, false));
     return (uint32_t)__builtin_amdgcn_readlane(v, 63);
 }
 
@@ -148,6 +179,15 @@ __device__ __forceinline__ int mad24(int a, int b, int c)
 }
 
 __device__ __forceinline__ int iabs(int a) { return a < 0 ? -a : a; }
+// A value that IS the same in every lane, stated to the compiler: everything computed from it stays on the scalar
+// unit (SALU has slack, the vector ALU is the kernel's bottleneck).  Without it the compiler's divergence analysis
+// gives up on some wave-uniform chains (the half-pel decision, the coded-block pattern) and runs them - and the
+// exec-mask juggling of their "divergent" branches - on the vector unit.
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// The same statement for a value the compiler already holds in a scalar register: the empty asm pins it to an SGPR and
+// hides where it came from, so that it cannot be merged with an equal expression that some vector instruction needs as
+// a lane mask or VGPR (which would drag this copy, and its users, onto the vector ALU as well).
+__device__ __forceinline__ int sgpr(int v) { asm("" : "+s"(v)); return v; }
 __device__ __forceinline__ int sext(int v, int bits) { return (int)((uint32_t)v << (32 - bits)) >> (32 - bits); }
 
 // the same two means on four packed bytes with v_lerp_u8: D.b = (S0.b + S1.b + (S2.b & 1)) >> 1
@@ -375,6 +415,45 @@ __device__ __forceinline__ MbDep mb_dependent(uint32_t info, const MbAux &aux, b
     return d;
 }
 
+constexpr uint32_t SYM_RAW = 0x80000000u;     // symbol list entry: raw = code[23:0], len[28:24]; else level[15:0], run[21:16]
+
+// Pass 1 of the coefficient VLC for one coded tile (lane = zig-zag index): rank the non-zero levels, append their
+// {run, level} symbols and the end_of_block code to the macroblock's symbol list; returns the new list length.
+// INTER = non-intra block: every position counts and there is no DC code; intra: position 0 is the DC level, which
+// leaves through `dc` (for Y01 / Y10 / Y11 its differential against `dc_prev` is coded right here, RTL:2784-2786).
+template <bool INTER>
+__device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_t *s_sym, uint32_t *s_pos, int lane, uint32_t nsym,
+                                                     int &dc, int dc_prev, bool dc_chained)
+{
+    const int v = zig[lane];
+    if constexpr (!INTER) {
+        dc = __builtin_amdgcn_readlane(v, 0);
+        if (dc_chained) {
+            const BitCode c = dc_code(dc - dc_prev, 0);
+            if (lane == 0) s_sym[nsym] = SYM_RAW | (c.len << 24) | c.code;
+            nsym += 1u;
+        }
+    }
+    const bool nz = INTER ? v != 0 : (v != 0 && lane > 0);
+    const unsigned long long mask = ballot(nz);
+    const uint32_t nnz = (uint32_t)__builtin_popcountll(mask);
+    if (nz) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        s_pos[rank] = (uint32_t)lane;
+        // the load below reads what ANOTHER lane just stored: in one thread's view the two addresses differ, so the compiler
+        // may hoist the load above the store - the memory clobber pins the order (the LDS itself executes a wave's
+        // operations in program order, no wait is needed)
+        asm volatile("" ::: "memory");
+        const uint32_t prev = s_pos[(int)rank - 1];            // s_pos[-1] = -1 (inter) / 0 (intra), set once per macroblock
+        const uint32_t run = (uint32_t)lane - prev - 1u;
+        s_sym[nsym + rank] = (run << 16) | ((uint32_t)v & 0xFFFFu);
+        // end_of_block '10' (RTL:2835) behind the last level: every active lane stores the same word to the same address
+        if (INTER) s_sym[nsym + nnz] = SYM_RAW | (2u << 24) | 2u;
+    }
+    if (!INTER && lane == 0) s_sym[nsym + nnz] = SYM_RAW | (2u << 24) | 2u;     // an intra block may have no AC level at all
+    return nsym + nnz + 1u;
+}
+
 // ----------------------------------------------------------------------------------------------
 // k_mb: one wavefront = one macroblock, stages A..T
 // ----------------------------------------------------------------------------------------------
@@ -453,7 +532,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     uint32_t *const s_cur = (uint32_t *)(lds + 2 * kCwinBytes);                // current luma, dword [row][4-px group]
     uint32_t *const s_win = (uint32_t *)(lds + kOffWin);                       // luma window: row stride kWS dwords, 32 bytes = frame cols 16bx-8 .. 16bx+23
     uint32_t *const s_winb = (uint32_t *)(lds + kOffWinB);                     // the same, one dword to the left
-    uint32_t *const s_sym = (uint32_t *)lds;                                   // VLC symbol list (<= 6 * 66), reuses R1
+    uint32_t *const s_sym = (uint32_t *)(lds + 16);                            // VLC symbol list (<= 3 + 6 * 64 entries; [-1] is read), reuses R1
     uint8_t (*const s_pred)[64] = (uint8_t (*)[64])(lds + kOffPred);           // prediction, later reconstruction, tile layout
     int16_t (*const s_x)[64] = (int16_t (*)[64])(lds + kOffX);                 // residual, later dequantised coefficients
     int32_t (*const s_t)[64] = (int32_t (*)[64])(lds + kOffT);                 // DCT phase 1, later IDCT row pass
@@ -469,6 +548,11 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     const FrameJob job = jobs[fidx];
     const int W = g.W;
     const int r = lane >> 2, c4 = lane & 3;
+    // 1 = the macroblock has a neighbour on that side (left, right, up, down).  Sign-bit arithmetic, not compares: these
+    // wave-uniform flags feed range limits and candidate masks that must stay on the scalar unit, and a compare that is
+    // also needed as a lane mask somewhere gets computed by the vector ALU - with everything downstream of it.
+    const int in_l = sgpr((int)((uint32_t)-bx >> 31)), in_r = sgpr((int)((uint32_t)(bx + 1 - g.mbw) >> 31));
+    const int in_u = sgpr((int)((uint32_t)-by >> 31)), in_d = sgpr((int)((uint32_t)(by + 1 - g.mbh) >> 31));
 
     // ---- stages A..E: current macroblock; 4:4:4 -> 4:2:0 with two-stage rounding -------------
     // (RTL:1086-1089 horizontal mean2, RTL:1167-1170 vertical mean2 of the two means)
@@ -566,11 +650,11 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %5 offset:8"
                              : "=&v"(ra.w01), "=&v"(ra.w12), "=&v"(ra.w23), "=&v"(ra.w34) : "v"(ae), "v"(ao));
                 search_rows<0, kWS>(s_cur, ae, ao, acc, ra, rb);
-                const int dy = dyi - YR;
-                const bool rowok = !((by == 0 && dy < 0) || (by == g.mbh - 1 && dy > 0));   // RTL:1644-1645
-                // live dx range of this macroblock column (RTL:1642-1643), wave-uniform: one unsigned compare per candidate
-                const int lo = bx == 0 ? 0 : -YR, hi = bx == g.mbw - 1 ? 0 : YR;
-                const uint32_t span = (uint32_t)(hi - lo);
+                // live dy / dx range of this macroblock (RTL:1642-1645), wave-uniform and kept on the scalar unit: one
+                // unsigned range compare per axis per candidate
+                const int lo = -YR & -in_l, hi = YR & -in_r, ylo = -YR & -in_u, yhi = YR & -in_d;
+                const uint32_t span = (uint32_t)(hi - lo), yspan = (uint32_t)(yhi - ylo);
+                const bool rowok = (uint32_t)(dyi - YR - ylo) <= yspan;
                 const int d0 = 4 * gq - 8 - lo;
                 // minimum SAD; among equals the largest dy, then the largest dx (RTL:1694-1710): key = sad << 8 | (255 - index),
                 // index = dy' << 4 | dx + 8.  A SAD >= 4096 kills a candidate (RTL:1669-1670): such keys are >= 1 << 20 and lose
@@ -585,11 +669,14 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 }
             }
             key = wave_min_u32(key);
+            key = (uint32_t)sgpr(uniform((int)key));
             if (key < (4096u << 8)) {           // no live candidate: (0,0) (RTL:1695, 1707)
                 const int c = 255 - (int)(key & 255u);
                 fy = (c >> 4) - YR;
                 fx = (c & 15) - 8;
             }
+            fy = sgpr(fy);
+            fx = sgpr(fx);
         }
 
         // ---- half-pel refinement + intra cost (RTL:1743-1816), four pixels per lane, packed bytes ----
@@ -622,32 +709,38 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         hp[6] = avg4<CONF>(L1, C1, L2, C2);  hp[7] = avg2x4(C1, C2);  hp[8] = avg4<CONF>(C1, R1, C2, R2);
         int v10[10] = {4096, 4096, 4096, 4096, 0, 4096, 4096, 4096, 4096, 4095};
         if (!(kDebug && (g.ablate & 2))) {
-            uint32_t s[10];
+            // "intra cost" accumulates the absolute deviation from the mean on top of the pixel sum, 16-bit wrap
+            // (RTL:1744, 1774-1777, 1791): the pixel sum S first, then the deviation rides along with the nine SADs
+            const uint32_t S = (uint32_t)wave_sum((int)__builtin_amdgcn_sad_u8(cur4, 0u, 0u));
+            const uint32_t m = (S >> 8) & 255u;
+            // ten sums as five packed pairs (each total <= 65280; v_sad_hi_u8 packs for free), four of them reduced
+            // together by wave_sum4
+            uint32_t pk[5];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) s[k] = __builtin_amdgcn_sad_u8(cur4, hp[k], 0u);
-            s[9] = __builtin_amdgcn_sad_u8(cur4, 0u, 0u);       // pixel sum
-            int tot[10];
-#pragma unroll
-            for (int k = 0; k < 10; k += 2) {                   // two 16-bit sums per reduction (each total <= 65280)
-                const int t = wave_sum((int)(s[k] | (s[k + 1] << 16)));
-                tot[k] = t & 0xFFFF;
-                tot[k + 1] = (int)((uint32_t)t >> 16);
-            }
+            for (int k = 0; k < 4; ++k)
+                pk[k] = __builtin_amdgcn_sad_hi_u8(cur4, hp[2 * k + 1], __builtin_amdgcn_sad_u8(cur4, hp[2 * k], 0u));
+            pk[4] = __builtin_amdgcn_sad_hi_u8(cur4, m * 0x01010101u, __builtin_amdgcn_sad_u8(cur4, hp[8], 0u));
+            const int q4 = wave_sum4((int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]);
+            const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane(q4, 15), t23 = (uint32_t)__builtin_amdgcn_readlane(q4, 47);
+            const uint32_t t45 = (uint32_t)__builtin_amdgcn_readlane(q4, 31), t67 = (uint32_t)__builtin_amdgcn_readlane(q4, 63);
+            const uint32_t t8d = (uint32_t)wave_sum((int)pk[4]);
+            const int tot[9] = {(int)(t01 & 0xFFFFu), (int)(t01 >> 16), (int)(t23 & 0xFFFFu), (int)(t23 >> 16), (int)(t45 & 0xFFFFu),
+                                (int)(t45 >> 16), (int)(t67 & 0xFFFFu), (int)(t67 >> 16), (int)(t8d & 0xFFFFu)};
+            // half-pel candidates that would reach outside the frame or beyond the search range are dead (RTL:1757-1760)
+            // as 0 / 1 integers by sign-bit arithmetic: fx + YR - 1 is negative exactly for fx = -YR, and so on
+            const int no_l = (in_l ^ 1) | (int)((uint32_t)(fx + YR - 1) >> 31), no_r = (in_r ^ 1) | (int)((uint32_t)(YR - 1 - fx) >> 31);
+            const int no_u = (in_u ^ 1) | (int)((uint32_t)(fy + YR - 1) >> 31), no_d = (in_d ^ 1) | (int)((uint32_t)(YR - 1 - fy) >> 31);
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const int khy = k / 3 - 1, khx = k % 3 - 1;
-                const bool masked = ((bx == 0 || fx == -YR) && khx < 0) || ((bx == g.mbw - 1 || fx == YR) && khx > 0) ||
-                                    ((by == 0 || fy == -YR) && khy < 0) || ((by == g.mbh - 1 || fy == YR) && khy > 0);   // RTL:1757-1760
-                v10[k] = (masked || tot[k] >= 4096) ? 4096 : tot[k];   // {over, diff}: only "over" matters (RTL:1784-1785)
+                const int dead = (khx < 0 ? no_l : 0) | (khx > 0 ? no_r : 0) | (khy < 0 ? no_u : 0) | (khy > 0 ? no_d : 0);
+                const int t = tot[k] | (dead << 12);                   // totals are < 2^16: a dead candidate reads >= 4096
+                v10[k] = t < 4096 ? t : 4096;                          // {over, diff}: only "over" matters (RTL:1784-1785)
             }
-            // "intra cost" accumulates on top of the pixel sum, 16-bit wrap (RTL:1744, 1774-1777, 1791)
-            const uint32_t S = (uint32_t)tot[9];
-            const uint32_t m = (S >> 8) & 255u;
-            const int dev = wave_sum((int)__builtin_amdgcn_sad_u8(cur4, m * 0x01010101u, 0u));
-            const uint32_t S2 = (S + (uint32_t)dev) & 0xFFFFu;
+            const uint32_t S2 = (S + (t8d >> 16)) & 0xFFFFu;
             v10[9] = (S2 >> 12) == 0 ? (int)S2 : 0xFFF;
         }
-        const int idx = find_min_in_10_values(v10);
+        const int idx = uniform(find_min_in_10_values(v10));
         inter = idx != 9;
         int hy = 0, hx = 0;
         if (inter) {
@@ -752,15 +845,15 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             q = q < -2047 ? -2047 : q > 2047 ? 2047 : q;
             s_zig[t][zz] = (int16_t)q;
             if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
-            cbp = (cbp << 1) | (__ballot(q != 0) != 0ull ? 1 : 0);
+            cbp = (cbp << 1) | (int)any_lane(q != 0);
             if (need_rec) {                             // RTL:2134-2137: (2q + sign(q)) << Q, clamped to +-2047
                 int x = (2 * q + (q != 0 ? (sg | 1) : 0)) << Q;
                 if constexpr (CONF) {
                     // ISO 7.4.2.3 gives the same product; saturation to [-2048, 2047] (7.4.3), mismatch control (7.4.4);
                     // a block without coefficients is not reconstructed at all
                     x = x < -2048 ? -2048 : x > 2047 ? 2047 : x;
-                    const bool coded = __ballot(q != 0) != 0ull;
-                    const bool even = (__popcll(__ballot(x & 1)) & 1) == 0;
+                    const bool coded = ballot(q != 0) != 0ull;
+                    const bool even = (__popcll(ballot(x & 1)) & 1) == 0;
                     if (coded && even && lane == 63) x ^= 1;
                 } else {
                     x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
@@ -795,7 +888,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     } else {
                         x = 2 * q;
                     }
-                    const bool even = (__popcll(__ballot(x & 1)) & 1) == 0;      // mismatch control (7.4.4)
+                    const bool even = (__popcll(ballot(x & 1)) & 1) == 0;      // mismatch control (7.4.4)
                     if (even && lane == 63) x ^= 1;
                 } else if (lane != 0) {
                     x = sext(__mul24(q, wq), 17);       // 17-bit temporary (RTL:2093, 2139)
@@ -819,53 +912,28 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // the rest forms three bit-contiguous segments: A = [cbp][all tiles] (inter) or
     // [AC of Y00][Y01][Y10][Y11] (intra), B = AC of U, C = AC of V.
     {
-        constexpr uint32_t SYM_RAW = 0x80000000u;          // raw: code[23:0], len[28:24]; else level[15:0], run[21:16]
         uint32_t nsym = 0, idxB = 0, idxC = 0;
-        int dcs[6];
-        if (inter) {
-            const uint32_t e = d_cbp_code[cbp];
-            if (lane == 0) s_sym[0] = SYM_RAW | ((e >> 8) << 24) | (e & 255u);
-            nsym = 1;
-        }
+        int dcs[6] = {0, 0, 0, 0, 0, 0};
         // positions of the non-zero levels of the tile in rank order: the previous non-zero position of the level with
         // rank k is s_pos[k - 1].  The region is the DCT scratch, free until the bit buffer is cleared below; one
         // wavefront, LDS operations in program order: the read below sees every lane's write.
-        uint32_t *const s_pos = (uint32_t *)(lds + kOffT) + 1;       // s_pos[-1] exists (read by rank 0, value unused)
+        uint32_t *const s_pos = (uint32_t *)(lds + kOffT) + 1;       // s_pos[-1]: "previous position" of the first level
+        if (!(kDebug && (g.ablate & 4))) {
+            if (inter) {
+                const uint32_t e = d_cbp_code[cbp];
+                if (lane == 0) { s_sym[0] = SYM_RAW | ((e >> 8) << 24) | (e & 255u); s_pos[-1] = 0xFFFFFFFFu; }
+                nsym = 1;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            const int v = s_zig[t][lane];
-            const int v0 = __builtin_amdgcn_readlane(v, 0);
-            dcs[t] = v0;
-            if (kDebug && (g.ablate & 4)) continue;
-            if (t == 4) idxB = nsym;
-            if (t == 5) idxC = nsym;
-            const bool coded = (cbp >> (5 - t)) & 1;
-            if (coded) {
-                uint32_t hasdc = 0;
-                if (!inter && t >= 1 && t <= 3) {           // DC of Y01/Y10/Y11 chains inside the macroblock (RTL:2784-2786)
-                    const BitCode c = dc_code(v0 - dcs[t - 1], 0);
-                    if (lane == 0) s_sym[nsym] = SYM_RAW | (c.len << 24) | c.code;
-                    hasdc = 1;
+                for (int t = 0; t < 6; ++t)
+                    if ((cbp >> (5 - t)) & 1) nsym = vlc_tile_symbols<true>(s_zig[t], s_sym, s_pos, lane, nsym, dcs[t], 0, false);
+            } else {
+                if (lane == 0) s_pos[-1] = 0u;                  // runs of an intra block count from the first AC position
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    if (t == 4) idxB = nsym;
+                    if (t == 5) idxC = nsym;
+                    nsym = vlc_tile_symbols<false>(s_zig[t], s_sym, s_pos, lane, nsym, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3);
                 }
-                const bool nz = v != 0 && (inter || lane > 0);
-                const unsigned long long mask = __ballot(nz);
-                const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
-                const uint32_t nnz = (uint32_t)__popcll(mask);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));   // non-zero levels in lower lanes
-                if (nz) s_pos[rank] = (uint32_t)lane;
-                if (nz) {
-                    // index of the previous non-zero level (or the position before the first AC slot)
-                    const int before = (int)s_pos[(int)rank - 1];
-                    const int prev = rank ? before : (inter ? -1 : 0);
-                    const int run = lane - prev - 1;
-                    uint32_t sym = ((uint32_t)run << 16) | ((uint32_t)v & 0xFFFFu);
-                    // first coefficient of a non-intra block with level +-1: '1s' (RTL:2798-2802); v0 is wave-uniform, so the
-                    // test is scalar and only lane 0 is touched
-                    if (inter && (v0 == 1 || v0 == -1) && lane == 0) sym = SYM_RAW | (2u << 24) | 2u | (v0 < 0 ? 1u : 0u);
-                    s_sym[nsym + hasdc + rank] = sym;
-                }
-                if (lane == 0) s_sym[nsym + hasdc + nnz] = SYM_RAW | (2u << 24) | 2u;      // end_of_block '10' (RTL:2835)
-                nsym += hasdc + nnz + 1u;
             }
         }
 #pragma unroll
@@ -887,6 +955,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     const int a = iabs(v);
                     uint32_t e = 0;
                     if (run < 32 && a <= 40) e = d_ac_code[run * 40 + a - 1];
+                    // first coefficient of a non-intra block with level +-1: '1s' instead of '11s' (RTL:2798-2802).  First
+                    // = the symbol before it in the list is a raw one (the pattern code or the previous block's end code)
+                    if (inter && run == 0 && a == 1 && (s_sym[(int)i - 1] & SYM_RAW)) e = (1u << 8) | 1u;
                     if (e) {                                 // run/level VLC + sign (RTL:2535-2540)
                         code = ((e & 255u) << 1) | (v < 0 ? 1u : 0u);
                         len = (e >> 8) + 1u;

@@ -6,11 +6,11 @@ export TMPDIR=/tmp
 TAG=${1:-prof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw_stats -o s -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw_stats -o s -- python3 bench.py --split 1 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
 grep -h '^{' $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
 python3 tools/summarize_rocprof.py $OUT/raw_stats/s_kernel_stats.csv $OUT/kernel_stats.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/raw_f -o f -- python3 bench.py --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/raw_w -o w -- python3 bench.py --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/raw_f -o f -- python3 bench.py --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/raw_w -o w -- python3 bench.py --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
 python3 tools/summarize_pmc2.py $OUT/raw_f $OUT/raw_w > $OUT/pmc_hbm.json
 sh tools/pmc_sq.sh $OUT/sq > /dev/null 2>&1
 cp $OUT/sq/summary.json $OUT/pmc_sq.json
