@@ -85,7 +85,7 @@ struct StreamCtl {          // device-resident stream bookkeeping, carried acros
 
 // device copies of the tables
 __constant__ int8_t   c_dct[64];
-__constant__ uint32_t c_dct_pk[32];       // c_dct rows as packed int16 pairs: [j][k] = basis[j][2k] | basis[j][2k+1] << 16
+__constant__ int8_t   c_dct_neg[64];      // -c_dct: the prediction's half of the residual dot product (k_mb, stage G)
 __constant__ int32_t  c_dct32[64];        // c_dct widened: a lane loads its basis row as two 16-byte reads, no unpacking
 __constant__ uint8_t  c_intra_w[64];
 __constant__ uint8_t  c_zigzag[64];
@@ -175,6 +175,21 @@ __device__ __forceinline__ int mad24(int a, int b, int c)
 {
     int d;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// the same with the addend in a scalar register (the chain's rounding constant: no v_mov to start an accumulator)
+__device__ __forceinline__ int mad24_s(int a, int b, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+// first link of a v_dot4 chain: the VOP3P form takes the inline constant 0 as accumulator (v_dot4c needs a zeroed register)
+__device__ __forceinline__ int dot4_first(uint32_t a, uint32_t b)
+{
+    int d;
+    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
 
@@ -534,7 +549,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     uint32_t *const s_winb = (uint32_t *)(lds + kOffWinB);                     // the same, one dword to the left
     uint32_t *const s_sym = (uint32_t *)(lds + 16);                            // VLC symbol list (<= 3 + 6 * 64 entries; [-1] is read), reuses R1
     uint8_t (*const s_pred)[64] = (uint8_t (*)[64])(lds + kOffPred);           // prediction, later reconstruction, tile layout
-    int16_t (*const s_x)[64] = (int16_t (*)[64])(lds + kOffX);                 // residual, later dequantised coefficients
+    int16_t (*const s_x)[64] = (int16_t (*)[64])(lds + kOffX);                 // dequantised coefficients (stage K onwards)
+    uint8_t (*const s_cp)[8][16] = (uint8_t (*)[8][16])(lds + kOffX);          // before that: signed current | prediction bytes per tile row
     int32_t (*const s_t)[64] = (int32_t (*)[64])(lds + kOffT);                 // DCT phase 1, later IDCT row pass
     uint32_t *const s_bits = (uint32_t *)(lds + kOffT);                        // VLC bit segments (<= 1216 bytes), reuses s_t
     int16_t (*const s_zig)[64] = (int16_t (*)[64])(lds + kOffZig);             // quantised levels in zig-zag order
@@ -602,15 +618,14 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         cur4 = 0u; u4 = 0x80808080u; v4 = 0x80808080u;                            // the first test is wave-uniform and almost always false
     }
     s_cur[lane] = cur4;
-    int cu0, cu1, cv0, cv1;                     // this lane's two 4:2:0 chroma samples (used by even rows)
+    uint32_t cuv;                               // this lane's two 4:2:0 samples of U (bytes 0, 1) and of V (bytes 2, 3); even rows only
     {
         const uint32_t hu = avg2x4(u4, u4 >> 8);          // bytes 0 and 2: horizontal means of the two pixel pairs
         const uint32_t hv = avg2x4(v4, v4 >> 8);
         const uint32_t hu_p = lane_xor4(hu);                            // the other row of the pair
         const uint32_t hv_p = lane_xor4(hv);
         const uint32_t cu = avg2x4(hu, hu_p), cv = avg2x4(hv, hv_p);
-        cu0 = cu & 255;  cu1 = (cu >> 16) & 255;
-        cv0 = cv & 255;  cv1 = (cv >> 16) & 255;
+        cuv = __builtin_amdgcn_perm(cv, cu, 0x06040200u);
     }
 
     int inter = 0, mvx = 0, mvy = 0;
@@ -753,13 +768,15 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         mvx = 2 * fx + hx;
     }
 
-    // ---- prediction + residual into tile layout (RTL:1891-1917, 1980-2014) -----------------------
+    // ---- prediction into tile layout; current and predicted samples as SIGNED bytes for the transform (RTL:1891-1917,
+    // 1980-2014).  The 9-bit residual c - p is never formed: stage G needs only sum_k M[j][k] (c_k - p_k), which is
+    // sum_k M[j][k] (c_k - 128) + sum_k (-M[j][k]) (p_k - 128), two v_dot4_i32_i8 chains on the bytes XOR 0x80.
+    // s_cp[tile][row] = 8 current bytes, then 8 prediction bytes: one 16-byte LDS read per tile row in stage G.
     {
         const int tile = ((r >> 3) << 1) | (c4 >> 1), ti = ((r & 7) << 3) | ((c4 & 1) << 2);
         *(uint32_t *)&s_pred[tile][ti] = pred4;
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            s_x[tile][ti + p] = (int16_t)((int)((cur4 >> (8 * p)) & 255u) - (int)((pred4 >> (8 * p)) & 255u));
+        *(uint32_t *)&s_cp[tile][r & 7][(c4 & 1) << 2] = cur4 ^ 0x80808080u;
+        *(uint32_t *)&s_cp[tile][r & 7][8 + ((c4 & 1) << 2)] = pred4 ^ 0x80808080u;
     }
     if (!(r & 1)) {
         // chroma: integer part mv>>2 (floor), half flag = bit 1 of mv (RTL:1854-1887, 1904-1916);
@@ -793,29 +810,26 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         const int ti = (yc << 3) | xc;
         *(uint16_t *)&s_pred[4][ti] = (uint16_t)pu;
         *(uint16_t *)&s_pred[5][ti] = (uint16_t)pv;
-        s_x[4][ti] = (int16_t)(cu0 - (int)(pu & 255u));  s_x[4][ti + 1] = (int16_t)(cu1 - (int)(pu >> 8));
-        s_x[5][ti] = (int16_t)(cv0 - (int)(pv & 255u));  s_x[5][ti + 1] = (int16_t)(cv1 - (int)(pv >> 8));
+        const uint32_t cs = cuv ^ 0x80808080u, ps = (pu | (pv << 16)) ^ 0x80808080u;
+        *(uint16_t *)&s_cp[4][yc][xc] = (uint16_t)cs;      *(uint16_t *)&s_cp[5][yc][xc] = (uint16_t)(cs >> 16);
+        *(uint16_t *)&s_cp[4][yc][8 + xc] = (uint16_t)ps;  *(uint16_t *)&s_cp[5][yc][8 + xc] = (uint16_t)(ps >> 16);
     }
     M2V_WAVE_SYNC();
 
     // ---- stage G: 2-D forward DCT (RTL:2029-2062); lane = (i = lane>>3, j = lane&7) ------------
     const int di = lane >> 3, dj = lane & 7;
     int bi[8];
-    typedef short short2_t __attribute__((ext_vector_type(2)));
-    short2_t bjp[4];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bi[k] = c_dct32[di * 8 + k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) bjp[k] = __builtin_bit_cast(short2_t, c_dct_pk[dj * 4 + k]);
+    const uint2 mj = *(const uint2 *)&c_dct[dj * 8], nj = *(const uint2 *)&c_dct_neg[dj * 8];   // basis row j and its negative, int8 x 8
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
-        // R1[r][j] = sum_k X[r][k] * DCTM[j][k]: 8 int16 residuals = one 16-byte LDS read, 4 v_dot2
-        const uint4 xr = *(const uint4 *)&s_x[t][di * 8];
-        int acc = 0;
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, xr.x), bjp[0], acc, false);
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, xr.y), bjp[1], acc, false);
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, xr.z), bjp[2], acc, false);
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, xr.w), bjp[3], acc, false);
+        // R1[r][j] = sum_k (c[r][k] - p[r][k]) * DCTM[j][k]: 16 bytes of LDS, 4 v_dot4
+        const uint4 xr = *(const uint4 *)&s_cp[t][di][0];
+        int acc = dot4_first(xr.x, mj.x);
+        acc = __builtin_amdgcn_sdot4((int)xr.y, (int)mj.y, acc, false);
+        acc = __builtin_amdgcn_sdot4((int)xr.z, (int)nj.x, acc, false);
+        acc = __builtin_amdgcn_sdot4((int)xr.w, (int)nj.y, acc, false);
         s_t[t][lane] = acc;
     }
     M2V_WAVE_SYNC();
@@ -832,22 +846,26 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         for (int t = 0; t < 6; ++t) s_zig[t][lane] = 0;
         cbp = inter ? 0 : 63;
     } else if (inter) {
+        const int qneg = sgpr(((1 << (4 + Q)) - 5) << 12);
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            int acc = 2048;                             // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12
+            int acc = mad24_s(bi[0], s_t[t][dj], 2048);   // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc = mad24(bi[k], s_t[t][k * 8 + dj], acc);   // |R1| < 2^18
-            const int C = acc >> 12;
-            // RTL:2070: sign(C) * min((|C| + 2) >> s, 2047), s = 4 + Q, computed on the signed value: for C < 0 it is
-            // ceil((C - 2) / 2^s) = (C + 2^s - 3) >> s (identity checked over the 17-bit range in tests/test_host_logic.py)
-            const int sg = C >> 31;                     // 0 / -1
-            int q = (C + 2 + (sg & ((1 << (4 + Q)) - 5))) >> (4 + Q);
-            q = q < -2047 ? -2047 : q > 2047 ? 2047 : q;
+            for (int k = 1; k < 8; ++k) acc = mad24(bi[k], s_t[t][k * 8 + dj], acc);   // |R1| < 2^18
+            // RTL:2070: sign(C) * min((|C| + 2) >> s, 2047) with C = acc >> 12 and s = 4 + Q, computed on the signed value:
+            // for C < 0 it is ceil((C - 2) / 2^s) = (C + 2^s - 3) >> s (identity checked over the 17-bit range in
+            // tests/test_host_logic.py).  Two floor shifts with an integer added in between are one:
+            // ((acc >> 12) + k) >> s = (acc + (k << 12)) >> (12 + s).  The clamp cannot bind on this path: the basis rows
+            // sum to at most 512 in magnitude, so |C| <= (255 * 512 * 512 + 2048) >> 12 = 16320 and |q| <= 16322 >> 5 = 510
+            // (tests/test_host_logic.py::test_inter_quantiser_never_reaches_its_clamp).
+            const int sg = acc >> 31;                   // 0 / -1: C has the sign of acc
+            const int q = (acc + (2 << 12) + (sg & qneg)) >> (16 + Q);
             s_zig[t][zz] = (int16_t)q;
             if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
             cbp = (cbp << 1) | (int)any_lane(q != 0);
             if (need_rec) {                             // RTL:2134-2137: (2q + sign(q)) << Q, clamped to +-2047
-                int x = (2 * q + (q != 0 ? (sg | 1) : 0)) << Q;
+                const int sgn = q < -1 ? -1 : q > 1 ? 1 : q;          // v_med3_i32
+                int x = (2 * q + sgn) << Q;
                 if constexpr (CONF) {
                     // ISO 7.4.2.3 gives the same product; saturation to [-2048, 2047] (7.4.3), mismatch control (7.4.4);
                     // a block without coefficients is not reconstructed at all
@@ -865,9 +883,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         const uint32_t qoff = __umul24((uint32_t)wq, (3u << Q) + 2u) >> 3;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            int acc = 2048;
+            int acc = mad24_s(bi[0], s_t[t][dj], 2048);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc = mad24(bi[k], s_t[t][k * 8 + dj], acc);
+            for (int k = 1; k < 8; ++k) acc = mad24(bi[k], s_t[t][k * 8 + dj], acc);
             const int C = acc >> 12;
             const int sg = C >> 31;
             uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;

@@ -216,11 +216,9 @@ std::once_flag g_tables_once[kMaxDevices];
 void upload_tables_now()
 {
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dct), kDctBasis, sizeof kDctBasis));
-    uint32_t dct_pk[32];
-    for (int j = 0; j < 8; ++j)
-        for (int k = 0; k < 4; ++k)
-            dct_pk[j * 4 + k] = (uint32_t)(uint16_t)(int16_t)kDctBasis[j * 8 + 2 * k] | ((uint32_t)(uint16_t)(int16_t)kDctBasis[j * 8 + 2 * k + 1] << 16);
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dct_pk), dct_pk, sizeof dct_pk));
+    int8_t dct_neg[64];
+    for (int i = 0; i < 64; ++i) dct_neg[i] = (int8_t)-kDctBasis[i];       // |basis| <= 89: the negative fits
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dct_neg), dct_neg, sizeof dct_neg));
     int32_t dct32[64];
     for (int i = 0; i < 64; ++i) dct32[i] = kDctBasis[i];
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dct32), dct32, sizeof dct32));
