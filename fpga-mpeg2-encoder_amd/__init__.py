@@ -110,6 +110,8 @@ class Mpeg2Encoder:
         if not self._h:
             raise M2VError("m2v_create failed with code %d (parameters %r, device %d): %s"
                            % (err.value, self.params, device, self._L.m2v_last_error(None).decode()))
+        if os.environ.get("M2V_DCT_MFMA") in ("0", "1"):      # development hook: A/B runs of the DCT-as-GEMM variant of the kernel
+            self.set_option("dct_mfma", int(os.environ["M2V_DCT_MFMA"]))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -95,6 +95,16 @@ __device__ uint16_t   d_dc_code[2][12];
 __device__ uint8_t    d_dc_len[2][12];
 __device__ uint16_t   d_ac_code[32 * 40];
 __constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for n < 25575 (tests/test_host_logic.py)
+// DCT-as-GEMM variant of stage G (k_mb<.., MFMA = true>): per-lane operands of the matrix-core formulation, lane = (g = lane >> 4,
+// c = lane & 15); register v of a 16x16 accumulator holds block row 4g + v, column c.  Filled by fill_mfma_tables().
+struct MfmaLane {
+    uint32_t b1[2];      // pass 1 B operand: +-basis row (c & 7) for the k group that matches c's tile column, else 0
+    uint32_t a2;         // pass 2 A operand: basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1, else 0
+    uint32_t wq;         // intra quantiser weights of this lane's four coefficients (bytes)
+    uint32_t zoff[4];    // byte offset of coefficient v inside s_zig: tile * 128 + zigzag position * 2
+    uint32_t recip[4];   // ceil(2^21 / W) of the four coefficients
+};
+__constant__ MfmaLane c_mfma[64];
 
 
 // ----------------------------------------------------------------------------------------------
@@ -103,12 +113,10 @@ __constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for
 // ----------------------------------------------------------------------------------------------
 #define M2V_DPP(old, src, ctrl, rmask, bound) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xF, (bound))
 
-// value of lane ^ 4: two DPP moves (row_shl:4 into banks 0 and 2, row_shr:4 into banks 1 and 3), no LDS crossbar
-__device__ __forceinline__ uint32_t lane_xor4(uint32_t v)
+// value of lane + 4 for the lanes of banks 0 and 2 (lanes 0-3, 8-11 of every row of 16; the others get 0): one DPP move
+__device__ __forceinline__ uint32_t lane_plus4(uint32_t v)
 {
-    int r = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);
-    r = __builtin_amdgcn_update_dpp(r, (int)v, 0x114, 0xF, 0xA, false);
-    return (uint32_t)r;
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, true);    // row_shl:4
 }
 
 __device__ __forceinline__ int wave_scan_incl(int v)
@@ -512,7 +520,7 @@ __device__ __forceinline__ void search_rows(const uint32_t *s_cur, uint32_t ae, 
 // quantiser truncating toward zero with [-2048, 2047] saturation and mismatch control, blocks that are not coded are
 // not reconstructed.  The IDCT needs no change: for in-range coefficients its 18-bit row store never wraps and the
 // +-255 clip gives the same pixel after the final clip to 0..255.  Checked against the oracle's conformant mode.
-template <int VL, bool P, bool CONF = false>
+template <int VL, bool P, bool CONF = false, bool MFMA = false>
 __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
                                            Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
                                            uint32_t *__restrict__ slots_small, uint32_t *__restrict__ slots,
@@ -614,16 +622,18 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             wcv = *(gld32)(refV + coff);
         }
     }
-    if (job.valid_beats < (g.ysz >> 2) && (pix_off >> 2) >= job.valid_beats) {    // beats after i_sequence_stop are black (RTL:1036-1056);
-        cur4 = 0u; u4 = 0x80808080u; v4 = 0x80808080u;                            // the first test is wave-uniform and almost always false
+    if (sgpr((int)((job.valid_beats - (g.ysz >> 2)) >> 31))) {    // a frame cut short by i_sequence_stop: wave-uniform, almost never
+        if ((pix_off >> 2) >= job.valid_beats) {                 // beats after the stop are black (RTL:1036-1056)
+            cur4 = 0u; u4 = 0x80808080u; v4 = 0x80808080u;
+        }
     }
     s_cur[lane] = cur4;
     uint32_t cuv;                               // this lane's two 4:2:0 samples of U (bytes 0, 1) and of V (bytes 2, 3); even rows only
     {
         const uint32_t hu = avg2x4(u4, u4 >> 8);          // bytes 0 and 2: horizontal means of the two pixel pairs
         const uint32_t hv = avg2x4(v4, v4 >> 8);
-        const uint32_t hu_p = lane_xor4(hu);                            // the other row of the pair
-        const uint32_t hv_p = lane_xor4(hv);
+        const uint32_t hu_p = lane_plus4(hu);                           // the odd row below (only even rows use the result)
+        const uint32_t hv_p = lane_plus4(hv);
         const uint32_t cu = avg2x4(hu, hu_p), cv = avg2x4(hv, hv_p);
         cuv = __builtin_amdgcn_perm(cv, cu, 0x06040200u);
     }
@@ -698,24 +708,26 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         // T[y][x] = window[y+fy+YR][x+fx+8]; L/C/R = T[.][x-1 .. x+2], T[.][x .. x+3], T[.][x+1 .. x+4]
         uint32_t L0, C0, R0, L1, C1, R1, L2, C2, R2;
         {
-            int r0 = r - 1 + fy + YR, r1 = r + fy + YR, r2 = r + 1 + fy + YR;
-            r0 = r0 < 0 ? 0 : r0;                              // rows beyond the window belong to masked candidates
-            r2 = r2 > WROWS - 1 ? WROWS - 1 : r2;
-            const int cb = 4 * c4 - 1 + fx + 8;                // 1 .. 25
-            const int wi = cb >> 2, wi2 = wi + 2 > 7 ? 7 : wi + 2;
-            const uint32_t sft = (uint32_t)cb & 3u;
-#define M2V_ROW3(ROW, L, C, R)                                                                  \
+            // window row r + fy + YR, first byte 4 c4 + 7 + fx: the dword index splits into a lane part (r, c4) and a
+            // wave-uniform part (fy, fx), and the byte shift (7 + fx) & 3 is wave-uniform: one address add per lane, every
+            // other offset is an immediate.  Row -1 (r = 0, fy = -YR) and row WROWS (r = 15, fy = YR) lie outside the window
+            // but inside this kernel's LDS; they only feed half-pel candidates that are dead in exactly those cases
+            // (RTL:1757-1760), and so does the third dword of a row when it is the padding dword 8.
+            const int kx = 7 + fx;                             // 1 .. 13
+            const uint32_t sft = (uint32_t)kx & 3u;
+            const uint32_t *const pw = s_win + (r * kWS + c4) + sgpr((fy + YR) * kWS + (kx >> 2));
+#define M2V_ROW3(OFF, L, C, R)                                                                  \
             {                                                                                   \
-                const uint32_t a0 = s_win[__mul24((ROW), kWS) + wi], a1 = s_win[__mul24((ROW), kWS) + wi + 1], a2 = s_win[__mul24((ROW), kWS) + wi2]; \
+                const uint32_t a0 = pw[(OFF)], a1 = pw[(OFF) + 1], a2 = pw[(OFF) + 2];          \
                 const uint32_t lo = __builtin_amdgcn_alignbyte(a1, a0, sft);                    \
                 const uint32_t hi = __builtin_amdgcn_alignbyte(a2, a1, sft);                    \
                 L = lo;                                                                         \
                 C = __builtin_amdgcn_alignbyte(hi, lo, 1u);                                     \
                 R = __builtin_amdgcn_alignbyte(hi, lo, 2u);                                     \
             }
-            M2V_ROW3(r0, L0, C0, R0)
-            M2V_ROW3(r1, L1, C1, R1)
-            M2V_ROW3(r2, L2, C2, R2)
+            M2V_ROW3(-kWS, L0, C0, R0)
+            M2V_ROW3(0, L1, C1, R1)
+            M2V_ROW3(kWS, L2, C2, R2)
 #undef M2V_ROW3
         }
         uint32_t hp[9];                                         // the nine half-pel predictions (RTL:1746-1752)
@@ -779,40 +791,40 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         *(uint32_t *)&s_cp[tile][r & 7][8 + ((c4 & 1) << 2)] = pred4 ^ 0x80808080u;
     }
     if (!(r & 1)) {
-        // chroma: integer part mv>>2 (floor), half flag = bit 1 of mv (RTL:1854-1887, 1904-1916);
-        // this lane owns chroma pixels (yc, 2*c4) and (yc, 2*c4+1) of U and of V
-        const int yc = r >> 1, xc = 2 * c4;
-        uint32_t pu = 0x8080u, pv = 0x8080u;            // two packed prediction bytes per plane
+        // the 4:2:0 samples of the current macroblock: even-row lanes own (r >> 1, 2 c4 .. 2 c4 + 1) of U and of V
+        const uint32_t cs = cuv ^ 0x80808080u;
+        *(uint16_t *)&s_cp[4][r >> 1][2 * c4] = (uint16_t)cs;
+        *(uint16_t *)&s_cp[5][r >> 1][2 * c4] = (uint16_t)(cs >> 16);
+    }
+    {
+        // chroma prediction: integer part mv>>2 (floor), half flag = bit 1 of mv (RTL:1854-1887, 1904-1916).  Every lane owns
+        // two samples (yc, xc .. xc + 1) of ONE plane - lanes 0-31 U, lanes 32-63 V - so both planes are predicted at once.
+        const int pl = lane >> 5, yc = (lane >> 2) & 7, xc = 2 * c4;
+        uint32_t pr = 0x8080u;                          // two packed prediction bytes
         if constexpr (P) {
             if (inter) {
                 // chroma vector in chroma half samples: RTL floor; ISO 7.6.3.7 divides with truncation toward zero
                 const int cmy = CONF ? (mvy - (mvy >> 31)) >> 1 : mvy >> 1, cmx = CONF ? (mvx - (mvx >> 31)) >> 1 : mvx >> 1;
                 const int cyi = cmy >> 1, cxi = cmx >> 1, fyh = cmy & 1, fxh = cmx & 1;
-                const int row = yc + cyi + UR, col = xc + cxi + 4;         // col .. col+2 are needed, col <= 13
-                const int row1 = row + 1 > CROWS - 1 ? CROWS - 1 : row + 1;
-                const int wi = col >> 2, wi1 = wi + 1 > 3 ? 3 : wi + 1;
+                // col .. col+2 are needed, col <= 13: the fourth byte fetched may belong to the next row, it is never used.
+                // Row row + 1 is only used with a vertical half sample, and then cyi <= UR - 1: it stays inside the window
+                // (without one the fetch below may reach one row past it - inside this kernel's LDS, value unused).
+                const int row = yc + cyi + UR, col = xc + cxi + 4;
+                const int wi = col >> 2;
                 const uint32_t sft = (uint32_t)col & 3u;
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    const uint32_t *cw = s_cwin[pl];
-                    const uint32_t a = __builtin_amdgcn_alignbyte(cw[row * 4 + wi1], cw[row * 4 + wi], sft);      // T[row][col..col+3]
-                    const uint32_t c = __builtin_amdgcn_alignbyte(cw[row1 * 4 + wi1], cw[row1 * 4 + wi], sft);    // T[row+1][col..]
-                    const uint32_t b = a >> 8, d = c >> 8;
-                    uint32_t pr;
-                    if (fyh && fxh) pr = avg4<CONF>(a, b, c, d);
-                    else if (fxh)   pr = avg2x4(a, b);
-                    else if (fyh)   pr = avg2x4(a, c);
-                    else            pr = a;
-                    if (pl == 0) pu = pr & 0xFFFFu; else pv = pr & 0xFFFFu;
-                }
+                const uint32_t *const cw = &s_cwin[0][0] + pl * (CROWS * 4) + row * 4 + wi;
+                const uint32_t a = __builtin_amdgcn_alignbyte(cw[1], cw[0], sft);      // T[row][col..col+3]
+                const uint32_t c = __builtin_amdgcn_alignbyte(cw[5], cw[4], sft);      // T[row+1][col..]
+                const uint32_t b = a >> 8, d = c >> 8;
+                if (fyh && fxh) pr = avg4<CONF>(a, b, c, d);
+                else if (fxh)   pr = avg2x4(a, b);
+                else if (fyh)   pr = avg2x4(a, c);
+                else            pr = a;
+                pr &= 0xFFFFu;
             }
         }
-        const int ti = (yc << 3) | xc;
-        *(uint16_t *)&s_pred[4][ti] = (uint16_t)pu;
-        *(uint16_t *)&s_pred[5][ti] = (uint16_t)pv;
-        const uint32_t cs = cuv ^ 0x80808080u, ps = (pu | (pv << 16)) ^ 0x80808080u;
-        *(uint16_t *)&s_cp[4][yc][xc] = (uint16_t)cs;      *(uint16_t *)&s_cp[5][yc][xc] = (uint16_t)(cs >> 16);
-        *(uint16_t *)&s_cp[4][yc][8 + xc] = (uint16_t)ps;  *(uint16_t *)&s_cp[5][yc][8 + xc] = (uint16_t)(ps >> 16);
+        *(uint16_t *)&s_pred[4 + pl][(yc << 3) | xc] = (uint16_t)pr;
+        *(uint16_t *)&s_cp[4 + pl][yc][8 + xc] = (uint16_t)(pr ^ 0x8080u);
     }
     M2V_WAVE_SYNC();
 
@@ -822,8 +834,11 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 #pragma unroll
     for (int k = 0; k < 8; ++k) bi[k] = c_dct32[di * 8 + k];
     const uint2 mj = *(const uint2 *)&c_dct[dj * 8], nj = *(const uint2 *)&c_dct_neg[dj * 8];   // basis row j and its negative, int8 x 8
+    // DCT-as-GEMM trial (north star): the four luma tiles through the matrix cores, the two chroma tiles as before
+    constexpr bool kMfmaLuma = MFMA && !CONF;
+    constexpr int kT0 = kMfmaLuma ? 4 : 0;             // first tile on the VALU path
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
+    for (int t = kT0; t < 6; ++t) {
         // R1[r][j] = sum_k (c[r][k] - p[r][k]) * DCTM[j][k]: 16 bytes of LDS, 4 v_dot4
         const uint4 xr = *(const uint4 *)&s_cp[t][di][0];
         int acc = dot4_first(xr.x, mj.x);
@@ -831,6 +846,35 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         acc = __builtin_amdgcn_sdot4((int)xr.z, (int)nj.x, acc, false);
         acc = __builtin_amdgcn_sdot4((int)xr.w, (int)nj.y, acc, false);
         s_t[t][lane] = acc;
+    }
+    // The 16x16 luma block Z = current - prediction holds the 2x2 tiles; with B16 = blockdiag(DCTM, DCTM) the four 8x8
+    // transforms are B16 . Z . B16^T in place (tools/ubench/mfma_dct_check.hip checks this formulation on its own).
+    //   pass 1  T = Z . B16^T: ONE v_mfma_i32_16x16x32_i8, K = 16 current columns (+B16) and 16 prediction columns (-B16);
+    //           A = a row of signed bytes straight from s_cp, B = per-lane constant
+    //   pass 2  Y = B16 . T: T is 19 bit, i8 operands: three signed byte limbs (T + 0x808080) ^ 0x808080, the accumulator
+    //           layout of pass 1 (rows 4g .. 4g+3 of column c) IS the B layout of a K = 4g .. 4g+3 slice, a 4x4 byte transpose
+    //           (7 v_perm) sorts the limbs, one MFMA per limb, recombined by two shift-adds per coefficient.
+    int yacc[4] = {0, 0, 0, 0};                        // sum + 2048 of block row 4g + v, column c
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const int mg = lane >> 4, mc = lane & 15;
+    if constexpr (kMfmaLuma) {
+        const MfmaLane ml = c_mfma[lane];
+        const long a1 = *(const long *)&s_cp[((mc >> 3) << 1) | (mg & 1)][mc & 7][8 * (mg >> 1)];
+        const long b1 = (long)(((unsigned long long)ml.b1[1] << 32) | ml.b1[0]);
+        const v4i_t zero4 = {0, 0, 0, 0};
+        const v4i_t tt = __builtin_amdgcn_mfma_i32_16x16x32_i8(a1, b1, zero4, 0, 0, 0);
+        uint32_t e[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) e[v] = ((uint32_t)tt[v] + 0x808080u) ^ 0x808080u;
+        const uint32_t p01 = __builtin_amdgcn_perm(e[1], e[0], 0x05010400u), p23 = __builtin_amdgcn_perm(e[3], e[2], 0x05010400u);
+        const uint32_t w0 = __builtin_amdgcn_perm(p23, p01, 0x05040100u), w1 = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+        const uint32_t q01 = __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), q23 = __builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u);
+        const uint32_t w2 = __builtin_amdgcn_perm(q23, q01, 0x05040100u);
+        const v4i_t y0 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)ml.a2, (long)w0, zero4, 0, 0, 0);
+        const v4i_t y1 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)ml.a2, (long)w1, zero4, 0, 0, 0);
+        const v4i_t y2 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)ml.a2, (long)w2, zero4, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) yacc[v] = (y0[v] + 2048) + (y1[v] << 8) + (y2[v] << 16);
     }
     M2V_WAVE_SYNC();
 
@@ -847,8 +891,35 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         cbp = inter ? 0 : 63;
     } else if (inter) {
         const int qneg = sgpr(((1 << (4 + Q)) - 5) << 12);
+        if constexpr (kMfmaLuma) {
+            // the four luma tiles in accumulator layout: lane (g, c) owns rows 4g .. 4g+3 of column c of the 16x16 block,
+            // i.e. four coefficients of tile 2 (g >> 1) + (c >> 3); their s_zig slots come from the lane table, their
+            // raster slots in s_x are 16 bytes apart
+            const MfmaLane ml = c_mfma[lane];
+            int16_t *const xrow = &s_x[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)];
+            int nzor = 0;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
+            for (int v = 0; v < 4; ++v) {
+                const int acc = yacc[v];
+                const int sg = acc >> 31;
+                const int q = (acc + (2 << 12) + (sg & qneg)) >> (16 + Q);
+                *(int16_t *)((uint8_t *)&s_zig[0][0] + ml.zoff[v]) = (int16_t)q;
+                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + (ml.zoff[v] >> 1)] = (int16_t)q;
+                nzor |= q;
+                if (need_rec) {
+                    const int sgn = q < -1 ? -1 : q > 1 ? 1 : q;
+                    int x = (2 * q + sgn) << Q;
+                    x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
+                    xrow[v * 8] = (int16_t)x;
+                }
+            }
+            // coded flags of the four tiles: tile 2 ty + tx lives in lanes 32 ty + 16 h + 8 tx + (0 .. 7), h = 0, 1
+            const unsigned long long nzm = ballot(nzor != 0);
+            const uint32_t lo = (uint32_t)nzm, hi = (uint32_t)(nzm >> 32);
+            cbp = ((lo & 0x00FF00FFu) ? 8 : 0) | ((lo & 0xFF00FF00u) ? 4 : 0) | ((hi & 0x00FF00FFu) ? 2 : 0) | ((hi & 0xFF00FF00u) ? 1 : 0);
+        }
+#pragma unroll
+        for (int t = kT0; t < 6; ++t) {
             int acc = mad24_s(bi[0], s_t[t][dj], 2048);   // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12
 #pragma unroll
             for (int k = 1; k < 8; ++k) acc = mad24(bi[k], s_t[t][k * 8 + dj], acc);   // |R1| < 2^18
@@ -881,8 +952,38 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         }
     } else {
         const uint32_t qoff = __umul24((uint32_t)wq, (3u << Q) + 2u) >> 3;
+        if constexpr (kMfmaLuma) {
+            const MfmaLane ml = c_mfma[lane];
+            int16_t *const xrow = &s_x[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)];
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
+            for (int v = 0; v < 4; ++v) {
+                const int wv = (int)((ml.wq >> (8 * v)) & 255u);
+                const uint32_t qo = __umul24((uint32_t)wv, (3u << Q) + 2u) >> 3;
+                const bool is_dc = v == 0 && (lane & 0x17) == 0;           // row 0 of a tile (g even, v = 0), column 0 of a tile
+                const int C = yacc[v] >> 12;
+                const int sg = C >> 31;
+                uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
+                if (!is_dc) a = __umul24((a + qo) >> Q, ml.recip[v]) >> 21;
+                else        a = (a + 8u) >> 4;
+                if (a > 2047u) a = 2047u;
+                const int q = (int)(a ^ (uint32_t)sg) - sg;
+                *(int16_t *)((uint8_t *)&s_zig[0][0] + ml.zoff[v]) = (int16_t)q;
+                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + (ml.zoff[v] >> 1)] = (int16_t)q;
+                if (need_rec) {
+                    int x;
+                    if (!is_dc) {
+                        x = sext(__mul24(q, wv), 17);
+                        x = Q >= 3 ? sext((int)((uint32_t)x << (Q - 3)), 17) : (x >> (3 - Q));
+                        x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
+                    } else {
+                        x = 2 * q;
+                    }
+                    xrow[v * 8] = (int16_t)x;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = kT0; t < 6; ++t) {
             int acc = mad24_s(bi[0], s_t[t][dj], 2048);
 #pragma unroll
             for (int k = 1; k < 8; ++k) acc = mad24(bi[k], s_t[t][k * 8 + dj], acc);

@@ -104,6 +104,8 @@ struct m2v_enc {
     int cur = 0;                  // stage being filled by m2v_push_*
     HostStage &st() { return hs[cur]; }
     std::deque<int> pending;      // submitted stages, oldest first
+    bool dct_mfma = true;         // option "dct_mfma": luma DCT through the matrix cores (k_mb<.., MFMA = true>); 0 = integer VALU / LDS
+                                  // path.  Same results; kept by the rocprofv3 number (profiles/r02_mfma_*: 138.3 vs 140.3 us per launch)
     bool conformant = false;      // option "conformant": ISO reconstruction loop instead of the RTL's (NOT byte-identical to the reference)
     int copy_threads = 4;         // option "copy_threads": threads that copy m2v_push_frames input into pinned memory
     int split_streams = 2;        // GOP segments of a chunk run as this many independent groups on as many streams (encode_chunk)
@@ -232,6 +234,28 @@ void upload_tables_now()
     uint32_t recip[64];
     for (int i = 0; i < 64; ++i) recip[i] = ((1u << 21) + kIntraW[i] - 1u) / kIntraW[i];      // ceil(2^21 / W)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_intra_recip), recip, sizeof recip));
+    // per-lane operands of the DCT-as-GEMM variant (k_mb<.., MFMA = true>, see MfmaLane)
+    MfmaLane ml[64];
+    for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, c = lane & 15;
+        MfmaLane &m = ml[lane];
+        memset(&m, 0, sizeof m);
+        if ((c >> 3) == (g & 1))
+            for (int b = 0; b < 8; ++b) {
+                const int8_t w = (int8_t)(g < 2 ? kDctBasis[(c & 7) * 8 + b] : -kDctBasis[(c & 7) * 8 + b]);
+                m.b1[b >> 2] |= (uint32_t)(uint8_t)w << (8 * (b & 3));
+            }
+        if ((c >> 3) == (g >> 1))
+            for (int b = 0; b < 4; ++b) m.a2 |= (uint32_t)(uint8_t)kDctBasis[(c & 7) * 8 + 4 * (g & 1) + b] << (8 * b);
+        const int tile = ((g >> 1) << 1) | (c >> 3);
+        for (int v = 0; v < 4; ++v) {
+            const int raster = (4 * (g & 1) + v) * 8 + (c & 7);
+            m.zoff[v] = (uint32_t)(tile * 128 + kZigzagPos[raster] * 2);
+            m.wq |= (uint32_t)kIntraW[raster] << (8 * v);
+            m.recip[v] = recip[raster];
+        }
+    }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma), ml, sizeof ml));
     HIPCHK(hipDeviceSynchronize());         // the copies read stack arrays: complete before they go out of scope
 }
 
@@ -302,8 +326,14 @@ void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Ge
     Timer t(e, s, P ? 0 : 1, (double)count * g.ysz);
     int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
 #define M2V_LAUNCH_MB(VLV, PV, CV) \
-    hipLaunchKernelGGL((k_mb<VLV, PV, CV>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
-                       e->d_slots_small.p, e->d_slots.p, dbg)
+    do { \
+        if (e->dct_mfma && !(CV)) \
+            hipLaunchKernelGGL((k_mb<VLV, PV, false, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
+                               e->d_slots_small.p, e->d_slots.p, dbg); \
+        else \
+            hipLaunchKernelGGL((k_mb<VLV, PV, CV, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
+                               e->d_slots_small.p, e->d_slots.p, dbg); \
+    } while (0)
     if (P) {
         if (e->conformant) {
             switch (e->VL) {
@@ -1321,6 +1351,7 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
         e->conformant = value != 0;
         return M2V_OK;
     }
+    if (!strcmp(name, "dct_mfma")) { e->dct_mfma = value != 0; return M2V_OK; }
     if (!strcmp(name, "copy_threads")) { if (value < 1 || value > 64) return M2V_E_PARAM; e->copy_threads = (int)value; return M2V_OK; }
     if (kDebug) {       // libm2v_mi355x_dbg.so only (-DM2V_DEBUG): the shipped library does not know these names
         if (!strcmp(name, "keep_recon")) { e->keep_recon = value != 0; return M2V_OK; }

@@ -163,6 +163,9 @@ int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t 
  * "split_streams" (default 2; 1..8 = the closed GOPs of a chunk are encoded as this many independent groups on as many
  * HIP streams, so that the partially filled tail of one group's launch overlaps with another group's next launch;
  * 1 = a single stream; ignored while "profile" is on, which times every launch with in-band events on one stream),
+ * "dct_mfma" (default 1: the four luma tiles' 2-D DCT runs on the matrix cores as two chained i8 GEMMs,
+ * B16 . Z . B16^T with the 19-bit intermediate in three byte limbs; 0 = every tile on the integer v_dot4 / v_mad_i32_i24
+ * path through LDS.  Bit-identical results either way; the default is the faster one under rocprofv3),
  * "conformant" (default 0 = the reference's arithmetic, byte-identical to the RTL.  1 = NOT the reference's
  * behaviour: the reconstruction loop follows ISO/IEC 13818-2 where the RTL deviates from it - four-sample average
  * rounded with +2, 4:2:0 chroma vector = mv / 2 toward zero, inverse quantiser truncating toward zero with

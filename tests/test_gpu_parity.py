@@ -58,21 +58,51 @@ def test_multi_gop_and_chunking(G):
         assert got == want, "batch_frames=%d" % bf
 
 
-def test_split_streams_option(G):
-    """Option "split_streams": the GOP segments of a chunk run as two independent halves on two HIP streams (fills the
-    tail of every launch).  Same bytes, resident and port path, odd and even GOP counts."""
+@pytest.mark.parametrize("streams", [1, 2, 3, 5, 8])
+def test_split_streams_option(G, streams):
+    """Option "split_streams": the closed GOPs of a chunk run as N independent groups on N HIP streams (fills the tail of
+    every launch; default 2).  Same bytes, resident and port path, more / fewer GOPs than streams, odd and even counts."""
     from oracle import m2v_oracle_ctypes as orc
-    for n, pf in ((15, 2), (12, 3), (3, 4)):
+    for n, pf in ((15, 2), (12, 3), (3, 4), (21, 1)):
         f = G.M.synth.clip(112, 80, n, clip_index=11)
         want = orc.encode(f, 7, 5, pf, XL=6, YL=6)
         enc = G.M.Mpeg2Encoder(6, 6, 3, 2, device=0)
         try:
-            enc.set_option("split_streams", 1)
+            enc.set_option("split_streams", streams)
             assert G.resident_encode(f, 7, 5, pf, XL=6, YL=6, enc=enc) == want
             enc.set_option("batch_frames", 7)
             assert enc.encode(f, 7, 5, pf) == want
         finally:
             enc.close()
+
+
+@pytest.mark.parametrize("mfma", [0, 1])
+@pytest.mark.parametrize("kind", ["synth", "noise", "checker", "flat255vs0"])
+def test_dct_variants_are_bit_identical(G, mfma, kind):
+    """Option "dct_mfma": the luma 2-D DCT on the matrix cores (two chained i8 GEMMs, 19-bit intermediate as three byte
+    limbs; default) or on the integer v_dot4 / v_mad_i32_i24 path - both must give the oracle's bytes, on ordinary content
+    and on content that drives the intermediate to its extremes (white noise, full-swing checkerboards, 255 against 0),
+    for intra and inter macroblocks and every Q_LEVEL."""
+    from oracle import m2v_oracle_ctypes as orc
+    W, H, n = 96, 80, 4
+    if kind == "synth":
+        f = G.M.synth.clip(W, H, n, clip_index=12, scene_len=2)
+    elif kind == "noise":
+        f = np.random.default_rng(7).integers(0, 256, (n, 3, H, W), dtype=np.uint8)
+    elif kind == "checker":
+        f = G.M.synth.degenerate("checker", W, H, n)
+    else:
+        f = np.zeros((n, 3, H, W), np.uint8)
+        f[0::2] = 255                                   # 255 against a reconstruction of 0 and back: the largest residuals
+    for Q in (1, 2, 3, 4):
+        for pf in (0, 3):
+            want = orc.encode(f, W // 16, H // 16, pf, XL=6, YL=6, VL=2, Q=Q)
+            enc = G.M.Mpeg2Encoder(6, 6, 2, Q, device=0)
+            try:
+                enc.set_option("dct_mfma", mfma)
+                assert G.resident_encode(f, W // 16, H // 16, pf, XL=6, YL=6, VL=2, Q=Q, enc=enc) == want, "Q=%d pf=%d" % (Q, pf)
+            finally:
+                enc.close()
 
 
 @pytest.mark.parametrize("VL,Q,pf", [(3, 2, 8), (2, 1, 3), (1, 4, 5), (3, 3, 0)])
