@@ -97,6 +97,8 @@ struct m2v_enc {
                                               // while the kernels of chunk k read the other stage's buffer
         DevBuf<uint8_t> d_out;                // chunk output when it goes to the host
         hipEvent_t ev_ctl = nullptr, ev_out = nullptr, ev_up = nullptr;
+        size_t uploaded = 0;                  // leading frames of the chunk being filled that are already in d_in (page-locked
+                                              // caller memory goes to the device directly, without the pinned staging copy)
         int stage = 0;                        // 0 free, 1 encode submitted, 2 stream read-back submitted
         bool last = false;
         size_t bytes = 0;
@@ -107,7 +109,8 @@ struct m2v_enc {
     bool dct_mfma = true;         // option "dct_mfma": luma DCT through the matrix cores (k_mb<.., MFMA = true>); 0 = integer VALU / LDS
                                   // path.  Same results; kept by the rocprofv3 number (profiles/r02_mfma_*: 138.3 vs 140.3 us per launch)
     bool conformant = false;      // option "conformant": ISO reconstruction loop instead of the RTL's (NOT byte-identical to the reference)
-    int copy_threads = 4;         // option "copy_threads": threads that copy m2v_push_frames input into pinned memory
+    int copy_threads = 8;         // option "copy_threads": threads that copy m2v_push_frames input into pinned memory
+    bool direct_upload = true;    // option "direct_upload": page-locked caller memory is uploaded without the staging copy
     int split_streams = 2;        // GOP segments of a chunk run as this many independent groups on as many streams (encode_chunk)
     static constexpr int kMaxSplit = 8;
     hipStream_t side[kMaxSplit - 1] = {};            // group 0 runs on the caller's stream
@@ -726,8 +729,11 @@ void flush_buffered(m2v_enc *e, bool last)
     m2v_enc::HostStage &h = e->st();
     // the stage's own device buffer, filled on the upload stream: the copy of chunk k+1 crosses PCIe while the kernels
     // of chunk k run (the stage is only refilled after its previous chunk has completed, see the end of this function)
-    h.d_in.ensure(nf * frame_bytes);
-    HIPCHK(hipMemcpyAsync(h.d_in.p, h.h_in, nf * frame_bytes, hipMemcpyHostToDevice, e->up_stream));
+    h.d_in.ensure(std::max(nf, h.uploaded ? e->batch_frames : (size_t)0) * frame_bytes);
+    if (h.uploaded < nf)
+        HIPCHK(hipMemcpyAsync(h.d_in.p + h.uploaded * frame_bytes, h.h_in + h.uploaded * frame_bytes, (nf - h.uploaded) * frame_bytes,
+                              hipMemcpyHostToDevice, e->up_stream));
+    h.uploaded = 0;
     HIPCHK(hipEventRecord(h.ev_up, e->up_stream));
     HIPCHK(hipStreamWaitEvent(s, h.ev_up, 0));
     // worst case ~1.2 KB per macroblock; typical streams are ~100x smaller
@@ -767,6 +773,7 @@ void start_sequence(m2v_enc *e, uint32_t xs, uint32_t ys, uint32_t pf)
     e->persist_slot = -1;
     e->end_pending = false;
     e->last_frame_valid_beats = e->g.ysz / 4;
+    for (auto &h : e->hs) h.uploaded = 0;
     // the FIFO total counts stream bytes of THIS sequence (padding rule): must be empty
     e->fifo.clear();
     e->fifo_rd = 0;
@@ -901,7 +908,7 @@ int m2v_reset(m2v_enc *e)
     if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
     for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
     if (e->strip_stream && e->strip_stream != e->stream) (void)hipStreamSynchronize(e->strip_stream);
-    for (auto &h : e->hs) h.stage = 0;
+    for (auto &h : e->hs) { h.stage = 0; h.uploaded = 0; }
     e->pending.clear();
     e->state = m2v_enc::IDLE;
     e->buffered = 0; e->beat_pos = 0; e->frames_total = 0; e->persist_slot = -1;
@@ -1020,15 +1027,32 @@ static int push_frames_impl(m2v_enc *e, void *argp)
         e->set_err("m2v_push_frames: a frame is partially filled by m2v_push_beats");
         return M2V_E_STATE;
     }
+    // Frames that already sit in page-locked host memory (hipHostMalloc / hipHostRegister: capture buffers, pinned tensors)
+    // cross PCIe straight from there; anything else is first copied into the stage's pinned buffer by a few threads (one core
+    // moves ~25 GB/s, less than half of what the link takes).
+    hipPointerAttribute_t attr;
+    const bool pinned = e->direct_upload && hipPointerGetAttributes(&attr, a->frames) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();           // an ordinary pointer is "invalid value" to the query: not an error here
+    bool direct_pending = false;
     for (size_t k = 0; k < a->n;) {
-        // as many frames as fit into the stage being filled, copied by a few threads: one core moves ~25 GB/s into
-        // pinned memory, less than half of what the PCIe link takes
+        m2v_enc::HostStage &h = e->st();
         const size_t take = std::min(a->n - k, e->batch_frames - e->buffered);
-        parallel_copy(e->st().h_in + e->buffered * fb, a->frames + k * fb, take * fb, e->copy_threads);
+        if (pinned) {
+            h.d_in.ensure(e->batch_frames * fb);
+            if (h.uploaded < e->buffered)           // frames staged on the host earlier in this chunk go first
+                HIPCHK(hipMemcpyAsync(h.d_in.p + h.uploaded * fb, h.h_in + h.uploaded * fb, (e->buffered - h.uploaded) * fb,
+                                      hipMemcpyHostToDevice, e->up_stream));
+            HIPCHK(hipMemcpyAsync(h.d_in.p + e->buffered * fb, a->frames + k * fb, take * fb, hipMemcpyHostToDevice, e->up_stream));
+            h.uploaded = e->buffered + take;
+            direct_pending = true;
+        } else {
+            parallel_copy(h.h_in + e->buffered * fb, a->frames + k * fb, take * fb, e->copy_threads);
+        }
         e->buffered += take;
         k += take;
         if (e->buffered == e->batch_frames) flush_buffered(e, false);
     }
+    if (direct_pending) HIPCHK(hipStreamSynchronize(e->up_stream));     // the caller may reuse its buffer when this returns
     progress(e, false);
     return M2V_OK;
 }
@@ -1352,6 +1376,7 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
         return M2V_OK;
     }
     if (!strcmp(name, "dct_mfma")) { e->dct_mfma = value != 0; return M2V_OK; }
+    if (!strcmp(name, "direct_upload")) { e->direct_upload = value != 0; return M2V_OK; }
     if (!strcmp(name, "copy_threads")) { if (value < 1 || value > 64) return M2V_E_PARAM; e->copy_threads = (int)value; return M2V_OK; }
     if (kDebug) {       // libm2v_mi355x_dbg.so only (-DM2V_DEBUG): the shipped library does not know these names
         if (!strcmp(name, "keep_recon")) { e->keep_recon = value != 0; return M2V_OK; }

@@ -159,7 +159,10 @@ int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t 
  * "async" (default 1: the port path keeps two chunks in flight - while one chunk is uploaded, encoded and
  * read back, m2v_push_* fills the pinned staging of the next one; 0 = a chunk is complete when the push
  * that filled it returns.  The bytes are the same either way),
- * "copy_threads" (default 4: threads m2v_push_frames uses to copy large inputs into pinned memory),
+ * "copy_threads" (default 8: threads m2v_push_frames uses to copy large inputs into pinned memory),
+ * "direct_upload" (default 1: frames handed to m2v_push_frames in page-locked host memory - hipHostMalloc / hipHostRegister -
+ * are uploaded straight from the caller's buffer, without the copy into the handle's pinned staging; the call returns when
+ * the upload of its frames has completed, the encoding continues asynchronously),
  * "split_streams" (default 2; 1..8 = the closed GOPs of a chunk are encoded as this many independent groups on as many
  * HIP streams, so that the partially filled tail of one group's launch overlaps with another group's next launch;
  * 1 = a single stream; ignored while "profile" is on, which times every launch with in-band events on one stream),

@@ -236,3 +236,49 @@ def test_long_sequence_many_chunks_in_flight(env):
         assert not enc.busy
     finally:
         enc.close()
+
+
+def test_page_locked_frames_are_uploaded_directly_and_mix_with_beats():
+    """m2v_push_frames from page-locked caller memory (option direct_upload, default on): the frames cross PCIe straight from
+    the caller's buffer, which may be overwritten as soon as the call returns; beats and pageable frames pushed into the
+    same chunk go through the pinned staging - every mixture must give the oracle's bytes."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    W, H, n, pf = 128, 96, 11, 3
+    clip = M.synth.clip(W, H, n, clip_index=77, scene_len=4)
+    want = orc.encode(clip, W // 16, H // 16, pf, 6, 6, 3, 2)
+    bpf = W * H // 4
+    for batch in (4, 3, 96):
+        for direct in (1, 0):
+            enc = M.Mpeg2Encoder(6, 6, 3, 2)
+            try:
+                enc.set_option("batch_frames", batch)
+                enc.set_option("direct_upload", direct)
+                scratch = torch.empty((2, 3, H, W), dtype=torch.uint8).pin_memory()
+                sview = scratch.numpy()
+                out = []
+                k = 0
+                while k < n:
+                    kind = k % 3
+                    if kind == 0 and k + 2 <= n:            # two frames from page-locked memory, then the buffer is trashed
+                        sview[:] = clip[k:k + 2]
+                        enc.push_frames(W // 16, H // 16, pf, sview)
+                        sview[:] = 0x5A
+                        k += 2
+                    elif kind == 1:                         # one frame as beats, in two pieces
+                        f = clip[k].reshape(3, -1)
+                        cut = bpf // 3
+                        enc.push_beats(W // 16, H // 16, pf, f[0][:cut * 4], f[1][:cut * 4], f[2][:cut * 4])
+                        enc.push_beats(W // 16, H // 16, pf, f[0][cut * 4:], f[1][cut * 4:], f[2][cut * 4:])
+                        k += 1
+                    else:                                   # one pageable frame
+                        enc.push_frames(W // 16, H // 16, pf, clip[k:k + 1])
+                        k += 1
+                    out.append(enc.pull()[0])
+                enc.sequence_stop()
+                out.append(enc.pull_all())
+                assert b"".join(out) == want, "batch_frames=%d direct_upload=%d" % (batch, direct)
+            finally:
+                enc.close()
