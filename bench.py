@@ -185,40 +185,89 @@ def hbm_copy_rate(torch, dev):
 
 def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
     """Config c5: one 2048x2048 (XL=YL=7) I+P sequence, 128 macroblock rows cut into `world` strips; the +-6 luma /
-    +-3 chroma reference rows cross xGMI once per GOP step (fpga-mpeg2-encoder_amd/parallel.py)."""
+    +-3 chroma reference rows cross xGMI once per GOP step (fpga-mpeg2-encoder_amd/parallel.py).  Strong scaling: the
+    total work is fixed.  The line carries what the sequences mode carries (roofline of this rank's P-frame launches,
+    CPU baseline, whole-stream check against the oracle on rank 0) plus the halo / gather time per step."""
     Ws = Hs = 2048
-    nframes = args.gops * (PFRAMES + 1)
+    gop = PFRAMES + 1
+    nframes = args.gops * gop
     clip = M.synth.clip_torch(Ws, Hs, nframes, clip_index=0, device=dev)        # every rank holds the same clip
     enc = M.Mpeg2Encoder(7, 7, VL, Q, device=local_rank)
     eng = M.parallel.GpuStripEngine(enc, clip, 128, 128, PFRAMES, dev)
     out = None
     for _ in range((20 if args.prewarm > 0 else 0) + args.warmup):     # fixed count: every rank takes part in the halo exchange
         out = M.parallel.encode_strips(eng, rank, world, dist)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = M.parallel.encode_strips(eng, rank, world, dist)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     dt = time.perf_counter() - t0
+    # one more pass with per-launch HIP events (option profile) and the exchange bracketed by events on the engine's stream
+    enc.set_option("profile", 1)
+    timings = {}
+    M.parallel.encode_strips(eng, rank, world, dist, timings=timings)
+    M.parallel.encode_strips(eng, rank, world, dist, timings=timings)
+    launches, ms_p, px_p = enc.kernel_stats(0)
+    _, ms_i, _ = enc.kernel_stats(1)
+    enc.set_option("profile", 0)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, timings.get("halo_exposed", 0.0), timings.get("halo_total", 0.0), timings.get("gather", 0.0)],
+                         dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, timings["halo_exposed"], timings["halo_total"], timings["gather"] = (float(v) for v in t.tolist())
     if rank == 0:
         px = nframes * Ws * Hs
-        print(json.dumps({
+        rows = M.parallel.partition_rows(128, world)[0]
+        strip_px = (rows[1] - rows[0]) * 16 * Ws
+        alg_bytes = args.gops * ((PFRAMES - 1) * 6.0 + 4.5) * strip_px          # this rank's P-frame launches of one step
+        achieved = alg_bytes / (ms_p * 1e-3) * 1e-9 if ms_p > 0 else 0.0
+        line = {
             "metric": "MPixels/s encoded, 2048x2048 I+P, macroblock-row strips", "value": round(args.steps * px / dt * 1e-6, 2),
             "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "vs_baseline": round(args.steps * px / dt * 1e-6 / FPGA_MPIXELS, 3), "dtype": "u8", "data": "synthetic",
             "config": {"workload": "c5: ONE 2048x2048 yuv444p sequence, %d GOPs of 1 I + %d P, VECTOR_LEVEL=3 Q_LEVEL=2, "
                                    "%d strips of macroblock rows, halo = 9 rows x 2048 B per frame per direction"
                                    % (args.gops, PFRAMES, world), "frames": nframes,
-                       "stream_bytes": int(out.numel()) if out is not None else None}}))
+                       "stream_bytes": int(out.numel()) if out is not None else None,
+                       "baseline": "FPGA Kintex-7 268 MPixels/s (README.md:22)"},
+            "roofline": {"bound": "hbm", "kernel": "k_mb<3,true> on rank 0's strip (%d macroblock rows), P-frame launches of one step" % (rows[1] - rows[0]),
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None, "launches_per_step": launches, "kernel_ms_per_step": round(ms_p, 3),
+                         "algorithmic_bytes_per_step": round(alg_bytes),
+                         "timed_in": "extra pass with option profile (HIP events around every launch on the engine's stream)"},
+            "exchange_ms_per_step": {"halo_exposed": round(timings.get("halo_exposed", 0.0), 3), "halo_total": round(timings.get("halo_total", 0.0), 3),
+                                     "gather_and_assembly": round(timings.get("gather", 0.0), 3),
+                                     "note": "max over ranks; halo_exposed = stream time spent waiting for neighbour rows after the "
+                                             "interior rows were done, halo_total = from edge rows packed to neighbour rows there"},
+            "kernel_ms_per_step": {"k_mb_P": round(ms_p, 3), "k_mb_I": round(ms_i, 3)},
+        }
+        if not args.no_cpu_baseline:
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import m2v_oracle_ctypes as orc
+            orc.build()
+            clip_np = clip.cpu().numpy()
+            t1 = time.perf_counter()
+            first = orc.encode(clip_np[:gop], 128, 128, PFRAMES, 7, 7, VL, Q)
+            d1 = time.perf_counter() - t1
+            line["cpu_baseline"] = dict(value=round(gop * Ws * Hs / d1 * 1e-6, 4), unit="MPixels/s", cores=1, kind="port",
+                                        sample="first GOP (%d frames) of the 2048x2048 clip, oracle/m2v_oracle.c, %.1f s" % (gop, d1))
+            with ThreadPoolExecutor(args.gops) as ex:
+                refs = [first] + list(ex.map(lambda k: orc.encode(clip_np[k * gop:(k + 1) * gop], 128, 128, PFRAMES, 7, 7, VL, Q),
+                                             range(1, args.gops)))
+            bad = compare_with_per_gop_oracle(out.cpu().numpy().tobytes(), refs, gop)
+            line["parity_check"] = {"gops_compared": args.gops, "stream_bytes_compared": int(out.numel()), "identical_to_oracle": not bad,
+                                    "problems": bad[:5]}
+            line["rtl_sim"] = rtl_sim_probe()
+        print(json.dumps(line))
         sys.stdout.flush()
     enc.close()
     if dist is not None:

@@ -152,6 +152,9 @@ struct m2v_enc {
     bool strip_active = false;            // between m2v_strip_begin and m2v_strip_finish
     hipStream_t strip_stream = nullptr;
     DevBuf<uint8_t> d_segs;               // CopySeg table of m2v_strip_assemble
+    uint8_t *h_asm = nullptr;             // pinned staging of m2v_strip_assemble's tables
+    size_t h_asm_cap = 0;
+    hipEvent_t ev_asm = nullptr;          // the staging may be rewritten once this has been reached
 
     // debug bookkeeping of the last resident encode
     size_t dbg_frames = 0;
@@ -890,6 +893,8 @@ void m2v_destroy(m2v_enc *e)
         if (h.ev_ctl) (void)hipEventDestroy(h.ev_ctl);
         if (h.ev_out) (void)hipEventDestroy(h.ev_out);
     }
+    if (e->ev_asm) { (void)hipEventSynchronize(e->ev_asm); (void)hipEventDestroy(e->ev_asm); }
+    if (e->h_asm) (void)hipHostFree(e->h_asm);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     for (auto ev : e->ev_join) if (ev) (void)hipEventDestroy(ev);
     for (auto sd : e->side) if (sd) (void)hipStreamDestroy(sd);
@@ -1330,18 +1335,34 @@ static int strip_assemble_impl(m2v_enc *e, void *argp)
     e->d_jobs.ensure(nf);
     e->d_frame_off.ensure(nf + 1);
     e->d_segs.ensure(segs.size() * sizeof(CopySeg) + 16);
+    // The three small tables go up from ONE pinned staging block with asynchronous copies on the caller's stream: the call
+    // neither blocks on a pageable copy nor synchronises the stream (the byte count is known on the host).  The staging is
+    // rewritten by the next call only after this call's copies have been consumed (ev_asm).
+    const size_t b_jobs = nf * sizeof(FrameJob), b_foff = (nf + 1) * sizeof(unsigned long long), b_segs = segs.size() * sizeof(CopySeg);
+    const size_t need = b_jobs + b_foff + b_segs + 64;
+    if (!e->ev_asm) HIPCHK(hipEventCreateWithFlags(&e->ev_asm, hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(e->ev_asm));
+    if (e->h_asm_cap < need) {
+        if (e->h_asm) (void)hipHostFree(e->h_asm);
+        e->h_asm = nullptr; e->h_asm_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&e->h_asm, need * 2));
+        e->h_asm_cap = need * 2;
+    }
+    memcpy(e->h_asm, jobs.data(), b_jobs);
+    memcpy(e->h_asm + b_jobs, foff.data(), b_foff);
+    if (b_segs) memcpy(e->h_asm + b_jobs + b_foff, segs.data(), b_segs);
     ctl_init(e, s, a->cap);
-    HIPCHK(hipMemcpy(e->d_jobs.p, jobs.data(), nf * sizeof(FrameJob), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_frame_off.p, foff.data(), (nf + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice));
-    if (!segs.empty()) HIPCHK(hipMemcpy(e->d_segs.p, segs.data(), segs.size() * sizeof(CopySeg), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(e->d_jobs.p, e->h_asm, b_jobs, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->d_frame_off.p, e->h_asm + b_jobs, b_foff, hipMemcpyHostToDevice, s));
+    if (b_segs) HIPCHK(hipMemcpyAsync(e->d_segs.p, e->h_asm + b_jobs + b_foff, b_segs, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(e->ev_asm, s));
     if (!segs.empty())
         hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)segs.size()), dim3(256), 0, s, (const CopySeg *)e->d_segs.p, a->d_out);
     hipLaunchKernelGGL(k_headers, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, s, e->d_jobs.p, g, (int)nf, 1,
                        e->d_frame_off.p, a->d_out, e->d_ctl.p);
     hipLaunchKernelGGL(k_trailer, dim3(1), dim3(256), 0, s, a->d_out, pos, total);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));
-    if (a->bytes) *a->bytes = (size_t)total;
+    if (a->bytes) *a->bytes = (size_t)total;            // known on the host: the stream is NOT synchronised here
     return M2V_OK;
 }
 

@@ -54,6 +54,15 @@ class GpuStripEngine:
     def stream_ctx(self):
         return self.torch.cuda.stream(self.tstream)
 
+    def mark(self):
+        """a timing event on the engine's stream (encode_strips(timings=...))"""
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(self.tstream)
+        return ev
+
+    def sync(self):
+        self.tstream.synchronize()
+
     def begin(self, row0, row1):
         self.steps, self.halo_bytes = self.enc.strip_begin(self.clip.data_ptr(), self.nframes, self.xs, self.ys, self.pf,
                                                            row0, row1, self.stream)
@@ -95,18 +104,23 @@ class GpuStripEngine:
         return out[:n]
 
 
-def encode_strips(engine, rank, world, dist=None, dst=0):
+def encode_strips(engine, rank, world, dist=None, dst=0, timings=None):
     """Encode one sequence as `world` macroblock-row strips.  Returns the stream (engine tensor) on rank `dst`, None
-    elsewhere.  `dist` = torch.distributed (initialised) or None for world == 1."""
+    elsewhere.  `dist` = torch.distributed (initialised) or None for world == 1.
+    timings: optional dict; with an engine that has `mark()` (GPU events on the engine's stream) it receives, in ms,
+    "halo_exposed" (time the stream waited for neighbour rows after the interior rows were done), "halo_total" (from the
+    edge rows being packed to the neighbour rows being there) and "gather" (sizes + strips to the output rank + assembly)."""
     ctx = engine.stream_ctx() if hasattr(engine, "stream_ctx") else None
     if ctx is None:
-        return _encode_strips(engine, rank, world, dist, dst)
+        return _encode_strips(engine, rank, world, dist, dst, timings)
     with ctx:
-        return _encode_strips(engine, rank, world, dist, dst)
+        return _encode_strips(engine, rank, world, dist, dst, timings)
 
 
-def _encode_strips(engine, rank, world, dist, dst):
+def _encode_strips(engine, rank, world, dist, dst, timings=None):
     import torch
+    mark = engine.mark if (timings is not None and hasattr(engine, "mark")) else (lambda: None)
+    marks = []
     rows = partition_rows(engine.mbh, world)
     row0, row1 = rows[rank]
     steps, halo_bytes = engine.begin(row0, row1)
@@ -127,25 +141,45 @@ def _encode_strips(engine, rank, world, dist, dst):
             if rank < world - 1:
                 ops.append(dist.P2POp(dist.isend, send_down[:nbytes], rank + 1))
                 ops.append(dist.P2POp(dist.irecv, recv_down[:nbytes], rank + 1))
+            ma = mark()
             reqs = dist.batch_isend_irecv(ops)
         if split:
             engine.step_interior(j)
+        mb = mark() if reqs else None
         for req in reqs:
             req.wait()
+        if reqs:
+            marks.append((ma, mb, mark()))
         if nbytes:
             engine.halo_in(j, recv_up if rank > 0 else None, recv_down if rank < world - 1 else None)
     strip, off = engine.finish()
+    g0 = mark()
+
+    def done(out):
+        if timings is not None and g0 is not None:
+            g1 = mark()
+            engine.sync()
+            timings["halo_total"] = sum(a.elapsed_time(c) for a, b, c in marks)
+            timings["halo_exposed"] = sum(b.elapsed_time(c) for a, b, c in marks)
+            timings["gather"] = g0.elapsed_time(g1)
+        return out
+
     if world == 1:
-        return engine.assemble([strip], [off])
-    # sizes to everyone (tiny), strips to the output rank (padded to the longest)
+        return done(engine.assemble([strip], [off]))
+    # sizes to everyone (tiny); then every strip goes to the output rank in ONE batch of point-to-point transfers of
+    # exactly its size (xGMI is point-to-point: the 7 senders use 7 different links into `dst`, no padding to the longest)
     off_t = torch.as_tensor(off, dtype=torch.int64, device=strip.device)
     all_off = [torch.empty_like(off_t) for _ in range(world)]
     dist.all_gather(all_off, off_t)
-    maxlen = max(int(o[-1]) for o in all_off)
-    padded = engine.alloc(maxlen)
-    padded[:strip.numel()] = strip
-    gathered = [engine.alloc(maxlen) for _ in range(world)] if rank == dst else None
-    dist.gather(padded[:maxlen], gathered, dst=dst)
+    sizes = [int(o[-1]) for o in all_off]
     if rank != dst:
-        return None
-    return engine.assemble([gathered[r][:int(all_off[r][-1])] for r in range(world)], [o.cpu().numpy() for o in all_off])
+        if sizes[rank]:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, strip[:sizes[rank]], dst)]):
+                req.wait()
+        return done(None)
+    bufs = [strip if r == dst else engine.alloc(sizes[r]) for r in range(world)]
+    ops = [dist.P2POp(dist.irecv, bufs[r][:sizes[r]], r) for r in range(world) if r != dst and sizes[r]]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return done(engine.assemble([bufs[r][:sizes[r]] for r in range(world)], [o.cpu().numpy() for o in all_off]))

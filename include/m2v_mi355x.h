@@ -134,7 +134,8 @@ int m2v_encode_resident(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t
  *   m2v_strip_finish(d_strip, cap, frame_off)    this strip's slices of every frame, contiguous;
  *                                                frame_off[f]..frame_off[f+1] = bytes of frame f (nframes+1 entries)
  *   m2v_strip_assemble(...)                      on the rank that owns the output: headers + strips
- *                                                of all ranks -> the final stream
+ *                                                of all ranks -> the final stream (enqueued, NOT synchronised:
+ *                                                *out_bytes is valid at return, the bytes in stream order)
  * Everything is enqueued on the stream given to m2v_strip_begin (NULL = the handle's own stream).
  * Buffers are device pointers except frame_off (host).
  */

@@ -124,7 +124,24 @@ def _worker(rank, world, port, W, H, n, pf, VL, q):
     try:
         clip = M.synth.clip(W, H, n, clip_index=70)
         eng = OracleStripEngine(clip, W // 16, H // 16, pf, VL)
+
+        def no_padded_gather(*a, **k):          # the strips travel as sized point-to-point transfers, not as a padded gather
+            raise AssertionError("encode_strips must not use dist.gather")
+        dist.gather = no_padded_gather
+        sent = []
+        real_batch = dist.batch_isend_irecv
+
+        def counting_batch(ops):
+            sent.extend((op.op.__name__, int(op.tensor.numel()), op.peer) for op in ops)
+            return real_batch(ops)
+        dist.batch_isend_irecv = counting_batch
         out = M.parallel.encode_strips(eng, rank, world, dist, dst=0)
+        # the last batch is the gather of the strips: rank 0 receives exactly every other rank's strip size, the others send theirs
+        strip_len = len(eng.finish()[0])
+        if rank != 0:
+            assert sent[-1] == ("isend", strip_len, 0), sent[-1]
+        else:
+            assert [x[0] for x in sent[-(world - 1):]] == ["irecv"] * (world - 1) and [x[2] for x in sent[-(world - 1):]] == list(range(1, world))
         ok = True if rank != 0 else (out == eng.stream_bytes)
         q.put((rank, bool(ok), eng.checked, M.parallel.partition_rows(H // 16, world)[rank]))
     finally:
