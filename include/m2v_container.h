@@ -55,6 +55,12 @@ int m2vc_scan(const uint8_t *es, size_t es_bytes, m2vc_stream_info *info, m2vc_p
               size_t *npics);
 
 /*
+ * Both multiplexers are for FILE PLAYBACK: SCR / PCR advance with the byte position at a constant multiplex rate a little
+ * above the stream's average rate and a picture's PTS is its index times the picture period; the delivery is not paced
+ * against the P-STD / T-STD buffer model (a very large first picture can arrive after its PTS, a long stream runs ahead of
+ * the decoder).  Software players and remultiplexers accept that; a hardware or strictly STD-checking demultiplexer needs
+ * the stream re-paced by a real multiplexer.
+ *
  * MPEG-2 Program Stream (ISO/IEC 13818-1 2.5): packs of at most 2048 bytes, a system header in the first pack, one
  * video PES stream (stream_id 0xE0); every picture starts a PES packet that carries its PTS (no B pictures: DTS =
  * PTS; the sequence headers travel with the first picture), MPEG_program_end_code at the end.  The multiplex
