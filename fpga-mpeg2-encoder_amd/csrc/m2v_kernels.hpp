@@ -438,14 +438,15 @@ __device__ __forceinline__ MbDep mb_dependent(uint32_t info, const MbAux &aux, b
     return d;
 }
 
-constexpr uint32_t SYM_RAW = 0x80000000u;     // symbol list entry: raw = code[23:0], len[28:24]; else level[15:0], run[21:16]
+constexpr uint32_t SYM_RAW = 0x80000000u;     // symbol list entry: raw = code[23:0], len[28:24]; else level[15:0], zig-zag position[21:16]
 
 // Pass 1 of the coefficient VLC for one coded tile (lane = zig-zag index): rank the non-zero levels, append their
-// {run, level} symbols and the end_of_block code to the macroblock's symbol list; returns the new list length.
+// {position, level} symbols and the end_of_block code to the macroblock's symbol list; returns the new list length.  The run
+// of a level is formed in pass 2 from the position of the symbol before it (a raw symbol = block start).
 // INTER = non-intra block: every position counts and there is no DC code; intra: position 0 is the DC level, which
 // leaves through `dc` (for Y01 / Y10 / Y11 its differential against `dc_prev` is coded right here, RTL:2784-2786).
 template <bool INTER>
-__device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_t *s_sym, uint32_t *s_pos, int lane, uint32_t nsym,
+__device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_t *s_sym, int lane, uint32_t lane16, uint32_t nsym,
                                                      int &dc, int dc_prev, bool dc_chained)
 {
     const int v = zig[lane];
@@ -462,14 +463,7 @@ __device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_
     const uint32_t nnz = (uint32_t)__builtin_popcountll(mask);
     if (nz) {
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        s_pos[rank] = (uint32_t)lane;
-        // the load below reads what ANOTHER lane just stored: in one thread's view the two addresses differ, so the compiler
-        // may hoist the load above the store - the memory clobber pins the order (the LDS itself executes a wave's
-        // operations in program order, no wait is needed)
-        asm volatile("" ::: "memory");
-        const uint32_t prev = s_pos[(int)rank - 1];            // s_pos[-1] = -1 (inter) / 0 (intra), set once per macroblock
-        const uint32_t run = (uint32_t)lane - prev - 1u;
-        s_sym[nsym + rank] = (run << 16) | ((uint32_t)v & 0xFFFFu);
+        s_sym[nsym + rank] = lane16 | ((uint32_t)v & 0xFFFFu);
         // end_of_block '10' (RTL:2835) behind the last level: every active lane stores the same word to the same address
         if (INTER) s_sym[nsym + nnz] = SYM_RAW | (2u << 24) | 2u;
     }
@@ -675,22 +669,34 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %5 offset:8"
                              : "=&v"(ra.w01), "=&v"(ra.w12), "=&v"(ra.w23), "=&v"(ra.w34) : "v"(ae), "v"(ao));
                 search_rows<0, kWS>(s_cur, ae, ao, acc, ra, rb);
-                // live dy / dx range of this macroblock (RTL:1642-1645), wave-uniform and kept on the scalar unit: one
-                // unsigned range compare per axis per candidate
-                const int lo = -YR & -in_l, hi = YR & -in_r, ylo = -YR & -in_u, yhi = YR & -in_d;
-                const uint32_t span = (uint32_t)(hi - lo), yspan = (uint32_t)(yhi - ylo);
-                const bool rowok = (uint32_t)(dyi - YR - ylo) <= yspan;
-                const int d0 = 4 * gq - 8 - lo;
                 // minimum SAD; among equals the largest dy, then the largest dx (RTL:1694-1710): key = sad << 8 | (255 - index),
                 // index = dy' << 4 | dx + 8.  A SAD >= 4096 kills a candidate (RTL:1669-1670): such keys are >= 1 << 20 and lose
-                // against every live one, so the test is made once on the reduced key instead of per candidate
+                // against every live one, so the test is made once on the reduced key instead of per candidate.
+                // index has its two low bits clear, so 255 - index ends in 11 and candidate j's key is (sad_j << 8 | cbase) - j.
                 const uint32_t cbase = 255u - (uint32_t)((dyi << 4) | (4 * gq));
+                if (YR == 6 && sgpr(in_l & in_r & in_u & in_d)) {
+                    // VECTOR_LEVEL 3, a macroblock with all four neighbours (wave-uniform, 95 % of a frame): every dy is live and
+                    // the dead dx are the three slots beyond +-6 (dx = -8, -7 in group 0, dx = 7 in group 3): a dead slot gets SAD 0xFFFF
+                    const uint32_t l32 = (uint32_t)acc | (gq == 0 ? 0xFFFFFFFFu : 0u);
+                    const uint32_t h32 = (uint32_t)(acc >> 32) | (gq == 3 ? 0xFFFF0000u : 0u);
+                    const uint32_t m = 0x00FFFF00u;
+                    const uint32_t k0 = ((l32 << 8) & m) | cbase, k1 = (((l32 >> 8) & m) | cbase) - 1u;
+                    const uint32_t k2 = (((h32 << 8) & m) | cbase) - 2u, k3 = (((h32 >> 8) & m) | cbase) - 3u;
+                    key = umin32(umin32(k0, k1), umin32(k2, k3));
+                } else {
+                    // live dy / dx range at the frame border (RTL:1642-1645), wave-uniform and kept on the scalar unit: one
+                    // unsigned range compare per axis per candidate
+                    const int lo = -YR & -in_l, hi = YR & -in_r, ylo = -YR & -in_u, yhi = YR & -in_d;
+                    const uint32_t span = (uint32_t)(hi - lo), yspan = (uint32_t)(yhi - ylo);
+                    const bool rowok = (uint32_t)(dyi - YR - ylo) <= yspan;
+                    const int d0 = 4 * gq - 8 - lo;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t sad = (uint32_t)(acc >> (16 * j)) & 0xFFFFu;
-                    const uint32_t k = (sad << 8) | (cbase - (uint32_t)j);
-                    const bool ok = rowok && (uint32_t)(d0 + j) <= span;
-                    if (ok && k < key) key = k;
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t sad = (uint32_t)(acc >> (16 * j)) & 0xFFFFu;
+                        const uint32_t k = (sad << 8) | (cbase - (uint32_t)j);
+                        const bool ok = rowok && (uint32_t)(d0 + j) <= span;
+                        if (ok && k < key) key = k;
+                    }
                 }
             }
             key = wave_min_u32(key);
@@ -1033,25 +1039,22 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     {
         uint32_t nsym = 0, idxB = 0, idxC = 0;
         int dcs[6] = {0, 0, 0, 0, 0, 0};
-        // positions of the non-zero levels of the tile in rank order: the previous non-zero position of the level with
-        // rank k is s_pos[k - 1].  The region is the DCT scratch, free until the bit buffer is cleared below; one
-        // wavefront, LDS operations in program order: the read below sees every lane's write.
-        uint32_t *const s_pos = (uint32_t *)(lds + kOffT) + 1;       // s_pos[-1]: "previous position" of the first level
+        const uint32_t lane16 = (uint32_t)lane << 16;
         if (!(kDebug && (g.ablate & 4))) {
             if (inter) {
                 const uint32_t e = d_cbp_code[cbp];
-                if (lane == 0) { s_sym[0] = SYM_RAW | ((e >> 8) << 24) | (e & 255u); s_pos[-1] = 0xFFFFFFFFu; }
+                if (lane == 0) s_sym[0] = SYM_RAW | ((e >> 8) << 24) | (e & 255u);
                 nsym = 1;
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
-                    if ((cbp >> (5 - t)) & 1) nsym = vlc_tile_symbols<true>(s_zig[t], s_sym, s_pos, lane, nsym, dcs[t], 0, false);
+                    if ((cbp >> (5 - t)) & 1) nsym = vlc_tile_symbols<true>(s_zig[t], s_sym, lane, lane16, nsym, dcs[t], 0, false);
             } else {
-                if (lane == 0) s_pos[-1] = 0u;                  // runs of an intra block count from the first AC position
+                if (lane == 0) s_sym[-1] = SYM_RAW;             // the symbol "before" the first one: a block start
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
                     if (t == 4) idxB = nsym;
                     if (t == 5) idxC = nsym;
-                    nsym = vlc_tile_symbols<false>(s_zig[t], s_sym, s_pos, lane, nsym, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3);
+                    nsym = vlc_tile_symbols<false>(s_zig[t], s_sym, lane, lane16, nsym, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3);
                 }
             }
         }
@@ -1070,13 +1073,17 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     len = (sym >> 24) & 31u;
                 } else {
                     const int v = (int16_t)(sym & 0xFFFFu);
-                    const int run = (int)(sym >> 16) & 63;
+                    // run = zig-zag positions skipped since the previous level of the block; a raw symbol in front (pattern
+                    // code, DC code or the previous block's end code) is a block start: position -1 (inter) or 0 (intra: DC)
+                    const uint32_t before = s_sym[(int)i - 1];
+                    const bool first = (before & SYM_RAW) != 0u;
+                    const int prevpos = first ? (inter ? -1 : 0) : (int)((before >> 16) & 63u);
+                    const int run = (int)((sym >> 16) & 63u) - prevpos - 1;
                     const int a = iabs(v);
                     uint32_t e = 0;
                     if (run < 32 && a <= 40) e = d_ac_code[run * 40 + a - 1];
-                    // first coefficient of a non-intra block with level +-1: '1s' instead of '11s' (RTL:2798-2802).  First
-                    // = the symbol before it in the list is a raw one (the pattern code or the previous block's end code)
-                    if (inter && run == 0 && a == 1 && (s_sym[(int)i - 1] & SYM_RAW)) e = (1u << 8) | 1u;
+                    // first coefficient of a non-intra block with level +-1: '1s' instead of '11s' (RTL:2798-2802)
+                    if (inter && first && run == 0 && a == 1) e = (1u << 8) | 1u;
                     if (e) {                                 // run/level VLC + sign (RTL:2535-2540)
                         code = ((e & 255u) << 1) | (v < 0 ? 1u : 0u);
                         len = (e >> 8) + 1u;
