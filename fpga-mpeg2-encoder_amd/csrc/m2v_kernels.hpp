@@ -778,9 +778,18 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         int hy = 0, hx = 0;
         if (inter) {
             hy = idx / 3 - 1; hx = idx % 3 - 1;
-            pred4 = hp[0];
-#pragma unroll
-            for (int k = 1; k < 9; ++k) pred4 = idx == k ? hp[k] : pred4;
+            // the winner is wave-uniform: a scalar jump picks the register (one v_mov) instead of eight selects in every lane
+            switch (sgpr(idx)) {
+                case 0: pred4 = hp[0]; break;
+                case 1: pred4 = hp[1]; break;
+                case 2: pred4 = hp[2]; break;
+                case 3: pred4 = hp[3]; break;
+                case 4: pred4 = hp[4]; break;
+                case 5: pred4 = hp[5]; break;
+                case 6: pred4 = hp[6]; break;
+                case 7: pred4 = hp[7]; break;
+                default: pred4 = hp[8]; break;
+            }
         }
         mvy = 2 * fy + hy;                                      // RTL:1827-1828
         mvx = 2 * fx + hx;
@@ -860,7 +869,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     //   pass 2  Y = B16 . T: T is 19 bit, i8 operands: three signed byte limbs (T + 0x808080) ^ 0x808080, the accumulator
     //           layout of pass 1 (rows 4g .. 4g+3 of column c) IS the B layout of a K = 4g .. 4g+3 slice, a 4x4 byte transpose
     //           (7 v_perm) sorts the limbs, one MFMA per limb, recombined by two shift-adds per coefficient.
-    int yacc[4] = {0, 0, 0, 0};                        // sum + 2048 of block row 4g + v, column c
+    int yacc[4] = {0, 0, 0, 0};                        // transform sum of block row 4g + v, column c (the + 2048 is added by the quantiser)
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     const int mg = lane >> 4, mc = lane & 15;
     if constexpr (kMfmaLuma) {
@@ -880,7 +889,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         const v4i_t y1 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)ml.a2, (long)w1, zero4, 0, 0, 0);
         const v4i_t y2 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)ml.a2, (long)w2, zero4, 0, 0, 0);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) yacc[v] = (y0[v] + 2048) + (y1[v] << 8) + (y2[v] << 16);
+        for (int v = 0; v < 4; ++v) yacc[v] = y0[v] + ((y1[v] + (y2[v] << 8)) << 8);           // the sum WITHOUT its rounding constant
     }
     M2V_WAVE_SYNC();
 
@@ -906,9 +915,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             int nzor = 0;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int acc = yacc[v];
-                const int sg = acc >> 31;
-                const int q = (acc + (2 << 12) + (sg & qneg)) >> (16 + Q);
+                // acc = yacc + 2048; C = acc >> 12 is negative exactly for yacc < -2048
+                const int q = (yacc[v] + (2048 + (2 << 12)) + (yacc[v] < -2048 ? qneg : 0)) >> (16 + Q);
                 *(int16_t *)((uint8_t *)&s_zig[0][0] + ml.zoff[v]) = (int16_t)q;
                 if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + (ml.zoff[v] >> 1)] = (int16_t)q;
                 nzor |= q;
@@ -966,7 +974,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 const int wv = (int)((ml.wq >> (8 * v)) & 255u);
                 const uint32_t qo = __umul24((uint32_t)wv, (3u << Q) + 2u) >> 3;
                 const bool is_dc = v == 0 && (lane & 0x17) == 0;           // row 0 of a tile (g even, v = 0), column 0 of a tile
-                const int C = yacc[v] >> 12;
+                const int C = (yacc[v] + 2048) >> 12;
                 const int sg = C >> 31;
                 uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
                 if (!is_dc) a = __umul24((a + qo) >> Q, ml.recip[v]) >> 21;
