@@ -97,14 +97,24 @@ __device__ uint16_t   d_ac_code[32 * 40];
 __constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for n < 25575 (tests/test_host_logic.py)
 // DCT-as-GEMM variant of stage G (k_mb<.., MFMA = true>): per-lane operands of the matrix-core formulation, lane = (g = lane >> 4,
 // c = lane & 15); register v of a 16x16 accumulator holds block row 4g + v, column c.  Filled by fill_mfma_tables().
-struct MfmaLane {
+struct MfmaLane {        // 64 bytes: one shift forms the lane's offset, what a non-intra macroblock needs comes first
     uint32_t b1[2];      // pass 1 B operand: +-basis row (c & 7) for the k group that matches c's tile column, else 0
-    uint32_t a2;         // pass 2 A operand: basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1, else 0
-    uint32_t wq;         // intra quantiser weights of this lane's four coefficients (bytes)
+    uint32_t a2[4];      // pass 2 A operand {a, 0, 0, a}: a = basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1,
+                         // else 0; the pair {a, 0} multiplies the low dword of a B operand, the pair {0, a} the high dword
     uint32_t zoff[4];    // byte offset of coefficient v inside s_zig: tile * 128 + zigzag position * 2
-    uint32_t recip[4];   // ceil(2^21 / W) of the four coefficients
+    // full-pel search (lane = dy' << 2 | dx group, k_mb stage B): position byte of the lane's four candidates,
+    // 255 - (dy' << 4 | dx + 8), and the SAD bits that mark the dx slots outside +-6 as dead (VECTOR_LEVEL 3)
+    uint32_t cb4, dead_lo, dead_hi;
+    uint32_t pad[3];
 };
+struct MfmaLaneIntra {   // the part only intra macroblocks read
+    uint32_t wq;         // quantiser weights of this lane's four coefficients (bytes)
+    uint32_t recip[4];   // ceil(2^21 / W) of the four coefficients
+    uint32_t pad[3];
+};
+static_assert(sizeof(MfmaLane) == 64 && sizeof(MfmaLaneIntra) == 32, "lane tables are indexed by a shift");
 __constant__ MfmaLane c_mfma[64];
+__constant__ MfmaLaneIntra c_mfma_intra[64];
 
 
 // ----------------------------------------------------------------------------------------------
@@ -150,13 +160,22 @@ __device__ __forceinline__ int wave_sum4(int a, int b, int c, int d)
     return v;
 }
 
+// A value that IS the same in every lane, stated to the compiler: everything computed from it stays on the scalar
+// unit (SALU has slack, the vector ALU is the kernel's bottleneck).  Without it the compiler's divergence analysis
+// gives up on some wave-uniform chains (the half-pel decision, the coded-block pattern) and runs them - and the
+// exec-mask juggling of their "divergent" branches - on the vector unit.
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// The same statement for a value the compiler already holds in a scalar register: the empty asm pins it to an SGPR and
+// hides where it came from, so that it cannot be merged with an equal expression that some vector instruction needs as
+// a lane mask or VGPR (which would drag this copy, and its users, onto the vector ALU as well).
+__device__ __forceinline__ int sgpr(int v) { asm("" : "+s"(v)); return v; }
 // EXEC-masked lane mask of a predicate as the compare instruction leaves it (HIP's __ballot goes through a 0/1 select
 // and a second compare: two VALU instructions more per use)
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // 1 if any lane's predicate holds, on the scalar unit
 __device__ __forceinline__ uint32_t any_lane(bool p)
 {
-    const uint32_t n = (uint32_t)__builtin_popcountll(ballot(p));
+    const uint32_t n = (uint32_t)sgpr(__builtin_popcountll(ballot(p)));
     return n < 1u ? n : 1u;
 }
 
@@ -193,6 +212,33 @@ __device__ __forceinline__ int mad24_s(int a, int b, int c)
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
     return d;
 }
+// the same with the multiplier in a scalar register
+__device__ __forceinline__ int mad24_ms(int a, int b, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
+// sign(q) in {-1, 0, 1}: one v_med3_i32 with inline constants (the compiler builds it from two compares and two selects)
+__device__ __forceinline__ int sign_of(int q)
+{
+    int d;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(d) : "v"(q));
+    return d;
+}
+// a constant that stays in ONE vector register (the compiler otherwise re-materialises it with a v_mov at every use)
+__device__ __forceinline__ int vgpr_const(int c)
+{
+    asm("" : "+v"(c));
+    return c;
+}
+// clamp with both bounds in vector registers: one v_med3_i32 (two literal bounds cost the compiler a v_mov per use)
+__device__ __forceinline__ int clamp_vv(int x, int lo, int hi)
+{
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(lo), "v"(hi));
+    return d;
+}
 // first link of a v_dot4 chain: the VOP3P form takes the inline constant 0 as accumulator (v_dot4c needs a zeroed register)
 __device__ __forceinline__ int dot4_first(uint32_t a, uint32_t b)
 {
@@ -202,15 +248,6 @@ __device__ __forceinline__ int dot4_first(uint32_t a, uint32_t b)
 }
 
 __device__ __forceinline__ int iabs(int a) { return a < 0 ? -a : a; }
-// A value that IS the same in every lane, stated to the compiler: everything computed from it stays on the scalar
-// unit (SALU has slack, the vector ALU is the kernel's bottleneck).  Without it the compiler's divergence analysis
-// gives up on some wave-uniform chains (the half-pel decision, the coded-block pattern) and runs them - and the
-// exec-mask juggling of their "divergent" branches - on the vector unit.
-__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// The same statement for a value the compiler already holds in a scalar register: the empty asm pins it to an SGPR and
-// hides where it came from, so that it cannot be merged with an equal expression that some vector instruction needs as
-// a lane mask or VGPR (which would drag this copy, and its users, onto the vector ALU as well).
-__device__ __forceinline__ int sgpr(int v) { asm("" : "+s"(v)); return v; }
 __device__ __forceinline__ int sext(int v, int bits) { return (int)((uint32_t)v << (32 - bits)) >> (32 - bits); }
 
 // the same two means on four packed bytes with v_lerp_u8: D.b = (S0.b + S1.b + (S2.b & 1)) >> 1
@@ -450,6 +487,7 @@ __device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_
                                                      int &dc, int dc_prev, bool dc_chained)
 {
     const int v = zig[lane];
+    nsym = (uint32_t)sgpr((int)nsym);               // the list length is wave-uniform: keep its arithmetic on the scalar unit
     if constexpr (!INTER) {
         dc = __builtin_amdgcn_readlane(v, 0);
         if (dc_chained) {
@@ -461,14 +499,15 @@ __device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_
     const bool nz = INTER ? v != 0 : (v != 0 && lane > 0);
     const unsigned long long mask = ballot(nz);
     const uint32_t nnz = (uint32_t)__builtin_popcountll(mask);
+    const uint32_t eob_at = (uint32_t)sgpr((int)(nsym + nnz));
     if (nz) {
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        s_sym[nsym + rank] = lane16 | ((uint32_t)v & 0xFFFFu);
+        *(uint32_t *)((uint8_t *)s_sym + ((rank << 2) + (uint32_t)sgpr((int)(nsym << 2)))) = lane16 | ((uint32_t)v & 0xFFFFu);
         // end_of_block '10' (RTL:2835) behind the last level: every active lane stores the same word to the same address
-        if (INTER) s_sym[nsym + nnz] = SYM_RAW | (2u << 24) | 2u;
+        if (INTER) s_sym[eob_at] = SYM_RAW | (2u << 24) | 2u;
     }
-    if (!INTER && lane == 0) s_sym[nsym + nnz] = SYM_RAW | (2u << 24) | 2u;     // an intra block may have no AC level at all
-    return nsym + nnz + 1u;
+    if (!INTER && lane == 0) s_sym[eob_at] = SYM_RAW | (2u << 24) | 2u;     // an intra block may have no AC level at all
+    return (uint32_t)sgpr((int)(eob_at + 1u));
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -656,6 +695,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         {
             uint32_t key = 0xFFFFFFFFu;
             const int dyi = lane >> 2, gq = lane & 3;        // dy = dyi - YR, dx = 4*gq - 8 + j
+            const uint32_t sl_cb4 = c_mfma[lane].cb4, sl_dead_lo = c_mfma[lane].dead_lo, sl_dead_hi = c_mfma[lane].dead_hi;
             if (dyi <= 2 * YR && !(kDebug && (g.ablate & 1))) {
                 // the pairs (w0,w1) (w2,w3) start at dword gq, the pairs (w1,w2) (w3,w4) at gq + 1: one of the two is even
                 // in copy A, the other one in copy B (which holds dword j + 1 at index j)
@@ -677,11 +717,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 if (YR == 6 && sgpr(in_l & in_r & in_u & in_d)) {
                     // VECTOR_LEVEL 3, a macroblock with all four neighbours (wave-uniform, 95 % of a frame): every dy is live and
                     // the dead dx are the three slots beyond +-6 (dx = -8, -7 in group 0, dx = 7 in group 3): a dead slot gets SAD 0xFFFF
-                    const uint32_t l32 = (uint32_t)acc | (gq == 0 ? 0xFFFFFFFFu : 0u);
-                    const uint32_t h32 = (uint32_t)(acc >> 32) | (gq == 3 ? 0xFFFF0000u : 0u);
-                    const uint32_t m = 0x00FFFF00u;
-                    const uint32_t k0 = ((l32 << 8) & m) | cbase, k1 = (((l32 >> 8) & m) | cbase) - 1u;
-                    const uint32_t k2 = (((h32 << 8) & m) | cbase) - 2u, k3 = (((h32 >> 8) & m) | cbase) - 3u;
+                    // (the lane table holds those bits and the four position bytes cbase - j); one v_perm per key: [0, sad_hi, sad_lo, pos]
+                    const uint32_t l32 = (uint32_t)acc | sl_dead_lo, h32 = (uint32_t)(acc >> 32) | sl_dead_hi;
+                    const uint32_t k0 = __builtin_amdgcn_perm(l32, sl_cb4, 0x0C050400u), k1 = __builtin_amdgcn_perm(l32, sl_cb4, 0x0C070601u);
+                    const uint32_t k2 = __builtin_amdgcn_perm(h32, sl_cb4, 0x0C050402u), k3 = __builtin_amdgcn_perm(h32, sl_cb4, 0x0C070603u);
                     key = umin32(umin32(k0, k1), umin32(k2, k3));
                 } else {
                     // live dy / dx range at the frame border (RTL:1642-1645), wave-uniform and kept on the scalar unit: one
@@ -869,33 +908,51 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     //   pass 2  Y = B16 . T: T is 19 bit, i8 operands: three signed byte limbs (T + 0x808080) ^ 0x808080, the accumulator
     //           layout of pass 1 (rows 4g .. 4g+3 of column c) IS the B layout of a K = 4g .. 4g+3 slice, a 4x4 byte transpose
     //           (7 v_perm) sorts the limbs, one MFMA per limb, recombined by two shift-adds per coefficient.
-    int yacc[4] = {0, 0, 0, 0};                        // transform sum of block row 4g + v, column c (the + 2048 is added by the quantiser)
+    // transform sum of block row 4g + v, column c, PLUS kRound = 2048 + (2 << 12): the DCT's rounding constant and the inter
+    // quantiser's "+ 2" (below), both added for free as the accumulator input 40 of the middle limb (40 << 8)
+    constexpr int kRound = 2048 + (2 << 12);
+    int yacc[4] = {0, 0, 0, 0};
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     const int mg = lane >> 4, mc = lane & 15;
     if constexpr (kMfmaLuma) {
-        const MfmaLane ml = c_mfma[lane];
         const long a1 = *(const long *)&s_cp[((mc >> 3) << 1) | (mg & 1)][mc & 7][8 * (mg >> 1)];
-        const long b1 = (long)(((unsigned long long)ml.b1[1] << 32) | ml.b1[0]);
+        const long b1 = *(const long *)&c_mfma[lane].b1[0];
+        const long a2lo = *(const long *)&c_mfma[lane].a2[0], a2hi = *(const long *)&c_mfma[lane].a2[2];
         const v4i_t zero4 = {0, 0, 0, 0};
         const v4i_t tt = __builtin_amdgcn_mfma_i32_16x16x32_i8(a1, b1, zero4, 0, 0, 0);
         uint32_t e[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) e[v] = ((uint32_t)tt[v] + 0x808080u) ^ 0x808080u;
+        for (int v = 0; v < 4; ++v) e[v] = (uint32_t)tt[v] + 0x808080u;       // bias here, the sign flip on the three sorted registers
         const uint32_t p01 = __builtin_amdgcn_perm(e[1], e[0], 0x05010400u), p23 = __builtin_amdgcn_perm(e[3], e[2], 0x05010400u);
-        const uint32_t w0 = __builtin_amdgcn_perm(p23, p01, 0x05040100u), w1 = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+        const uint32_t w0 = __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u, w1 = __builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u;
         const uint32_t q01 = __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), q23 = __builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u);
-        const uint32_t w2 = __builtin_amdgcn_perm(q23, q01, 0x05040100u);
-        const v4i_t y0 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)ml.a2, (long)w0, zero4, 0, 0, 0);
-        const v4i_t y1 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)ml.a2, (long)w1, zero4, 0, 0, 0);
-        const v4i_t y2 = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)ml.a2, (long)w2, zero4, 0, 0, 0);
+        const uint32_t w2 = __builtin_amdgcn_perm(q23, q01, 0x05040100u) ^ 0x80808080u;
+        // K = 32 per instruction, a limb fills 16: limbs 0 and 1 share one B operand (A = {a, 0} picks the low dword, {0, a} the
+        // high one); limb 2 rides with a dword that A multiplies by zero - any register will do, none is written for it
+        uint32_t junk;
+        asm volatile("" : "=v"(junk));
+        const long b01 = (long)(((unsigned long long)w1 << 32) | w0), b2 = (long)(((unsigned long long)junk << 32) | w2);
+        const v4i_t y0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2lo, b01, zero4, 0, 0, 0);
+        const v4i_t round4 = {kRound >> 8, kRound >> 8, kRound >> 8, kRound >> 8};
+        const v4i_t y1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2hi, b01, round4, 0, 0, 0);
+        const v4i_t y2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2lo, b2, zero4, 0, 0, 0);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) yacc[v] = y0[v] + ((y1[v] + (y2[v] << 8)) << 8);           // the sum WITHOUT its rounding constant
+        for (int v = 0; v < 4; ++v) {
+            // two v_lshl_add_u32.  Both are left to the compiler: an instruction that reads a matrix-core result needs wait
+            // states behind the MFMA which the compiler inserts for its own instructions only, never for inline asm.  The
+            // empty asm in between merely keeps it from re-associating the chain into two shifts and a three-operand add.
+            int t = (y2[v] << 8) + y1[v];
+            asm("" : "+v"(t));
+            yacc[v] = (t << 8) + y0[v];
+        }
     }
     M2V_WAVE_SYNC();
 
     // ---- quantise (RTL:2065-2077), zig-zag + coded flags (RTL:2452-2468), dequantise (RTL:2129-2150)
-    const int wq = c_intra_w[lane];
-    const uint32_t wrecip = c_intra_recip[lane];
+    // the intra quantiser's lane constants: an I frame loads them up front, a P frame only inside its (rare) intra branch
+    int wq = 0;
+    uint32_t wrecip = 0;
+    if constexpr (!P) { wq = c_intra_w[lane]; wrecip = c_intra_recip[lane]; }
     const int zz = c_zigzag[lane];
     const int Q = g.Q;
     const size_t mbidx = (size_t)fidx * g.mbs + mb;
@@ -905,36 +962,37 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         for (int t = 0; t < 6; ++t) s_zig[t][lane] = 0;
         cbp = inter ? 0 : 63;
     } else if (inter) {
-        const int qneg = sgpr(((1 << (4 + Q)) - 5) << 12);
+        const int k2047 = vgpr_const(2047), kn2047 = vgpr_const(-2047);
+        const int qneg = sgpr(-(((1 << (4 + Q)) - 5) << 12));      // MINUS the bias of a negative value (it multiplies the sign mask)
         if constexpr (kMfmaLuma) {
             // the four luma tiles in accumulator layout: lane (g, c) owns rows 4g .. 4g+3 of column c of the 16x16 block,
             // i.e. four coefficients of tile 2 (g >> 1) + (c >> 3); their s_zig slots come from the lane table, their
             // raster slots in s_x are 16 bytes apart
-            const MfmaLane ml = c_mfma[lane];
+            const uint4 zoff = *(const uint4 *)&c_mfma[lane].zoff[0];
+            const uint32_t zo[4] = {zoff.x, zoff.y, zoff.z, zoff.w};
             int16_t *const xrow = &s_x[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)];
             int nzor = 0;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                // acc = yacc + 2048; C = acc >> 12 is negative exactly for yacc < -2048
-                const int q = (yacc[v] + (2048 + (2 << 12)) + (yacc[v] < -2048 ? qneg : 0)) >> (16 + Q);
-                *(int16_t *)((uint8_t *)&s_zig[0][0] + ml.zoff[v]) = (int16_t)q;
-                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + (ml.zoff[v] >> 1)] = (int16_t)q;
+                // see the chroma loop below for the arithmetic; yacc already holds acc + (2 << 12)
+                const int q = mad24_ms(yacc[v] >> 31, qneg, yacc[v]) >> (16 + Q);
+                *(int16_t *)((uint8_t *)&s_zig[0][0] + zo[v]) = (int16_t)q;
+                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + (zo[v] >> 1)] = (int16_t)q;
                 nzor |= q;
                 if (need_rec) {
-                    const int sgn = q < -1 ? -1 : q > 1 ? 1 : q;
-                    int x = (2 * q + sgn) << Q;
-                    x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
+                    int x = (2 * q + sign_of(q)) << Q;
+                    x = clamp_vv(x, kn2047, k2047);
                     xrow[v * 8] = (int16_t)x;
                 }
             }
             // coded flags of the four tiles: tile 2 ty + tx lives in lanes 32 ty + 16 h + 8 tx + (0 .. 7), h = 0, 1
             const unsigned long long nzm = ballot(nzor != 0);
-            const uint32_t lo = (uint32_t)nzm, hi = (uint32_t)(nzm >> 32);
-            cbp = ((lo & 0x00FF00FFu) ? 8 : 0) | ((lo & 0xFF00FF00u) ? 4 : 0) | ((hi & 0x00FF00FFu) ? 2 : 0) | ((hi & 0xFF00FF00u) ? 1 : 0);
+            const uint32_t lo = (uint32_t)sgpr((int)(uint32_t)nzm), hi = (uint32_t)sgpr((int)(uint32_t)(nzm >> 32));
+            cbp = ((lo & 0x00FF00FFu) ? 8 : 0) | ((lo & 0xFF00FF00u) ? 4 : 0) | ((hi & 0x00FF00FFu) ? 2 : 0) | (int)umin32(hi & 0xFF00FF00u, 1u);
         }
 #pragma unroll
         for (int t = kT0; t < 6; ++t) {
-            int acc = mad24_s(bi[0], s_t[t][dj], 2048);   // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12
+            int acc = mad24_s(bi[0], s_t[t][dj], kRound);   // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12, and + (2 << 12)
 #pragma unroll
             for (int k = 1; k < 8; ++k) acc = mad24(bi[k], s_t[t][k * 8 + dj], acc);   // |R1| < 2^18
             // RTL:2070: sign(C) * min((|C| + 2) >> s, 2047) with C = acc >> 12 and s = 4 + Q, computed on the signed value:
@@ -943,14 +1001,14 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             // ((acc >> 12) + k) >> s = (acc + (k << 12)) >> (12 + s).  The clamp cannot bind on this path: the basis rows
             // sum to at most 512 in magnitude, so |C| <= (255 * 512 * 512 + 2048) >> 12 = 16320 and |q| <= 16322 >> 5 = 510
             // (tests/test_host_logic.py::test_inter_quantiser_never_reaches_its_clamp).
-            const int sg = acc >> 31;                   // 0 / -1: C has the sign of acc
-            const int q = (acc + (2 << 12) + (sg & qneg)) >> (16 + Q);
+            // The "+ 2" rides in the accumulator, so the sign taken is that of C + 2, not of C: they differ for C = -2, -1,
+            // where both formulas give 0 (s >= 4).  sign mask * (-bias) + acc is one v_mad_i32_i24.
+            const int q = mad24_ms(acc >> 31, qneg, acc) >> (16 + Q);
             s_zig[t][zz] = (int16_t)q;
             if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
             cbp = (cbp << 1) | (int)any_lane(q != 0);
             if (need_rec) {                             // RTL:2134-2137: (2q + sign(q)) << Q, clamped to +-2047
-                const int sgn = q < -1 ? -1 : q > 1 ? 1 : q;          // v_med3_i32
-                int x = (2 * q + sgn) << Q;
+                int x = (2 * q + sign_of(q)) << Q;
                 if constexpr (CONF) {
                     // ISO 7.4.2.3 gives the same product; saturation to [-2048, 2047] (7.4.3), mismatch control (7.4.4);
                     // a block without coefficients is not reconstructed at all
@@ -959,30 +1017,33 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     const bool even = (__popcll(ballot(x & 1)) & 1) == 0;
                     if (coded && even && lane == 63) x ^= 1;
                 } else {
-                    x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
+                    x = clamp_vv(x, kn2047, k2047);
                 }
                 s_x[t][lane] = (int16_t)x;
             }
         }
     } else {
+        if constexpr (P) { wq = c_intra_w[lane]; wrecip = c_intra_recip[lane]; }
         const uint32_t qoff = __umul24((uint32_t)wq, (3u << Q) + 2u) >> 3;
         if constexpr (kMfmaLuma) {
-            const MfmaLane ml = c_mfma[lane];
+            const uint4 zoff = *(const uint4 *)&c_mfma[lane].zoff[0];
+            const uint32_t zo[4] = {zoff.x, zoff.y, zoff.z, zoff.w};
+            const MfmaLaneIntra ml = c_mfma_intra[lane];
             int16_t *const xrow = &s_x[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int wv = (int)((ml.wq >> (8 * v)) & 255u);
                 const uint32_t qo = __umul24((uint32_t)wv, (3u << Q) + 2u) >> 3;
                 const bool is_dc = v == 0 && (lane & 0x17) == 0;           // row 0 of a tile (g even, v = 0), column 0 of a tile
-                const int C = (yacc[v] + 2048) >> 12;
+                const int C = (yacc[v] >> 12) - 2;             // yacc carries kRound = 2048 + 2 * 4096
                 const int sg = C >> 31;
                 uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
                 if (!is_dc) a = __umul24((a + qo) >> Q, ml.recip[v]) >> 21;
                 else        a = (a + 8u) >> 4;
                 if (a > 2047u) a = 2047u;
                 const int q = (int)(a ^ (uint32_t)sg) - sg;
-                *(int16_t *)((uint8_t *)&s_zig[0][0] + ml.zoff[v]) = (int16_t)q;
-                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + (ml.zoff[v] >> 1)] = (int16_t)q;
+                *(int16_t *)((uint8_t *)&s_zig[0][0] + zo[v]) = (int16_t)q;
+                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + (zo[v] >> 1)] = (int16_t)q;
                 if (need_rec) {
                     int x;
                     if (!is_dc) {
@@ -1117,6 +1178,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             if (lane < kSmallSlotWords) slots_small[mbidx * kSmallSlotWords + lane] = s_bits[lane];
         } else {
             uint32_t *slot = slots + mbidx * kSlotWords;
+#pragma unroll 1
             for (uint32_t k = lane; k < nwords; k += 64) slot[k] = s_bits[k];
         }
         if (lane == 0) {

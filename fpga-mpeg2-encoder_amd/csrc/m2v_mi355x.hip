@@ -242,26 +242,36 @@ void upload_tables_now()
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_intra_recip), recip, sizeof recip));
     // per-lane operands of the DCT-as-GEMM variant (k_mb<.., MFMA = true>, see MfmaLane)
     MfmaLane ml[64];
+    MfmaLaneIntra mi[64];
     for (int lane = 0; lane < 64; ++lane) {
         const int g = lane >> 4, c = lane & 15;
         MfmaLane &m = ml[lane];
+        MfmaLaneIntra &n = mi[lane];
         memset(&m, 0, sizeof m);
+        memset(&n, 0, sizeof n);
         if ((c >> 3) == (g & 1))
             for (int b = 0; b < 8; ++b) {
                 const int8_t w = (int8_t)(g < 2 ? kDctBasis[(c & 7) * 8 + b] : -kDctBasis[(c & 7) * 8 + b]);
                 m.b1[b >> 2] |= (uint32_t)(uint8_t)w << (8 * (b & 3));
             }
         if ((c >> 3) == (g >> 1))
-            for (int b = 0; b < 4; ++b) m.a2 |= (uint32_t)(uint8_t)kDctBasis[(c & 7) * 8 + 4 * (g & 1) + b] << (8 * b);
+            for (int b = 0; b < 4; ++b) m.a2[0] |= (uint32_t)(uint8_t)kDctBasis[(c & 7) * 8 + 4 * (g & 1) + b] << (8 * b);
+        m.a2[3] = m.a2[0];
         const int tile = ((g >> 1) << 1) | (c >> 3);
         for (int v = 0; v < 4; ++v) {
             const int raster = (4 * (g & 1) + v) * 8 + (c & 7);
             m.zoff[v] = (uint32_t)(tile * 128 + kZigzagPos[raster] * 2);
-            m.wq |= (uint32_t)kIntraW[raster] << (8 * v);
-            m.recip[v] = recip[raster];
+            n.wq |= (uint32_t)kIntraW[raster] << (8 * v);
+            n.recip[v] = recip[raster];
         }
+        // search lane = (dy' = lane >> 2, dx group = lane & 3), candidate j has dx = 4 * group - 8 + j
+        const uint32_t cbase = 255u - (uint32_t)(((lane >> 2) << 4) | (4 * (lane & 3)));
+        m.cb4 = cbase | ((cbase - 1u) << 8) | ((cbase - 2u) << 16) | ((cbase - 3u) << 24);
+        m.dead_lo = (lane & 3) == 0 ? 0xFFFFFFFFu : 0u;          // dx = -8, -7
+        m.dead_hi = (lane & 3) == 3 ? 0xFFFF0000u : 0u;          // dx = +7
     }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma), ml, sizeof ml));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma_intra), mi, sizeof mi));
     HIPCHK(hipDeviceSynchronize());         // the copies read stack arrays: complete before they go out of scope
 }
 

@@ -75,7 +75,8 @@ def test_inter_quantiser_never_reaches_its_clamp():
     """The kernel's non-intra quantiser works on the accumulator acc = sum + 2048 directly,
     q = (acc + (2 << 12) + (acc < 0 ? (2^s - 5) << 12 : 0)) >> (12 + s), without the min(.., 2047) of RTL:2070: over the
     whole reachable range |C| <= 16320 (test_dct_coefficient_bound) it equals the RTL's expression, the clamp never binds
-    (|q| <= 510), and sign(q) = med3(q, -1, 1) feeds the inverse quantiser (RTL:2134-2137)."""
+    (|q| <= 510), and sign(q) = med3(q, -1, 1) feeds the inverse quantiser (RTL:2134-2137).  The shipped form carries the
+    (2 << 12) inside the accumulator (t = acc + (2 << 12)) and takes the sign of t instead of the sign of acc."""
     acc = np.arange(-16321 * 4096, 16321 * 4096 + 1, 997, dtype=np.int64)      # every 997th accumulator value ...
     acc = np.concatenate([acc, np.arange(-70000, 70001, dtype=np.int64), np.array([-16320 * 4096, 16320 * 4096 + 4095])])
     C = acc >> 12
@@ -85,6 +86,9 @@ def test_inter_quantiser_never_reaches_its_clamp():
         q_ref = np.where(C < 0, -a, a)
         q_new = (acc + (2 << 12) + np.where(acc < 0, ((1 << s) - 5) << 12, 0)) >> (12 + s)
         assert np.array_equal(q_ref, q_new)
+        t = acc + (2 << 12)
+        q_t = (t + (t >> 63) * -(((1 << s) - 5) << 12)) >> (12 + s)          # sign mask times MINUS the bias, plus t
+        assert np.array_equal(q_ref, q_t)
         assert np.abs(q_new).max() <= 510
         x_ref = np.clip((2 * q_ref + np.sign(q_ref)) << Q, -2047, 2047)
         x_new = np.clip((2 * q_new + np.clip(q_new, -1, 1)) << Q, -2047, 2047)

@@ -69,6 +69,10 @@
 #define I_SADA(D)     "v_sad_u8 " #D ", %4, %5, %6\n\t"
 #define I_CNDV(D)     "v_cndmask_b32 " #D ", %4, %5, vcc\n\t"
 #define I_CNDS(D)     "v_cndmask_b32 " #D ", %4, %5, s[20:21]\n\t"
+#define I_CNDV64(D)   "v_cndmask_b32_e64 " #D ", %4, %5, vcc\n\t"
+#define I_CNDVK(D)    "v_cndmask_b32 " #D ", 0, %5, vcc\n\t"
+#define I_CMPCND(D)   "v_cmp_lt_u32 vcc, %4, %5\n\tv_cndmask_b32 " #D ", %4, %5, vcc\n\t"
+#define I_CMPCNDS(D)  "v_cmp_lt_u32 s[20:21], %4, %5\n\tv_cndmask_b32 " #D ", %4, %5, s[20:21]\n\t"
 #define I_CMPV(D)     "v_cmp_lt_u32 vcc, %4, %5\n\t"
 #define I_CMPS(D)     "v_cmp_lt_u32 s[20:21], %4, %5\n\t"
 #define I_DOT2(D)     "v_dot2_i32_i16 " #D ", %4, %5, %6\n\t"
@@ -101,7 +105,7 @@ T(k_add, I_ADD) T(k_and, I_AND) T(k_mov, I_MOV) T(k_movk, I_MOVK) T(k_lshl, I_LS
 T(k_lshladd, I_LSHLADD) T(k_lshlor, I_LSHLOR) T(k_andor, I_ANDOR) T(k_bfeu, I_BFEU) T(k_bfei, I_BFEI) T(k_mad24, I_MAD24)
 T(k_madu24, I_MADU24) T(k_mul24, I_MUL24) T(k_mullo, I_MULLO) T(k_mulhi, I_MULHI) T(k_med3, I_MED3) T(k_maxi, I_MAXI)
 T(k_perm, I_PERM) T(k_align, I_ALIGN) T(k_alignv, I_ALIGNV) T(k_lerp, I_LERP) T(k_sad, I_SAD) T(k_sada, I_SADA)
-T(k_cndv, I_CNDV) T(k_cnds, I_CNDS) T(k_cmpv, I_CMPV) T(k_cmps, I_CMPS) T(k_dot2, I_DOT2) T(k_dot2c, I_DOT2C)
+T(k_cndv, I_CNDV) T(k_cnds, I_CNDS) T(k_cndv64, I_CNDV64) T(k_cndvk, I_CNDVK) T(k_cmpcnd, I_CMPCND) T(k_cmpcnds, I_CMPCNDS) T(k_cmpv, I_CMPV) T(k_cmps, I_CMPS) T(k_dot2, I_DOT2) T(k_dot2c, I_DOT2C)
 T(k_dot4, I_DOT4) T(k_dot4c, I_DOT4C) T(k_pkadd, I_PKADD) T(k_pksub, I_PKSUB) T(k_pkmax, I_PKMAX) T(k_pkmad, I_PKMAD)
 T(k_pkmul, I_PKMUL) T(k_pkashr, I_PKASHR) T(k_sdwa, I_SDWA) T(k_dppadd, I_DPPADD) T(k_dppmov, I_DPPMOV) T(k_dppbc, I_DPPBC)
 T(k_mbcnt, I_MBCNT) T(k_ffbh, I_FFBH) T(k_bcnt, I_BCNT) T(k_xad, I_XAD) T(k_addlshl, I_ADDLSHL)
@@ -189,7 +193,7 @@ int main()
         E(k_add, 32), E(k_and, 32), E(k_mov, 32), E(k_movk, 32), E(k_lshl, 32), E(k_subs, 32), E(k_add3, 32), E(k_lshladd, 32),
         E(k_lshlor, 32), E(k_andor, 32), E(k_bfeu, 32), E(k_bfei, 32), E(k_mad24, 32), E(k_madu24, 32), E(k_mul24, 32), E(k_mullo, 32),
         E(k_mulhi, 32), E(k_med3, 32), E(k_maxi, 32), E(k_perm, 32), E(k_align, 32), E(k_alignv, 32), E(k_lerp, 32), E(k_sad, 32),
-        E(k_sada, 32), E(k_cndv, 32), E(k_cnds, 32), E(k_cmpv, 32), E(k_cmps, 32), E(k_dot2, 32), E(k_dot2c, 32), E(k_dot4, 32),
+        E(k_sada, 32), E(k_cndv, 32), E(k_cnds, 32), E(k_cndv64, 32), E(k_cndvk, 32), E(k_cmpcnd, 64), E(k_cmpcnds, 64), E(k_cmpv, 32), E(k_cmps, 32), E(k_dot2, 32), E(k_dot2c, 32), E(k_dot4, 32),
         E(k_dot4c, 32), E(k_pkadd, 32), E(k_pksub, 32), E(k_pkmax, 32), E(k_pkmad, 32), E(k_pkmul, 32), E(k_pkashr, 32), E(k_sdwa, 32),
         E(k_dppadd, 32), E(k_dppmov, 32), E(k_dppbc, 32), E(k_mbcnt, 32), E(k_ffbh, 32), E(k_bcnt, 32), E(k_xad, 32), E(k_addlshl, 32),
         E(k_sadhi, 32), E(k_bitop3, 32), E(k_swap32, 32), E(k_swap16, 32), E(k_qsad, 32), E(k_mqsad, 32), E(k_lshl64, 32), E(k_lshladd64, 32), E(k_madu64, 32),
