@@ -94,6 +94,11 @@ __device__ uint16_t   d_cbp_code[64];
 __device__ uint16_t   d_dc_code[2][12];
 __device__ uint8_t    d_dc_len[2][12];
 __device__ uint16_t   d_ac_code[32 * 40];
+// The same table for the symbol pass of k_mb, padded so that clamped indices need no range test: [bank][min(run, 32)][min(|level|, 41) - 1],
+// row 32 and column 40 hold 0 (= escape); bank 1 differs in one entry: run 0 / level 1 as the first coefficient of a non-intra
+// block is '1s' instead of '11s' (RTL:2798-2802)
+constexpr int kAcRuns = 33, kAcLevels = 41;
+__device__ uint16_t   d_ac_code2[2 * kAcRuns * kAcLevels];
 __constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for n < 25575 (tests/test_host_logic.py)
 // DCT-as-GEMM variant of stage G (k_mb<.., MFMA = true>): per-lane operands of the matrix-core formulation, lane = (g = lane >> 4,
 // c = lane & 15); register v of a 16x16 accumulator holds block row 4g + v, column c.  Filled by fill_mfma_tables().
@@ -105,8 +110,12 @@ struct MfmaLane {        // 64 bytes: one shift forms the lane's offset, what a 
     // full-pel search (lane = dy' << 2 | dx group, k_mb stage B): position byte of the lane's four candidates,
     // 255 - (dy' << 4 | dx + 8), and the SAD bits that mark the dx slots outside +-6 as dead (VECTOR_LEVEL 3)
     uint32_t cb4, dead_lo, dead_hi;
-    uint32_t pad[3];
+    uint32_t qs_even, qs_odd;   // byte offsets from the luma window to the lane's two ds_read_b64 streams (k_mb stage B, VECTOR_LEVEL 3)
+    uint32_t pad;
 };
+// luma window in LDS (k_mb): row stride in dwords, and the distance in dwords from copy A to copy B (see the LDS map in k_mb)
+constexpr int kWinStride = 12;
+constexpr int win_b_gap(int wrows) { return ((wrows * kWinStride - 32 + 63) / 64) * 64 + 32; }
 struct MfmaLaneIntra {   // the part only intra macroblocks read
     uint32_t wq;         // quantiser weights of this lane's four coefficients (bytes)
     uint32_t recip[4];   // ceil(2^21 / W) of the four coefficients
@@ -475,7 +484,11 @@ __device__ __forceinline__ MbDep mb_dependent(uint32_t info, const MbAux &aux, b
     return d;
 }
 
-constexpr uint32_t SYM_RAW = 0x80000000u;     // symbol list entry: raw = code[23:0], len[28:24]; else level[15:0], zig-zag position[21:16]
+// Symbol list entry, 32 bits.  A level: [15:0] level, [25:20] zig-zag position, everything else 0.  A raw code: [19:0] code,
+// [31:27] its length (never 0: that is how the two kinds are told apart), [26:20] the "position" a following level measures its
+// run from, as a signed 7-bit number: 0 behind an intra DC code (position 0 is the DC), -1 at the start of a non-intra block -
+// whose bit 26 also selects bank 1 of d_ac_code2 for the level right behind it.
+__host__ __device__ constexpr uint32_t sym_raw(uint32_t len, uint32_t code, bool inter_start) { return (len << 27) | (inter_start ? 127u << 20 : 0u) | code; }
 
 // Pass 1 of the coefficient VLC for one coded tile (lane = zig-zag index): rank the non-zero levels, append their
 // {position, level} symbols and the end_of_block code to the macroblock's symbol list; returns the new list length.  The run
@@ -483,7 +496,7 @@ constexpr uint32_t SYM_RAW = 0x80000000u;     // symbol list entry: raw = code[2
 // INTER = non-intra block: every position counts and there is no DC code; intra: position 0 is the DC level, which
 // leaves through `dc` (for Y01 / Y10 / Y11 its differential against `dc_prev` is coded right here, RTL:2784-2786).
 template <bool INTER>
-__device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_t *s_sym, int lane, uint32_t lane16, uint32_t nsym,
+__device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_t *s_sym, int lane, uint32_t lane_pos, uint32_t nsym,
                                                      int &dc, int dc_prev, bool dc_chained)
 {
     const int v = zig[lane];
@@ -492,21 +505,22 @@ __device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_
         dc = __builtin_amdgcn_readlane(v, 0);
         if (dc_chained) {
             const BitCode c = dc_code(dc - dc_prev, 0);
-            if (lane == 0) s_sym[nsym] = SYM_RAW | (c.len << 24) | c.code;
+            if (lane == 0) s_sym[nsym] = sym_raw(c.len, c.code, false);
             nsym += 1u;
         }
     }
     const bool nz = INTER ? v != 0 : (v != 0 && lane > 0);
-    const unsigned long long mask = ballot(nz);
+    // intra: lane 0 (the DC level) is cleared on the scalar side (a ballot of the combined predicate costs two VALU more)
+    const unsigned long long mask = INTER ? ballot(v != 0) : ballot(v != 0) & ~1ull;
     const uint32_t nnz = (uint32_t)__builtin_popcountll(mask);
     const uint32_t eob_at = (uint32_t)sgpr((int)(nsym + nnz));
     if (nz) {
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        *(uint32_t *)((uint8_t *)s_sym + ((rank << 2) + (uint32_t)sgpr((int)(nsym << 2)))) = lane16 | ((uint32_t)v & 0xFFFFu);
+        *(uint32_t *)((uint8_t *)s_sym + ((rank << 2) + (uint32_t)sgpr((int)(nsym << 2)))) = lane_pos | ((uint32_t)v & 0xFFFFu);
         // end_of_block '10' (RTL:2835) behind the last level: every active lane stores the same word to the same address
-        if (INTER) s_sym[eob_at] = SYM_RAW | (2u << 24) | 2u;
+        if (INTER) s_sym[eob_at] = sym_raw(2u, 2u, true);
     }
-    if (!INTER && lane == 0) s_sym[eob_at] = SYM_RAW | (2u << 24) | 2u;     // an intra block may have no AC level at all
+    if (!INTER && lane == 0) s_sym[eob_at] = sym_raw(2u, 2u, false);     // an intra block may have no AC level at all
     return (uint32_t)sgpr((int)(eob_at + 1u));
 }
 
@@ -574,10 +588,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // the 32 lanes of a ds_read_b64 group on 64 different banks.  Both copies sit LAST in R1 and run over into the
     // prediction / residual / transform regions, which are first written after the window's last read (one wavefront:
     // LDS operations execute in program order), so neither the padding nor the copy costs LDS.
-    constexpr int kWS = 12;
+    constexpr int kWS = kWinStride;
     constexpr int kWinBytes = P ? WROWS * kWS * 4 : 0, kCwinBytes = P ? CROWS * 16 : 0;
     constexpr int kOffWin = 2 * kCwinBytes + 256;
-    constexpr int kWinBGap = ((kWinBytes / 4 - 32 + 63) / 64) * 64 + 32;       // dwords from A to B: >= window, = 32 mod 64
+    constexpr int kWinBGap = win_b_gap(WROWS);                                 // dwords from A to B: >= window, = 32 mod 64
     constexpr int kOffWinB = kOffWin + kWinBGap * 4;
     constexpr int kR1 = 1600;
     static_assert(!P || (kOffWin % 8 == 0 && kOffWinB + kWinBytes <= 1600 + 384 + 768 + 1536), "window copies may run over s_pred, s_x, s_t only");
@@ -656,6 +670,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         }
     }
     if (sgpr((int)((job.valid_beats - (g.ysz >> 2)) >> 31))) {    // a frame cut short by i_sequence_stop: wave-uniform, almost never
+        // the empty asm keeps this a scalar branch (flattened, it is a compare and three selects in every macroblock)
+        asm volatile("");
         if ((pix_off >> 2) >= job.valid_beats) {                 // beats after the stop are black (RTL:1036-1056)
             cur4 = 0u; u4 = 0x80808080u; v4 = 0x80808080u;
         }
@@ -699,11 +715,18 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             if (dyi <= 2 * YR && !(kDebug && (g.ablate & 1))) {
                 // the pairs (w0,w1) (w2,w3) start at dword gq, the pairs (w1,w2) (w3,w4) at gq + 1: one of the two is even
                 // in copy A, the other one in copy B (which holds dword j + 1 at index j)
-                const uint32_t *const pe = (gq & 1) ? s_winb + dyi * kWS + gq - 1 : s_win + dyi * kWS + gq;
-                const uint32_t *const po = (gq & 1) ? s_win + dyi * kWS + gq + 1 : s_winb + dyi * kWS + gq;
                 // hand-issued ds_read_b64, one row ahead (left to itself the compiler fuses them into ds_read2_b64,
                 // which runs at half the LDS rate - MI355X_MICROARCH.md, LDS table)
-                const uint32_t ae = (uint32_t)(uintptr_t)(LdsU32 *)pe, ao = (uint32_t)(uintptr_t)(LdsU32 *)po;
+                uint32_t ae, ao;
+                if constexpr (VL == 3) {        // the two stream offsets are lane constants: from the lane table, one add each
+                    ae = (uint32_t)(uintptr_t)(LdsU32 *)s_win + c_mfma[lane].qs_even;
+                    ao = (uint32_t)(uintptr_t)(LdsU32 *)s_win + c_mfma[lane].qs_odd;
+                } else {
+                    const uint32_t *const pe = (gq & 1) ? s_winb + dyi * kWS + gq - 1 : s_win + dyi * kWS + gq;
+                    const uint32_t *const po = (gq & 1) ? s_win + dyi * kWS + gq + 1 : s_winb + dyi * kWS + gq;
+                    ae = (uint32_t)(uintptr_t)(LdsU32 *)pe;
+                    ao = (uint32_t)(uintptr_t)(LdsU32 *)po;
+                }
                 unsigned long long acc = 0;
                 QsadRow ra, rb{};
                 asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %5 offset:8"
@@ -1108,22 +1131,22 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     {
         uint32_t nsym = 0, idxB = 0, idxC = 0;
         int dcs[6] = {0, 0, 0, 0, 0, 0};
-        const uint32_t lane16 = (uint32_t)lane << 16;
+        const uint32_t lane_pos = (uint32_t)lane << 20;
         if (!(kDebug && (g.ablate & 4))) {
             if (inter) {
                 const uint32_t e = d_cbp_code[cbp];
-                if (lane == 0) s_sym[0] = SYM_RAW | ((e >> 8) << 24) | (e & 255u);
-                nsym = 1;
+                if (lane == 0) s_sym[0] = sym_raw(e >> 8, e & 255u, true);
+                nsym = cbp ? 1u : 0u;          // pattern 0 (motion vector only) has no code, and a raw symbol needs a length
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
-                    if ((cbp >> (5 - t)) & 1) nsym = vlc_tile_symbols<true>(s_zig[t], s_sym, lane, lane16, nsym, dcs[t], 0, false);
+                    if ((cbp >> (5 - t)) & 1) nsym = vlc_tile_symbols<true>(s_zig[t], s_sym, lane, lane_pos, nsym, dcs[t], 0, false);
             } else {
-                if (lane == 0) s_sym[-1] = SYM_RAW;             // the symbol "before" the first one: a block start
+                if (lane == 0) s_sym[-1] = sym_raw(1u, 0u, false);  // the symbol "before" the first one: a block start
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
                     if (t == 4) idxB = nsym;
                     if (t == 5) idxC = nsym;
-                    nsym = vlc_tile_symbols<false>(s_zig[t], s_sym, lane, lane16, nsym, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3);
+                    nsym = vlc_tile_symbols<false>(s_zig[t], s_sym, lane, lane_pos, nsym, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3);
                 }
             }
         }
@@ -1137,22 +1160,22 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             uint32_t code = 0, len = 0;
             if (i < nsym) {
                 const uint32_t sym = s_sym[i];
-                if (sym & SYM_RAW) {
-                    code = sym & 0xFFFFFFu;
-                    len = (sym >> 24) & 31u;
+                const uint32_t rawlen = sym >> 27;
+                if (rawlen) {
+                    code = sym & 0xFFFFFu;
+                    len = rawlen;
                 } else {
                     const int v = (int16_t)(sym & 0xFFFFu);
-                    // run = zig-zag positions skipped since the previous level of the block; a raw symbol in front (pattern
-                    // code, DC code or the previous block's end code) is a block start: position -1 (inter) or 0 (intra: DC)
+                    // run = zig-zag positions skipped since the symbol in front: the previous level of the block, or a raw code
+                    // (pattern code, DC code, the previous block's end code) that carries the position a block starts from
                     const uint32_t before = s_sym[(int)i - 1];
-                    const bool first = (before & SYM_RAW) != 0u;
-                    const int prevpos = first ? (inter ? -1 : 0) : (int)((before >> 16) & 63u);
-                    const int run = (int)((sym >> 16) & 63u) - prevpos - 1;
-                    const int a = iabs(v);
-                    uint32_t e = 0;
-                    if (run < 32 && a <= 40) e = d_ac_code[run * 40 + a - 1];
-                    // first coefficient of a non-intra block with level +-1: '1s' instead of '11s' (RTL:2798-2802)
-                    if (inter && first && run == 0 && a == 1) e = (1u << 8) | 1u;
+                    const int run = (int)((sym >> 20) & 63u) - ((int)(before << 5) >> 25) - 1;
+                    const uint32_t a = (uint32_t)iabs(v);
+                    // no range test, no select: clamped indices land on the table's zero row / column, the '1s' rule is bank 1
+                    typedef const __attribute__((address_space(1))) uint16_t *gld16;
+                    const uint32_t idx = __umul24(umin32((uint32_t)run, (uint32_t)kAcRuns - 1u), (uint32_t)kAcLevels) + umin32(a, (uint32_t)kAcLevels) - 1u +
+                                         __umul24((before >> 26) & 1u, (uint32_t)(kAcRuns * kAcLevels));
+                    const uint32_t e = *(gld16)((const uint8_t *)d_ac_code2 + 2u * idx);
                     if (e) {                                 // run/level VLC + sign (RTL:2535-2540)
                         code = ((e & 255u) << 1) | (v < 0 ? 1u : 0u);
                         len = (e >> 8) + 1u;
@@ -1219,17 +1242,19 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             }
         }
         M2V_WAVE_SYNC();
-        uint8_t *recY = job.rec, *recU = recY + g.ysz, *recV = recU + g.csz;
+        // scalar base + 32-bit lane offset (a generic pointer costs a 64-bit vector add per store); V sits csz bytes behind U
+        typedef __attribute__((address_space(1))) uint32_t *gst32;
+        uint8_t *recY = job.rec, *recU = recY + g.ysz;
         {
             const int tile = ((r >> 3) << 1) | (c4 >> 1);
             const uint32_t v = *(const uint32_t *)&s_pred[tile][((r & 7) << 3) | ((c4 & 1) << 2)];
-            *(uint32_t *)(recY + pix_off) = v;
+            *(gst32)(recY + pix_off) = v;
         }
         if (lane < 32) {
             const int pl = lane >> 4, l16 = lane & 15, yc = l16 >> 1, half = l16 & 1;
             const uint32_t v = *(const uint32_t *)&s_pred[4 + pl][(yc << 3) | (half << 2)];
-            uint8_t *dst = pl ? recV : recU;
-            *(uint32_t *)(dst + (uint32_t)(8 * by + yc) * g.cw + 8 * bx + 4 * half) = v;
+            const uint32_t coff = __umul24((uint32_t)(8 * by + yc), (uint32_t)g.cw) + (uint32_t)(8 * bx + 4 * half) + __umul24((uint32_t)pl, (uint32_t)g.csz);
+            *(gst32)(recU + coff) = v;
         }
     }
 }

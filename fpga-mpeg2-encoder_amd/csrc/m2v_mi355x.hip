@@ -237,6 +237,13 @@ void upload_tables_now()
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_dc_code), kDcSizeCode, sizeof kDcSizeCode));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_dc_len), kDcSizeLen, sizeof kDcSizeLen));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_ac_code), kAcCode, sizeof kAcCode));
+    static uint16_t ac2[2 * kAcRuns * kAcLevels];            // static: the copy below is synchronised at the end of this function
+    memset(ac2, 0, sizeof ac2);
+    for (int bank = 0; bank < 2; ++bank)
+        for (int run = 0; run < 32; ++run)
+            for (int lev = 1; lev <= 40; ++lev) ac2[(bank * kAcRuns + run) * kAcLevels + lev - 1] = kAcCode[run * 40 + lev - 1];
+    ac2[kAcRuns * kAcLevels] = (1u << 8) | 1u;               // bank 1, run 0, level 1: '1' + sign
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_ac_code2), ac2, sizeof ac2));
     uint32_t recip[64];
     for (int i = 0; i < 64; ++i) recip[i] = ((1u << 21) + kIntraW[i] - 1u) / kIntraW[i];      // ceil(2^21 / W)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_intra_recip), recip, sizeof recip));
@@ -269,6 +276,11 @@ void upload_tables_now()
         m.cb4 = cbase | ((cbase - 1u) << 8) | ((cbase - 2u) << 16) | ((cbase - 3u) << 24);
         m.dead_lo = (lane & 3) == 0 ? 0xFFFFFFFFu : 0u;          // dx = -8, -7
         m.dead_hi = (lane & 3) == 3 ? 0xFFFF0000u : 0u;          // dx = +7
+        // the reference pairs (w0,w1) (w2,w3) start at dword gq of window row dy', the pairs (w1,w2) (w3,w4) at gq + 1: one of the
+        // two starts is even in copy A, the other in copy B (which holds dword j + 1 at index j); VECTOR_LEVEL 3 geometry
+        const int dyi = lane >> 2, gq = lane & 3, gap = win_b_gap(16 + 4 * 3);
+        m.qs_even = 4u * (uint32_t)((gq & 1) ? gap + dyi * kWinStride + gq - 1 : dyi * kWinStride + gq);
+        m.qs_odd = 4u * (uint32_t)((gq & 1) ? dyi * kWinStride + gq + 1 : gap + dyi * kWinStride + gq);
     }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma), ml, sizeof ml));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma_intra), mi, sizeof mi));
