@@ -107,15 +107,37 @@ struct MfmaLane {        // 64 bytes: one shift forms the lane's offset, what a 
     uint32_t a2[4];      // pass 2 A operand {a, 0, 0, a}: a = basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1,
                          // else 0; the pair {a, 0} multiplies the low dword of a B operand, the pair {0, a} the high dword
     uint32_t zoff[4];    // byte offset of coefficient v inside s_zig: tile * 128 + zigzag position * 2
-    // full-pel search (lane = dy' << 2 | dx group, k_mb stage B): position byte of the lane's four candidates,
-    // 255 - (dy' << 4 | dx + 8), and the SAD bits that mark the dx slots outside +-6 as dead (VECTOR_LEVEL 3)
-    uint32_t cb4, dead_lo, dead_hi;
-    uint32_t qs_even, qs_odd;   // byte offsets from the luma window to the lane's two ds_read_b64 streams (k_mb stage B, VECTOR_LEVEL 3)
-    uint32_t pad;
+    uint32_t pad[6];
 };
 // luma window in LDS (k_mb): row stride in dwords, and the distance in dwords from copy A to copy B (see the LDS map in k_mb)
 constexpr int kWinStride = 12;
 constexpr int win_b_gap(int wrows) { return ((wrows * kWinStride - 32 + 63) / 64) * 64 + 32; }
+
+// VECTOR_LEVEL 3 full-pel search with all 64 lanes at work (k_mb stage B).  13 x 4 lanes own a candidate group (dy', 4 dx) and
+// run macroblock rows 0..12 of it; the other 12 lanes ("helpers", lane = 52 + 4 t + group) look like the lanes of dy' = 13 + t:
+// at step i they read window row 13 + t + i like everybody else, but pair it with macroblock row 13 + i % 3 (step 12: row
+// 13 + t), which is row 13 / 14 / 15 of the group with dy' = t + 3 (i / 3) (step 12: dy' = 12).  So every lane issues 13 x 4
+// v_qsad instead of 16 x 4 by 52 lanes.  A helper never clears its sums: after each triple it stores the running sum, the
+// owner of dy' = t + 3 k adds (sum k) - (sum k - 1); the three step-12 parts of dy' = 12 meet in one ds_add_u64 cell.
+// LDS byte offsets inside k_mb<3, true>'s block, shared with the host-side lane table (static_assert-ed in the kernel):
+constexpr int kS3Cur = 2 * (8 + 2 * 3) * 16;             // current luma rows (behind the two chroma windows)
+constexpr int kS3Win = kS3Cur + 256;                     // luma window, copy A
+constexpr int kS3Scratch = 1600 + 384 + 768 + 1536;      // the level buffer s_zig: unused until the quantiser
+constexpr int kS3Rep = kS3Scratch;                       // macroblock rows 13 14 15 13 14 15 ... (12 x 16 bytes) for the helpers
+constexpr int kS3Flush = kS3Rep + 192;                   // running sums [t][group][k], 8 bytes each
+constexpr int kS3Sum12 = kS3Flush + 3 * 4 * 4 * 8;       // rows 13..15 of dy' = 12, per group
+constexpr int kS3Zero = kS3Sum12 + 4 * 8;                // 8 zero bytes: "sum -1"
+struct SearchLane {      // absolute LDS byte offsets of one lane
+    uint32_t even, odd;  // its two ds_read_b64 streams through the window (k_mb stage B)
+    uint32_t cur, cur12; // macroblock rows of steps 0..11 (+ 16 per step) and of step 12
+    uint32_t plus, minus;// owner: the two running sums it takes its rows 13..15 from; helper: where it stores them / the dy' = 12 cell
+    // position byte of the lane's four candidates, 255 - (dy' << 4 | dx + 8), and the SAD bits that mark the dx slots outside +-6
+    // (and everything in a helper lane) as dead
+    uint32_t cb4, dead_lo, dead_hi;
+    uint32_t pad[7];
+};
+static_assert(sizeof(SearchLane) == 64, "indexed by a shift");
+__constant__ SearchLane c_search[64];
 struct MfmaLaneIntra {   // the part only intra macroblocks read
     uint32_t wq;         // quantiser weights of this lane's four coefficients (bytes)
     uint32_t recip[4];   // ceil(2^21 / W) of the four coefficients
@@ -561,6 +583,42 @@ __device__ __forceinline__ void search_rows(const uint32_t *s_cur, uint32_t ae, 
     }
 }
 
+// The same for VECTOR_LEVEL 3 with the helper lanes (see kS3Cur above): 13 steps, the current row through a per-lane address,
+// the helpers' running sums stored after steps 2, 5, 8, 11 with EXEC narrowed to them (hmask) inside the asm statement.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) u32x4_t *LdsU4;
+typedef const __attribute__((address_space(3))) u32x2_t *LdsU2;
+template <int RR>
+__device__ __forceinline__ void search_rows13(uint32_t cur, uint32_t cur12, uint32_t ae, uint32_t ao, uint32_t flush, unsigned long long hmask,
+                                              unsigned long long &acc, QsadRow &p, QsadRow &q)
+{
+    if constexpr (RR < 13) {
+        if constexpr (RR + 1 < 13) {
+            asm volatile("ds_read_b64 %0, %8 offset:%10\n\tds_read_b64 %1, %9 offset:%10\n\t"
+                         "ds_read_b64 %2, %8 offset:%11\n\tds_read_b64 %3, %9 offset:%11\n\t"
+                         "s_waitcnt lgkmcnt(4)"
+                         : "=&v"(q.w01), "=&v"(q.w12), "=&v"(q.w23), "=&v"(q.w34),
+                           "+v"(p.w01), "+v"(p.w12), "+v"(p.w23), "+v"(p.w34)
+                         : "v"(ae), "v"(ao), "n"((RR + 1) * kWinStride * 4), "n"((RR + 1) * kWinStride * 4 + 8));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p.w01), "+v"(p.w12), "+v"(p.w23), "+v"(p.w34));
+        }
+        const u32x4_t c = RR < 12 ? *(LdsU4)(uintptr_t)(cur + RR * 16) : *(LdsU4)(uintptr_t)cur12;
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w01, c.x, acc);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w12, c.y, acc);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w23, c.z, acc);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w34, c.w, acc);
+        if constexpr (RR == 2 || RR == 5 || RR == 8)
+            asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %1, %0 offset:%3\n\ts_mov_b64 exec, -1"
+                         : : "v"(acc), "v"(flush), "s"(hmask), "n"((RR / 3) * 8) : "memory");
+        if constexpr (RR == 11)      // the last triple; step 12 starts from zero (its parts are summed by ds_add_u64)
+            asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %1, %0 offset:24\n\ts_nop 0\n\tv_mov_b64 %0, 0\n\ts_mov_b64 exec, -1"
+                         : "+v"(acc) : "v"(flush), "s"(hmask) : "memory");
+        search_rows13<RR + 1>(cur, cur12, ae, ao, flush, hmask, acc, q, p);
+    }
+}
+
 // CONF = option "conformant" (NOT the reference's behaviour): the reconstruction loop follows
 // ISO/IEC 13818-2 where the RTL deviates from it, so that a standard decoder reproduces the encoder's reference frames
 // exactly (no drift inside a GOP): four-sample average with +2, 4:2:0 chroma vector = mv / 2 toward zero, inverse
@@ -638,6 +696,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     uint32_t u4 = *(gld32)(inU + pix_off);
     uint32_t v4 = *(gld32)(inV + pix_off);
     uint32_t wv[P ? (WROWS * 8 + 63) / 64 : 1], wcu = 0, wcv = 0;
+    SearchLane sl{};                             // the lane's search addresses: loaded with the pixels, one memory round trip
+    if constexpr (P && VL == 3) sl = c_search[lane];
     if constexpr (P) {
         const uint8_t *refY = job.ref, *refU = refY + g.ysz, *refV = refU + g.csz;
         if (bx > 0 && bx < g.mbw - 1 && by > 0 && by < g.mbh - 1) {
@@ -677,6 +737,14 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         }
     }
     s_cur[lane] = cur4;
+    if constexpr (P && VL == 3) {               // full-pel search with helper lanes: their copy of rows 13..15, the zeroed sum cells
+        static_assert(2 * kCwinBytes == kS3Cur && kOffWin == kS3Win && kOffZig == kS3Scratch && kS3Zero + 8 <= kLdsBytes, "c_search holds these offsets");
+        if (lane >= 52) {
+            uint32_t *const rep = (uint32_t *)(lds + kS3Rep) + (lane - 52);
+            rep[0] = cur4; rep[12] = cur4; rep[24] = cur4; rep[36] = cur4;
+        }
+        if (lane < 10) ((uint32_t *)(lds + kS3Sum12))[lane] = 0u;
+    }
     uint32_t cuv;                               // this lane's two 4:2:0 samples of U (bytes 0, 1) and of V (bytes 2, 3); even rows only
     {
         const uint32_t hu = avg2x4(u4, u4 >> 8);          // bytes 0 and 2: horizontal means of the two pixel pairs
@@ -711,27 +779,37 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         {
             uint32_t key = 0xFFFFFFFFu;
             const int dyi = lane >> 2, gq = lane & 3;        // dy = dyi - YR, dx = 4*gq - 8 + j
-            const uint32_t sl_cb4 = c_mfma[lane].cb4, sl_dead_lo = c_mfma[lane].dead_lo, sl_dead_hi = c_mfma[lane].dead_hi;
-            if (dyi <= 2 * YR && !(kDebug && (g.ablate & 1))) {
-                // the pairs (w0,w1) (w2,w3) start at dword gq, the pairs (w1,w2) (w3,w4) at gq + 1: one of the two is even
-                // in copy A, the other one in copy B (which holds dword j + 1 at index j)
-                // hand-issued ds_read_b64, one row ahead (left to itself the compiler fuses them into ds_read2_b64,
-                // which runs at half the LDS rate - MI355X_MICROARCH.md, LDS table)
-                uint32_t ae, ao;
-                if constexpr (VL == 3) {        // the two stream offsets are lane constants: from the lane table, one add each
-                    ae = (uint32_t)(uintptr_t)(LdsU32 *)s_win + c_mfma[lane].qs_even;
-                    ao = (uint32_t)(uintptr_t)(LdsU32 *)s_win + c_mfma[lane].qs_odd;
-                } else {
-                    const uint32_t *const pe = (gq & 1) ? s_winb + dyi * kWS + gq - 1 : s_win + dyi * kWS + gq;
-                    const uint32_t *const po = (gq & 1) ? s_win + dyi * kWS + gq + 1 : s_winb + dyi * kWS + gq;
-                    ae = (uint32_t)(uintptr_t)(LdsU32 *)pe;
-                    ao = (uint32_t)(uintptr_t)(LdsU32 *)po;
-                }
+            const uint32_t sl_cb4 = sl.cb4, sl_dead_lo = sl.dead_lo, sl_dead_hi = sl.dead_hi;
+            if ((VL == 3 || dyi <= 2 * YR) && !(kDebug && (g.ablate & 1))) {
                 unsigned long long acc = 0;
                 QsadRow ra, rb{};
-                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %5 offset:8"
-                             : "=&v"(ra.w01), "=&v"(ra.w12), "=&v"(ra.w23), "=&v"(ra.w34) : "v"(ae), "v"(ao));
-                search_rows<0, kWS>(s_cur, ae, ao, acc, ra, rb);
+                if constexpr (VL == 3) {
+                    // all 64 lanes, 13 steps (see kS3Cur); every LDS address of the lane comes from the lane table
+                    const uint32_t lds0 = (uint32_t)(uintptr_t)(LdsU32 *)lds;      // 0: the block's only LDS object
+                    const uint32_t ae = lds0 + sl.even, ao = lds0 + sl.odd;
+                    const unsigned long long hmask = 0xFFF0000000000000ull;          // lanes 52..63
+                    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %5 offset:8"
+                                 : "=&v"(ra.w01), "=&v"(ra.w12), "=&v"(ra.w23), "=&v"(ra.w34) : "v"(ae), "v"(ao));
+                    search_rows13<0>(lds0 + sl.cur, lds0 + sl.cur12, ae, ao, lds0 + sl.plus, hmask, acc, ra, rb);
+                    asm volatile("s_mov_b64 exec, %2\n\tds_add_u64 %1, %0\n\ts_mov_b64 exec, -1"
+                                 : : "v"(acc), "v"(lds0 + sl.minus), "s"(hmask) : "memory");
+                    // owner lanes: + rows 13..15 = a difference of two running sums (no field borrows or carries: the sums grow
+                    // monotonically and a complete SAD is at most 65280); the helper lanes compute garbage and are dead below
+                    const u32x2_t sp = *(LdsU2)(uintptr_t)(lds0 + sl.plus), sm = *(LdsU2)(uintptr_t)(lds0 + sl.minus);
+                    const uint32_t lo = (uint32_t)acc + (sp.x - sm.x), hi = (uint32_t)(acc >> 32) + (sp.y - sm.y);
+                    acc = ((unsigned long long)hi << 32) | lo;
+                } else {
+                    // the pairs (w0,w1) (w2,w3) start at dword gq, the pairs (w1,w2) (w3,w4) at gq + 1: one of the two is even
+                    // in copy A, the other one in copy B (which holds dword j + 1 at index j)
+                    // hand-issued ds_read_b64, one row ahead (left to itself the compiler fuses them into ds_read2_b64,
+                    // which runs at half the LDS rate - MI355X_MICROARCH.md, LDS table)
+                    const uint32_t *const pe = (gq & 1) ? s_winb + dyi * kWS + gq - 1 : s_win + dyi * kWS + gq;
+                    const uint32_t *const po = (gq & 1) ? s_win + dyi * kWS + gq + 1 : s_winb + dyi * kWS + gq;
+                    const uint32_t ae = (uint32_t)(uintptr_t)(LdsU32 *)pe, ao = (uint32_t)(uintptr_t)(LdsU32 *)po;
+                    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %5 offset:8"
+                                 : "=&v"(ra.w01), "=&v"(ra.w12), "=&v"(ra.w23), "=&v"(ra.w34) : "v"(ae), "v"(ao));
+                    search_rows<0, kWS>(s_cur, ae, ao, acc, ra, rb);
+                }
                 // minimum SAD; among equals the largest dy, then the largest dx (RTL:1694-1710): key = sad << 8 | (255 - index),
                 // index = dy' << 4 | dx + 8.  A SAD >= 4096 kills a candidate (RTL:1669-1670): such keys are >= 1 << 20 and lose
                 // against every live one, so the test is made once on the reduced key instead of per candidate.

@@ -250,6 +250,7 @@ void upload_tables_now()
     // per-lane operands of the DCT-as-GEMM variant (k_mb<.., MFMA = true>, see MfmaLane)
     MfmaLane ml[64];
     MfmaLaneIntra mi[64];
+    SearchLane sl[64];
     for (int lane = 0; lane < 64; ++lane) {
         const int g = lane >> 4, c = lane & 15;
         MfmaLane &m = ml[lane];
@@ -271,17 +272,33 @@ void upload_tables_now()
             n.wq |= (uint32_t)kIntraW[raster] << (8 * v);
             n.recip[v] = recip[raster];
         }
-        // search lane = (dy' = lane >> 2, dx group = lane & 3), candidate j has dx = 4 * group - 8 + j
-        const uint32_t cbase = 255u - (uint32_t)(((lane >> 2) << 4) | (4 * (lane & 3)));
-        m.cb4 = cbase | ((cbase - 1u) << 8) | ((cbase - 2u) << 16) | ((cbase - 3u) << 24);
-        m.dead_lo = (lane & 3) == 0 ? 0xFFFFFFFFu : 0u;          // dx = -8, -7
-        m.dead_hi = (lane & 3) == 3 ? 0xFFFF0000u : 0u;          // dx = +7
         // the reference pairs (w0,w1) (w2,w3) start at dword gq of window row dy', the pairs (w1,w2) (w3,w4) at gq + 1: one of the
         // two starts is even in copy A, the other in copy B (which holds dword j + 1 at index j); VECTOR_LEVEL 3 geometry
         const int dyi = lane >> 2, gq = lane & 3, gap = win_b_gap(16 + 4 * 3);
-        m.qs_even = 4u * (uint32_t)((gq & 1) ? gap + dyi * kWinStride + gq - 1 : dyi * kWinStride + gq);
-        m.qs_odd = 4u * (uint32_t)((gq & 1) ? dyi * kWinStride + gq + 1 : gap + dyi * kWinStride + gq);
+        SearchLane &q = sl[lane];
+        memset(&q, 0, sizeof q);
+        // candidate j of the lane has dx = 4 gq - 8 + j
+        const uint32_t cbase = 255u - (uint32_t)((dyi << 4) | (4 * gq));
+        q.cb4 = cbase | ((cbase - 1u) << 8) | ((cbase - 2u) << 16) | ((cbase - 3u) << 24);
+        q.dead_lo = lane >= 52 || gq == 0 ? 0xFFFFFFFFu : 0u;                  // dx = -8, -7; lanes 52..63 own no candidates
+        q.dead_hi = lane >= 52 ? 0xFFFFFFFFu : gq == 3 ? 0xFFFF0000u : 0u;     // dx = +7
+        q.even = (uint32_t)kS3Win + 4u * (uint32_t)((gq & 1) ? gap + dyi * kWinStride + gq - 1 : dyi * kWinStride + gq);
+        q.odd = (uint32_t)kS3Win + 4u * (uint32_t)((gq & 1) ? dyi * kWinStride + gq + 1 : gap + dyi * kWinStride + gq);
+        if (dyi <= 12) {                                         // owner of the candidates (dy', 4 gq - 8 .. + 3)
+            const int t = dyi % 3, k = dyi / 3;
+            q.cur = (uint32_t)kS3Cur;
+            q.cur12 = (uint32_t)kS3Cur + 12 * 16;
+            q.plus = dyi < 12 ? (uint32_t)kS3Flush + 8u * (uint32_t)((t * 4 + gq) * 4 + k) : (uint32_t)kS3Sum12 + 8u * (uint32_t)gq;
+            q.minus = dyi < 12 && k > 0 ? q.plus - 8u : (uint32_t)kS3Zero;
+        } else {                                                 // helper t = dy' - 13: rows 13..15 of dy' = t, t + 3, t + 6, t + 9, one row of 12
+            const int t = dyi - 13;
+            q.cur = (uint32_t)kS3Rep;
+            q.cur12 = (uint32_t)kS3Cur + (uint32_t)(13 + t) * 16;
+            q.plus = (uint32_t)kS3Flush + 8u * (uint32_t)((t * 4 + gq) * 4);
+            q.minus = (uint32_t)kS3Sum12 + 8u * (uint32_t)gq;
+        }
     }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_search), sl, sizeof sl));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma), ml, sizeof ml));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma_intra), mi, sizeof mi));
     HIPCHK(hipDeviceSynchronize());         // the copies read stack arrays: complete before they go out of scope
