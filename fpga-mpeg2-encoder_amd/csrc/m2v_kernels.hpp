@@ -114,18 +114,26 @@ constexpr int kWinStride = 12;
 constexpr int win_b_gap(int wrows) { return ((wrows * kWinStride - 32 + 63) / 64) * 64 + 32; }
 
 // VECTOR_LEVEL 3 full-pel search with all 64 lanes at work (k_mb stage B).  13 x 4 lanes own a candidate group (dy', 4 dx) and
-// run macroblock rows 0..12 of it; the other 12 lanes ("helpers", lane = 52 + 4 t + group) look like the lanes of dy' = 13 + t:
+// run macroblock rows 0..12 of it; the other 12 lanes ("helpers") look like the lanes of dy' = 13 + t:
 // at step i they read window row 13 + t + i like everybody else, but pair it with macroblock row 13 + i % 3 (step 12: row
 // 13 + t), which is row 13 / 14 / 15 of the group with dy' = t + 3 (i / 3) (step 12: dy' = 12).  So every lane issues 13 x 4
 // v_qsad instead of 16 x 4 by 52 lanes.  A helper never clears its sums: after each triple it stores the running sum, the
 // owner of dy' = t + 3 k adds (sum k) - (sum k - 1); the three step-12 parts of dy' = 12 meet in one ds_add_u64 cell.
-// LDS byte offsets inside k_mb<3, true>'s block, shared with the host-side lane table (static_assert-ed in the kernel):
+// Lane -> (dy', group): dy' = (lane >> 1) & 15, group = (lane & 1) << 1 | lane >> 5.  A ds_read_b64 is served 32 lanes at a
+// time; with the group's parity in lane bit 5 a half-wave reads one window copy only (A or B, see the LDS map in k_mb) and its
+// 8 x 4 pairs of dwords fall on 64 different banks whatever the distance of the copies (with lane = dy' << 2 | group half of
+// the reads were 2-way conflicted).  LDS byte offsets inside k_mb<3, true>'s block, shared with the host-side lane table
+// (static_assert-ed in the kernel):
+__host__ __device__ constexpr int s3_dy(int lane) { return (lane >> 1) & 15; }
+__host__ __device__ constexpr int s3_group(int lane) { return ((lane & 1) << 1) | (lane >> 5); }
+constexpr unsigned long long kS3Helpers = 0xFC000000FC000000ull;       // the lanes with s3_dy >= 13
 constexpr int kS3Cur = 2 * (8 + 2 * 3) * 16;             // current luma rows (behind the two chroma windows)
 constexpr int kS3Win = kS3Cur + 256;                     // luma window, copy A
 constexpr int kS3Scratch = 1600 + 384 + 768 + 1536;      // the level buffer s_zig: unused until the quantiser
-constexpr int kS3Rep = kS3Scratch;                       // macroblock rows 13 14 15 13 14 15 ... (12 x 16 bytes) for the helpers
-constexpr int kS3Flush = kS3Rep + 192;                   // running sums [t][group][k], 8 bytes each
-constexpr int kS3Sum12 = kS3Flush + 3 * 4 * 4 * 8;       // rows 13..15 of dy' = 12, per group
+constexpr int kS3Flush = kS3Scratch;                     // running sums [t][group][k], 8 bytes each
+constexpr int kS3Rep = kS3Flush + 3 * 4 * 4 * 8;         // macroblock rows 13 14 15 13 14 15 ... (12 x 16 bytes) for the helpers
+static_assert((kS3Rep - kS3Cur) % 256 == 128, "a step reads one row of each in the same instruction: 32 banks apart");
+constexpr int kS3Sum12 = kS3Rep + 192;                   // rows 13..15 of dy' = 12, per group
 constexpr int kS3Zero = kS3Sum12 + 4 * 8;                // 8 zero bytes: "sum -1"
 struct SearchLane {      // absolute LDS byte offsets of one lane
     uint32_t even, odd;  // its two ds_read_b64 streams through the window (k_mb stage B)
@@ -778,7 +786,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         int fy = 0, fx = 0;
         {
             uint32_t key = 0xFFFFFFFFu;
-            const int dyi = lane >> 2, gq = lane & 3;        // dy = dyi - YR, dx = 4*gq - 8 + j
+            // dy = dyi - YR, dx = 4*gq - 8 + j
+            const int dyi = VL == 3 ? s3_dy(lane) : lane >> 2, gq = VL == 3 ? s3_group(lane) : lane & 3;
             const uint32_t sl_cb4 = sl.cb4, sl_dead_lo = sl.dead_lo, sl_dead_hi = sl.dead_hi;
             if ((VL == 3 || dyi <= 2 * YR) && !(kDebug && (g.ablate & 1))) {
                 unsigned long long acc = 0;
@@ -787,7 +796,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     // all 64 lanes, 13 steps (see kS3Cur); every LDS address of the lane comes from the lane table
                     const uint32_t lds0 = (uint32_t)(uintptr_t)(LdsU32 *)lds;      // 0: the block's only LDS object
                     const uint32_t ae = lds0 + sl.even, ao = lds0 + sl.odd;
-                    const unsigned long long hmask = 0xFFF0000000000000ull;          // lanes 52..63
+                    const unsigned long long hmask = kS3Helpers;
                     asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %5 offset:8"
                                  : "=&v"(ra.w01), "=&v"(ra.w12), "=&v"(ra.w23), "=&v"(ra.w34) : "v"(ae), "v"(ao));
                     search_rows13<0>(lds0 + sl.cur, lds0 + sl.cur12, ae, ao, lds0 + sl.plus, hmask, acc, ra, rb);

@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <stdexcept>
 #include <deque>
 #include <exception>
 #include <mutex>
@@ -274,14 +275,15 @@ void upload_tables_now()
         }
         // the reference pairs (w0,w1) (w2,w3) start at dword gq of window row dy', the pairs (w1,w2) (w3,w4) at gq + 1: one of the
         // two starts is even in copy A, the other in copy B (which holds dword j + 1 at index j); VECTOR_LEVEL 3 geometry
-        const int dyi = lane >> 2, gq = lane & 3, gap = win_b_gap(16 + 4 * 3);
+        const int dyi = s3_dy(lane), gq = s3_group(lane), gap = win_b_gap(16 + 4 * 3);
+        if ((int)((kS3Helpers >> lane) & 1u) != (dyi > 12)) throw std::logic_error("kS3Helpers does not match s3_dy");
         SearchLane &q = sl[lane];
         memset(&q, 0, sizeof q);
         // candidate j of the lane has dx = 4 gq - 8 + j
         const uint32_t cbase = 255u - (uint32_t)((dyi << 4) | (4 * gq));
         q.cb4 = cbase | ((cbase - 1u) << 8) | ((cbase - 2u) << 16) | ((cbase - 3u) << 24);
-        q.dead_lo = lane >= 52 || gq == 0 ? 0xFFFFFFFFu : 0u;                  // dx = -8, -7; lanes 52..63 own no candidates
-        q.dead_hi = lane >= 52 ? 0xFFFFFFFFu : gq == 3 ? 0xFFFF0000u : 0u;     // dx = +7
+        q.dead_lo = dyi > 12 || gq == 0 ? 0xFFFFFFFFu : 0u;                    // dx = -8, -7; the helper lanes own no candidates
+        q.dead_hi = dyi > 12 ? 0xFFFFFFFFu : gq == 3 ? 0xFFFF0000u : 0u;       // dx = +7
         q.even = (uint32_t)kS3Win + 4u * (uint32_t)((gq & 1) ? gap + dyi * kWinStride + gq - 1 : dyi * kWinStride + gq);
         q.odd = (uint32_t)kS3Win + 4u * (uint32_t)((gq & 1) ? dyi * kWinStride + gq + 1 : gap + dyi * kWinStride + gq);
         if (dyi <= 12) {                                         // owner of the candidates (dy', 4 gq - 8 .. + 3)
