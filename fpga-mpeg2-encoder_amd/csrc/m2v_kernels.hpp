@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 
 #include "m2v_tables.hpp"
 
@@ -102,12 +103,17 @@ __device__ uint16_t   d_ac_code2[2 * kAcRuns * kAcLevels];
 __constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for n < 25575 (tests/test_host_logic.py)
 // DCT-as-GEMM variant of stage G (k_mb<.., MFMA = true>): per-lane operands of the matrix-core formulation, lane = (g = lane >> 4,
 // c = lane & 15); register v of a 16x16 accumulator holds block row 4g + v, column c.  Filled by fill_mfma_tables().
-struct MfmaLane {        // 64 bytes: one shift forms the lane's offset, what a non-intra macroblock needs comes first
+// Per-lane tables are stored QUAD-MAJOR on the device ([16-byte quad of the row][lane]): the 64 lanes of a dwordx4 load then read
+// 1 KB of consecutive bytes (8 cache lines).  Row-major, every lane of such a load touches its own cache line, and a dozen
+// of those per macroblock kept the vector memory pipe busier than the pixels do (profiles/r02_n_*).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+struct MfmaLane {        // three quads: b1 | a2 | zoff
     uint32_t b1[2];      // pass 1 B operand: +-basis row (c & 7) for the k group that matches c's tile column, else 0
+    uint32_t pad0[2];
     uint32_t a2[4];      // pass 2 A operand {a, 0, 0, a}: a = basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1,
                          // else 0; the pair {a, 0} multiplies the low dword of a B operand, the pair {0, a} the high dword
     uint32_t zoff[4];    // byte offset of coefficient v inside s_zig: tile * 128 + zigzag position * 2
-    uint32_t pad[6];
 };
 // luma window in LDS (k_mb): row stride in dwords, and the distance in dwords from copy A to copy B (see the LDS map in k_mb)
 constexpr int kWinStride = 12;
@@ -142,17 +148,16 @@ struct SearchLane {      // absolute LDS byte offsets of one lane
     // position byte of the lane's four candidates, 255 - (dy' << 4 | dx + 8), and the SAD bits that mark the dx slots outside +-6
     // (and everything in a helper lane) as dead
     uint32_t cb4, dead_lo, dead_hi;
-    uint32_t pad[7];
+    uint32_t pad[3];
 };
-static_assert(sizeof(SearchLane) == 64, "indexed by a shift");
-__constant__ SearchLane c_search[64];
+
 struct MfmaLaneIntra {   // the part only intra macroblocks read
     uint32_t wq;         // quantiser weights of this lane's four coefficients (bytes)
     uint32_t recip[4];   // ceil(2^21 / W) of the four coefficients
     uint32_t pad[3];
 };
-static_assert(sizeof(MfmaLane) == 64 && sizeof(MfmaLaneIntra) == 32, "lane tables are indexed by a shift");
-__constant__ MfmaLane c_mfma[64];
+static_assert(sizeof(MfmaLaneIntra) == 32, "indexed by a shift");
+
 __constant__ MfmaLaneIntra c_mfma_intra[64];
 
 
@@ -214,8 +219,8 @@ __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_
 // 1 if any lane's predicate holds, on the scalar unit
 __device__ __forceinline__ uint32_t any_lane(bool p)
 {
-    const uint32_t n = (uint32_t)sgpr(__builtin_popcountll(ballot(p)));
-    return n < 1u ? n : 1u;
+    const int n = sgpr(__builtin_popcountll(ballot(p)));
+    return (uint32_t)-n >> 31;                  // n > 0 as 0 / 1 without a boolean (see find_min_in_10_values)
 }
 
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -419,19 +424,26 @@ __device__ __forceinline__ void idct_col(const int a[8], int r[8])
     r[7] = (x7 - x1) >> 14;
 }
 
-// 10-way argmin with the RTL's tree tie-breaks (RTL:804-840)
+// 10-way argmin with the RTL's tree tie-breaks (RTL:804-840).  The inputs are wave-uniform, non-negative and < 2^17.
+// Written without booleans: "a < b" is the sign bit of a - b and a selection is a multiply-add, so that the whole tree stays
+// integer arithmetic on the scalar unit (an i1 lives in a lane-mask register pair and turns into v_cndmask + v_readfirstlane
+// as soon as it is needed as a number).
 __device__ __forceinline__ int find_min_in_10_values(const int v[10])
 {
-    const int wi1 = v[1] < v[0], w01 = wi1 ? v[1] : v[0];
-    const int wi3 = v[3] < v[2], w23 = wi3 ? v[3] : v[2];
-    const int wi5 = v[5] < v[4], w45 = wi5 ? v[5] : v[4];
-    const int wi7 = v[7] < v[6], w67 = wi7 ? v[7] : v[6];
-    const int wi9 = v[9] < v[8], w89 = wi9 ? v[9] : v[8];
-    const int xi23 = w23 < w01, x0123 = xi23 ? w23 : w01;
-    const int xi67 = w67 < w45, x4567 = xi67 ? w67 : w45;
-    if (w89 <= x0123 && w89 <= x4567) return 8 + wi9;
-    if (x0123 < x4567) return xi23 ? 2 + wi3 : wi1;
-    return xi67 ? 6 + wi7 : 4 + wi5;
+    auto lt = [](int a, int b) { return (int)((uint32_t)(a - b) >> 31); };      // a < b as 0 / 1
+    auto mn = [](int a, int b) { return a < b ? a : b; };
+    const int wi1 = lt(v[1], v[0]), w01 = mn(v[1], v[0]);
+    const int wi3 = lt(v[3], v[2]), w23 = mn(v[3], v[2]);
+    const int wi5 = lt(v[5], v[4]), w45 = mn(v[5], v[4]);
+    const int wi7 = lt(v[7], v[6]), w67 = mn(v[7], v[6]);
+    const int wi9 = lt(v[9], v[8]), w89 = mn(v[9], v[8]);
+    const int xi23 = lt(w23, w01), x0123 = mn(w23, w01);
+    const int xi67 = lt(w67, w45), x4567 = mn(w67, w45);
+    const int a = wi1 + xi23 * (2 + wi3 - wi1);                  // argmin of 0..3
+    const int b = 4 + wi5 + xi67 * (2 + wi7 - wi5);              // argmin of 4..7
+    const int ab = b + lt(x0123, x4567) * (a - b);
+    const int use89 = (1 - lt(x0123, w89)) & (1 - lt(x4567, w89));   // w89 <= both
+    return sgpr(ab + use89 * (8 + wi9 - ab));
 }
 
 
@@ -561,6 +573,9 @@ __device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_
 // exactly the LDS write -> read ordering the phases need, and the static LDS base keeps every DS offset an immediate.
 // (Measured alternatives: 4 wavefronts per workgroup with per-wave LDS regions -16 %, a seq_cst wavefront fence -14 %.)
 #define M2V_WAVE_SYNC() __syncthreads()
+// -DM2V_DEBUG profiling aid: option "ablate" = n << 8 ends the kernel at stop point n (tools/phase_valu.sh: the counters of the
+// truncated kernels give the instruction count of every phase by difference; output invalid)
+#define M2V_STOP(n) do { if (kDebug && (g.ablate >> 8) == (n)) return; } while (0)
 
 typedef __attribute__((address_space(3))) uint32_t LdsU32;
 struct QsadRow { unsigned long long w01, w12, w23, w34; };    // the four overlapping 8-byte reference operands of one window row
@@ -593,8 +608,6 @@ __device__ __forceinline__ void search_rows(const uint32_t *s_cur, uint32_t ae, 
 
 // The same for VECTOR_LEVEL 3 with the helper lanes (see kS3Cur above): 13 steps, the current row through a per-lane address,
 // the helpers' running sums stored after steps 2, 5, 8, 11 with EXEC narrowed to them (hmask) inside the asm statement.
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) u32x4_t *LdsU4;
 typedef const __attribute__((address_space(3))) u32x2_t *LdsU2;
 template <int RR>
@@ -627,13 +640,47 @@ __device__ __forceinline__ void search_rows13(uint32_t cur, uint32_t cur12, uint
     }
 }
 
+// Everything in k_mb that depends on the lane number alone - pixel / window coordinates, LDS addresses in the tile layouts,
+// the lane's row and column of the transform basis - comes from this table instead of being recomputed by every wavefront
+// (about 60 shifts, masks and adds per macroblock on a vector ALU that is the kernel's bottleneck; a load costs it nothing).
+// Constants that many lanes share (the transform basis rows) stay in their compact tables: per lane they would only multiply
+// the bytes the vector memory pipe has to move.
+// The table of an instantiation k_mb<VL, P> is written by the SAME kernel template (FILL = true: the lambda lane_consts below is
+// its only source), so the values cannot drift from the LDS map they describe.
+struct LaneK {
+    // quads 0..2: requested with the pixels
+    uint32_t win_st;                // LDS address of s_win[(lane >> 3) kWS + (lane & 7)]
+    uint32_t hp;                    // LDS address of s_win[r kWS + c4]: the lane part of the half-pel neighbourhood
+    uint32_t pred_st, cp_st;        // &s_pred[tile][ti], &s_cp[tile][r & 7][(c4 & 1) << 2]
+    uint32_t cpc_st;                // &s_cp[4][r >> 1][2 c4]
+    uint32_t cpred_st, cpc2_st;     // &s_pred[4 + pl][yc << 3 | xc], &s_cp[4 + pl][yc][8 + xc]
+    uint32_t cwin_rd;               // &s_cwin[pl][(yc + UR) * 4]: the lane part of the chroma prediction fetch
+    uint32_t xc4;                   // xc + 4
+    uint32_t cp_rd;                 // &s_cp[0][lane >> 3][0]
+    uint32_t a1;                    // pass-1 A operand of the matrix-core transform
+    uint32_t xrow;                  // &s_x[..] of the lane's first accumulator register
+    // quads 3, 4: requested before the transform
+    uint32_t zz2;                   // 2 * zig-zag position of the lane
+    uint32_t col_rd, col_pred;      // &s_t[t][col], &s_pred[t][col] of the column pass
+    uint32_t crec_rd;               // &s_pred[4 + pl][yc << 3 | half << 2] of the chroma store
+    uint32_t crec_r, crec_c, crec_p;// yc, 4 half, pl
+    uint32_t pad;
+};
+static_assert(sizeof(LaneK) == 80 && sizeof(MfmaLane) == 48 && sizeof(SearchLane) == 48, "whole quads");
+// One block of quads per instantiation k_mb<VL, P>: LaneK (written by the FILL instantiation), then SearchLane and MfmaLane
+// (uploaded by the host, the same in every block).  One block = one scalar base register pair for all of the kernel's lane
+// tables: the base points 4 KB into the block, so that the first eight quads are reached by the load's immediate offset.
+constexpr int kQuadsLaneK = sizeof(LaneK) / 16, kQuadsSearch = sizeof(SearchLane) / 16, kQuadsMfma = sizeof(MfmaLane) / 16;
+constexpr int kQuadSearch0 = kQuadsLaneK, kQuadMfma0 = kQuadSearch0 + kQuadsSearch, kQuadsPerBlock = kQuadMfma0 + kQuadsMfma;
+__device__ u32x4_t d_lanetab[3][2][kQuadsPerBlock][64];
+
 // CONF = option "conformant" (NOT the reference's behaviour): the reconstruction loop follows
 // ISO/IEC 13818-2 where the RTL deviates from it, so that a standard decoder reproduces the encoder's reference frames
 // exactly (no drift inside a GOP): four-sample average with +2, 4:2:0 chroma vector = mv / 2 toward zero, inverse
 // quantiser truncating toward zero with [-2048, 2047] saturation and mismatch control, blocks that are not coded are
 // not reconstructed.  The IDCT needs no change: for in-range coefficients its 18-bit row store never wraps and the
 // +-255 clip gives the same pixel after the final clip to 0..255.  Checked against the oracle's conformant mode.
-template <int VL, bool P, bool CONF = false, bool MFMA = false>
+template <int VL, bool P, bool CONF = false, bool MFMA = false, bool FILL = false>
 __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
                                            Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
                                            uint32_t *__restrict__ slots_small, uint32_t *__restrict__ slots,
@@ -677,6 +724,51 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     int16_t (*const s_zig)[64] = (int16_t (*)[64])(lds + kOffZig);             // quantised levels in zig-zag order
 
     const int lane = threadIdx.x;
+    auto lds_off = [](const void *q) { return (uint32_t)(uintptr_t)(LdsU32 *)q; };     // LDS byte address
+    auto lane_consts = [&]() {
+        LaneK k{};
+        const int r = lane >> 2, c4 = lane & 3;
+        k.win_st = lds_off(&s_win[(lane >> 3) * kWS + (lane & 7)]);
+        k.hp = lds_off(&s_win[r * kWS + c4]);
+        const int tile = ((r >> 3) << 1) | (c4 >> 1), ti = ((r & 7) << 3) | ((c4 & 1) << 2);
+        k.pred_st = lds_off(&s_pred[tile][ti]);
+        k.cp_st = lds_off(&s_cp[tile][r & 7][(c4 & 1) << 2]);
+        k.cpc_st = lds_off(&s_cp[4][r >> 1][2 * c4]);
+        const int pl = lane >> 5, yc = (lane >> 2) & 7, xc = 2 * c4;
+        k.cpred_st = lds_off(&s_pred[4 + pl][(yc << 3) | xc]);
+        k.cpc2_st = lds_off(&s_cp[4 + pl][yc][8 + xc]);
+        k.cwin_rd = lds_off(&s_cwin[0][0] + pl * (CROWS * 4) + (yc + UR) * 4);
+        k.xc4 = (uint32_t)(xc + 4);
+        const int di = lane >> 3;
+        k.cp_rd = lds_off(&s_cp[0][di][0]);
+        const int mg = lane >> 4, mc = lane & 15;
+        k.a1 = lds_off(&s_cp[((mc >> 3) << 1) | (mg & 1)][mc & 7][8 * (mg >> 1)]);
+        k.xrow = lds_off(&s_x[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)]);
+        k.zz2 = 2u * c_zigzag[lane];
+        const int ct = lane < 48 ? lane >> 3 : 5;               // column pass: 48 lanes
+        k.col_rd = lds_off(&s_t[ct][lane & 7]);
+        k.col_pred = lds_off(&s_pred[ct][lane & 7]);
+        const int pl2 = (lane >> 4) & 1, l16 = lane & 15, yc2 = l16 >> 1, half = l16 & 1;     // chroma store: 32 lanes
+        k.crec_rd = lds_off(&s_pred[4 + pl2][(yc2 << 3) | (half << 2)]);
+        k.crec_r = (uint32_t)yc2; k.crec_c = (uint32_t)(4 * half); k.crec_p = (uint32_t)pl2;
+        return k;
+    };
+    if constexpr (FILL) {
+        const LaneK k = lane_consts();
+        for (int q = 0; q < kQuadsLaneK; ++q) d_lanetab[VL - 1][P ? 1 : 0][q][lane] = ((const u32x4_t *)&k)[q];
+        return;
+    }
+    // quad-major tables: ONE scalar base (pinned: the compiler would re-derive the symbol's address with s_getpc at every use),
+    // 1 KB per quad as the load's immediate, 16 * lane in a register
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    typedef const __attribute__((address_space(1))) u32x4_t *gld128;
+    const uint8_t *ltab = (const uint8_t *)&d_lanetab[VL - 1][P ? 1 : 0][4][0];
+    asm volatile("" : "+s"(ltab));
+#define M2V_QUAD(q0, T, member) (*(gld128)(ltab + ((q0) + (int)(offsetof(T, member) / 16) - 4) * 1024 + lane16))
+#define M2V_LANEK4(member) M2V_QUAD(0, LaneK, member)
+    // Requested with the pixels (whose own addresses stay arithmetic: a table value in front of them would put a second memory
+    // round trip before the first load); the last two quads follow before the transform.
+    const u32x4_t kq0 = M2V_LANEK4(win_st), kq1 = M2V_LANEK4(cpc_st), kq2 = M2V_LANEK4(xc4);
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t li = udiv_magic(blk, g.strip_mbs, g.magic_strip);           // which frame of the launch list
     const int fidx = frame_list[li];
@@ -705,7 +797,12 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     uint32_t v4 = *(gld32)(inV + pix_off);
     uint32_t wv[P ? (WROWS * 8 + 63) / 64 : 1], wcu = 0, wcv = 0;
     SearchLane sl{};                             // the lane's search addresses: loaded with the pixels, one memory round trip
-    if constexpr (P && VL == 3) sl = c_search[lane];
+    if constexpr (P && VL == 3) {
+        const u32x4_t s0 = M2V_QUAD(kQuadSearch0, SearchLane, even), s1 = M2V_QUAD(kQuadSearch0, SearchLane, plus);
+        const u32x4_t s2 = M2V_QUAD(kQuadSearch0, SearchLane, dead_hi);
+        sl.even = s0.x; sl.odd = s0.y; sl.cur = s0.z; sl.cur12 = s0.w;
+        sl.plus = s1.x; sl.minus = s1.y; sl.cb4 = s1.z; sl.dead_lo = s1.w; sl.dead_hi = s2.x;
+    }
     if constexpr (P) {
         const uint8_t *refY = job.ref, *refU = refY + g.ysz, *refV = refU + g.csz;
         if (bx > 0 && bx < g.mbw - 1 && by > 0 && by < g.mbh - 1) {
@@ -765,20 +862,37 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 
     int inter = 0, mvx = 0, mvy = 0;
     uint32_t pred4 = 0x80808080u;               // intra prediction (RTL:1894-1903)
+    long mf_b1 = 0, mf_a2lo = 0, mf_a2hi = 0;   // matrix-core operands of the lane (c_mfma), requested with group 3
+    u32x4_t mf_zoff = {0, 0, 0, 0};
+    u32x4_t kq3, kq4;                           // the lane table's last two quads
+#define M2V_REQUEST_G3()                                                                                             \
+    do {                                                                                                             \
+        kq3 = M2V_LANEK4(zz2); kq4 = M2V_LANEK4(crec_r);                                                             \
+        if constexpr (MFMA && !CONF) {                                                                               \
+            const u32x4_t m0 = M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]), m1 = M2V_QUAD(kQuadMfma0, MfmaLane, a2[0]);  \
+            mf_b1 = (long)(((unsigned long long)m0.y << 32) | m0.x);                                                 \
+            mf_a2lo = (long)(((unsigned long long)m1.y << 32) | m1.x); mf_a2hi = (long)(((unsigned long long)m1.w << 32) | m1.z); \
+        }                                                                                                            \
+    } while (0)
+    if constexpr (!P) M2V_REQUEST_G3();
 
     if constexpr (P) {
         // ---- stages X..Z: reference window of recon(f-1) into LDS (RTL:1350-1425, 1612-1629) --
 #pragma unroll
         for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass)
             if ((pass + 1) * 64 <= WROWS * 8 || lane < WROWS * 8 - pass * 64) {
-                s_win[(pass * 8 + (lane >> 3)) * kWS + (lane & 7)] = wv[pass];
-                s_winb[(pass * 8 + (lane >> 3)) * kWS + (lane & 7) - 1] = wv[pass];     // column 0 lands in padding
+                // s_win[(pass * 8 + (lane >> 3)) * kWS + (lane & 7)] and the same element of copy B, one dword to the left
+                // (column 0 lands in padding): the lane's address from the table, everything else an immediate
+                typedef __attribute__((address_space(3))) uint32_t *LdsW;
+                *(LdsW)(uintptr_t)(kq0.x + (uint32_t)(pass * 8 * kWS * 4)) = wv[pass];
+                *(LdsW)(uintptr_t)(kq0.x + (uint32_t)(pass * 8 * kWS * 4 + kWinBGap * 4 - 4)) = wv[pass];
             }
         if (lane < CROWS * 4) {
             s_cwin[0][lane] = wcu;
             s_cwin[1][lane] = wcv;
         }
         M2V_WAVE_SYNC();
+        M2V_STOP(1);        // loads, chroma subsampling, window staging
 
         // ---- full-pel search: (2YR+1)^2 SADs (RTL:1634-1715) ---------------------------------
         // lane = (dy, group of 4 consecutive dx); v_qsad_pk_u16_u8 slides the 4 current pixels
@@ -859,6 +973,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             fx = sgpr(fx);
         }
 
+        M2V_STOP(2);        // ... up to the full-pel search
+        M2V_REQUEST_G3();                                       // requested here, used in stage G
         // ---- half-pel refinement + intra cost (RTL:1743-1816), four pixels per lane, packed bytes ----
         // T[y][x] = window[y+fy+YR][x+fx+8]; L/C/R = T[.][x-1 .. x+2], T[.][x .. x+3], T[.][x+1 .. x+4]
         uint32_t L0, C0, R0, L1, C1, R1, L2, C2, R2;
@@ -870,7 +986,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             // (RTL:1757-1760), and so does the third dword of a row when it is the padding dword 8.
             const int kx = 7 + fx;                             // 1 .. 13
             const uint32_t sft = (uint32_t)kx & 3u;
-            const uint32_t *const pw = s_win + (r * kWS + c4) + sgpr((fy + YR) * kWS + (kx >> 2));
+            const uint32_t *const pw = (const uint32_t *)(LdsU32 *)(uintptr_t)(kq0.y + 4u * (uint32_t)sgpr((fy + YR) * kWS + (kx >> 2)));
 #define M2V_ROW3(OFF, L, C, R)                                                                  \
             {                                                                                   \
                 const uint32_t a0 = pw[(OFF)], a1 = pw[(OFF) + 1], a2 = pw[(OFF) + 2];          \
@@ -922,7 +1038,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             const uint32_t S2 = (S + (t8d >> 16)) & 0xFFFFu;
             v10[9] = (S2 >> 12) == 0 ? (int)S2 : 0xFFF;
         }
-        const int idx = uniform(find_min_in_10_values(v10));
+        const int idx = find_min_in_10_values(v10);
         inter = idx != 9;
         int hy = 0, hx = 0;
         if (inter) {
@@ -948,22 +1064,24 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // 1980-2014).  The 9-bit residual c - p is never formed: stage G needs only sum_k M[j][k] (c_k - p_k), which is
     // sum_k M[j][k] (c_k - 128) + sum_k (-M[j][k]) (p_k - 128), two v_dot4_i32_i8 chains on the bytes XOR 0x80.
     // s_cp[tile][row] = 8 current bytes, then 8 prediction bytes: one 16-byte LDS read per tile row in stage G.
+    typedef __attribute__((address_space(3))) uint32_t *LdsW32;
+    typedef __attribute__((address_space(3))) uint16_t *LdsW16;
     {
-        const int tile = ((r >> 3) << 1) | (c4 >> 1), ti = ((r & 7) << 3) | ((c4 & 1) << 2);
-        *(uint32_t *)&s_pred[tile][ti] = pred4;
-        *(uint32_t *)&s_cp[tile][r & 7][(c4 & 1) << 2] = cur4 ^ 0x80808080u;
-        *(uint32_t *)&s_cp[tile][r & 7][8 + ((c4 & 1) << 2)] = pred4 ^ 0x80808080u;
+        // tile = ((r >> 3) << 1) | (c4 >> 1), ti = ((r & 7) << 3) | ((c4 & 1) << 2)
+        *(LdsW32)(uintptr_t)kq0.z = pred4;                                   // s_pred[tile][ti]
+        *(LdsW32)(uintptr_t)kq0.w = cur4 ^ 0x80808080u;                      // s_cp[tile][r & 7][(c4 & 1) << 2]
+        *(LdsW32)(uintptr_t)(kq0.w + 8u) = pred4 ^ 0x80808080u;              // ... [8 + ((c4 & 1) << 2)]
     }
-    if (!(r & 1)) {
+    if (!(lane & 4)) {
         // the 4:2:0 samples of the current macroblock: even-row lanes own (r >> 1, 2 c4 .. 2 c4 + 1) of U and of V
         const uint32_t cs = cuv ^ 0x80808080u;
-        *(uint16_t *)&s_cp[4][r >> 1][2 * c4] = (uint16_t)cs;
-        *(uint16_t *)&s_cp[5][r >> 1][2 * c4] = (uint16_t)(cs >> 16);
+        *(LdsW16)(uintptr_t)kq1.x = (uint16_t)cs;                            // s_cp[4][r >> 1][2 * c4]
+        *(LdsW16)(uintptr_t)(kq1.x + 128u) = (uint16_t)(cs >> 16);           // s_cp[5][..]
     }
     {
         // chroma prediction: integer part mv>>2 (floor), half flag = bit 1 of mv (RTL:1854-1887, 1904-1916).  Every lane owns
         // two samples (yc, xc .. xc + 1) of ONE plane - lanes 0-31 U, lanes 32-63 V - so both planes are predicted at once.
-        const int pl = lane >> 5, yc = (lane >> 2) & 7, xc = 2 * c4;
+        // pl = lane >> 5, yc = (lane >> 2) & 7, xc = 2 * c4
         uint32_t pr = 0x8080u;                          // two packed prediction bytes
         if constexpr (P) {
             if (inter) {
@@ -973,10 +1091,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 // col .. col+2 are needed, col <= 13: the fourth byte fetched may belong to the next row, it is never used.
                 // Row row + 1 is only used with a vertical half sample, and then cyi <= UR - 1: it stays inside the window
                 // (without one the fetch below may reach one row past it - inside this kernel's LDS, value unused).
-                const int row = yc + cyi + UR, col = xc + cxi + 4;
-                const int wi = col >> 2;
-                const uint32_t sft = (uint32_t)col & 3u;
-                const uint32_t *const cw = &s_cwin[0][0] + pl * (CROWS * 4) + row * 4 + wi;
+                // row = yc + cyi + UR, col = xc + cxi + 4: the lane parts (plane, yc + UR; xc + 4) from the table
+                const uint32_t col = kq2.x + (uint32_t)cxi;
+                const uint32_t sft = col & 3u;
+                const uint32_t *const cw = (const uint32_t *)(LdsU32 *)(uintptr_t)(kq1.w + (uint32_t)sgpr(cyi * 16) + (col & ~3u));
                 const uint32_t a = __builtin_amdgcn_alignbyte(cw[1], cw[0], sft);      // T[row][col..col+3]
                 const uint32_t c = __builtin_amdgcn_alignbyte(cw[5], cw[4], sft);      // T[row+1][col..]
                 const uint32_t b = a >> 8, d = c >> 8;
@@ -987,13 +1105,15 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 pr &= 0xFFFFu;
             }
         }
-        *(uint16_t *)&s_pred[4 + pl][(yc << 3) | xc] = (uint16_t)pr;
-        *(uint16_t *)&s_cp[4 + pl][yc][8 + xc] = (uint16_t)(pr ^ 0x8080u);
+        *(LdsW16)(uintptr_t)kq1.y = (uint16_t)pr;                              // s_pred[4 + pl][(yc << 3) | xc]
+        *(LdsW16)(uintptr_t)kq1.z = (uint16_t)(pr ^ 0x8080u);                 // s_cp[4 + pl][yc][8 + xc]
     }
     M2V_WAVE_SYNC();
 
+    M2V_STOP(3);            // ... up to the prediction
     // ---- stage G: 2-D forward DCT (RTL:2029-2062); lane = (i = lane>>3, j = lane&7) ------------
-    const int di = lane >> 3, dj = lane & 7;
+    const int dj = lane & 7;
+    const int di = lane >> 3;
     int bi[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bi[k] = c_dct32[di * 8 + k];
@@ -1004,7 +1124,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 #pragma unroll
     for (int t = kT0; t < 6; ++t) {
         // R1[r][j] = sum_k (c[r][k] - p[r][k]) * DCTM[j][k]: 16 bytes of LDS, 4 v_dot4
-        const uint4 xr = *(const uint4 *)&s_cp[t][di][0];
+        const u32x4_t xr = *(LdsU4)(uintptr_t)(kq2.y + (uint32_t)(t * 128));       // s_cp[t][lane >> 3][0 .. 15]
         int acc = dot4_first(xr.x, mj.x);
         acc = __builtin_amdgcn_sdot4((int)xr.y, (int)mj.y, acc, false);
         acc = __builtin_amdgcn_sdot4((int)xr.z, (int)nj.x, acc, false);
@@ -1023,11 +1143,12 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     constexpr int kRound = 2048 + (2 << 12);
     int yacc[4] = {0, 0, 0, 0};
     typedef int v4i_t __attribute__((ext_vector_type(4)));
-    const int mg = lane >> 4, mc = lane & 15;
+    // (matrix-core lane = (g = lane >> 4, c = lane & 15); its LDS slots come from the lane table)
     if constexpr (kMfmaLuma) {
-        const long a1 = *(const long *)&s_cp[((mc >> 3) << 1) | (mg & 1)][mc & 7][8 * (mg >> 1)];
-        const long b1 = *(const long *)&c_mfma[lane].b1[0];
-        const long a2lo = *(const long *)&c_mfma[lane].a2[0], a2hi = *(const long *)&c_mfma[lane].a2[2];
+        // s_cp[((mc >> 3) << 1) | (mg & 1)][mc & 7][8 * (mg >> 1)]
+        const long a1 = *(const __attribute__((address_space(3))) long *)(uintptr_t)kq2.z;
+        const long b1 = mf_b1, a2lo = mf_a2lo, a2hi = mf_a2hi;
+        mf_zoff = M2V_QUAD(kQuadMfma0, MfmaLane, zoff[0]);     // for the quantiser
         const v4i_t zero4 = {0, 0, 0, 0};
         const v4i_t tt = __builtin_amdgcn_mfma_i32_16x16x32_i8(a1, b1, zero4, 0, 0, 0);
         uint32_t e[4];
@@ -1058,13 +1179,16 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     }
     M2V_WAVE_SYNC();
 
+    M2V_STOP(4);            // ... up to the forward transform
     // ---- quantise (RTL:2065-2077), zig-zag + coded flags (RTL:2452-2468), dequantise (RTL:2129-2150)
     // the intra quantiser's lane constants: an I frame loads them up front, a P frame only inside its (rare) intra branch
     int wq = 0;
     uint32_t wrecip = 0;
     if constexpr (!P) { wq = c_intra_w[lane]; wrecip = c_intra_recip[lane]; }
-    const int zz = c_zigzag[lane];
+    const int zz = (int)(kq3.x >> 1);                 // zig-zag position of the lane (the table holds the byte offset in a tile)
     const int Q = g.Q;
+    // group 4 (column pass and chroma store of the reconstruction), requested two phases ahead
+    const uint32_t k4r = kq4.y, k4p = kq4.z;
     const size_t mbidx = (size_t)fidx * g.mbs + mb;
     const bool need_rec = job.rec != nullptr && !(kDebug && (g.ablate & 8));
     int cbp = 0;
@@ -1078,9 +1202,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             // the four luma tiles in accumulator layout: lane (g, c) owns rows 4g .. 4g+3 of column c of the 16x16 block,
             // i.e. four coefficients of tile 2 (g >> 1) + (c >> 3); their s_zig slots come from the lane table, their
             // raster slots in s_x are 16 bytes apart
-            const uint4 zoff = *(const uint4 *)&c_mfma[lane].zoff[0];
-            const uint32_t zo[4] = {zoff.x, zoff.y, zoff.z, zoff.w};
-            int16_t *const xrow = &s_x[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)];
+            const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
+            int16_t *const xrow = (int16_t *)(__attribute__((address_space(3))) int16_t *)(uintptr_t)kq2.w;   // &s_x[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)]
             int nzor = 0;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -1098,7 +1221,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             // coded flags of the four tiles: tile 2 ty + tx lives in lanes 32 ty + 16 h + 8 tx + (0 .. 7), h = 0, 1
             const unsigned long long nzm = ballot(nzor != 0);
             const uint32_t lo = (uint32_t)sgpr((int)(uint32_t)nzm), hi = (uint32_t)sgpr((int)(uint32_t)(nzm >> 32));
-            cbp = ((lo & 0x00FF00FFu) ? 8 : 0) | ((lo & 0xFF00FF00u) ? 4 : 0) | ((hi & 0x00FF00FFu) ? 2 : 0) | (int)umin32(hi & 0xFF00FF00u, 1u);
+            cbp = ((lo & 0x00FF00FFu) ? 8 : 0) | ((lo & 0xFF00FF00u) ? 4 : 0) | ((hi & 0x00FF00FFu) ? 2 : 0) | (int)(((hi & 0xFF00FF00u) | (0u - (hi & 0xFF00FF00u))) >> 31);
         }
 #pragma unroll
         for (int t = kT0; t < 6; ++t) {
@@ -1114,7 +1237,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             // The "+ 2" rides in the accumulator, so the sign taken is that of C + 2, not of C: they differ for C = -2, -1,
             // where both formulas give 0 (s >= 4).  sign mask * (-bias) + acc is one v_mad_i32_i24.
             const int q = mad24_ms(acc >> 31, qneg, acc) >> (16 + Q);
-            s_zig[t][zz] = (int16_t)q;
+            *(LdsW16)(uintptr_t)(lds_off(&s_zig[t][0]) + kq3.x) = (uint16_t)q;      // s_zig[t][zz]
             if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
             cbp = (cbp << 1) | (int)any_lane(q != 0);
             if (need_rec) {                             // RTL:2134-2137: (2q + sign(q)) << Q, clamped to +-2047
@@ -1136,10 +1259,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         if constexpr (P) { wq = c_intra_w[lane]; wrecip = c_intra_recip[lane]; }
         const uint32_t qoff = __umul24((uint32_t)wq, (3u << Q) + 2u) >> 3;
         if constexpr (kMfmaLuma) {
-            const uint4 zoff = *(const uint4 *)&c_mfma[lane].zoff[0];
-            const uint32_t zo[4] = {zoff.x, zoff.y, zoff.z, zoff.w};
+            const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
             const MfmaLaneIntra ml = c_mfma_intra[lane];
-            int16_t *const xrow = &s_x[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)];
+            int16_t *const xrow = (int16_t *)(__attribute__((address_space(3))) int16_t *)(uintptr_t)kq2.w;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int wv = (int)((ml.wq >> (8 * v)) & 255u);
@@ -1179,7 +1301,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             else           a = (a + 8u) >> 4;                                       // (a >> 4) + bit 3, RTL:2074
             if (a > 2047u) a = 2047u;
             const int q = (int)(a ^ (uint32_t)sg) - sg;
-            s_zig[t][zz] = (int16_t)q;
+            *(LdsW16)(uintptr_t)(lds_off(&s_zig[t][0]) + kq3.x) = (uint16_t)q;      // s_zig[t][zz]
             if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
             if (need_rec) {
                 int x;
@@ -1208,6 +1330,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     }
     M2V_WAVE_SYNC();
 
+    M2V_STOP(5);            // ... up to the quantiser / inverse quantiser
     // ---- stage T, coefficient part: run/level VLC of the six tiles (RTL:2777-2847) -----------------
     // Pass 1 (per tile, lane = zig-zag index): ballot the non-zero levels, rank them, and append
     // {run, level} / raw-code symbols to one compact list.  Pass 2 (once per macroblock): table lookup,
@@ -1223,7 +1346,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             if (inter) {
                 const uint32_t e = d_cbp_code[cbp];
                 if (lane == 0) s_sym[0] = sym_raw(e >> 8, e & 255u, true);
-                nsym = cbp ? 1u : 0u;          // pattern 0 (motion vector only) has no code, and a raw symbol needs a length
+                nsym = (uint32_t)-cbp >> 31;   // pattern 0 (motion vector only) has no code, and a raw symbol needs a length
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
                     if ((cbp >> (5 - t)) & 1) nsym = vlc_tile_symbols<true>(s_zig[t], s_sym, lane, lane_pos, nsym, dcs[t], 0, false);
@@ -1303,6 +1426,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         }
     }
 
+    M2V_STOP(6);            // everything but the reconstruction loop
     // ---- stages H..R: Chen-Wang IDCT, reconstruction, store as next reference ------------------
     if (need_rec) {
         M2V_WAVE_SYNC();                                // s_t doubles as the bit buffer that was just copied out
@@ -1317,15 +1441,17 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         }
         M2V_WAVE_SYNC();
         if (lane < 48) {                                // columns: lane = tile*8 + col (RTL:2238-2279)
-            const int t = lane >> 3, col = lane & 7;
+            typedef const __attribute__((address_space(3))) int32_t *LdsI32;
+            typedef __attribute__((address_space(3))) uint8_t *LdsW8;
             int a[8], o[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a[k] = s_t[t][k * 8 + col];
+            for (int k = 0; k < 8; ++k) a[k] = *(LdsI32)(uintptr_t)(kq3.y + (uint32_t)(k * 32));      // s_t[t][k * 8 + col]
             idct_col(a, o);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {               // add_clip_0_255 (RTL:786-795, 2352)
-                const int v = (int)s_pred[t][k * 8 + col] + o[k];
-                s_pred[t][k * 8 + col] = (uint8_t)(v > 255 ? 255 : v < 0 ? 0 : v);
+                LdsW8 const pp = (LdsW8)(uintptr_t)(kq3.z + (uint32_t)(k * 8));                        // s_pred[t][k * 8 + col]
+                const int v = (int)*pp + o[k];
+                *pp = (uint8_t)(v > 255 ? 255 : v < 0 ? 0 : v);
             }
         }
         M2V_WAVE_SYNC();
@@ -1333,14 +1459,15 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         typedef __attribute__((address_space(1))) uint32_t *gst32;
         uint8_t *recY = job.rec, *recU = recY + g.ysz;
         {
-            const int tile = ((r >> 3) << 1) | (c4 >> 1);
-            const uint32_t v = *(const uint32_t *)&s_pred[tile][((r & 7) << 3) | ((c4 & 1) << 2)];
+            const uint32_t v = *(LdsU32 *)(uintptr_t)kq0.z;                  // the lane's four pixels: s_pred[tile][ti] again
             *(gst32)(recY + pix_off) = v;
         }
         if (lane < 32) {
-            const int pl = lane >> 4, l16 = lane & 15, yc = l16 >> 1, half = l16 & 1;
-            const uint32_t v = *(const uint32_t *)&s_pred[4 + pl][(yc << 3) | (half << 2)];
-            const uint32_t coff = __umul24((uint32_t)(8 * by + yc), (uint32_t)g.cw) + (uint32_t)(8 * bx + 4 * half) + __umul24((uint32_t)pl, (uint32_t)g.csz);
+            // pl = lane >> 4, yc = (lane & 15) >> 1, half = lane & 1: s_pred[4 + pl][(yc << 3) | (half << 2)] goes to
+            // (8 by + yc) cw + 8 bx + 4 half + pl csz: two multiply-adds on the table's (yc, 4 half, pl)
+            const uint32_t v = *(LdsU32 *)(uintptr_t)kq3.w;
+            const uint32_t c0 = __umul24(k4p, (uint32_t)g.csz) + (k4r + (uint32_t)sgpr((int)(__umul24((uint32_t)(8 * by), (uint32_t)g.cw) + (uint32_t)(8 * bx))));
+            const uint32_t coff = __umul24(kq4.x, (uint32_t)g.cw) + c0;
             *(gst32)(recU + coff) = v;
         }
     }

@@ -300,10 +300,32 @@ void upload_tables_now()
             q.minus = (uint32_t)kS3Sum12 + 8u * (uint32_t)gq;
         }
     }
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_search), sl, sizeof sl));
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma), ml, sizeof ml));
+    // quad-major on the device (see MfmaLane): [quad][lane][4 dwords]
+    static uint32_t slq[sizeof(SearchLane) / 16][64][4], mlq[sizeof(MfmaLane) / 16][64][4];
+    for (int lane = 0; lane < 64; ++lane) {
+        for (size_t q = 0; q < sizeof(SearchLane) / 16; ++q) memcpy(slq[q][lane], (const uint8_t *)&sl[lane] + 16 * q, 16);
+        for (size_t q = 0; q < sizeof(MfmaLane) / 16; ++q) memcpy(mlq[q][lane], (const uint8_t *)&ml[lane] + 16 * q, 16);
+    }
+    for (int vl = 0; vl < 3; ++vl)
+        for (int pf = 0; pf < 2; ++pf) {
+            const size_t blk = ((size_t)(vl * 2 + pf) * kQuadsPerBlock) * 64 * 16;
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), slq, sizeof slq, blk + (size_t)kQuadSearch0 * 64 * 16));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), mlq, sizeof mlq, blk + (size_t)kQuadMfma0 * 64 * 16));
+        }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma_intra), mi, sizeof mi));
     HIPCHK(hipDeviceSynchronize());         // the copies read stack arrays: complete before they go out of scope
+    // the lane tables d_lanek[VL - 1][P]: every instantiation of the macroblock kernel writes its own (LaneK, FILL = true); they
+    // read the constant tables uploaded above
+    {
+        Geom g0{};
+        const dim3 one(1), wave(64);
+#define M2V_FILL(VLV, PV) hipLaunchKernelGGL((k_mb<VLV, PV, false, false, true>), one, wave, 0, 0, (const FrameJob *)nullptr, (const int *)nullptr, g0, \
+                                             (uint32_t *)nullptr, (MbAux *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int16_t *)nullptr)
+        M2V_FILL(1, false); M2V_FILL(1, true); M2V_FILL(2, false); M2V_FILL(2, true); M2V_FILL(3, false); M2V_FILL(3, true);
+#undef M2V_FILL
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+    }
 }
 
 void upload_tables(int device)
