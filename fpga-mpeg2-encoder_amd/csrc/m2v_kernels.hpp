@@ -1580,24 +1580,32 @@ __device__ inline void write_sequence_headers(uint8_t *p, const Geom &g)
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_assemble: one workgroup per slice, one LANE per 32-bit word of the stream (gather).  A slice is
-// [slice header] then per macroblock p1 A p2 B p3 C, MSB first.  The per-macroblock piece table of the slice
-// (bit offsets from k_slice_scan, the neighbour-dependent codes, the segment lengths) is staged in LDS once;
-// each lane then finds the macroblock that holds the first bit of its word (binary search), walks the
-// macroblocks that overlap the word (1-2 typically) and ORs in the overlapping bits of every piece, reading
-// the stored segments straight from the slot the macroblock kernel wrote (compact or overflow slot - same
-// code).  Slices are byte aligned, not word aligned: only the first and the last word of a slice can be
-// shared with a neighbour (previous slice, headers) and use atomics; everything else is a plain store.
+// k_assemble: one workgroup per slice, one THREAD per macroblock.  A slice is [slice header] then per macroblock
+// p1 A p2 B p3 C, MSB first.  The stored segments of the slice are staged in LDS (only the filled 16-byte chunks of the
+// compact slots are fetched, coalesced); every thread then ORs its macroblock's pieces, shifted to their bit offset
+// (k_slice_scan), into an LDS image of the slice with ds_or; the image goes out with coalesced dword stores.  A slice is
+// byte aligned, not word aligned: only its first and last word can be shared with a neighbour (previous slice,
+// headers) and use atomics.  Slices longer than the 16 KB image take several passes over it.
+// (Round 1-2 had one thread per OUTPUT word, which finds its macroblocks by binary search and looks at all six
+// pieces of each: 385 vector instructions per output word, 57 us per 90 frames; this form needs about a sixth.)
 // ----------------------------------------------------------------------------------------------
-// bits of a left-aligned 32-bit code `c32` (length l) placed at bit offset `o`, seen through the window [r0, r0+32)
-__device__ __forceinline__ uint32_t window_code(uint32_t c32, int l, int o, int r0)
-{
-    const int rel = o - r0;
-    if (l == 0 || rel >= 32 || rel + l <= 0) return 0u;
-    return rel >= 0 ? (c32 >> rel) : (c32 << (-rel));
-}
+constexpr int kAsmThreads = 128;          // >= macroblocks per row (W <= 2048)
+constexpr int kAsmImageWords = 1024;      // 4 KB image: a P-frame slice in one pass, an I-frame slice in a few (LDS bounds the occupancy
+                                          // of this latency-bound kernel: 9 KB per workgroup = 16 workgroups, all 32 wavefronts, per CU)
+constexpr int kAsmStageWords = 1024;      // packed staging of the slice's compact slots (16-byte chunks); what does not fit is read from memory
 
-constexpr int kAsmThreads = 256;
+// OR the low `len` bits of `code` (len <= 32) into the MSB-first image at bit `pos`; words outside [0, nw) are dropped
+__device__ __forceinline__ void asm_put(uint32_t *img, int nw, int pos, uint32_t code, int len)
+{
+    if (len <= 0) return;
+    const int w = pos >> 5;
+    if (w < -1 || w >= nw) return;
+    const int b = (int)(pos & 31);
+    const unsigned long long v = (unsigned long long)code << (64 - len - b);
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    if (w >= 0 && hi) atomicOr(&img[w], hi);
+    if (w + 1 < nw && lo) atomicOr(&img[w + 1], lo);
+}
 
 __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__restrict__ jobs, Geom g, int nframes,
                                                  const MbAux *__restrict__ mbaux, const MbDepRec *__restrict__ mbdep,
@@ -1608,79 +1616,113 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
                                                  int first, int last, const unsigned long long *__restrict__ frame_off,
                                                  const uint32_t *__restrict__ slice_bytes)
 {
-    __shared__ uint32_t s_off[129];                       // bit offset of every macroblock in the slice, [mbw] = slice bits
-    __shared__ uint32_t s_c1[128], s_c2[128], s_c3[128];  // neighbour-dependent codes
-    __shared__ uint32_t s_lens[128];                      // l1 | l2 << 8 | l3 << 16
-    __shared__ uint32_t s_lab[128], s_lc[128];            // lenA | lenB << 16, lenC
+    __shared__ uint32_t s_img[kAsmImageWords];
+    __shared__ uint32_t s_slot[kAsmStageWords];
+    __shared__ uint32_t s_nw[kAsmThreads];                 // stored words of every macroblock (compact slots only)
+    __shared__ uint32_t s_so[kAsmThreads];                 // where its chunks start in s_slot (inclusive scan of the chunk words)
+    __shared__ uint32_t s_total, s_wave0;
+    static_assert(kAsmThreads == 128, "two wavefronts: the scan below");
     const int tid = threadIdx.x;
     const int rows = g.row1 - g.row0;
     const int f = blockIdx.x / rows, by = g.row0 + (int)(blockIdx.x % rows);
     if (f >= nframes) return;
     const size_t base = ((size_t)f * g.mbh + by) * g.mbw;
-    if (tid < g.mbw) {
+    const bool have = tid < g.mbw;
+    uint32_t off = 0, lens = 0, c1 = 0, c2 = 0, c3 = 0;
+    int lenA = 0, lenB = 0, lenC = 0;
+    if (have) {
         const MbAux aux = mbaux[base + tid];
         const MbDepRec dep = mbdep[base + tid];
-        const uint32_t off = mb_bitoff[base + tid];
-        s_off[tid] = off;
-        if (tid == g.mbw - 1) s_off[g.mbw] = off + mb_len[base + tid];
-        s_c1[tid] = dep.c1; s_c2[tid] = dep.c2; s_c3[tid] = dep.c3; s_lens[tid] = dep.lens;
-        s_lab[tid] = aux.w0; s_lc[tid] = aux.w1 & 0xFFFFu;
+        off = mb_bitoff[base + tid];
+        lenA = (int)(aux.w0 & 0xFFFFu); lenB = (int)(aux.w0 >> 16); lenC = (int)(aux.w1 & 0xFFFFu);
+        c1 = dep.c1; c2 = dep.c2; c3 = dep.c3; lens = dep.lens;
+        if (tid == g.mbw - 1) s_total = off + mb_len[base + tid];
     }
+    const uint32_t nwords = (uint32_t)(lenA + lenB + lenC + 31) >> 5;
+    const bool small = nwords <= (uint32_t)kSmallSlotWords;
+    s_nw[tid] = have && small ? nwords : 0u;
+    // inclusive scan of the staged words: inside each wavefront by DPP, the first wavefront's total through LDS
+    const uint32_t scan = (uint32_t)wave_scan_incl((int)(have && small ? (nwords + 3u) & ~3u : 0u));
+    if (tid == 63) s_wave0 = scan;
     const unsigned long long q = (ctl->base_bytes + slice_off[(size_t)f * g.mbh + by]) * 8ull;
     const bool overflow = ctl->overflow != 0;
     __syncthreads();
     if (overflow) return;
+    s_so[tid] = scan + (tid >= 64 ? s_wave0 : 0u);
+    __syncthreads();
+    // stage the compact slots: up to 8 chunks of 16 bytes per macroblock, only the filled ones, packed.  All loads of a
+    // thread are issued before the first LDS store (one memory round trip, not one per chunk).
+    {
+        constexpr int kIter = kAsmThreads * (kSmallSlotWords / 4) / kAsmThreads;          // 8: 128 macroblocks x 8 chunks / 128 threads
+        uint4 v[kIter];
+        uint32_t dst[kIter];
+#pragma unroll
+        for (int i = 0; i < kIter; ++i) {
+            const int idx = tid + i * kAsmThreads, m = idx >> 3, c = idx & 7;
+            const uint32_t nwm = s_nw[m], end = s_so[m];   // end: one past the macroblock's last staged word
+            const bool take = m < g.mbw && (uint32_t)(4 * c) < nwm && end <= (uint32_t)kAsmStageWords;
+            dst[i] = take ? end - ((nwm + 3u) & ~3u) + 4u * (uint32_t)c : 0xFFFFFFFFu;
+            v[i] = take ? *(const uint4 *)(slots_small + (base + m) * kSmallSlotWords + 4 * c) : uint4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < kIter; ++i)
+            if (dst[i] != 0xFFFFFFFFu) {
+                uint32_t *d = &s_slot[dst[i]];
+                d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+            }
+    }
     const int sh = (int)(q & 31ull);
     const unsigned long long w0 = q >> 5;
-    const uint32_t total = s_off[g.mbw];
+    const uint32_t total = s_total;
     const uint32_t nout = ((uint32_t)sh + total + 31u) / 32u;
+    // this thread's segments: staged, or in memory (the overflow slot, or a compact slot that found no room in the staging)
+    const bool staged = small && s_so[tid] <= (uint32_t)kAsmStageWords;
+    const uint32_t *const big = small ? slots_small + (base + tid) * kSmallSlotWords : slots + (base + tid) * kSlotWords;
+    const uint32_t *const stg = &s_slot[staged ? s_so[tid] - ((nwords + 3u) & ~3u) : 0u];
+    const int l1 = (int)(lens & 255u), l2 = (int)((lens >> 8) & 255u), l3 = (int)((lens >> 16) & 255u);
 
-    for (uint32_t k = tid; k < nout; k += kAsmThreads) {
-        const int r0 = 32 * (int)k - sh;                  // this word as a window in slice bit coordinates
-        const uint32_t p = r0 < 0 ? 0u : (uint32_t)r0;
-        int lo = 0, hi = g.mbw - 1;                       // largest m with s_off[m] <= p
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (s_off[mid] <= p) lo = mid; else hi = mid - 1;
-        }
-        uint32_t word = 0;
-        for (int m = lo; m < g.mbw && (int)s_off[m] < r0 + 32; ++m) {
-            const int r = r0 - (int)s_off[m];             // window start relative to the first bit of macroblock m
-            const uint32_t lens = s_lens[m], lab = s_lab[m];
-            const int l1 = (int)(lens & 255u), l2 = (int)((lens >> 8) & 255u), l3 = (int)((lens >> 16) & 255u);
-            const int lenA = (int)(lab & 0xFFFFu), lenB = (int)(lab >> 16), lenC = (int)s_lc[m];
-            int o1 = 0;
-            if (m == 0) {
+    for (uint32_t c0 = 0; c0 < nout; c0 += kAsmImageWords) {
+        const int nw = (int)(nout - c0 < (uint32_t)kAsmImageWords ? nout - c0 : (uint32_t)kAsmImageWords);
+        for (int k = tid; k < nw; k += kAsmThreads) s_img[k] = 0u;
+        __syncthreads();                                   // image cleared, slots staged
+        if (have) {
+            int pos = sh + (int)off - 32 * (int)c0;        // this macroblock's first bit in the image (a slice is < 2^21 bits)
+            if (tid == 0) {
                 // slice header: start code, slice_vertical_position, quantiser_scale_code, extra_bit_slice (RTL:2708-2710)
-                word |= window_code(0x000001u << 8, 24, 0, r);
-                word |= window_code((((uint32_t)(by + 1) << 6) | (2u << g.Q)) << 18, 14, 24, r);
-                o1 = 38;
+                asm_put(s_img, nw, pos, 0x000001u, 24);
+                asm_put(s_img, nw, pos + 24, ((uint32_t)(by + 1) << 6) | (2u << g.Q), 14);
+                pos += 38;
             }
-            const int oA = o1 + l1, o2 = oA + lenA, oB = o2 + l2, o3 = oB + lenB, oC = o3 + l3;
-            word |= window_code(l1 ? s_c1[m] << (32 - l1) : 0u, l1, o1, r);
-            word |= window_code(l2 ? s_c2[m] << (32 - l2) : 0u, l2, o2, r);
-            word |= window_code(l3 ? s_c3[m] << (32 - l3) : 0u, l3, o3, r);
-            const bool small = ((uint32_t)(lenA + lenB + lenC + 31) >> 5) <= (uint32_t)kSmallSlotWords;
-            const uint32_t *slot = small ? slots_small + (base + m) * kSmallSlotWords : slots + (base + m) * kSlotWords;
-            const int segoff[3] = {oA, oB, oC}, seglen[3] = {lenA, lenB, lenC}, segsrc[3] = {0, lenA, lenA + lenB};
+            const uint32_t codes[3] = {c1, c2, c3};
+            const int clen[3] = {l1, l2, l3}, slen[3] = {lenA, lenB, lenC};
+            int src = 0;                                   // bit offset of the segment inside the slot
 #pragma unroll
             for (int sgm = 0; sgm < 3; ++sgm) {
-                const int n = seglen[sgm], t = r - segoff[sgm];           // window start in segment coordinates
-                const int tt = t < 0 ? 0 : t;
-                const int valid = n - tt;                                 // bits of the segment left from tt on
-                if (t > -32 && valid > 0) {
-                    const int src = segsrc[sgm] + tt;
-                    const uint32_t a0 = slot[src >> 5], a1 = slot[(src >> 5) + 1];   // +1: slots are padded by one word
-                    const uint32_t sb = (uint32_t)src & 31u;
-                    uint32_t w = sb ? ((a0 << sb) | (a1 >> (32u - sb))) : a0;
-                    if (valid < 32) w &= ~0u << (32 - valid);
-                    word |= t < 0 ? (w >> (-t)) : w;
+                asm_put(s_img, nw, pos, codes[sgm], clen[sgm]);
+                pos += clen[sgm];
+                const int n = slen[sgm];
+                // words of the segment that can touch the image: bits [pos, pos + n) against [0, 32 nw)
+                if (n > 0 && pos + n > 0 && pos < 32 * nw) {
+                    for (int b = 0; b < n; b += 32) {
+                        const int sb = src + b, valid = n - b < 32 ? n - b : 32;
+                        const uint32_t a0 = staged ? stg[sb >> 5] : big[sb >> 5];
+                        uint32_t w = a0 << (sb & 31);
+                        if ((sb & 31) && (sb & 31) + valid > 32) w |= (staged ? stg[(sb >> 5) + 1] : big[(sb >> 5) + 1]) >> (32 - (sb & 31));
+                        asm_put(s_img, nw, pos + b, w >> (32 - valid), valid);
+                    }
                 }
+                pos += n;
+                src += n;
             }
         }
-        const uint32_t be = __builtin_bswap32(word);
-        if (k == 0 || k == nout - 1) { if (be) atomicOr(&out32[w0 + k], be); }
-        else out32[w0 + k] = be;
+        __syncthreads();
+        for (int k = tid; k < nw; k += kAsmThreads) {
+            const uint32_t gk = c0 + (uint32_t)k;
+            const uint32_t be = __builtin_bswap32(s_img[k]);
+            if (gk == 0 || gk == nout - 1) { if (be) atomicOr(&out32[w0 + gk], be); }
+            else out32[w0 + gk] = be;
+        }
+        __syncthreads();                                   // the image is reused by the next pass
     }
     // The frame's headers travel with its first slice and the sequence end code with the very last one: plain byte
     // stores by one thread.  A header byte may share a dword with a slice's boundary word; that dword was cleared by
@@ -1717,8 +1759,8 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
                                                      unsigned long long *__restrict__ frame_off, StreamCtl *ctl,
                                                      int advance, uint32_t *__restrict__ out32)
 {
-    __shared__ unsigned long long s_sum[1024];
     __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_wtot[16];
     const int tid = threadIdx.x;
     if (tid == 0) {
         // advance = this chunk continues the stream of the previous one in the same buffer: base = previous total
@@ -1734,22 +1776,45 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
         if (g.strip) return 0ull;
         return (unsigned long long)frame_header_bytes(jobs[f].i_frame) + (first && f == 0 ? kSeqHeaderBytes : 0u);
     };
+    // The thread's first kCached items are fetched in one go (all loads in flight together: this single workgroup is pure
+    // latency) and kept for the second pass; longer lists (more than 8192 slices in a chunk) walk the rest one by one.
+    constexpr int kCached = 8;
+    const int f0 = i0 / rows, r0 = i0 - f0 * rows;
+    uint32_t sbv[kCached], hbv[kCached];
+    {
+        int f = f0, r = r0;
+#pragma unroll
+        for (int j = 0; j < kCached; ++j) {
+            const bool in = i0 + j < i1;
+            sbv[j] = in ? slice_bytes[(size_t)f * g.mbh + g.row0 + r] : 0u;
+            hbv[j] = in && r == 0 ? (uint32_t)header_bytes(f) : 0u;
+            if (++r == rows) { r = 0; ++f; }
+        }
+    }
     unsigned long long sum = 0;
-    for (int i = i0; i < i1; ++i) {
+#pragma unroll
+    for (int j = 0; j < kCached; ++j) sum += sbv[j] + hbv[j];
+    for (int i = i0 + kCached; i < i1; ++i) {
         const int f = i / rows, r = i - f * rows;
         sum += slice_bytes[(size_t)f * g.mbh + g.row0 + r];
         if (r == 0) sum += header_bytes(f);
     }
-    s_sum[tid] = sum;
+    // block scan on 32 bits (a chunk is < 2^32 bytes: m2v_set_option("batch_frames") caps it): inside a wavefront by DPP,
+    // then the 16 wavefront totals through LDS - one barrier
+    // instead of the twenty of a Hillis-Steele scan over 1024 threads
+    const uint32_t wscan = (uint32_t)wave_scan_incl((int)(uint32_t)sum);
+    if ((tid & 63) == 63) s_wtot[tid >> 6] = wscan;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned long long t = tid >= o ? s_sum[tid - o] : 0ull;
-        __syncthreads();
-        s_sum[tid] += t;
-        __syncthreads();
+    uint32_t before = 0, grand = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t t = s_wtot[w];
+        before += w < (tid >> 6) ? t : 0u;
+        grand += t;
     }
+    const unsigned long long incl = (unsigned long long)(before + wscan);
     // stream length and overflow: every thread derives them from the grand total (thread 1023 publishes them)
-    const unsigned long long base = s_base, all_frames = s_sum[1023];
+    const unsigned long long base = s_base, all_frames = grand;
     unsigned long long total = base + all_frames;
     if (last) {
         total += 4;                                           // sequence_end_code (RTL:2621-2628)
@@ -1761,20 +1826,30 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
     // and headers are byte aligned, not dword aligned): only those boundary dwords have to be cleared beforehand, not
     // the whole stream.  None of them can hold bytes of the previous chunk: at least a 17-byte picture header lies between
     // `base` and the first slice.  The tail (end code + padding of the final 32-byte word) is cleared as a whole.
-    unsigned long long run = s_sum[tid] - sum;
-    for (int i = i0; i < i1; ++i) {
-        const int f = i / rows, r = i - f * rows;
+    unsigned long long run = incl - sum;
+    auto place = [&](int f, int r, uint32_t sb, uint32_t hb) {
         if (r == 0) {
             frame_off[f] = run + (!g.strip && first && f == 0 ? kSeqHeaderBytes : 0u);   // the frame's own headers start here
-            run += header_bytes(f);
+            run += hb;
         }
-        const uint32_t sb = slice_bytes[(size_t)f * g.mbh + g.row0 + r];
         slice_off[(size_t)f * g.mbh + g.row0 + r] = run;
         if (!ov) {
             out32[(base + run) >> 2] = 0u;
             if (sb) out32[(base + run + sb - 1u) >> 2] = 0u;
         }
         run += sb;
+    };
+    {
+        int f = f0, r = r0;
+#pragma unroll
+        for (int j = 0; j < kCached; ++j) {
+            if (i0 + j < i1) place(f, r, sbv[j], hbv[j]);
+            if (++r == rows) { r = 0; ++f; }
+        }
+    }
+    for (int i = i0 + kCached; i < i1; ++i) {
+        const int f = i / rows, r = i - f * rows;
+        place(f, r, slice_bytes[(size_t)f * g.mbh + g.row0 + r], r == 0 ? (uint32_t)header_bytes(f) : 0u);
     }
     __syncthreads();                                          // every thread has read ctl->overflow / cap before they change
     if (tid == 1023) {

@@ -1444,7 +1444,9 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
     if (!e || !name) return M2V_E_PARAM;
     if (!strcmp(name, "batch_frames")) {
         if (value < 1 || e->state != m2v_enc::IDLE) return M2V_E_PARAM;
-        e->batch_frames = (size_t)value;
+        // at most 200: the byte offsets inside one chunk are scanned in 32 bits (k_frame_scan), and 200 frames of the largest
+        // geometry at the worst-case 1216 bytes per macroblock stay below 2^32
+        e->batch_frames = (size_t)(value > 200 ? 200 : value);
         return M2V_OK;
     }
     if (!strcmp(name, "profile")) { e->profile = value != 0; return M2V_OK; }

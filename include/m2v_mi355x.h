@@ -155,7 +155,7 @@ int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t 
                        const unsigned long long *const *frame_off, void *d_out, size_t cap,
                        size_t *out_bytes, void *hip_stream);
 
-/* Options: "batch_frames" (frames buffered before the GPU is kicked, default 96),
+/* Options: "batch_frames" (frames buffered before the GPU is kicked, default 96, at most 200: larger values are taken as 200),
  * "profile" (1 = time the per-kernel launches with HIP events),
  * "async" (default 1: the port path keeps two chunks in flight - while one chunk is uploaded, encoded and
  * read back, m2v_push_* fills the pinned staging of the next one; 0 = a chunk is complete when the push
