@@ -451,7 +451,10 @@ __device__ __forceinline__ int find_min_in_10_values(const int v[10])
 // VLC helpers shared by k_mb (coefficients) and k_slice_scan / k_assemble (neighbour-dependent codes)
 // ----------------------------------------------------------------------------------------------
 constexpr int kSlotWords = 304;       // per-macroblock bit slot: 3 bit-contiguous segments, <= 9300 bits
-constexpr int kSmallSlotWords = 32;   // macroblocks of <= 1024 stored bits (nearly all) use a compact 128-byte slot instead
+constexpr int kSmallSlotWords = 32;   // macroblocks of <= 1024 stored bits (nearly all) use a compact 128-byte slot instead (64-byte slots were
+                                      // tried: k_assemble touches half the lines for P frames, but most macroblocks of an I frame then sit in
+                                      // the overflow slots, which it reads word by word - no net gain, profiles/r02_v_bench.json)
+constexpr int kSlotChunks = kSmallSlotWords / 4;
 
 struct MbAux {                        // 16 bytes per macroblock next to the uint32 info word
     uint32_t w0;                      // lenA | lenB << 16        (bits)
@@ -1650,15 +1653,15 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
     if (overflow) return;
     s_so[tid] = scan + (tid >= 64 ? s_wave0 : 0u);
     __syncthreads();
-    // stage the compact slots: up to 8 chunks of 16 bytes per macroblock, only the filled ones, packed.  All loads of a
+    // stage the compact slots: up to kSlotChunks chunks of 16 bytes per macroblock, only the filled ones, packed.  All loads of a
     // thread are issued before the first LDS store (one memory round trip, not one per chunk).
     {
-        constexpr int kIter = kAsmThreads * (kSmallSlotWords / 4) / kAsmThreads;          // 8: 128 macroblocks x 8 chunks / 128 threads
+        constexpr int kIter = kSlotChunks;                  // 128 macroblocks x kSlotChunks chunks / 128 threads
         uint4 v[kIter];
         uint32_t dst[kIter];
 #pragma unroll
         for (int i = 0; i < kIter; ++i) {
-            const int idx = tid + i * kAsmThreads, m = idx >> 3, c = idx & 7;
+            const int idx = tid + i * kAsmThreads, m = idx / kSlotChunks, c = idx % kSlotChunks;
             const uint32_t nwm = s_nw[m], end = s_so[m];   // end: one past the macroblock's last staged word
             const bool take = m < g.mbw && (uint32_t)(4 * c) < nwm && end <= (uint32_t)kAsmStageWords;
             dst[i] = take ? end - ((nwm + 3u) & ~3u) + 4u * (uint32_t)c : 0xFFFFFFFFu;
