@@ -1363,8 +1363,12 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 }
             }
         }
-#pragma unroll
-        for (int k = lane; k < kSlotWords; k += 64) s_bits[k] = 0u;
+        // clear what pass 2 can reach: a symbol is at most 26 bits (typically 25 symbols: ONE store of 64 words instead of five
+        // predicated ones over the whole 304-word buffer); the first 64 words always, they are what a compact slot copies out
+        s_bits[lane] = 0u;
+        const int need = sgpr((int)((nsym * 26u) >> 5) + 2);
+        for (int k = 64; k < need && k < kSlotWords; k += 64)
+            if (k + lane < kSlotWords) s_bits[k + lane] = 0u;
         M2V_WAVE_SYNC();
 
         uint32_t pos = 0, offB = 0, offC = 0;
