@@ -569,6 +569,26 @@ __device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_
     return (uint32_t)sgpr((int)(eob_at + 1u));
 }
 
+// The same for a coded tile of a non-intra macroblock, trimmed for instruction count (this runs five times per macroblock):
+// the list position is kept in BYTES (no shifts), and instead of narrowing EXEC to the non-zero lanes (s_and_saveexec,
+// s_cbranch_execz, s_or per tile) the zero lanes store to a dump word in front of the list; the end-of-block symbol is stored by
+// all lanes.  sym_base = LDS byte address of the list, eob = the end-of-block symbol in a register; returns the new byte length.
+__device__ __forceinline__ uint32_t vlc_tile_symbols_inter(const int16_t *zig, uint32_t sym_base, int lane, uint32_t lane_pos, uint32_t nsym4, uint32_t eob)
+{
+    typedef __attribute__((address_space(3))) uint32_t *LdsW;
+    const int v = zig[lane];
+    const unsigned long long mask = ballot(v != 0);
+    const uint32_t end4 = (uint32_t)sgpr((int)(nsym4 + 4u * (uint32_t)__builtin_popcountll(mask)));
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    // zero lanes -> the dump word; one v_cndmask on the compare's mask (left to the compiler this becomes an EXEC region again)
+    const uint32_t slot = (rank << 2) + (uint32_t)sgpr((int)(sym_base + nsym4));
+    uint32_t at;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(at) : "v"(sym_base - 8u), "v"(slot), "s"(mask));
+    *(LdsW)(uintptr_t)at = lane_pos | ((uint32_t)v & 0xFFFFu);
+    *(LdsW)(uintptr_t)(sym_base + end4) = eob;      // end_of_block '10' (RTL:2835) behind the last level
+    return (uint32_t)sgpr((int)(end4 + 4u));
+}
+
 // ----------------------------------------------------------------------------------------------
 // k_mb: one wavefront = one macroblock, stages A..T
 // ----------------------------------------------------------------------------------------------
@@ -674,7 +694,14 @@ static_assert(sizeof(LaneK) == 80 && sizeof(MfmaLane) == 48 && sizeof(SearchLane
 // (uploaded by the host, the same in every block).  One block = one scalar base register pair for all of the kernel's lane
 // tables: the base points 4 KB into the block, so that the first eight quads are reached by the load's immediate offset.
 constexpr int kQuadsLaneK = sizeof(LaneK) / 16, kQuadsSearch = sizeof(SearchLane) / 16, kQuadsMfma = sizeof(MfmaLane) / 16;
-constexpr int kQuadSearch0 = kQuadsLaneK, kQuadMfma0 = kQuadSearch0 + kQuadsSearch, kQuadsPerBlock = kQuadMfma0 + kQuadsMfma;
+constexpr int kQuadSearch0 = kQuadsLaneK, kQuadMfma0 = kQuadSearch0 + kQuadsSearch;
+// behind the lane quads, the small constant tables k_mb reads (copies: the originals stay where the other kernels and the FILL
+// pass read them) - reached from the same pinned bases instead of one s_getpc_b64 / s_add_u32 / s_addc_u32 triple per access
+constexpr int kQuadConst0 = kQuadMfma0 + kQuadsMfma;                 // 1 KB: c_dct32 | c_dct | c_dct_neg | d_cbp_code
+constexpr int kConstDct32 = 0, kConstDct = 256, kConstDctNeg = 320, kConstCbp = 384;
+constexpr int kQuadAc0 = kQuadConst0 + 1;                            // d_ac_code2
+constexpr int kQuadsPerBlock = kQuadAc0 + (2 * 2 * 33 * 41 + 1023) / 1024;
+static_assert(kQuadConst0 == 11 && kQuadAc0 == 12, "k_mb's second table base points at quad 12");
 __device__ u32x4_t d_lanetab[3][2][kQuadsPerBlock][64];
 
 // CONF = option "conformant" (NOT the reference's behaviour): the reconstruction loop follows
@@ -767,7 +794,11 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     typedef const __attribute__((address_space(1))) u32x4_t *gld128;
     const uint8_t *ltab = (const uint8_t *)&d_lanetab[VL - 1][P ? 1 : 0][4][0];
     asm volatile("" : "+s"(ltab));
-#define M2V_QUAD(q0, T, member) (*(gld128)(ltab + ((q0) + (int)(offsetof(T, member) / 16) - 4) * 1024 + lane16))
+    const uint8_t *ltab2 = ltab + 8 * 1024;       // quads 8 .. (their offsets do not fit the immediate: without a base of their own the
+    asm volatile("" : "+s"(ltab2));               // compiler forms 64-bit vector addresses)
+#define M2V_QUAD(q0, T, member) ((q0) + (int)(offsetof(T, member) / 16) < 8                                              \
+                                     ? *(gld128)(ltab + ((q0) + (int)(offsetof(T, member) / 16) - 4) * 1024 + lane16)  \
+                                     : *(gld128)(ltab2 + ((q0) + (int)(offsetof(T, member) / 16) - 12) * 1024 + lane16))
 #define M2V_LANEK4(member) M2V_QUAD(0, LaneK, member)
     // Requested with the pixels (whose own addresses stay arithmetic: a table value in front of them would put a second memory
     // round trip before the first load); the last two quads follow before the transform.
@@ -808,7 +839,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     }
     if constexpr (P) {
         const uint8_t *refY = job.ref, *refU = refY + g.ysz, *refV = refU + g.csz;
-        if (bx > 0 && bx < g.mbw - 1 && by > 0 && by < g.mbh - 1) {
+        if (sgpr(in_l & in_r & in_u & in_d)) {
             // interior macroblock (wave-uniform test): the whole window lies inside the frame, no clamping, and the
             // passes differ by a constant row offset
             const uint32_t w0 = __umul24((uint32_t)(16 * by - YR + (lane >> 3)), (uint32_t)W) + (uint32_t)(16 * bx - 8 + 4 * (lane & 7));
@@ -1119,8 +1150,11 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     const int di = lane >> 3;
     int bi[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bi[k] = c_dct32[di * 8 + k];
-    const uint2 mj = *(const uint2 *)&c_dct[dj * 8], nj = *(const uint2 *)&c_dct_neg[dj * 8];   // basis row j and its negative, int8 x 8
+    for (int k = 0; k < 8; ++k) bi[k] = *(const __attribute__((address_space(1))) int32_t *)(ltab2 - 1024 + kConstDct32 + (uint32_t)(di * 32) + 4 * k);   // c_dct32[di * 8 + k]
+    // basis row j and its negative, int8 x 8 (c_dct, c_dct_neg)
+    typedef const __attribute__((address_space(1))) u32x2_t *gld64;
+    const u32x2_t mjv = *(gld64)(ltab2 - 1024 + kConstDct + (uint32_t)(dj * 8)), njv = *(gld64)(ltab2 - 1024 + kConstDctNeg + (uint32_t)(dj * 8));
+    const uint2 mj = {mjv.x, mjv.y}, nj = {njv.x, njv.y};
     // DCT-as-GEMM trial (north star): the four luma tiles through the matrix cores, the two chroma tiles as before
     constexpr bool kMfmaLuma = MFMA && !CONF;
     constexpr int kT0 = kMfmaLuma ? 4 : 0;             // first tile on the VALU path
@@ -1347,12 +1381,15 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         const uint32_t lane_pos = (uint32_t)lane << 20;
         if (!(kDebug && (g.ablate & 4))) {
             if (inter) {
-                const uint32_t e = d_cbp_code[cbp];
+                const uint32_t e = *(const __attribute__((address_space(1))) uint16_t *)(ltab2 - 1024 + kConstCbp + (uint32_t)(2 * cbp));    // d_cbp_code[cbp]
                 if (lane == 0) s_sym[0] = sym_raw(e >> 8, e & 255u, true);
-                nsym = (uint32_t)-cbp >> 31;   // pattern 0 (motion vector only) has no code, and a raw symbol needs a length
+                uint32_t nsym4 = ((uint32_t)-cbp >> 31) << 2;   // pattern 0 (motion vector only) has no code, and a raw symbol needs a length
+                const uint32_t eob = (uint32_t)vgpr_const((int)sym_raw(2u, 2u, true));
+                const uint32_t sym_base = lds_off(s_sym);
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
-                    if ((cbp >> (5 - t)) & 1) nsym = vlc_tile_symbols<true>(s_zig[t], s_sym, lane, lane_pos, nsym, dcs[t], 0, false);
+                    if ((cbp >> (5 - t)) & 1) nsym4 = vlc_tile_symbols_inter(s_zig[t], sym_base, lane, lane_pos, nsym4, eob);
+                nsym = nsym4 >> 2;
             } else {
                 if (lane == 0) s_sym[-1] = sym_raw(1u, 0u, false);  // the symbol "before" the first one: a block start
 #pragma unroll
@@ -1392,7 +1429,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     typedef const __attribute__((address_space(1))) uint16_t *gld16;
                     const uint32_t idx = __umul24(umin32((uint32_t)run, (uint32_t)kAcRuns - 1u), (uint32_t)kAcLevels) + umin32(a, (uint32_t)kAcLevels) - 1u +
                                          __umul24((before >> 26) & 1u, (uint32_t)(kAcRuns * kAcLevels));
-                    const uint32_t e = *(gld16)((const uint8_t *)d_ac_code2 + 2u * idx);
+                    const uint32_t e = *(gld16)(ltab2 + 2u * idx);          // d_ac_code2[idx]
                     if (e) {                                 // run/level VLC + sign (RTL:2535-2540)
                         code = ((e & 255u) << 1) | (v < 0 ? 1u : 0u);
                         len = (e >> 8) + 1u;

@@ -311,6 +311,12 @@ void upload_tables_now()
             const size_t blk = ((size_t)(vl * 2 + pf) * kQuadsPerBlock) * 64 * 16;
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), slq, sizeof slq, blk + (size_t)kQuadSearch0 * 64 * 16));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), mlq, sizeof mlq, blk + (size_t)kQuadMfma0 * 64 * 16));
+            const size_t cst = blk + (size_t)kQuadConst0 * 64 * 16;
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dct32, sizeof dct32, cst + kConstDct32));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), kDctBasis, sizeof kDctBasis, cst + kConstDct));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dct_neg, sizeof dct_neg, cst + kConstDctNeg));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), kCbpCode, sizeof kCbpCode, cst + kConstCbp));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), ac2, sizeof ac2, blk + (size_t)kQuadAc0 * 64 * 16));
         }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma_intra), mi, sizeof mi));
     HIPCHK(hipDeviceSynchronize());         // the copies read stack arrays: complete before they go out of scope
