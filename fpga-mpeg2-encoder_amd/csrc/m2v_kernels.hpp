@@ -536,43 +536,12 @@ __device__ __forceinline__ MbDep mb_dependent(uint32_t info, const MbAux &aux, b
 __host__ __device__ constexpr uint32_t sym_raw(uint32_t len, uint32_t code, bool inter_start) { return (len << 27) | (inter_start ? 127u << 20 : 0u) | code; }
 
 // Pass 1 of the coefficient VLC for one coded tile (lane = zig-zag index): rank the non-zero levels, append their
-// {position, level} symbols and the end_of_block code to the macroblock's symbol list; returns the new list length.  The run
-// of a level is formed in pass 2 from the position of the symbol before it (a raw symbol = block start).
-// INTER = non-intra block: every position counts and there is no DC code; intra: position 0 is the DC level, which
-// leaves through `dc` (for Y01 / Y10 / Y11 its differential against `dc_prev` is coded right here, RTL:2784-2786).
-template <bool INTER>
-__device__ __forceinline__ uint32_t vlc_tile_symbols(const int16_t *zig, uint32_t *s_sym, int lane, uint32_t lane_pos, uint32_t nsym,
-                                                     int &dc, int dc_prev, bool dc_chained)
-{
-    const int v = zig[lane];
-    nsym = (uint32_t)sgpr((int)nsym);               // the list length is wave-uniform: keep its arithmetic on the scalar unit
-    if constexpr (!INTER) {
-        dc = __builtin_amdgcn_readlane(v, 0);
-        if (dc_chained) {
-            const BitCode c = dc_code(dc - dc_prev, 0);
-            if (lane == 0) s_sym[nsym] = sym_raw(c.len, c.code, false);
-            nsym += 1u;
-        }
-    }
-    const bool nz = INTER ? v != 0 : (v != 0 && lane > 0);
-    // intra: lane 0 (the DC level) is cleared on the scalar side (a ballot of the combined predicate costs two VALU more)
-    const unsigned long long mask = INTER ? ballot(v != 0) : ballot(v != 0) & ~1ull;
-    const uint32_t nnz = (uint32_t)__builtin_popcountll(mask);
-    const uint32_t eob_at = (uint32_t)sgpr((int)(nsym + nnz));
-    if (nz) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        *(uint32_t *)((uint8_t *)s_sym + ((rank << 2) + (uint32_t)sgpr((int)(nsym << 2)))) = lane_pos | ((uint32_t)v & 0xFFFFu);
-        // end_of_block '10' (RTL:2835) behind the last level: every active lane stores the same word to the same address
-        if (INTER) s_sym[eob_at] = sym_raw(2u, 2u, true);
-    }
-    if (!INTER && lane == 0) s_sym[eob_at] = sym_raw(2u, 2u, false);     // an intra block may have no AC level at all
-    return (uint32_t)sgpr((int)(eob_at + 1u));
-}
-
-// The same for a coded tile of a non-intra macroblock, trimmed for instruction count (this runs five times per macroblock):
-// the list position is kept in BYTES (no shifts), and instead of narrowing EXEC to the non-zero lanes (s_and_saveexec,
-// s_cbranch_execz, s_or per tile) the zero lanes store to a dump word in front of the list; the end-of-block symbol is stored by
-// all lanes.  sym_base = LDS byte address of the list, eob = the end-of-block symbol in a register; returns the new byte length.
+// {position, level} symbols and the end_of_block code to the macroblock's symbol list.  The run of a level is formed in pass 2
+// from the position of the symbol before it (a raw symbol = block start).  Trimmed for instruction count (a non-intra
+// macroblock runs this five times): the list position is kept in BYTES (no shifts), and instead of narrowing EXEC to the
+// non-zero lanes (s_and_saveexec, s_cbranch_execz, s_or per tile) the zero lanes store to a dump word in front of the list;
+// the end-of-block symbol is stored by all lanes.  sym_base = LDS byte address of the list, eob = the end-of-block symbol in a
+// register; returns the new byte length.  First the non-intra form: every position counts and there is no DC code.
 __device__ __forceinline__ uint32_t vlc_tile_symbols_inter(const int16_t *zig, uint32_t sym_base, int lane, uint32_t lane_pos, uint32_t nsym4, uint32_t eob)
 {
     typedef __attribute__((address_space(3))) uint32_t *LdsW;
@@ -586,6 +555,31 @@ __device__ __forceinline__ uint32_t vlc_tile_symbols_inter(const int16_t *zig, u
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(at) : "v"(sym_base - 8u), "v"(slot), "s"(mask));
     *(LdsW)(uintptr_t)at = lane_pos | ((uint32_t)v & 0xFFFFu);
     *(LdsW)(uintptr_t)(sym_base + end4) = eob;      // end_of_block '10' (RTL:2835) behind the last level
+    return (uint32_t)sgpr((int)(end4 + 4u));
+}
+
+// and for a tile of an intra macroblock: lane 0 holds the DC level, which leaves through `dc` (for Y01 / Y10 / Y11 its differential
+// against `dc_prev` is coded right here, RTL:2784-2786) and is cleared from the mask on the scalar side
+__device__ __forceinline__ uint32_t vlc_tile_symbols_intra(const int16_t *zig, uint32_t sym_base, int lane, uint32_t lane_pos, uint32_t nsym4, uint32_t eob,
+                                                           int &dc, int dc_prev, bool dc_chained)
+{
+    typedef __attribute__((address_space(3))) uint32_t *LdsW;
+    const int v = zig[lane];
+    dc = __builtin_amdgcn_readlane(v, 0);
+    nsym4 = (uint32_t)sgpr((int)nsym4);
+    if (dc_chained) {
+        const BitCode c = dc_code(dc - dc_prev, 0);
+        if (lane == 0) *(LdsW)(uintptr_t)(sym_base + nsym4) = sym_raw(c.len, c.code, false);
+        nsym4 += 4u;
+    }
+    const unsigned long long mask = ballot(v != 0) & ~1ull;
+    const uint32_t end4 = (uint32_t)sgpr((int)(nsym4 + 4u * (uint32_t)__builtin_popcountll(mask)));
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const uint32_t slot = (rank << 2) + (uint32_t)sgpr((int)(sym_base + nsym4));
+    uint32_t at;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(at) : "v"(sym_base - 8u), "v"(slot), "s"(mask));
+    *(LdsW)(uintptr_t)at = lane_pos | ((uint32_t)v & 0xFFFFu);
+    *(LdsW)(uintptr_t)(sym_base + end4) = eob;      // an intra block may have no AC level at all: the end code is unconditional
     return (uint32_t)sgpr((int)(end4 + 4u));
 }
 
@@ -671,7 +665,7 @@ __device__ __forceinline__ void search_rows13(uint32_t cur, uint32_t cur12, uint
 // The table of an instantiation k_mb<VL, P> is written by the SAME kernel template (FILL = true: the lambda lane_consts below is
 // its only source), so the values cannot drift from the LDS map they describe.
 struct LaneK {
-    // quads 0..2: requested with the pixels
+    // quads 0, 1: requested with the pixels; quad 2 onwards: before the half-pel phase (registers)
     uint32_t win_st;                // LDS address of s_win[(lane >> 3) kWS + (lane & 7)]
     uint32_t hp;                    // LDS address of s_win[r kWS + c4]: the lane part of the half-pel neighbourhood
     uint32_t pred_st, cp_st;        // &s_pred[tile][ti], &s_cp[tile][r & 7][(c4 & 1) << 2]
@@ -682,7 +676,6 @@ struct LaneK {
     uint32_t cp_rd;                 // &s_cp[0][lane >> 3][0]
     uint32_t a1;                    // pass-1 A operand of the matrix-core transform
     uint32_t xrow;                  // &s_x[..] of the lane's first accumulator register
-    // quads 3, 4: requested before the transform
     uint32_t zz2;                   // 2 * zig-zag position of the lane
     uint32_t col_rd, col_pred;      // &s_t[t][col], &s_pred[t][col] of the column pass
     uint32_t crec_rd;               // &s_pred[4 + pl][yc << 3 | half << 2] of the chroma store
@@ -802,7 +795,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 #define M2V_LANEK4(member) M2V_QUAD(0, LaneK, member)
     // Requested with the pixels (whose own addresses stay arithmetic: a table value in front of them would put a second memory
     // round trip before the first load); the last two quads follow before the transform.
-    const u32x4_t kq0 = M2V_LANEK4(win_st), kq1 = M2V_LANEK4(cpc_st), kq2 = M2V_LANEK4(xc4);
+    const u32x4_t kq0 = M2V_LANEK4(win_st), kq1 = M2V_LANEK4(cpc_st);
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t li = udiv_magic(blk, g.strip_mbs, g.magic_strip);           // which frame of the launch list
     const int fidx = frame_list[li];
@@ -898,10 +891,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     uint32_t pred4 = 0x80808080u;               // intra prediction (RTL:1894-1903)
     long mf_b1 = 0, mf_a2lo = 0, mf_a2hi = 0;   // matrix-core operands of the lane (c_mfma), requested with group 3
     u32x4_t mf_zoff = {0, 0, 0, 0};
-    u32x4_t kq3, kq4;                           // the lane table's last two quads
+    u32x4_t kq2, kq3, kq4;                      // the lane table's last three quads (not before the search: registers)
 #define M2V_REQUEST_G3()                                                                                             \
     do {                                                                                                             \
-        kq3 = M2V_LANEK4(zz2); kq4 = M2V_LANEK4(crec_r);                                                             \
+        kq2 = M2V_LANEK4(xc4); kq3 = M2V_LANEK4(zz2); kq4 = M2V_LANEK4(crec_r);                                      \
         if constexpr (MFMA && !CONF) {                                                                               \
             const u32x4_t m0 = M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]), m1 = M2V_QUAD(kQuadMfma0, MfmaLane, a2[0]);  \
             mf_b1 = (long)(((unsigned long long)m0.y << 32) | m0.x);                                                 \
@@ -1392,12 +1385,16 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 nsym = nsym4 >> 2;
             } else {
                 if (lane == 0) s_sym[-1] = sym_raw(1u, 0u, false);  // the symbol "before" the first one: a block start
+                uint32_t nsym4 = 0;
+                const uint32_t eob = (uint32_t)vgpr_const((int)sym_raw(2u, 2u, false));
+                const uint32_t sym_base = lds_off(s_sym);
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
-                    if (t == 4) idxB = nsym;
-                    if (t == 5) idxC = nsym;
-                    nsym = vlc_tile_symbols<false>(s_zig[t], s_sym, lane, lane_pos, nsym, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3);
+                    if (t == 4) idxB = nsym4 >> 2;
+                    if (t == 5) idxC = nsym4 >> 2;
+                    nsym4 = vlc_tile_symbols_intra(s_zig[t], sym_base, lane, lane_pos, nsym4, eob, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3);
                 }
+                nsym = nsym4 >> 2;
             }
         }
         // clear what pass 2 can reach: a symbol is at most 26 bits (typically 25 symbols: ONE store of 64 words instead of five
