@@ -56,6 +56,7 @@ struct Geom {
     uint32_t strip_mbs;      // (row1 - row0) * mbw
     uint32_t magic_strip;    // floor(2^32 / strip_mbs), floor(2^32 / mbw): wave-uniform divisions on the scalar unit
     uint32_t magic_mbw;      // (geom_finish() fills the three after any change of the rows)
+    uint32_t s16_off;        // word offset of the 64-byte slot class inside the compact-slot buffer (plan_chunk: macroblocks of the chunk * 32)
 };
 
 inline void geom_finish(Geom &g)
@@ -455,6 +456,8 @@ constexpr int kSmallSlotWords = 32;   // macroblocks of <= 1024 stored bits (nea
                                       // tried: k_assemble touches half the lines for P frames, but most macroblocks of an I frame then sit in
                                       // the overflow slots, which it reads word by word - no net gain, profiles/r02_v_bench.json)
 constexpr int kSlotChunks = kSmallSlotWords / 4;
+constexpr int kTinySlotWords = 16;    // ... and those of <= 512 bits (99 % of a P frame) a 64-byte slot in a second array behind the first:
+                                      // k_assemble is bound by the cache lines it touches, two of these share one
 
 struct MbAux {                        // 16 bytes per macroblock next to the uint32 info word
     uint32_t w0;                      // lenA | lenB << 16        (bits)
@@ -1449,7 +1452,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         M2V_WAVE_SYNC();
         const uint32_t nwords = (pos + 31u) >> 5;
         if (nwords <= (uint32_t)kSmallSlotWords) {          // the common case: one 128-byte line
-            if (lane < kSmallSlotWords) slots_small[mbidx * kSmallSlotWords + lane] = s_bits[lane];
+            if (nwords <= (uint32_t)kTinySlotWords) {
+                if (lane < kTinySlotWords) slots_small[g.s16_off + mbidx * kTinySlotWords + lane] = s_bits[lane];
+            } else if (lane < kSmallSlotWords) slots_small[mbidx * kSmallSlotWords + lane] = s_bits[lane];
         } else {
             uint32_t *slot = slots + mbidx * kSlotWords;
 #pragma unroll 1
@@ -1703,7 +1708,9 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
             const uint32_t nwm = s_nw[m], end = s_so[m];   // end: one past the macroblock's last staged word
             const bool take = m < g.mbw && (uint32_t)(4 * c) < nwm && end <= (uint32_t)kAsmStageWords;
             dst[i] = take ? end - ((nwm + 3u) & ~3u) + 4u * (uint32_t)c : 0xFFFFFFFFu;
-            v[i] = take ? *(const uint4 *)(slots_small + (base + m) * kSmallSlotWords + 4 * c) : uint4{0, 0, 0, 0};
+            const uint32_t *const src = nwm <= (uint32_t)kTinySlotWords ? slots_small + g.s16_off + (base + m) * kTinySlotWords
+                                                                         : slots_small + (base + m) * kSmallSlotWords;
+            v[i] = take ? *(const uint4 *)(src + 4 * c) : uint4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int i = 0; i < kIter; ++i)
@@ -1718,7 +1725,9 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
     const uint32_t nout = ((uint32_t)sh + total + 31u) / 32u;
     // this thread's segments: staged, or in memory (the overflow slot, or a compact slot that found no room in the staging)
     const bool staged = small && s_so[tid] <= (uint32_t)kAsmStageWords;
-    const uint32_t *const big = small ? slots_small + (base + tid) * kSmallSlotWords : slots + (base + tid) * kSlotWords;
+    const uint32_t *const big = !small ? slots + (base + tid) * kSlotWords
+                                : nwords <= (uint32_t)kTinySlotWords ? slots_small + g.s16_off + (base + tid) * kTinySlotWords
+                                                                     : slots_small + (base + tid) * kSmallSlotWords;
     const uint32_t *const stg = &s_slot[staged ? s_so[tid] - ((nwords + 3u) & ~3u) : 0u];
     const int l1 = (int)(lens & 255u), l2 = (int)((lens >> 8) & 255u), l3 = (int)((lens >> 16) & 255u);
 

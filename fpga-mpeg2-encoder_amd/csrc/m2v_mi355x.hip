@@ -553,7 +553,8 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
     e->d_mbaux.ensure(nmb);
     e->d_mbdep.ensure(nmb);
     e->d_slots.ensure(nmb * (size_t)kSlotWords + 8);
-    e->d_slots_small.ensure(nmb * (size_t)kSmallSlotWords + 8);      // k_assemble reads one word past a segment's last word
+    e->d_slots_small.ensure(nmb * (size_t)(kSmallSlotWords + kTinySlotWords) + 8);      // the 128-byte class, then the 64-byte class
+    e->g.s16_off = (uint32_t)(nmb * (size_t)kSmallSlotWords);
     e->d_mbinfo.ensure(nmb);
     e->d_mblen.ensure(nmb);
     e->d_mboff.ensure(nmb);
