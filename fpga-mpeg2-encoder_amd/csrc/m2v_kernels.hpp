@@ -489,6 +489,20 @@ __device__ __forceinline__ BitCode dc_code(int diff, int chroma)
     return BitCode{((uint32_t)d_dc_code[chroma][size] << size) | bits, sl + (uint32_t)size};
 }
 
+// The same for a wave-uniform luma differential, on the scalar unit: the size code comes through a scalar load from `tab`
+// (kConstDcLuma: code | length << 16), everything else is integer arithmetic on uniform values.  k_mb codes the DC of
+// Y01 / Y10 / Y11 of every intra macroblock with it (the vector form costs 17 instructions in all 64 lanes for one value).
+__device__ __forceinline__ BitCode dc_code_uniform(int diff, const uint8_t *tab)
+{
+    diff = sgpr(diff);
+    const int a = diff < 0 ? -diff : diff;
+    const int size = sgpr(a ? 32 - __builtin_clz((unsigned)a) : 0);
+    uint32_t bits = (uint32_t)diff & 0xFFFu;
+    bits = (bits + ((uint32_t)(diff >> 31) & ((1u << size) - 1u))) & 0xFFFu;
+    const uint32_t e = *(const __attribute__((address_space(4))) uint32_t *)(tab + 4 * size);
+    return BitCode{(uint32_t)sgpr((int)(((e & 0xFFFFu) << size) | bits)), (uint32_t)sgpr((int)((e >> 16) + (uint32_t)size))};
+}
+
 // motion_code + sign of the wrapped delta (RTL:2736-2748), at most 11 bits
 __device__ __forceinline__ BitCode mv_code(int mv, int prev)
 {
@@ -564,14 +578,14 @@ __device__ __forceinline__ uint32_t vlc_tile_symbols_inter(const int16_t *zig, u
 // and for a tile of an intra macroblock: lane 0 holds the DC level, which leaves through `dc` (for Y01 / Y10 / Y11 its differential
 // against `dc_prev` is coded right here, RTL:2784-2786) and is cleared from the mask on the scalar side
 __device__ __forceinline__ uint32_t vlc_tile_symbols_intra(const int16_t *zig, uint32_t sym_base, int lane, uint32_t lane_pos, uint32_t nsym4, uint32_t eob,
-                                                           int &dc, int dc_prev, bool dc_chained)
+                                                           int &dc, int dc_prev, bool dc_chained, const uint8_t *dc_tab)
 {
     typedef __attribute__((address_space(3))) uint32_t *LdsW;
     const int v = zig[lane];
     dc = __builtin_amdgcn_readlane(v, 0);
     nsym4 = (uint32_t)sgpr((int)nsym4);
     if (dc_chained) {
-        const BitCode c = dc_code(dc - dc_prev, 0);
+        const BitCode c = dc_code_uniform(dc - dc_prev, dc_tab);
         if (lane == 0) *(LdsW)(uintptr_t)(sym_base + nsym4) = sym_raw(c.len, c.code, false);
         nsym4 += 4u;
     }
@@ -695,6 +709,7 @@ constexpr int kQuadSearch0 = kQuadsLaneK, kQuadMfma0 = kQuadSearch0 + kQuadsSear
 // pass read them) - reached from the same pinned bases instead of one s_getpc_b64 / s_add_u32 / s_addc_u32 triple per access
 constexpr int kQuadConst0 = kQuadMfma0 + kQuadsMfma;                 // 1 KB: c_dct32 | c_dct | c_dct_neg | d_cbp_code
 constexpr int kConstDct32 = 0, kConstDct = 256, kConstDctNeg = 320, kConstCbp = 384;
+constexpr int kConstDcLuma = 512;            // 12 dwords: dct_dc_size_luminance code | length << 16 (read by the SCALAR unit, dc_code_uniform)
 constexpr int kQuadAc0 = kQuadConst0 + 1;                            // d_ac_code2
 constexpr int kQuadsPerBlock = kQuadAc0 + (2 * 2 * 33 * 41 + 1023) / 1024;
 static_assert(kQuadConst0 == 11 && kQuadAc0 == 12, "k_mb's second table base points at quad 12");
@@ -1395,7 +1410,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 for (int t = 0; t < 6; ++t) {
                     if (t == 4) idxB = nsym4 >> 2;
                     if (t == 5) idxC = nsym4 >> 2;
-                    nsym4 = vlc_tile_symbols_intra(s_zig[t], sym_base, lane, lane_pos, nsym4, eob, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3);
+                    nsym4 = vlc_tile_symbols_intra(s_zig[t], sym_base, lane, lane_pos, nsym4, eob, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3,
+                                                   ltab2 - 1024 + kConstDcLuma);
                 }
                 nsym = nsym4 >> 2;
             }

@@ -316,6 +316,9 @@ void upload_tables_now()
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), kDctBasis, sizeof kDctBasis, cst + kConstDct));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dct_neg, sizeof dct_neg, cst + kConstDctNeg));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), kCbpCode, sizeof kCbpCode, cst + kConstCbp));
+            static uint32_t dcl[12];
+            for (int i = 0; i < 12; ++i) dcl[i] = (uint32_t)kDcSizeCode[0][i] | ((uint32_t)kDcSizeLen[0][i] << 16);
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dcl, sizeof dcl, cst + kConstDcLuma));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), ac2, sizeof ac2, blk + (size_t)kQuadAc0 * 64 * 16));
         }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma_intra), mi, sizeof mi));
