@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     //           (7 v_perm) sorts the limbs, one MFMA per limb, recombined by two shift-adds per coefficient.
     // transform sum of block row 4g + v, column c, PLUS kRound = 2048 + (2 << 12): the DCT's rounding constant and the inter
     // quantiser's "+ 2" (below), both added for free as the accumulator input 40 of the middle limb (40 << 8)
-    constexpr int kRound = 2048 + (2 << 12);
+    constexpr int kRound = P ? 2048 + (2 << 12) : 2048;        // an I frame has no non-intra macroblock: just the transform's rounding
     int yacc[4] = {0, 0, 0, 0};
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     // (matrix-core lane = (g = lane >> 4, c = lane & 15); its LDS slots come from the lane table)
@@ -1306,6 +1306,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     } else {
         if constexpr (P) { wq = c_intra_w[lane]; wrecip = c_intra_recip[lane]; }
         const uint32_t qoff = __umul24((uint32_t)wq, (3u << Q) + 2u) >> 3;
+        const int k2047 = vgpr_const(2047), kn2047 = vgpr_const(-2047);
         if constexpr (kMfmaLuma) {
             const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
             const MfmaLaneIntra ml = c_mfma_intra[lane];
@@ -1315,7 +1316,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 const int wv = (int)((ml.wq >> (8 * v)) & 255u);
                 const uint32_t qo = __umul24((uint32_t)wv, (3u << Q) + 2u) >> 3;
                 const bool is_dc = v == 0 && (lane & 0x17) == 0;           // row 0 of a tile (g even, v = 0), column 0 of a tile
-                const int C = (yacc[v] >> 12) - 2;             // yacc carries kRound = 2048 + 2 * 4096
+                const int C = (yacc[v] >> 12) - (kRound >> 12);        // yacc carries kRound
                 const int sg = C >> 31;
                 uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
                 if (!is_dc) a = __umul24((a + qo) >> Q, ml.recip[v]) >> 21;
@@ -1329,7 +1330,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     if (!is_dc) {
                         x = sext(__mul24(q, wv), 17);
                         x = Q >= 3 ? sext((int)((uint32_t)x << (Q - 3)), 17) : (x >> (3 - Q));
-                        x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
+                        x = clamp_vv(x, kn2047, k2047);
                     } else {
                         x = 2 * q;
                     }
@@ -1367,7 +1368,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 } else if (lane != 0) {
                     x = sext(__mul24(q, wq), 17);       // 17-bit temporary (RTL:2093, 2139)
                     x = Q >= 3 ? sext((int)((uint32_t)x << (Q - 3)), 17) : (x >> (3 - Q));
-                    x = x < -2047 ? -2047 : x > 2047 ? 2047 : x;
+                    x = clamp_vv(x, kn2047, k2047);
                 } else {
                     x = 2 * q;
                 }
