@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             // raster slots in s_x are 16 bytes apart
             const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
             int16_t *const xrow = (int16_t *)(__attribute__((address_space(3))) int16_t *)(uintptr_t)kq2.w;   // &s_x[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)]
-            int nzor = 0;
+            int nzor = 0, qv[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 // see the chroma loop below for the arithmetic; yacc already holds acc + (2 << 12)
@@ -1260,8 +1260,12 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 *(int16_t *)((uint8_t *)&s_zig[0][0] + zo[v]) = (int16_t)q;
                 if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + (zo[v] >> 1)] = (int16_t)q;
                 nzor |= q;
-                if (need_rec) {
-                    int x = (2 * q + sign_of(q)) << Q;
+                qv[v] = q;
+            }
+            if (need_rec) {                     // one test for the four coefficients
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    int x = (2 * qv[v] + sign_of(qv[v])) << Q;
                     x = clamp_vv(x, kn2047, k2047);
                     xrow[v * 8] = (int16_t)x;
                 }
@@ -1459,8 +1463,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             const int incl = wave_scan_incl((int)len);
             const uint32_t excl = pos + (uint32_t)incl - len;
             if (len) lds_put(s_bits, excl, code, len);
-            if (idxB >= base && idxB < base + 64) offB = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)(idxB - base));
-            if (idxC >= base && idxC < base + 64) offC = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)(idxC - base));
+            if (!inter) {                       // segment boundaries (intra only: a non-intra macroblock stores one segment)
+                if (idxB >= base && idxB < base + 64) offB = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)(idxB - base));
+                if (idxC >= base && idxC < base + 64) offC = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)(idxC - base));
+            }
             pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
         }
         uint32_t lenA, lenB = 0, lenC = 0;
