@@ -844,9 +844,11 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     SearchLane sl{};                             // the lane's search addresses: loaded with the pixels, one memory round trip
     if constexpr (P && VL == 3) {
         const u32x4_t s0 = M2V_QUAD(kQuadSearch0, SearchLane, even), s1 = M2V_QUAD(kQuadSearch0, SearchLane, plus);
-        const u32x4_t s2 = M2V_QUAD(kQuadSearch0, SearchLane, dead_hi);
+        // one dword of the third quad: a dwordx4 load whose other three registers are dead gets them reused right away, and the
+        // compiler then waits for the load (write-after-write) before it issues the window loads - a second round trip
+        const uint32_t s2 = *(const __attribute__((address_space(1))) uint32_t *)(ltab + (kQuadSearch0 + (int)(offsetof(SearchLane, dead_hi) / 16) - 4) * 1024 + lane16);
         sl.even = s0.x; sl.odd = s0.y; sl.cur = s0.z; sl.cur12 = s0.w;
-        sl.plus = s1.x; sl.minus = s1.y; sl.cb4 = s1.z; sl.dead_lo = s1.w; sl.dead_hi = s2.x;
+        sl.plus = s1.x; sl.minus = s1.y; sl.cb4 = s1.z; sl.dead_lo = s1.w; sl.dead_hi = s2;
     }
     if constexpr (P) {
         const uint8_t *refY = job.ref, *refU = refY + g.ysz, *refV = refU + g.csz;
