@@ -109,6 +109,7 @@ __constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for
 // of those per macroblock kept the vector memory pipe busier than the pixels do (profiles/r02_n_*).
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 struct MfmaLane {        // three quads: b1 | a2 | zoff
     uint32_t b1[2];      // pass 1 B operand: +-basis row (c & 7) for the k group that matches c's tile column, else 0
     uint32_t pad0[2];
@@ -911,12 +912,17 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     uint32_t pred4 = 0x80808080u;               // intra prediction (RTL:1894-1903)
     long mf_b1 = 0, mf_a2lo = 0, mf_a2hi = 0;   // matrix-core operands of the lane (c_mfma), requested with group 3
     u32x4_t mf_zoff = {0, 0, 0, 0};
-    u32x4_t kq2, kq3, kq4;                      // the lane table's last three quads (not before the search: registers)
+    u32x4_t kq2, kq3;                           // the lane table's last three quads (not before the search: registers)
+    u32x3_t kq4;
 #define M2V_REQUEST_G3()                                                                                             \
     do {                                                                                                             \
-        kq2 = M2V_LANEK4(xc4); kq3 = M2V_LANEK4(zz2); kq4 = M2V_LANEK4(crec_r);                                      \
+        kq2 = M2V_LANEK4(xc4); kq3 = M2V_LANEK4(zz2);                                                                \
+        /* only the words that are used: a dead register of a wide load is reused at once, and the write-after-write   \
+           wait then stalls the wavefront for the whole round trip */                                                  \
+        kq4 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_LANEK4(crec_r);                               \
         if constexpr (MFMA && !CONF) {                                                                               \
-            const u32x4_t m0 = M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]), m1 = M2V_QUAD(kQuadMfma0, MfmaLane, a2[0]);  \
+            const u32x2_t m0 = *(const __attribute__((address_space(1))) u32x2_t *)&M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]); \
+            const u32x4_t m1 = M2V_QUAD(kQuadMfma0, MfmaLane, a2[0]);                                                 \
             mf_b1 = (long)(((unsigned long long)m0.y << 32) | m0.x);                                                 \
             mf_a2lo = (long)(((unsigned long long)m1.y << 32) | m1.x); mf_a2hi = (long)(((unsigned long long)m1.w << 32) | m1.z); \
         }                                                                                                            \
@@ -1107,6 +1113,17 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         mvx = 2 * fx + hx;
     }
 
+    // the transform's basis rows, requested here (one phase ahead of stage G): basis row i = lane >> 3 widened to int32, basis
+    // row j = lane & 7 and its negative as int8 x 8
+    const int dj = lane & 7;
+    const int di = lane >> 3;
+    int bi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bi[k] = *(const __attribute__((address_space(1))) int32_t *)(ltab2 - 1024 + kConstDct32 + (uint32_t)(di * 32) + 4 * k);   // c_dct32[di * 8 + k]
+    // basis row j and its negative, int8 x 8 (c_dct, c_dct_neg)
+    typedef const __attribute__((address_space(1))) u32x2_t *gld64;
+    const u32x2_t mjv = *(gld64)(ltab2 - 1024 + kConstDct + (uint32_t)(dj * 8)), njv = *(gld64)(ltab2 - 1024 + kConstDctNeg + (uint32_t)(dj * 8));
+    const uint2 mj = {mjv.x, mjv.y}, nj = {njv.x, njv.y};
     // ---- prediction into tile layout; current and predicted samples as SIGNED bytes for the transform (RTL:1891-1917,
     // 1980-2014).  The 9-bit residual c - p is never formed: stage G needs only sum_k M[j][k] (c_k - p_k), which is
     // sum_k M[j][k] (c_k - 128) + sum_k (-M[j][k]) (p_k - 128), two v_dot4_i32_i8 chains on the bytes XOR 0x80.
@@ -1159,15 +1176,6 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 
     M2V_STOP(3);            // ... up to the prediction
     // ---- stage G: 2-D forward DCT (RTL:2029-2062); lane = (i = lane>>3, j = lane&7) ------------
-    const int dj = lane & 7;
-    const int di = lane >> 3;
-    int bi[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bi[k] = *(const __attribute__((address_space(1))) int32_t *)(ltab2 - 1024 + kConstDct32 + (uint32_t)(di * 32) + 4 * k);   // c_dct32[di * 8 + k]
-    // basis row j and its negative, int8 x 8 (c_dct, c_dct_neg)
-    typedef const __attribute__((address_space(1))) u32x2_t *gld64;
-    const u32x2_t mjv = *(gld64)(ltab2 - 1024 + kConstDct + (uint32_t)(dj * 8)), njv = *(gld64)(ltab2 - 1024 + kConstDctNeg + (uint32_t)(dj * 8));
-    const uint2 mj = {mjv.x, mjv.y}, nj = {njv.x, njv.y};
     // DCT-as-GEMM trial (north star): the four luma tiles through the matrix cores, the two chroma tiles as before
     constexpr bool kMfmaLuma = MFMA && !CONF;
     constexpr int kT0 = kMfmaLuma ? 4 : 0;             // first tile on the VALU path
