@@ -1408,13 +1408,17 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         if (!(kDebug && (g.ablate & 4))) {
             if (inter) {
                 const uint32_t e = *(const __attribute__((address_space(1))) uint16_t *)(ltab2 - 1024 + kConstCbp + (uint32_t)(2 * cbp));    // d_cbp_code[cbp]
-                if (lane == 0) s_sym[0] = sym_raw(e >> 8, e & 255u, true);
                 uint32_t nsym4 = ((uint32_t)-cbp >> 31) << 2;   // pattern 0 (motion vector only) has no code, and a raw symbol needs a length
                 const uint32_t eob = (uint32_t)vgpr_const((int)sym_raw(2u, 2u, true));
                 const uint32_t sym_base = lds_off(s_sym);
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
                     if ((cbp >> (5 - t)) & 1) nsym4 = vlc_tile_symbols_inter(s_zig[t], sym_base, lane, lane_pos, nsym4, eob);
+                // stored last: its table load has the tile passes to arrive (the empty asm keeps the loaded value in its vector
+                // register until here: a wave-uniform value is otherwise moved to a scalar register - and waited for - at once)
+                uint32_t ev = e;
+                asm volatile("" : "+v"(ev));
+                if (lane == 0) s_sym[0] = sym_raw(ev >> 8, ev & 255u, true);
                 nsym = nsym4 >> 2;
             } else {
                 if (lane == 0) s_sym[-1] = sym_raw(1u, 0u, false);  // the symbol "before" the first one: a block start
