@@ -73,7 +73,7 @@ struct FrameJob {           // one per frame of the chunk (device memory)
     int32_t        i_frame; // index inside the GOP, 0 = I frame (RTL:1078)
     uint32_t       n;       // frame number inside the sequence (time code, RTL:2685-2698)
     uint32_t       valid_beats;  // beats of real input in this frame; the rest is black (RTL:1048-1056)
-    uint32_t       pad;
+    uint32_t       fidx;    // k_mb's copies in launch-list order: the frame's index in the chunk (0 in the per-frame array)
 };
 
 struct StreamCtl {          // device-resident stream bookkeeping, carried across chunks
@@ -817,10 +817,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     const u32x4_t kq0 = M2V_LANEK4(win_st), kq1 = M2V_LANEK4(cpc_st);
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t li = udiv_magic(blk, g.strip_mbs, g.magic_strip);           // which frame of the launch list
-    const int fidx = frame_list[li];
+    const FrameJob job = jobs[li];                 // `jobs` = the launch list as jobs: one dependent scalar load, not list -> job
+    const int fidx = (int)job.fidx;
     const int mb = g.row0 * g.mbw + (int)(blk - li * g.strip_mbs);
     const int by = (int)udiv_magic((uint32_t)mb, (uint32_t)g.mbw, g.magic_mbw), bx = mb - by * g.mbw;
-    const FrameJob job = jobs[fidx];
     const int W = g.W;
     const int r = lane >> 2, c4 = lane & 3;
     // 1 = the macroblock has a neighbour on that side (left, right, up, down).  Sign-bit arithmetic, not compares: these

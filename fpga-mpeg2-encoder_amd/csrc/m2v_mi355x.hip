@@ -90,6 +90,7 @@ struct m2v_enc {
         StreamCtl *h_ctl = nullptr;           // pinned: [0] read-back, [1] initial values
         FrameJob *h_jobs = nullptr;           // pinned staging of the per-frame jobs
         size_t h_jobs_cap = 0;
+        FrameJob *h_joblist = nullptr;        // pinned staging of the jobs in launch-list order
         int *h_lists = nullptr;               // pinned staging of the launch lists
         size_t h_lists_cap = 0;
         uint8_t *h_out = nullptr;             // pinned read-back buffer
@@ -138,6 +139,7 @@ struct m2v_enc {
     DevBuf<unsigned long long> d_slice_off, d_frame_off;
     DevBuf<FrameJob> d_jobs;
     DevBuf<int> d_lists;
+    DevBuf<FrameJob> d_joblist;           // the jobs again, in launch-list order (k_mb reads its frame's job with ONE dependent scalar load)
     DevBuf<StreamCtl> d_ctl;
     std::vector<uint8_t *> rec_pool;      // reconstruction buffers (4:2:0 planar), each ysz + 2*csz
     size_t rec_bytes = 0;
@@ -403,13 +405,14 @@ void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Ge
     const dim3 grid((unsigned)((size_t)count * (size_t)(g.row1 - g.row0) * g.mbw)), block(64);      // one wavefront per macroblock
     Timer t(e, s, P ? 0 : 1, (double)count * g.ysz);
     int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
+    const FrameJob *const jl = e->d_joblist.p + (d_list - e->d_lists.p);      // the same launch list, as jobs
 #define M2V_LAUNCH_MB(VLV, PV, CV) \
     do { \
         if (e->dct_mfma && !(CV)) \
-            hipLaunchKernelGGL((k_mb<VLV, PV, false, true>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
+            hipLaunchKernelGGL((k_mb<VLV, PV, false, true>), grid, block, 0, s, jl, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
                                e->d_slots_small.p, e->d_slots.p, dbg); \
         else \
-            hipLaunchKernelGGL((k_mb<VLV, PV, CV, false>), grid, block, 0, s, e->d_jobs.p, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
+            hipLaunchKernelGGL((k_mb<VLV, PV, CV, false>), grid, block, 0, s, jl, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
                                e->d_slots_small.p, e->d_slots.p, dbg); \
     } while (0)
     if (P) {
@@ -461,7 +464,7 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
         jobs[k].valid_beats = (last && k == nf - 1) ? last_valid_beats : bpf;
         jobs[k].ref = nullptr;
         jobs[k].rec = nullptr;
-        jobs[k].pad = 0;
+        jobs[k].fidx = 0;
         if (k == 0 || jobs[k].i_frame == 0) seg_start.push_back((int)k);
     }
     const size_t nseg = seg_start.size();
@@ -552,6 +555,7 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
     const size_t nmb = nf * (size_t)g.mbs;
     e->d_jobs.ensure(nf);
     e->d_lists.ensure(lists.size());
+    e->d_joblist.ensure(lists.size());
     if (e->keep_recon) e->d_coef.ensure(nmb * 384);
     e->d_mbaux.ensure(nmb);
     e->d_mbdep.ensure(nmb);
@@ -575,12 +579,20 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
         if (e->st().h_lists) (void)hipHostFree(e->st().h_lists);
         e->st().h_lists = nullptr; e->st().h_lists_cap = 0;
         HIPCHK(hipHostMalloc((void **)&e->st().h_lists, lists.size() * sizeof(int)));
+        if (e->st().h_joblist) (void)hipHostFree(e->st().h_joblist);
+        e->st().h_joblist = nullptr;
+        HIPCHK(hipHostMalloc((void **)&e->st().h_joblist, lists.size() * sizeof(FrameJob)));
         e->st().h_lists_cap = lists.size();
     }
     memcpy(e->st().h_jobs, jobs.data(), nf * sizeof(FrameJob));
     memcpy(e->st().h_lists, lists.data(), lists.size() * sizeof(int));
     HIPCHK(hipMemcpyAsync(e->d_jobs.p, e->st().h_jobs, nf * sizeof(FrameJob), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(e->d_lists.p, e->st().h_lists, lists.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    for (size_t i = 0; i < lists.size(); ++i) {
+        e->st().h_joblist[i] = jobs[(size_t)lists[i]];
+        e->st().h_joblist[i].fidx = (uint32_t)lists[i];
+    }
+    HIPCHK(hipMemcpyAsync(e->d_joblist.p, e->st().h_joblist, lists.size() * sizeof(FrameJob), hipMemcpyHostToDevice, s));
     e->plan_nf = nf;
     e->dbg_frames = nf;
     e->dbg_rec_slot = rec_slot;
@@ -951,7 +963,7 @@ void m2v_destroy(m2v_enc *e)
     for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
     e->d_coef.release(); e->d_mbaux.release(); e->d_mbdep.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
     e->d_mboff.release(); e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
-    e->d_jobs.release(); e->d_lists.release(); e->d_ctl.release(); e->d_segs.release();
+    e->d_jobs.release(); e->d_lists.release(); e->d_joblist.release(); e->d_ctl.release(); e->d_segs.release();
     for (auto p : e->rec_pool) (void)hipFree(p);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto &h : e->hs) {
@@ -963,6 +975,7 @@ void m2v_destroy(m2v_enc *e)
         if (h.h_ctl) (void)hipHostFree(h.h_ctl);
         if (h.h_jobs) (void)hipHostFree(h.h_jobs);
         if (h.h_lists) (void)hipHostFree(h.h_lists);
+        if (h.h_joblist) (void)hipHostFree(h.h_joblist);
         if (h.ev_ctl) (void)hipEventDestroy(h.ev_ctl);
         if (h.ev_out) (void)hipEventDestroy(h.ev_out);
     }
