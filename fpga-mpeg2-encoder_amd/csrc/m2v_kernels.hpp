@@ -1039,7 +1039,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             // (RTL:1757-1760), and so does the third dword of a row when it is the padding dword 8.
             const int kx = 7 + fx;                             // 1 .. 13
             const uint32_t sft = (uint32_t)kx & 3u;
-            const uint32_t *const pw = (const uint32_t *)(LdsU32 *)(uintptr_t)(kq0.y + 4u * (uint32_t)sgpr((fy + YR) * kWS + (kx >> 2)));
+            // based at the row ABOVE (all three rows at non-negative immediate offsets: a negative one costs an address add per read)
+            const uint32_t *const pw = (const uint32_t *)(LdsU32 *)(uintptr_t)(kq0.y + 4u * (uint32_t)sgpr((fy + YR - 1) * kWS + (kx >> 2)));
 #define M2V_ROW3(OFF, L, C, R)                                                                  \
             {                                                                                   \
                 const uint32_t a0 = pw[(OFF)], a1 = pw[(OFF) + 1], a2 = pw[(OFF) + 2];          \
@@ -1049,9 +1050,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 C = __builtin_amdgcn_alignbyte(hi, lo, 1u);                                     \
                 R = __builtin_amdgcn_alignbyte(hi, lo, 2u);                                     \
             }
-            M2V_ROW3(-kWS, L0, C0, R0)
-            M2V_ROW3(0, L1, C1, R1)
-            M2V_ROW3(kWS, L2, C2, R2)
+            M2V_ROW3(0, L0, C0, R0)
+            M2V_ROW3(kWS, L1, C1, R1)
+            M2V_ROW3(2 * kWS, L2, C2, R2)
 #undef M2V_ROW3
         }
         uint32_t hp[9];                                         // the nine half-pel predictions (RTL:1746-1752)
