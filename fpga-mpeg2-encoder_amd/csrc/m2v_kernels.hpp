@@ -272,6 +272,14 @@ __device__ __forceinline__ int sign_of(int q)
     asm("v_med3_i32 %0, %1, -1, 1" : "=v"(d) : "v"(q));
     return d;
 }
+// Keeps every component of a loaded vector alive up to this point (no instruction).  A table quad with a component that some
+// instantiation does not use would otherwise have that register reused right after the load is issued - and the compiler then
+// waits for the load (write-after-write) long before its data is needed.
+template <typename T>
+__device__ __forceinline__ void keep_alive(const T &v)
+{
+    asm volatile("" : : "v"(v));
+}
 // a constant that stays in ONE vector register (the compiler otherwise re-materialises it with a v_mov at every use)
 __device__ __forceinline__ int vgpr_const(int c)
 {
@@ -814,7 +822,47 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 #define M2V_LANEK4(member) M2V_QUAD(0, LaneK, member)
     // Requested with the pixels (whose own addresses stay arithmetic: a table value in front of them would put a second memory
     // round trip before the first load); the last two quads follow before the transform.
-    const u32x4_t kq0 = M2V_LANEK4(win_st), kq1 = M2V_LANEK4(cpc_st);
+    // An I frame (no window, no search to hide behind) requests everything here, and of the first quad only the two words it uses.
+    u32x4_t kq0 = {0, 0, 0, 0};
+    if constexpr (P) kq0 = M2V_LANEK4(win_st);
+    else {
+        // (M2V_LANEK4 names the quad a member lies in: the member's own offset inside the quad is added here)
+        const u32x2_t t = *(const __attribute__((address_space(1))) u32x2_t *)((const uint8_t *)&M2V_LANEK4(pred_st) + offsetof(LaneK, pred_st) % 16);
+        kq0.z = t.x; kq0.w = t.y;
+    }
+    const u32x4_t kq1 = M2V_LANEK4(cpc_st);
+    long mf_b1 = 0, mf_a2lo = 0, mf_a2hi = 0;   // matrix-core operands of the lane (c_mfma), requested with group 3
+    u32x4_t mf_zoff = {0, 0, 0, 0};
+    u32x4_t kq2, kq3;                           // the lane table's last three quads (not before the search: registers)
+    u32x3_t kq4;
+#define M2V_REQUEST_G3()                                                                                             \
+    do {                                                                                                             \
+        kq2 = M2V_LANEK4(xc4); kq3 = M2V_LANEK4(zz2);                                                                \
+        /* only the words that are used: a dead register of a wide load is reused at once, and the write-after-write   \
+           wait then stalls the wavefront for the whole round trip */                                                  \
+        kq4 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_LANEK4(crec_r);                               \
+        if constexpr (MFMA && !CONF) {                                                                               \
+            const u32x2_t m0 = *(const __attribute__((address_space(1))) u32x2_t *)&M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]); \
+            const u32x4_t m1 = M2V_QUAD(kQuadMfma0, MfmaLane, a2[0]);                                                 \
+            mf_b1 = (long)(((unsigned long long)m0.y << 32) | m0.x);                                                 \
+            mf_a2lo = (long)(((unsigned long long)m1.y << 32) | m1.x); mf_a2hi = (long)(((unsigned long long)m1.w << 32) | m1.z); \
+        }                                                                                                            \
+    } while (0)
+    if constexpr (!P) M2V_REQUEST_G3();
+    // the transform's basis rows: basis row i = lane >> 3 widened to int32, basis row j = lane & 7 and its negative as int8 x 8
+    const int dj = lane & 7;
+    const int di = lane >> 3;
+    int bi[8];
+    uint2 mj, nj;
+#define M2V_REQUEST_BASIS()                                                                                                             \
+    do {                                                                                                                                \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k)                                                                                   \
+            bi[k] = *(const __attribute__((address_space(1))) int32_t *)(ltab2 - 1024 + kConstDct32 + (uint32_t)(di * 32) + 4 * k);    \
+        typedef const __attribute__((address_space(1))) u32x2_t *gld64;                                                                 \
+        const u32x2_t mjv = *(gld64)(ltab2 - 1024 + kConstDct + (uint32_t)(dj * 8)), njv = *(gld64)(ltab2 - 1024 + kConstDctNeg + (uint32_t)(dj * 8)); \
+        mj = uint2{mjv.x, mjv.y}; nj = uint2{njv.x, njv.y};                                                                             \
+    } while (0)
+    if constexpr (!P) M2V_REQUEST_BASIS();
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t li = udiv_magic(blk, g.strip_mbs, g.magic_strip);           // which frame of the launch list
     const FrameJob job = jobs[li];                 // `jobs` = the launch list as jobs: one dependent scalar load, not list -> job
@@ -910,24 +958,6 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 
     int inter = 0, mvx = 0, mvy = 0;
     uint32_t pred4 = 0x80808080u;               // intra prediction (RTL:1894-1903)
-    long mf_b1 = 0, mf_a2lo = 0, mf_a2hi = 0;   // matrix-core operands of the lane (c_mfma), requested with group 3
-    u32x4_t mf_zoff = {0, 0, 0, 0};
-    u32x4_t kq2, kq3;                           // the lane table's last three quads (not before the search: registers)
-    u32x3_t kq4;
-#define M2V_REQUEST_G3()                                                                                             \
-    do {                                                                                                             \
-        kq2 = M2V_LANEK4(xc4); kq3 = M2V_LANEK4(zz2);                                                                \
-        /* only the words that are used: a dead register of a wide load is reused at once, and the write-after-write   \
-           wait then stalls the wavefront for the whole round trip */                                                  \
-        kq4 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_LANEK4(crec_r);                               \
-        if constexpr (MFMA && !CONF) {                                                                               \
-            const u32x2_t m0 = *(const __attribute__((address_space(1))) u32x2_t *)&M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]); \
-            const u32x4_t m1 = M2V_QUAD(kQuadMfma0, MfmaLane, a2[0]);                                                 \
-            mf_b1 = (long)(((unsigned long long)m0.y << 32) | m0.x);                                                 \
-            mf_a2lo = (long)(((unsigned long long)m1.y << 32) | m1.x); mf_a2hi = (long)(((unsigned long long)m1.w << 32) | m1.z); \
-        }                                                                                                            \
-    } while (0)
-    if constexpr (!P) M2V_REQUEST_G3();
 
     if constexpr (P) {
         // ---- stages X..Z: reference window of recon(f-1) into LDS (RTL:1350-1425, 1612-1629) --
@@ -1114,23 +1144,14 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         mvx = 2 * fx + hx;
     }
 
-    // the transform's basis rows, requested here (one phase ahead of stage G): basis row i = lane >> 3 widened to int32, basis
-    // row j = lane & 7 and its negative as int8 x 8
-    const int dj = lane & 7;
-    const int di = lane >> 3;
-    int bi[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bi[k] = *(const __attribute__((address_space(1))) int32_t *)(ltab2 - 1024 + kConstDct32 + (uint32_t)(di * 32) + 4 * k);   // c_dct32[di * 8 + k]
-    // basis row j and its negative, int8 x 8 (c_dct, c_dct_neg)
-    typedef const __attribute__((address_space(1))) u32x2_t *gld64;
-    const u32x2_t mjv = *(gld64)(ltab2 - 1024 + kConstDct + (uint32_t)(dj * 8)), njv = *(gld64)(ltab2 - 1024 + kConstDctNeg + (uint32_t)(dj * 8));
-    const uint2 mj = {mjv.x, mjv.y}, nj = {njv.x, njv.y};
+    if constexpr (P) M2V_REQUEST_BASIS();       // one phase ahead of stage G (an I frame asked at the start)
     // ---- prediction into tile layout; current and predicted samples as SIGNED bytes for the transform (RTL:1891-1917,
     // 1980-2014).  The 9-bit residual c - p is never formed: stage G needs only sum_k M[j][k] (c_k - p_k), which is
     // sum_k M[j][k] (c_k - 128) + sum_k (-M[j][k]) (p_k - 128), two v_dot4_i32_i8 chains on the bytes XOR 0x80.
     // s_cp[tile][row] = 8 current bytes, then 8 prediction bytes: one 16-byte LDS read per tile row in stage G.
     typedef __attribute__((address_space(3))) uint32_t *LdsW32;
     typedef __attribute__((address_space(3))) uint16_t *LdsW16;
+    keep_alive(kq0); keep_alive(kq1);
     {
         // tile = ((r >> 3) << 1) | (c4 >> 1), ti = ((r & 7) << 3) | ((c4 & 1) << 2)
         *(LdsW32)(uintptr_t)kq0.z = pred4;                                   // s_pred[tile][ti]
@@ -1177,6 +1198,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 
     M2V_STOP(3);            // ... up to the prediction
     // ---- stage G: 2-D forward DCT (RTL:2029-2062); lane = (i = lane>>3, j = lane&7) ------------
+    keep_alive(kq2);
     // DCT-as-GEMM trial (north star): the four luma tiles through the matrix cores, the two chroma tiles as before
     constexpr bool kMfmaLuma = MFMA && !CONF;
     constexpr int kT0 = kMfmaLuma ? 4 : 0;             // first tile on the VALU path
@@ -1513,6 +1535,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     M2V_STOP(6);            // everything but the reconstruction loop
     // ---- stages H..R: Chen-Wang IDCT, reconstruction, store as next reference ------------------
     if (need_rec) {
+        keep_alive(kq3); keep_alive(kq4);
         M2V_WAVE_SYNC();                                // s_t doubles as the bit buffer that was just copied out
         if (lane < 48) {                                // rows: lane = tile*8 + row (RTL:2159-2189)
             const int t = lane >> 3, row = lane & 7;
