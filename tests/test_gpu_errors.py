@@ -39,6 +39,8 @@ def test_overflow_reset_and_options():
         assert L.m2v_set_option(enc._h, b"no_such_option", 1) == -1
         assert L.m2v_set_option(enc._h, b"batch_frames", 2) == 0
         assert enc.encode(clip, 6, 4, 3) == want
+        assert L.m2v_set_option(enc._h, b"batch_frames", 100000) == 0   # taken as 200 (32-bit offsets inside a chunk, k_frame_scan)
+        assert enc.encode(clip, 6, 4, 3) == want
         # zero frames: the sequence never starts (stop while idle does nothing, RTL:1090)
         assert enc.encode_resident(d_in.data_ptr(), 0, big.data_ptr(), big.numel(), 6, 4, 3) == 0
         enc.sequence_stop()
