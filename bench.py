@@ -5,11 +5,14 @@ One "step" = one pass of the hot path over one batch of synthetic input: a 1920x
 of 10 closed GOPs (1 I + 8 P frames each, VECTOR_LEVEL=3, Q_LEVEL=2, XL=YL=7) resident in HBM,
 encoded to the final MPEG-2 elementary stream in HBM through the C-ABI (m2v_encode_resident).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode sequences|strips] [--config c3|c2]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank encodes its own clip
-(BASELINE config c4: independent sequences, no data-path collective) -> "scaling": "weak".
-Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU.  Either the caller starts the ranks (torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in the environment), or - WORLD_SIZE unset - this process starts them itself: `python bench.py --gpus 8` alone is an
+8-rank job (launch_ranks(): N children before anything touches the GPU, rank 0's JSON line relayed, worst exit code).
+Every rank encodes its own clip (BASELINE config c4: independent sequences, no data-path collective) -> "scaling": "weak";
+--mode strips is config c5 (ONE sequence, macroblock-row strips, RCCL halo exchange) -> "scaling": "strong".
+Rank 0 prints ONE JSON line; "n_gpus" is the world size the process group reports ("ranks_seen").
 """
 import argparse
 import json
@@ -32,15 +35,51 @@ GOP_CODE, END_CODE = b"\x00\x00\x01\xb8", b"\x00\x00\x01\xb7"
 
 
 def cpu_baseline(frames_np):
-    """The CPU oracle (oracle/, a C restatement of the RTL: kind 'port') timed on ONE GOP of the same clip, 1 core."""
+    """The CPU oracle (oracle/, a C restatement of the RTL: kind 'port') timed on the first frames of the same clip, 1 core:
+    one GOP of config c3, 96 I frames of config c2."""
     from oracle import m2v_oracle_ctypes as orc
     orc.build()
     n = frames_np.shape[0]
     t0 = time.perf_counter()
     orc.encode(frames_np, XS16, YS16, PFRAMES, XL, YL, VL, Q)
     dt = time.perf_counter() - t0
+    what = "first GOP (%d frames, 1 I + %d P)" % (n, n - 1) if PFRAMES else "first %d I frames" % n
     return dict(value=round(n * W * H / dt * 1e-6, 4), unit="MPixels/s", cores=1, kind="port",
-                sample="first GOP (%d frames, 1 I + %d P) of the benchmark clip, oracle/m2v_oracle.c, %.1f s" % (n, n - 1, dt))
+                sample="%s of the benchmark clip, oracle/m2v_oracle.c, %.1f s" % (what, dt))
+
+
+def source_shas():
+    """What the running tree is: git HEAD (if this is a checkout) and the sha256 of the kernel source.  profiles/pmc_traffic.json
+    carries the same two values for the tree its PMC passes ran on (tools/profile_round.sh)."""
+    import hashlib
+    import subprocess
+    ksha = hashlib.sha256(open(os.path.join(ROOT, "fpga-mpeg2-encoder_amd", "csrc", "m2v_kernels.hpp"), "rb").read()).hexdigest()
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:  # noqa: BLE001
+        head = None
+    return head, ksha
+
+
+def pmc_traffic(key):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
+    MI355X_MICROARCH.md), collected by tools/profile_round.sh in separate rocprofv3 runs of this same command and kept in
+    profiles/pmc_traffic.json together with the tree they measured.  `traffic_stale` says whether the kernel source has changed
+    since (a counter pass cannot run inside the timed job: it serialises the dispatches)."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    out = {"traffic": None}
+    try:
+        t = json.load(open(tpath))
+    except Exception:  # noqa: BLE001
+        return out
+    if t.get(key) is None:
+        return out
+    head, ksha = source_shas()
+    out.update({"traffic": t[key], "traffic_source": "profiles/pmc_traffic.json (separate --pmc passes of this command)",
+                "traffic_measured_at": {"head": t.get("head"), "kernel_sha": t.get("kernel_sha")},
+                "running": {"head": head, "kernel_sha": ksha},
+                "traffic_stale": t.get("kernel_sha") != ksha})
+    return out
 
 
 def gop_time_code(n):
@@ -91,16 +130,17 @@ def cpu_baseline_all_cores(clip_np, gpu_stream_bytes):
     from oracle import m2v_oracle_ctypes as orc
     gop = PFRAMES + 1
     ngops = clip_np.shape[0] // gop
-    threads = max(ngops, min(os.cpu_count() or 1, 64))
+    workers = min(os.cpu_count() or 1, 64)
+    threads = max(ngops, workers)                 # jobs: every GOP at least once, and at least one per core
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
+    with ThreadPoolExecutor(workers) as ex:
         outs = list(ex.map(lambda t: orc.encode(clip_np[(t % ngops) * gop:(t % ngops + 1) * gop], XS16, YS16, PFRAMES, XL, YL, VL, Q),
                            range(threads)))
     dt = time.perf_counter() - t0
     bad = ["oracle not deterministic on GOP %d" % (t % ngops) for t in range(ngops, threads) if outs[t] != outs[t % ngops]]
     bad += compare_with_per_gop_oracle(gpu_stream_bytes, outs[:ngops], gop)
-    base = dict(value=round(threads * gop * W * H / dt * 1e-6, 3), unit="MPixels/s", cores=threads, kind="port",
-                sample="%d threads, each one GOP (%d frames) of the benchmark clip (GOP t mod %d), %.1f s" % (threads, gop, ngops, dt))
+    base = dict(value=round(threads * gop * W * H / dt * 1e-6, 3), unit="MPixels/s", cores=workers, kind="port",
+                sample="%d jobs on %d threads, each one GOP (%d frames) of the benchmark clip (GOP t mod %d), %.1f s" % (threads, workers, gop, ngops, dt))
     parity = {"gops_compared": ngops, "stream_bytes_compared": len(gpu_stream_bytes),
               "identical_to_oracle": not bad, "problems": bad[:5],
               "how": "every GOP of the timed clip encoded by the oracle as its own sequence (closed GOPs) and compared byte for "
@@ -132,7 +172,7 @@ def end_to_end(M, clip_np, want_bytes):
     straight from the caller's buffer; pageable frames (a plain numpy array) go through the handle's pinned staging."""
     import torch
     n = clip_np.shape[0]
-    gop = PFRAMES + 1
+    gop = PFRAMES + 1 if PFRAMES else 16          # frames per push (config c2: every frame is a GOP; 16 at a time)
 
     def run(frames, best_of=4):
         enc = M.Mpeg2Encoder(XL, YL, VL, Q)
@@ -191,12 +231,43 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
     Ws = Hs = 2048
     gop = PFRAMES + 1
     nframes = args.gops * gop
+    backend = dist.get_backend() if dist is not None else None
     clip = M.synth.clip_torch(Ws, Hs, nframes, clip_index=0, device=dev)        # every rank holds the same clip
     enc = M.Mpeg2Encoder(7, 7, VL, Q, device=local_rank)
-    eng = M.parallel.GpuStripEngine(enc, clip, 128, 128, PFRAMES, dev)
+    # The loop: native (m2v_strip_encode: the GOP steps and the RCCL send / recv issued from C++) whenever the ranks can talk
+    # RCCL - and for one rank, which has nothing to exchange.  parallel.encode_strips (the Python statement of the same call
+    # order, point-to-point ops through torch.distributed) is what the 1-GPU test hook (gloo, shared device) runs, and the
+    # agreed fallback should librccl refuse to initialise.
+    loop, comm, why = "native", None, None
+    if os.environ.get("M2V_STRIP_LOOP") == "python" or (world > 1 and backend != "nccl"):
+        loop, why = "python", "M2V_STRIP_LOOP=python" if os.environ.get("M2V_STRIP_LOOP") == "python" else "backend %s" % backend
+    elif world > 1:
+        ok = 1
+        try:
+            comm = M.StripComm.rccl(rank, world, local_rank, dist)
+        except Exception as ex:  # noqa: BLE001
+            ok, why = 0, "m2v_comm_init_rccl: %s" % ex
+        t = torch.tensor([ok], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 0:
+            loop, why = "python", why or "another rank could not initialise RCCL natively"
+            if comm is not None:
+                comm.close()
+                comm = None
+    torch.cuda.synchronize()
     out = None
+    if loop == "native":
+        d_out = torch.empty(M.parallel.strip_output_bound(nframes, Ws, Hs), dtype=torch.uint8, device=dev) if rank == 0 else None
+
+        def step(timings=None):
+            return M.parallel.encode_strips_native(enc, comm, rank, world, clip, 128, 128, PFRAMES, d_out)
+    else:
+        eng = M.parallel.GpuStripEngine(enc, clip, 128, 128, PFRAMES, dev)
+
+        def step(timings=None):
+            return M.parallel.encode_strips(eng, rank, world, dist, timings=timings)
     for _ in range((20 if args.prewarm > 0 else 0) + args.warmup):     # fixed count: every rank takes part in the halo exchange
-        out = M.parallel.encode_strips(eng, rank, world, dist)
+        out = step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -207,20 +278,25 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = M.parallel.encode_strips(eng, rank, world, dist)
+        out = step()
     barrier()
     dt = time.perf_counter() - t0
     # one more pass with per-launch HIP events (option profile) and the exchange bracketed by events on the engine's stream
     enc.set_option("profile", 1)
     timings = {}
-    M.parallel.encode_strips(eng, rank, world, dist, timings=timings)
-    M.parallel.encode_strips(eng, rank, world, dist, timings=timings)
+    step(timings)
+    step(timings)
+    if loop == "native":
+        timings = enc.strip_stats()
     launches, ms_p, px_p = enc.kernel_stats(0)
     _, ms_i, _ = enc.kernel_stats(1)
+    _, ms_asm, _ = enc.kernel_stats(3)
+    _, ms_scan, _ = enc.kernel_stats(4)
     enc.set_option("profile", 0)
+    host_us = timings.get("host_us_per_step")
     if dist is not None:
         t = torch.tensor([dt, timings.get("halo_exposed", 0.0), timings.get("halo_total", 0.0), timings.get("gather", 0.0)],
-                         dtype=torch.float64, device=dev)
+                         dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, timings["halo_exposed"], timings["halo_total"], timings["gather"] = (float(v) for v in t.tolist())
     if rank == 0:
@@ -231,14 +307,17 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
         achieved = alg_bytes / (ms_p * 1e-3) * 1e-9 if ms_p > 0 else 0.0
         line = {
             "metric": "MPixels/s encoded, 2048x2048 I+P, macroblock-row strips", "value": round(args.steps * px / dt * 1e-6, 2),
-            "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "MPixels/s", "n_gpus": dist.get_world_size() if dist is not None else 1,
+            "ranks_seen": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": round(args.steps * px / dt * 1e-6 / FPGA_MPIXELS, 3), "dtype": "u8", "data": "synthetic",
             "config": {"workload": "c5: ONE 2048x2048 yuv444p sequence, %d GOPs of 1 I + %d P, VECTOR_LEVEL=3 Q_LEVEL=2, "
                                    "%d strips of macroblock rows, halo = 9 rows x 2048 B per frame per direction"
                                    % (args.gops, PFRAMES, world), "frames": nframes,
                        "stream_bytes": int(out.numel()) if out is not None else None,
-                       "baseline": "FPGA Kintex-7 268 MPixels/s (README.md:22)"},
+                       "baseline": "FPGA Kintex-7 268 MPixels/s (README.md:22)",
+                       "strip_loop": loop, "strip_loop_why": why, "dist_backend": backend,
+                       "launched_by": os.environ.get("M2V_BENCH_LAUNCHED_BY", "caller")},
             "roofline": {"bound": "hbm", "kernel": "k_mb<3,true> on rank 0's strip (%d macroblock rows), P-frame launches of one step" % (rows[1] - rows[0]),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": None, "launches_per_step": launches, "kernel_ms_per_step": round(ms_p, 3),
@@ -246,9 +325,11 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
                          "timed_in": "extra pass with option profile (HIP events around every launch on the engine's stream)"},
             "exchange_ms_per_step": {"halo_exposed": round(timings.get("halo_exposed", 0.0), 3), "halo_total": round(timings.get("halo_total", 0.0), 3),
                                      "gather_and_assembly": round(timings.get("gather", 0.0), 3),
+                                     "host_us_per_gop_step": round(host_us, 1) if host_us is not None else None,
                                      "note": "max over ranks; halo_exposed = stream time spent waiting for neighbour rows after the "
                                              "interior rows were done, halo_total = from edge rows packed to neighbour rows there"},
-            "kernel_ms_per_step": {"k_mb_P": round(ms_p, 3), "k_mb_I": round(ms_i, 3)},
+            "kernel_ms_per_step": {"k_mb_P": round(ms_p, 3), "k_mb_I": round(ms_i, 3), "scans": round(ms_scan, 3),
+                                   "k_assemble + k_strip_layout / k_strip_assemble": round(ms_asm, 3)},
         }
         if not args.no_cpu_baseline:
             from concurrent.futures import ThreadPoolExecutor
@@ -270,14 +351,98 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
         print(json.dumps(line))
         sys.stdout.flush()
     enc.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def launch_ranks(nranks, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here.  This process has not imported torch and
+    has made no HIP call (a process that initialised the GPU must never exec or fork GPU work), it only starts N children
+    of this same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's stdout (the ONE JSON line)
+    and returns the worst exit code.  The other ranks' stdout goes to stderr.  A rank that dies takes the job down:
+    the survivors (exact PIDs, never a pattern) are terminated instead of waiting in a collective for ever."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                          # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), M2V_BENCH_LAUNCHED_BY="bench.py")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=ROOT))
+    line0 = procs[0].stdout
+    worst, live = 0, set(range(nranks))
+    relayed = []
+    import threading
+
+    def relay():
+        for raw in line0:
+            relayed.append(raw)
+            sys.stdout.buffer.write(raw)
+            sys.stdout.buffer.flush()
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    deadline = None
+    while live:
+        for r in list(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                if deadline is None:
+                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks in 20 s\n" % (r, rc))
+                    deadline = time.time() + 20.0
+        if deadline is not None and time.time() > deadline:
+            for r in live:
+                procs[r].terminate()
+            deadline = time.time() + 1e9
+        time.sleep(0.05)
+    t.join(timeout=10.0)
+    return worst
+
+
+def dry_launch(args, rank, world):
+    """--dry-launch: the rendezvous alone, no encoder - runs without a GPU (gloo), which is how tests/ checks on CPU that
+    `bench.py --gpus N` really is an N-rank job.  Every rank contributes 1 to an all-reduce; rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("M2V_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if os.environ.get("M2V_BENCH_TEST_FAIL_RANK") == str(rank):        # tests/test_bench_launch.py: a rank that dies early
+        return 3
+    seen, total = 1, 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        t = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        seen, total = dist.get_world_size(), int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": seen, "ranks_seen": seen, "ranks_counted": total, "gpus_arg": args.gpus,
+                          "backend": backend if world > 1 else None, "mode": args.mode,
+                          "launched_by": os.environ.get("M2V_BENCH_LAUNCHED_BY", "caller")}))
+        sys.stdout.flush()
+    return 0 if total == world == seen else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start / join the N ranks, all-reduce a 1 and print what the process group saw; no GPU work")
+    ap.add_argument("--config", choices=["c3", "c2"], default="c3",
+                    help="c3 (default, the metric's configuration): 1920x1152 I+P; c2: 640x480 I frames only (i_pframes_count = 0)")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gops", type=int, default=GOPS)
@@ -294,26 +459,46 @@ def main():
                          "strips: config c5, ONE 2048x2048 sequence cut into macroblock-row strips, RCCL halo exchange")
     args = ap.parse_args()
 
+    # ---- N ranks: started by the caller (WORLD_SIZE set) or, failing that, by this process before it touches the GPU ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.dry_launch:
+        sys.exit(dry_launch(args, rank, world))
+
+    global W, H, XS16, YS16, PFRAMES
+    if args.config == "c2":                    # BASELINE configs[1]: 640x480, I frames only, Q_LEVEL 2 - DCT + quantiser + VLC, no search
+        W, H, XS16, YS16, PFRAMES = 640, 480, 40, 30, 0
+        if args.gops == GOPS:
+            args.gops = 256                    # 256 frames = 307 200 macroblocks per launch (a frame is its own GOP)
+        if args.mode == "strips":
+            raise SystemExit("--config c2 is a --mode sequences workload")
+
     import torch
     import m2v_load
     M = m2v_load.load()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # Test hook for 1-GPU boxes only: M2V_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and M2V_DIST_BACKEND=gloo replaces
     # RCCL (which refuses two ranks on one device) for the barrier / max-over-ranks.  Never set by the driver.
     if os.environ.get("M2V_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks but %d visible GPUs (one rank per GPU)" % (world, torch.cuda.device_count()))
     backend = os.environ.get("M2V_DIST_BACKEND", "nccl")
     dist = None
     torch.cuda.set_device(local_rank)
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
+        ranks_seen = dist.get_world_size()
     dev = "cuda:%d" % local_rank
 
     if rank == 0 or world == 1:
@@ -322,7 +507,8 @@ def main():
         dist.barrier()
     if args.mode == "strips":
         return bench_strips(args, M, torch, dist, rank, local_rank, world, dev)
-    nframes = args.gops * (PFRAMES + 1)
+    gop = PFRAMES + 1
+    nframes = args.gops * gop
     clip = M.synth.clip_torch(W, H, nframes, clip_index=rank, device=dev)       # resident in HBM
     cap = nframes * W * H * 3 // 2
     d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -344,6 +530,7 @@ def main():
         nbytes = step()
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -375,52 +562,43 @@ def main():
     value = world * args.steps * pixels_per_step / dt * 1e-6
 
     if rank == 0:
-        # dominant kernel: k_mb<3,true> (P-frame macroblock kernel).  Statistics of the LAST step.
+        # dominant kernel: k_mb<3,true> (P-frame macroblock kernel); for the I-only config c2 it is k_mb<1,false>.
+        # Statistics of the LAST step.
         launches, ms, px = enc.kernel_stats(0)
         li, msi, pxi = enc.kernel_stats(1)
-        l2, ms2, _ = enc.kernel_stats(2)
         l3, ms3, _ = enc.kernel_stats(3)
         l4, ms4, _ = enc.kernel_stats(4)
-        # algorithmic HBM bytes per luma pixel of a P frame: 3.0 input 4:4:4 + 1.5 reference
-        # load + 1.5 reconstruction store (frames that are referenced later) ; bitstream is written by k_vlc
-        frames_with_rec = args.gops * (PFRAMES - 1)
-        frames_without = args.gops * 1
-        alg_bytes = (frames_with_rec * 6.0 + frames_without * 4.5) * W * H
-        achieved = alg_bytes / (ms * 1e-3) * 1e-9 if ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("k_mb_p_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+        if PFRAMES > 0:
+            # algorithmic HBM bytes per luma pixel of a P frame: 3.0 input 4:4:4 + 1.5 reference
+            # load + 1.5 reconstruction store (frames that are referenced later); the bitstream leaves through k_assemble
+            dom, dom_name, dom_launches, dom_ms, tkey = "P", "k_mb<3,true> (P-frame macroblock kernel)", launches, ms, "k_mb_p_bytes_per_launch"
+            alg_bytes = (args.gops * (PFRAMES - 1) * 6.0 + args.gops * 4.5) * W * H
+        else:
+            # I frames that nothing references: 3.0 B/px of input, no reconstruction store
+            dom, dom_name, dom_launches, dom_ms, tkey = "I", "k_mb<1,false> (I-frame macroblock kernel, no search)", li, msi, "k_mb_i_c2_bytes_per_launch"
+            alg_bytes = nframes * 3.0 * W * H
+        achieved = alg_bytes / (dom_ms * 1e-3) * 1e-9 if dom_ms > 0 else 0.0
+        traffic = pmc_traffic(tkey)
+        workload = ("c3: 1920x1152 yuv444p, %d closed GOPs of 1 I + %d P frames (%d frames), VECTOR_LEVEL=3 Q_LEVEL=2 XL=YL=7, "
+                    "one independent sequence per GPU (c4 for N > 1), no data-path collective" % (args.gops, PFRAMES, nframes)) if PFRAMES else \
+                   ("c2: 640x480 yuv444p, %d I frames (i_pframes_count = 0), Q_LEVEL=2 XL=YL=7, one independent sequence per GPU, "
+                    "no data-path collective" % nframes)
         out = {
-            "metric": "MPixels/s encoded, 1920x1152 I+P",
-            "value": round(value, 2), "unit": "MPixels/s", "n_gpus": world, "steps": args.steps,
+            "metric": "MPixels/s encoded, %dx%d %s" % (W, H, "I+P" if PFRAMES else "I only"),
+            "value": round(value, 2), "unit": "MPixels/s", "n_gpus": ranks_seen, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": round(value / FPGA_MPIXELS, 3), "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "c3: 1920x1152 yuv444p, %d closed GOPs of 1 I + %d P frames (%d frames), "
-                                   "VECTOR_LEVEL=3 Q_LEVEL=2 XL=YL=7, one independent sequence per GPU (c4 for N > 1), "
-                                   "no data-path collective" % (args.gops, PFRAMES, nframes),
-                       "frames": nframes, "stream_bytes": int(nbytes),
+            "config": {"workload": workload, "frames": nframes, "stream_bytes": int(nbytes),
                        "bits_per_pixel": round(nbytes * 8 / pixels_per_step, 4),
-                       "baseline": "FPGA Kintex-7 268 MPixels/s (README.md:22)"},
-            "roofline": {"bound": "hbm", "kernel": "k_mb<3,true> (P-frame macroblock kernel)",
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": "profiles/pmc_traffic.json (PMC passes of an earlier run of this same command)"
-                                           if traffic is not None else None,
-                         "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
-                         "algorithmic_bytes_per_launch": round(alg_bytes / max(launches, 1))},
-            # secondary "operation roofline" of SURVEY.md 8(d): the search alone is (2*6+1)^2 + 9 = 178 byte absolute
-            # differences per luma pixel of a P frame; v_qsad / v_sad retire one per lane per clock
-            "op_roofline": {"bound": "valu-sad", "unit": "T byte-absdiff/s",
-                            "achieved": round(178.0 * px / (ms * 1e-3) * 1e-12, 2) if ms > 0 else 0.0,
-                            "peak": round(256 * 4 * 64 * 2.4e9 * 1e-12, 1),
-                            "frac": round(178.0 * px / (ms * 1e-3) / (256 * 4 * 64 * 2.4e9), 4) if ms > 0 else 0.0,
-                            "note": "256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz; the macroblock kernel is VALU-issue bound "
-                                    "(VALUBusy 100 %), the SADs are ~21 % of its VALU cycles at 66 % lane efficiency"},
+                       "baseline": "FPGA Kintex-7 268 MPixels/s (README.md:22)",
+                       "launched_by": os.environ.get("M2V_BENCH_LAUNCHED_BY", "caller"),
+                       "dist_backend": backend if world > 1 else None},
+            "roofline": dict({"bound": "hbm", "kernel": dom_name,
+                              "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(achieved / HBM_PEAK_GBS, 5)}, **traffic,
+                             **{"launches_per_step": dom_launches, "avg_launch_ms": round(dom_ms / max(dom_launches, 1), 4),
+                                "algorithmic_bytes_per_launch": round(alg_bytes / max(dom_launches, 1))}),
             "kernel_ms_per_step": {"k_mb_P": round(ms, 3), "k_mb_I": round(msi, 3), "k_assemble": round(ms3, 3),
                                    "scans_headers": round(ms4, 3)},
             # `value` is the encoder as shipped: the closed GOPs of the chunk run as two groups on two HIP streams, so the
@@ -432,11 +610,20 @@ def main():
                               "streams": 1, "in_band_event_timers": True},
             "streams": args.split if args.split >= 0 else 2,
         }
+        if dom == "P":
+            # secondary "operation roofline" of SURVEY.md 8(d): the search alone is (2*6+1)^2 + 9 = 178 byte absolute
+            # differences per luma pixel of a P frame; v_qsad / v_sad retire one per lane per clock
+            out["op_roofline"] = {"bound": "valu-sad", "unit": "T byte-absdiff/s",
+                                  "achieved": round(178.0 * px / (ms * 1e-3) * 1e-12, 2) if ms > 0 else 0.0,
+                                  "peak": round(256 * 4 * 64 * 2.4e9 * 1e-12, 1),
+                                  "frac": round(178.0 * px / (ms * 1e-3) / (256 * 4 * 64 * 2.4e9), 4) if ms > 0 else 0.0,
+                                  "note": "256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz; the macroblock kernel is VALU-issue bound "
+                                          "(VALUBusy 100 %), the SADs are ~21 % of its VALU cycles at 66 % lane efficiency"}
         out["roofline"]["timed_in"] = "profiled_pass (one stream, HIP events around every launch on the launch stream)"
         if world == 1 and not args.no_cpu_baseline:
             clip_np = clip.cpu().numpy()
             gpu_bytes = d_out[:nbytes].cpu().numpy().tobytes()
-            out["cpu_baseline"] = cpu_baseline(clip_np[:PFRAMES + 1])
+            out["cpu_baseline"] = cpu_baseline(clip_np[:gop if PFRAMES else min(nframes, 96)])
             out["cpu_baseline_all_cores"], out["parity_check"] = cpu_baseline_all_cores(clip_np, gpu_bytes)
             out["rtl_sim"] = rtl_sim_probe()
             copy = hbm_copy_rate(torch, dev)

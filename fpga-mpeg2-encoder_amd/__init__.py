@@ -29,6 +29,8 @@ EXPORTS = [
     "m2v_sequence_stop", "m2v_busy", "m2v_pull", "m2v_geometry", "m2v_encode_resident", "m2v_set_option",
     "m2v_kernel_stats", "m2v_debug_read", "m2v_last_error", "m2v_debug_table",
     "m2v_strip_begin", "m2v_strip_info", "m2v_strip_step", "m2v_strip_step_edges", "m2v_strip_step_interior", "m2v_strip_halo_in", "m2v_strip_finish", "m2v_strip_assemble",
+    "m2v_strip_finish_async", "m2v_strip_offsets", "m2v_strip_encode", "m2v_strip_stats",
+    "m2v_comm_unique_id", "m2v_comm_init_rccl", "m2v_comm_init_local", "m2v_comm_destroy", "m2v_comm_last_error", "m2v_comm_selftest",
 ]
 
 
@@ -82,6 +84,19 @@ def lib(debug=False):
         L.m2v_strip_halo_in.argtypes = [vp, ci, vp, vp]
         L.m2v_strip_finish.argtypes = [vp, vp, sz, vp]
         L.m2v_strip_assemble.argtypes = [vp, u32, u32, u32, sz, ci, vp, vp, vp, sz, ctypes.POINTER(sz), vp]
+        L.m2v_strip_finish_async.argtypes = [vp, vp, sz]
+        L.m2v_strip_offsets.argtypes = [vp, vp]
+        L.m2v_strip_encode.argtypes = [vp, vp, ci, ci, ci, u32, u32, u32, vp, sz, vp, sz, ctypes.POINTER(sz), vp]
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.m2v_strip_stats.argtypes = [vp, dp, dp, dp, dp]
+        L.m2v_comm_unique_id.argtypes = [vp, sz]
+        L.m2v_comm_init_rccl.restype = vp
+        L.m2v_comm_init_rccl.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ci)]
+        L.m2v_comm_init_local.restype = vp
+        L.m2v_comm_init_local.argtypes = [ci, ctypes.POINTER(ci)]
+        L.m2v_comm_destroy.argtypes = [vp]
+        L.m2v_comm_last_error.restype = ctypes.c_char_p
+        L.m2v_comm_selftest.argtypes = [vp, ci, vp, vp, sz, vp]
         _libs[path] = L
     return _libs[path]
 
@@ -230,6 +245,28 @@ class Mpeg2Encoder:
         self._chk(self._L.m2v_strip_finish(self._h, d_strip_ptr, cap, off.ctypes.data), "m2v_strip_finish")
         return off
 
+    def strip_finish_async(self, d_strip_ptr, cap):
+        self._chk(self._L.m2v_strip_finish_async(self._h, d_strip_ptr, cap), "m2v_strip_finish_async")
+
+    def strip_offsets(self, nframes):
+        off = np.zeros(nframes + 1, np.uint64)
+        self._chk(self._L.m2v_strip_offsets(self._h, off.ctypes.data), "m2v_strip_offsets")
+        return off
+
+    def strip_encode(self, comm, rank, world, d_frames_ptr, nframes, xsize16, ysize16, pframes_count, d_out_ptr=None, cap=0, dst=0, stream=0):
+        """m2v_strip_encode: this rank's strip of one sequence, exchange included, in one native call.  `comm`: a StripComm
+        (None for world == 1).  Returns the stream's byte count on rank `dst`, 0 elsewhere."""
+        n = ctypes.c_size_t(0)
+        self._chk(self._L.m2v_strip_encode(self._h, comm.handle if comm is not None else None, rank, world, dst, xsize16, ysize16,
+                                           pframes_count, d_frames_ptr, nframes, d_out_ptr, cap, ctypes.byref(n), stream), "m2v_strip_encode")
+        return n.value
+
+    def strip_stats(self):
+        """-> dict of the last strip_encode: steps, host_us_per_step, and (option profile) halo_total / halo_exposed / gather in ms"""
+        v = [ctypes.c_double(0) for _ in range(4)]
+        steps = self._chk(self._L.m2v_strip_stats(self._h, *[ctypes.byref(x) for x in v]), "m2v_strip_stats")
+        return {"steps": steps, "halo_total": v[0].value, "halo_exposed": v[1].value, "gather": v[2].value, "host_us_per_step": v[3].value}
+
     def strip_assemble(self, strip_ptrs, frame_offs, nframes, d_out_ptr, cap, xsize16, ysize16, pframes_count, stream=0):
         n = len(strip_ptrs)
         ptrs = (ctypes.c_void_p * n)(*strip_ptrs)
@@ -249,3 +286,52 @@ class Mpeg2Encoder:
         buf = np.zeros(nbytes, np.uint8)
         n = self._chk(self._L.m2v_debug_read(self._h, what, buf.ctypes.data, nbytes), "m2v_debug_read")
         return buf[:n].view(dtype)
+
+
+class StripComm:
+    """The exchange between the strips of config c5 (include/m2v_mi355x.h, csrc/m2v_comm.hpp): RCCL between processes, or
+    mailboxes between the threads of one process."""
+
+    def __init__(self, handle, kind, world):
+        self.handle, self.kind, self.world = handle, kind, world
+
+    @classmethod
+    def rccl(cls, rank, world, device, dist=None):
+        """Collective over `dist` (an initialised torch.distributed of any backend, used ONLY to hand rank 0's ncclUniqueId to
+        the others); afterwards the data path talks to librccl directly."""
+        L = lib()
+        ident = None
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            r = L.m2v_comm_unique_id(buf, 128)
+            if r != 128:
+                raise M2VError("m2v_comm_unique_id failed (%d): %s" % (r, L.m2v_comm_last_error().decode()))
+            ident = buf.raw
+        if world > 1:
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            ident = box[0]
+        err = ctypes.c_int(0)
+        h = L.m2v_comm_init_rccl(ident, rank, world, device, ctypes.byref(err))
+        if not h:
+            raise M2VError("m2v_comm_init_rccl failed (%d): %s" % (err.value, L.m2v_comm_last_error().decode()))
+        return cls(h, "rccl", world)
+
+    @classmethod
+    def local(cls, world):
+        L = lib()
+        err = ctypes.c_int(0)
+        h = L.m2v_comm_init_local(world, ctypes.byref(err))
+        if not h:
+            raise M2VError("m2v_comm_init_local failed (%d): %s" % (err.value, L.m2v_comm_last_error().decode()))
+        return cls(h, "local", world)
+
+    def selftest(self, rank, d_send_ptr, d_recv_ptr, nbytes, stream=0):
+        r = lib().m2v_comm_selftest(self.handle, rank, d_send_ptr, d_recv_ptr, nbytes, stream)
+        if r < 0:
+            raise M2VError("m2v_comm_selftest failed (%d): %s" % (r, lib().m2v_comm_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().m2v_comm_destroy(self.handle)
+            self.handle = None

@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libm2v_mi355x.so")
 LIB_DBG = os.path.join(HERE, "libm2v_mi355x_dbg.so")       # -DM2V_DEBUG: level dump, keep_recon, ablate (tests / profiling only)
 TB = os.path.join(HERE, "m2v_tb")
 CONTAINER_LIB = os.path.join(HERE, "libm2v_container.so")      # CPU-only conveniences (include/m2v_container.h)
-SOURCES = ["m2v_mi355x.hip", "m2v_kernels.hpp", "m2v_tables.hpp"]
+SOURCES = ["m2v_mi355x.hip", "m2v_kernels.hpp", "m2v_tables.hpp", "m2v_comm.hpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function"]
 
 

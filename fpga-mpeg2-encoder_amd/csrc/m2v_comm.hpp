@@ -1,0 +1,275 @@
+// m2v_comm.hpp — the exchange step of strip mode (BASELINE config c5) behind one small interface.
+//
+// A strip needs, per GOP step, the neighbours' +-2*VECTOR_LEVEL luma / +-VECTOR_LEVEL chroma rows of the reconstruction it
+// just wrote (window geometry RTL:1446-1448), once per sequence everybody's per-frame strip sizes, and the strips themselves on
+// the rank that owns the output.  xGMI is point-to-point and so is this traffic: send / recv pairs with the two neighbours
+// and 7 sends into the output rank - nothing is reduced.  Two implementations:
+//
+//   RcclComm   one process per GPU; ncclSend / ncclRecv / ncclAllGather of librccl, which is dlopen()ed on first use (the
+//              encoder library itself has no link-time dependency on RCCL; a torch process has librccl mapped already and
+//              gets that copy).  The communicator is created from a ncclUniqueId that the caller distributes
+//              (m2v_comm_unique_id on rank 0, any broadcast, m2v_comm_init_rccl on every rank).
+//   LocalComm  `world` handles of ONE process - one host thread each, on one GPU or several - exchange through mailboxes:
+//              the sender posts a device pointer and an event, the receiver makes its stream wait for the event and copies
+//              device to device.  This is what runs the N-rank code path on a 1-GPU box (tests, tools/step_timeline.py).
+//
+// All calls enqueue on the stream they are given and return; nothing here synchronises a stream except LocalComm's
+// size exchange (which has to hand bytes from one thread to another through the host).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and prototypes only: the symbols are resolved with dlsym
+
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+struct m2v_comm {
+    int world = 1;
+    virtual ~m2v_comm() {}
+    // halo rows of one GOP step: nbytes to / from the rank above (rank - 1) and the rank below (rank + 1); a null pair = no neighbour
+    virtual void halo(int rank, const void *send_up, void *recv_up, const void *send_down, void *recv_down, size_t nbytes, hipStream_t s) = 0;
+    // every rank's `count` values into all[world][count] on every rank (device memory on both sides)
+    virtual void allgather_u64(int rank, const unsigned long long *d_src, unsigned long long *d_all, size_t count, hipStream_t s) = 0;
+    // rank r != dst sends sizes[r] bytes of d_strip to dst, which receives them in bufs[r]
+    virtual void gather(int rank, int dst, const void *d_strip, const size_t *sizes, void *const *bufs, hipStream_t s) = 0;
+    // self-test: nbytes from d_send to d_recv through the transport's own send / recv pair addressed to this very rank
+    virtual void loopback(int rank, const void *d_send, void *d_recv, size_t nbytes, hipStream_t s) = 0;
+    virtual const char *kind() const = 0;
+};
+
+namespace m2v {
+
+struct CommError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define M2V_COMM_HIP(expr)                                                                     \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) throw CommError(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// librccl through dlopen
+// ---------------------------------------------------------------------------------------------
+struct RcclApi {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    std::string err;
+
+    static RcclApi &get()
+    {
+        static RcclApi api;
+        static std::once_flag once;
+        std::call_once(once, [] { api.load(); });
+        return api;
+    }
+    bool ok() const { return h != nullptr && err.empty(); }
+
+private:
+    void load()
+    {
+        // a process that imported torch has its librccl mapped under this soname already; otherwise the ROCm copy
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) { err = std::string("librccl not found: ") + dlerror(); return; }
+#define M2V_RCCL_SYM(field, sym)                                         \
+        field = (decltype(field))dlsym(h, #sym);                         \
+        if (!field) { err = "librccl lacks " #sym; return; }
+        M2V_RCCL_SYM(GetUniqueId, ncclGetUniqueId)
+        M2V_RCCL_SYM(CommInitRank, ncclCommInitRank)
+        M2V_RCCL_SYM(CommDestroy, ncclCommDestroy)
+        M2V_RCCL_SYM(GetErrorString, ncclGetErrorString)
+        M2V_RCCL_SYM(GroupStart, ncclGroupStart)
+        M2V_RCCL_SYM(GroupEnd, ncclGroupEnd)
+        M2V_RCCL_SYM(Send, ncclSend)
+        M2V_RCCL_SYM(Recv, ncclRecv)
+        M2V_RCCL_SYM(AllGather, ncclAllGather)
+#undef M2V_RCCL_SYM
+    }
+};
+
+struct RcclComm final : m2v_comm {
+    RcclApi &api;
+    ncclComm_t comm = nullptr;
+    int rank;
+    RcclComm(const ncclUniqueId &id, int rank_, int world_) : api(RcclApi::get()), rank(rank_)
+    {
+        world = world_;
+        if (!api.ok()) throw CommError(api.err);
+        chk(api.CommInitRank(&comm, world_, id, rank_), "ncclCommInitRank");
+    }
+    ~RcclComm() override { if (comm) (void)api.CommDestroy(comm); }
+    const char *kind() const override { return "rccl"; }
+    void chk(ncclResult_t r, const char *what) const
+    {
+        if (r != ncclSuccess) throw CommError(std::string(what) + ": " + api.GetErrorString(r));
+    }
+    // ncclGroupStart; ncclSend / ncclRecv x 2; ncclGroupEnd - one fused point-to-point step per GOP step
+    void halo(int r, const void *send_up, void *recv_up, const void *send_down, void *recv_down, size_t n, hipStream_t s) override
+    {
+        if (!n) return;
+        chk(api.GroupStart(), "ncclGroupStart");
+        if (r > 0 && send_up && recv_up) {
+            chk(api.Send(send_up, n, ncclUint8, r - 1, comm, s), "ncclSend(up)");
+            chk(api.Recv(recv_up, n, ncclUint8, r - 1, comm, s), "ncclRecv(up)");
+        }
+        if (r < world - 1 && send_down && recv_down) {
+            chk(api.Send(send_down, n, ncclUint8, r + 1, comm, s), "ncclSend(down)");
+            chk(api.Recv(recv_down, n, ncclUint8, r + 1, comm, s), "ncclRecv(down)");
+        }
+        chk(api.GroupEnd(), "ncclGroupEnd");
+    }
+    void allgather_u64(int, const unsigned long long *d_src, unsigned long long *d_all, size_t count, hipStream_t s) override
+    {
+        chk(api.AllGather(d_src, d_all, count, ncclUint64, comm, s), "ncclAllGather");
+    }
+    void loopback(int r, const void *d_send, void *d_recv, size_t n, hipStream_t s) override
+    {
+        chk(api.GroupStart(), "ncclGroupStart");
+        chk(api.Send(d_send, n, ncclUint8, r, comm, s), "ncclSend(self)");
+        chk(api.Recv(d_recv, n, ncclUint8, r, comm, s), "ncclRecv(self)");
+        chk(api.GroupEnd(), "ncclGroupEnd");
+    }
+    void gather(int r, int dst, const void *d_strip, const size_t *sizes, void *const *bufs, hipStream_t s) override
+    {
+        chk(api.GroupStart(), "ncclGroupStart");
+        if (r != dst) {
+            if (sizes[r]) chk(api.Send(d_strip, sizes[r], ncclUint8, dst, comm, s), "ncclSend(strip)");
+        } else {
+            for (int k = 0; k < world; ++k)
+                if (k != dst && sizes[k]) chk(api.Recv(bufs[k], sizes[k], ncclUint8, k, comm, s), "ncclRecv(strip)");
+        }
+        chk(api.GroupEnd(), "ncclGroupEnd");
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// ranks = threads of this process
+// ---------------------------------------------------------------------------------------------
+struct LocalComm final : m2v_comm {
+    static constexpr int kMax = 16;
+    struct Slot {
+        const void *ptr = nullptr;
+        size_t n = 0;
+        hipEvent_t ready = nullptr, consumed = nullptr;
+        bool full = false, taken = false;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    Slot halo_slot[kMax][2];            // [sender][0 = to the rank above, 1 = to the rank below]
+    Slot strip_slot[kMax];              // [sender]: its strip for the output rank
+    std::vector<unsigned long long> stage[kMax];
+    int bar_count = 0;
+    unsigned long long bar_gen = 0;
+
+    explicit LocalComm(int w) { world = w; }
+    ~LocalComm() override
+    {
+        auto drop = [](Slot &sl) { if (sl.ready) (void)hipEventDestroy(sl.ready); if (sl.consumed) (void)hipEventDestroy(sl.consumed); };
+        for (auto &pair : halo_slot) for (auto &sl : pair) drop(sl);
+        for (auto &sl : strip_slot) drop(sl);
+    }
+    const char *kind() const override { return "local"; }
+
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const unsigned long long gen = bar_gen;
+        if (++bar_count == world) { bar_count = 0; ++bar_gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return bar_gen != gen; });
+    }
+    // sender: the bytes at ptr are final once everything enqueued on `s` so far has run
+    void post(Slot &sl, const void *ptr, size_t n, hipStream_t s)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !sl.full && !sl.taken; });
+        if (!sl.ready) {
+            M2V_COMM_HIP(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+            M2V_COMM_HIP(hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
+        }
+        M2V_COMM_HIP(hipEventRecord(sl.ready, s));
+        sl.ptr = ptr; sl.n = n; sl.full = true;
+        cv.notify_all();
+    }
+    // receiver: device-to-device copy on its own stream, behind the sender's event
+    void take(Slot &sl, void *dst, size_t n, hipStream_t s)
+    {
+        const void *src;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return sl.full; });
+            if (sl.n != n) throw CommError("local exchange: the two sides disagree about the size");
+            src = sl.ptr;
+        }
+        M2V_COMM_HIP(hipStreamWaitEvent(s, sl.ready, 0));
+        if (n) M2V_COMM_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
+        M2V_COMM_HIP(hipEventRecord(sl.consumed, s));
+        std::unique_lock<std::mutex> lk(mu);
+        sl.full = false; sl.taken = true;
+        cv.notify_all();
+    }
+    // sender again: its buffer may be rewritten by work enqueued on `s` after this
+    void release(Slot &sl, hipStream_t s)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return sl.taken; });
+        M2V_COMM_HIP(hipStreamWaitEvent(s, sl.consumed, 0));
+        sl.taken = false;
+        cv.notify_all();
+    }
+
+    void halo(int r, const void *send_up, void *recv_up, const void *send_down, void *recv_down, size_t n, hipStream_t s) override
+    {
+        if (!n) return;
+        const bool up = r > 0 && send_up && recv_up, down = r < world - 1 && send_down && recv_down;
+        // all posts first, then the receives (which only wait for the neighbours' posts), then the releases: no cycle
+        if (up) post(halo_slot[r][0], send_up, n, s);
+        if (down) post(halo_slot[r][1], send_down, n, s);
+        if (up) take(halo_slot[r - 1][1], recv_up, n, s);            // the bottom rows of the rank above
+        if (down) take(halo_slot[r + 1][0], recv_down, n, s);        // the top rows of the rank below
+        if (up) release(halo_slot[r][0], s);
+        if (down) release(halo_slot[r][1], s);
+    }
+    void allgather_u64(int r, const unsigned long long *d_src, unsigned long long *d_all, size_t count, hipStream_t s) override
+    {
+        barrier();                                  // the previous round's readers are done with the staging
+        stage[r].resize(count);
+        M2V_COMM_HIP(hipMemcpyAsync(stage[r].data(), d_src, count * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        M2V_COMM_HIP(hipStreamSynchronize(s));
+        barrier();
+        for (int k = 0; k < world; ++k)
+            M2V_COMM_HIP(hipMemcpyAsync(d_all + (size_t)k * count, stage[k].data(), count * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        M2V_COMM_HIP(hipStreamSynchronize(s));      // pageable staging: read before anyone resizes it
+    }
+    void loopback(int r, const void *d_send, void *d_recv, size_t n, hipStream_t s) override
+    {
+        post(strip_slot[r], d_send, n, s);
+        take(strip_slot[r], d_recv, n, s);
+        release(strip_slot[r], s);
+    }
+    void gather(int r, int dst, const void *d_strip, const size_t *sizes, void *const *bufs, hipStream_t s) override
+    {
+        if (r != dst) {
+            post(strip_slot[r], d_strip, sizes[r], s);
+            release(strip_slot[r], s);
+        } else {
+            for (int k = 0; k < world; ++k)
+                if (k != dst) take(strip_slot[k], bufs[k], sizes[k], s);
+        }
+    }
+};
+
+}  // namespace m2v

@@ -12,11 +12,12 @@
 //                   bit offset of each macroblock in its slice, byte size of each slice
 //   k_frame_scan    byte offset of every frame / slice in the stream (stage V alignment rules), stream
 //                   length; clears the boundary dwords of the slices and the padded tail
-//   k_assemble      one lane per 32-bit stream word: slice header + macroblock header + DC codes + the
-//                   stored segments gathered at their final bit positions (stages T,U,V); the
-//                   sequence / GOP / picture headers and the sequence end code (RTL:2590-2716)
-//                   travel with the first / last slice
-//   k_headers       the same headers as a kernel of its own (strip mode: m2v_strip_assemble)
+//   k_assemble      one workgroup per slice, one thread per macroblock: slice header + macroblock header + DC codes +
+//                   the stored segments ORed at their final bit positions into an LDS image of the slice, which
+//                   leaves with coalesced dword stores (stages T,U,V); the sequence / GOP / picture headers and
+//                   the sequence end code (RTL:2590-2716) travel with the first / last slice
+//   k_strip_layout / k_strip_assemble   strip mode (config c5): where every (frame, rank) piece goes, computed on the device; the
+//                   pieces moved with 16-byte stores, headers and trailer in the same launch
 //
 // All arithmetic is integer with the RTL's widths; see oracle/m2v_oracle.c for the plain-C
 // statement of the same semantics that the parity tests compare against.
@@ -1973,19 +1974,6 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_headers: byte-aligned headers, one thread per frame (+ thread 0 for the sequence headers).  Used by
-// m2v_strip_assemble; the single-GPU path writes the headers from k_assemble.
-// ----------------------------------------------------------------------------------------------
-__global__ void k_headers(const FrameJob *__restrict__ jobs, Geom g, int nframes, int first,
-                          const unsigned long long *__restrict__ frame_off, uint8_t *out, const StreamCtl *ctl)
-{
-    if (ctl->overflow) return;
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < nframes) write_frame_headers(out + ctl->base_bytes + frame_off[f], jobs[f]);
-    if (f == 0 && first) write_sequence_headers(out + ctl->base_bytes, g);
-}
-
-// ----------------------------------------------------------------------------------------------
 // strip mode (multi-GPU, config c5): rows of the reconstruction that the neighbouring strips need as
 // reference: YR luma + UR chroma rows (U and V) on each side (RTL:1446-1448 window geometry).
 // One block per (frame of the step, direction); packed layout per frame: [YR*W luma][UR*cw U][UR*cw V].
@@ -2029,20 +2017,125 @@ __global__ void k_halo_unpack(const FrameJob *__restrict__ jobs, const int *__re
     }
 }
 
-// final assembly on the rank that owns the output: byte segments (slices of one strip of one frame) to their place
+// ----------------------------------------------------------------------------------------------
+// Final assembly of strip mode on the rank that owns the output (m2v_strip_assemble / m2v_strip_encode).  The stream is
+//   sequence headers | per frame: [GOP header] picture headers, strip 0's slices, strip 1's, ... | end code + padding
+// k_strip_layout (one block) turns the per-rank frame offsets - device memory: they come out of k_frame_scan, or out of the
+// all-gather of the other ranks' - into one copy segment per (frame, rank) and the stream length, so the host neither reads the
+// sizes nor uploads a table in between; k_strip_assemble then moves the bytes with 16-byte stores, writes the headers and the
+// trailer in the same launch.
+// ----------------------------------------------------------------------------------------------
 struct CopySeg { const uint8_t *src; unsigned long long dst_off; unsigned long long len; };
+struct StripSrc { const uint8_t *strip[16]; };            // by value: the strips' device pointers (<= kMaxStripRanks)
+constexpr int kMaxStripRanks = 16;
+constexpr int kLayoutThreads = 256;
 
-__global__ void k_copy_segments(const CopySeg *__restrict__ segs, uint8_t *__restrict__ out)
+// all_off: [nranks][nframes + 1] byte offsets of every frame inside its rank's strip buffer.  Outputs: segs[f * nranks + r],
+// frame_pos[f] = where frame f's own headers start, ctl->total_bytes / overflow (cap is read from ctl->cap_bytes).
+__global__ __launch_bounds__(kLayoutThreads) void k_strip_layout(const unsigned long long *__restrict__ all_off, int nranks, int nframes, uint32_t gop,
+                                                                   StripSrc src, CopySeg *__restrict__ segs,
+                                                                   unsigned long long *__restrict__ frame_pos, StreamCtl *ctl)
 {
-    const CopySeg sg = segs[blockIdx.x];
-    for (unsigned long long i = threadIdx.x; i < sg.len; i += blockDim.x) out[sg.dst_off + i] = sg.src[i];
+    __shared__ unsigned long long s_scan[kLayoutThreads];
+    __shared__ unsigned long long s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = kSeqHeaderBytes;
+    __syncthreads();
+    for (int f0 = 0; f0 < nframes; f0 += kLayoutThreads) {
+        const int f = f0 + tid;
+        unsigned long long sz = 0;
+        if (f < nframes) {
+            sz = frame_header_bytes((int)((uint32_t)f % gop));
+            for (int r = 0; r < nranks; ++r) sz += all_off[(size_t)r * (nframes + 1) + f + 1] - all_off[(size_t)r * (nframes + 1) + f];
+        }
+        s_scan[tid] = sz;
+        __syncthreads();
+        for (int o = 1; o < kLayoutThreads; o <<= 1) {
+            const unsigned long long t = tid >= o ? s_scan[tid - o] : 0ull;
+            __syncthreads();
+            s_scan[tid] += t;
+            __syncthreads();
+        }
+        const unsigned long long carry = s_carry;
+        if (f < nframes) {
+            unsigned long long pos = carry + s_scan[tid] - sz;
+            frame_pos[f] = pos;
+            pos += frame_header_bytes((int)((uint32_t)f % gop));
+            for (int r = 0; r < nranks; ++r) {
+                const unsigned long long a = all_off[(size_t)r * (nframes + 1) + f], b = all_off[(size_t)r * (nframes + 1) + f + 1];
+                segs[(size_t)f * nranks + r] = CopySeg{src.strip[r] + a, pos, b - a};
+                pos += b - a;
+            }
+        }
+        __syncthreads();
+        if (tid == kLayoutThreads - 1) s_carry = carry + s_scan[tid];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const unsigned long long body = s_carry;
+        const unsigned long long total = ((body + 4ull) / 32ull + 1ull) * 32ull;       // end code + the final word rule (RTL:2932-2937)
+        frame_pos[nframes] = body;
+        ctl->base_bytes = 0;
+        ctl->total_bytes = total;
+        ctl->overflow = total > ctl->cap_bytes ? 1u : 0u;
+    }
 }
 
-// trailer: sequence_end_code + zero padding up to `total` (RTL:2621-2628, 2932-2937)
-__global__ void k_trailer(uint8_t *out, unsigned long long body_end, unsigned long long total)
+// Blocks [0, nsegs * split): segment b / split, part b % split of its 16-byte destination cells; 16-byte stores to aligned cells,
+// the source read as aligned dwords and shifted into place (segments start at any byte on both sides); the partial cells at
+// a segment's ends go byte by byte (a neighbouring segment owns the other bytes of that cell).  Then ceil(nframes / 256)
+// header blocks (one thread per frame; thread 0 also the sequence headers) and one trailer block.
+constexpr int kCopyThreads = 256;
+__global__ __launch_bounds__(kCopyThreads) void k_strip_assemble(const CopySeg *__restrict__ segs, int nsegs, int split, Geom g, int nframes, uint32_t gop,
+                                                                   const unsigned long long *__restrict__ frame_pos,
+                                                                   uint8_t *__restrict__ out, const StreamCtl *__restrict__ ctl)
 {
-    for (unsigned long long i = body_end + threadIdx.x; i < total; i += blockDim.x) {
-        const unsigned long long r = i - body_end;
+    if (ctl->overflow) return;
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int ncopy = nsegs * split;
+    if (b < ncopy) {
+        const CopySeg sg = segs[b / split];
+        if (sg.len == 0) return;
+        const int part = b % split;
+        const unsigned long long d0 = sg.dst_off, d1 = sg.dst_off + sg.len;
+        const unsigned long long c0 = d0 >> 4, c1 = (d1 + 15ull) >> 4;                   // destination cells [c0, c1)
+        const unsigned long long nc = c1 - c0, per = (nc + (unsigned long long)split - 1ull) / (unsigned long long)split;
+        const unsigned long long ca = c0 + per * (unsigned long long)part, cb = ca + per < c1 ? ca + per : c1;
+        for (unsigned long long c = ca + (unsigned long long)tid; c < cb; c += kCopyThreads) {
+            const unsigned long long lo = c << 4;
+            if (lo >= d0 && lo + 16ull <= d1) {
+                const uint8_t *sp = sg.src + (lo - d0);
+                const uint32_t sh = (uint32_t)((uintptr_t)sp & 3u);
+                const uint32_t *sw = (const uint32_t *)((uintptr_t)sp & ~(uintptr_t)3);
+                const uint32_t w0 = sw[0], w1 = sw[1], w2 = sw[2], w3 = sw[3];
+                const uint32_t w4 = sh ? sw[4] : 0u;                                      // holds source bytes of this cell whenever it is read
+                uint4 v;
+                v.x = __builtin_amdgcn_alignbyte(w1, w0, sh); v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                v.z = __builtin_amdgcn_alignbyte(w3, w2, sh); v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+                *(uint4 *)(out + lo) = v;
+            } else {
+                const unsigned long long a = lo > d0 ? lo : d0, e = lo + 16ull < d1 ? lo + 16ull : d1;
+                for (unsigned long long i = a; i < e; ++i) out[i] = sg.src[i - d0];
+            }
+        }
+        return;
+    }
+    const int hb = b - ncopy, nhb = (nframes + kCopyThreads - 1) / kCopyThreads;
+    if (hb < nhb) {
+        const int f = hb * kCopyThreads + tid;
+        if (f < nframes) {
+            FrameJob job{};
+            job.i_frame = (int32_t)((uint32_t)f % gop);
+            job.n = (uint32_t)f;
+            write_frame_headers(out + frame_pos[f], job);
+        }
+        if (f == 0) write_sequence_headers(out, g);
+        return;
+    }
+    // trailer: sequence_end_code + zero padding up to the stream length (RTL:2621-2628, 2932-2937)
+    const unsigned long long body = frame_pos[nframes], total = ctl->total_bytes;
+    for (unsigned long long i = body + (unsigned long long)tid; i < total; i += kCopyThreads) {
+        const unsigned long long r = i - body;
         out[i] = r == 2 ? 0x01 : r == 3 ? 0xB7 : 0x00;
     }
 }

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -24,6 +25,7 @@
 
 #include "../../include/m2v_mi355x.h"
 #include "m2v_kernels.hpp"
+#include "m2v_comm.hpp"
 
 using namespace m2v;
 
@@ -56,6 +58,7 @@ struct KStat { int launches = 0; double ms = 0, units = 0; };
 
 // why the last m2v_create on this thread failed: there is no handle yet to carry the text (m2v_last_error(NULL))
 thread_local std::string t_create_err;
+thread_local std::string t_comm_err;          // the same for the m2v_comm_* constructors
 
 struct TimedLaunch { hipEvent_t a, b; int kernel; double units; };
 
@@ -154,10 +157,21 @@ struct m2v_enc {
     size_t plan_nf = 0;
     bool strip_active = false;            // between m2v_strip_begin and m2v_strip_finish
     hipStream_t strip_stream = nullptr;
-    DevBuf<uint8_t> d_segs;               // CopySeg table of m2v_strip_assemble
-    uint8_t *h_asm = nullptr;             // pinned staging of m2v_strip_assemble's tables
+    DevBuf<uint8_t> d_segs;               // CopySeg table of the strip assembly (written by k_strip_layout)
+    DevBuf<unsigned long long> d_frame_pos;   // where every frame's headers start in the assembled stream (k_strip_layout)
+    DevBuf<unsigned long long> d_alloff;  // [ranks][frames + 1] frame offsets of every rank's strip
+    uint8_t *h_asm = nullptr;             // pinned staging of the offsets (m2v_strip_assemble: up; m2v_strip_encode: the all-gathered sizes down)
     size_t h_asm_cap = 0;
     hipEvent_t ev_asm = nullptr;          // the staging may be rewritten once this has been reached
+    uint8_t *h_strip = nullptr;           // pinned: this strip's frame offsets + control word (m2v_strip_finish_async -> m2v_strip_offsets)
+    size_t h_strip_cap = 0;
+    size_t strip_nf = 0;
+    hipEvent_t ev_strip = nullptr;
+    // m2v_strip_encode: the whole strip sequence in one call
+    DevBuf<uint8_t> d_halo, d_strip_own, d_gather;
+    hipStream_t comm_stream = nullptr;    // send / recv with the neighbours, beside the interior rows on the main stream
+    hipEvent_t ev_edges = nullptr, ev_halo = nullptr;
+    struct StripStats { double halo_total_ms = 0, halo_exposed_ms = 0, gather_ms = 0, host_us_per_step = 0; int steps = 0; } strip_stats;
 
     // debug bookkeeping of the last resident encode
     size_t dbg_frames = 0;
@@ -981,6 +995,12 @@ void m2v_destroy(m2v_enc *e)
     }
     if (e->ev_asm) { (void)hipEventSynchronize(e->ev_asm); (void)hipEventDestroy(e->ev_asm); }
     if (e->h_asm) (void)hipHostFree(e->h_asm);
+    if (e->ev_strip) { (void)hipEventSynchronize(e->ev_strip); (void)hipEventDestroy(e->ev_strip); }
+    if (e->h_strip) (void)hipHostFree(e->h_strip);
+    if (e->comm_stream) { (void)hipStreamSynchronize(e->comm_stream); (void)hipStreamDestroy(e->comm_stream); }
+    if (e->ev_edges) (void)hipEventDestroy(e->ev_edges);
+    if (e->ev_halo) (void)hipEventDestroy(e->ev_halo);
+    e->d_frame_pos.release(); e->d_alloff.release(); e->d_halo.release(); e->d_strip_own.release(); e->d_gather.release();
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     for (auto ev : e->ev_join) if (ev) (void)hipEventDestroy(ev);
     for (auto sd : e->side) if (sd) (void)hipStreamDestroy(sd);
@@ -1008,6 +1028,8 @@ int m2v_reset(m2v_enc *e)
     // a strip sequence abandoned between m2v_strip_begin and m2v_strip_finish: back to the full frame
     e->strip_active = false;
     e->strip_stream = nullptr;
+    e->strip_nf = 0;
+    if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
     e->plan_steps.clear();
     e->plan_nf = 0;
     e->g.row0 = 0; e->g.row1 = e->g.mbh; e->g.strip = 0;
@@ -1358,33 +1380,111 @@ int m2v_strip_halo_in(m2v_enc *e, int step, const void *d_from_up, const void *d
     return guard(e, strip_halo_in_impl, &a);
 }
 
-struct StripFinishArgs { uint8_t *d_strip; size_t cap; unsigned long long *frame_off; };
-
-static int strip_finish_impl(m2v_enc *e, void *argp)
+// end of a strip sequence: back to the full frame
+static void strip_close(m2v_enc *e)
 {
-    auto *a = (StripFinishArgs *)argp;
-    if (!e->strip_active) return M2V_E_STATE;
-    hipStream_t s = e->strip_stream;
-    const size_t nf = e->plan_nf;
-    ctl_init(e, s, a->cap);
-    finish_chunk(e, s, false, false, a->d_strip);
-    HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipMemcpy(a->frame_off, e->d_frame_off.p, (nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    collect_timers(e);
     e->strip_active = false;
     Geom full = e->g; full.row0 = 0; full.row1 = full.mbh; full.strip = 0;
     geom_finish(full);
     e->g = full;
-    if (e->st().h_ctl->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
+}
+
+// pinned host memory of at least `bytes`, kept with the handle
+static void ensure_pinned(uint8_t *&p, size_t &cap, size_t bytes)
+{
+    if (cap >= bytes) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    HIPCHK(hipHostMalloc((void **)&p, bytes * 2));
+    cap = bytes * 2;
+}
+
+// scans + slice assembly of this strip into d_strip; the frame offsets stay on the device (d_frame_off) and are also
+// copied to pinned host memory behind ev_strip: NOTHING is synchronised here
+static void strip_finish_enqueue(m2v_enc *e, uint8_t *d_strip, size_t cap)
+{
+    hipStream_t s = e->strip_stream;
+    const size_t nf = e->plan_nf;
+    e->chain_ev = nullptr;
+    e->d_ctl.ensure(1);
+    hipLaunchKernelGGL(k_ctl_chain, dim3(1), dim3(1), 0, s, e->d_ctl.p, (unsigned long long)cap, 1);
+    finish_chunk(e, s, false, false, d_strip);
+    ensure_pinned(e->h_strip, e->h_strip_cap, (nf + 1) * sizeof(unsigned long long) + sizeof(StreamCtl));
+    HIPCHK(hipMemcpyAsync(e->h_strip, e->d_frame_off.p, (nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(e->h_strip + (nf + 1) * sizeof(unsigned long long), e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
+    if (!e->ev_strip) HIPCHK(hipEventCreateWithFlags(&e->ev_strip, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->ev_strip, s));
+    e->strip_nf = nf;
+    strip_close(e);
+}
+
+struct StripFinishArgs { uint8_t *d_strip; size_t cap; unsigned long long *frame_off; };
+
+static int strip_finish_async_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripFinishArgs *)argp;
+    if (!e->strip_active) return M2V_E_STATE;
+    e->d_ctl.ensure(1);
+    strip_finish_enqueue(e, a->d_strip, a->cap);
     return M2V_OK;
+}
+
+static int strip_offsets_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripFinishArgs *)argp;
+    if (!e->ev_strip || e->strip_nf == 0) { e->set_err("m2v_strip_offsets: no finished strip"); return M2V_E_STATE; }
+    HIPCHK(hipEventSynchronize(e->ev_strip));           // the one wait of a strip sequence: its sizes are needed on the host
+    collect_timers(e);
+    memcpy(a->frame_off, e->h_strip, (e->strip_nf + 1) * sizeof(unsigned long long));
+    const StreamCtl *c = (const StreamCtl *)(e->h_strip + (e->strip_nf + 1) * sizeof(unsigned long long));
+    if (c->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
+    return M2V_OK;
+}
+
+int m2v_strip_finish_async(m2v_enc *e, void *d_strip, size_t cap)
+{
+    if (!e || !d_strip) return M2V_E_PARAM;
+    StripFinishArgs a{(uint8_t *)d_strip, cap, nullptr};
+    return guard(e, strip_finish_async_impl, &a);
+}
+
+int m2v_strip_offsets(m2v_enc *e, unsigned long long *frame_off)
+{
+    if (!e || !frame_off) return M2V_E_PARAM;
+    StripFinishArgs a{nullptr, 0, frame_off};
+    return guard(e, strip_offsets_impl, &a);
 }
 
 int m2v_strip_finish(m2v_enc *e, void *d_strip, size_t cap, unsigned long long *frame_off)
 {
-    if (!e || !d_strip || !frame_off) return M2V_E_PARAM;
-    StripFinishArgs a{(uint8_t *)d_strip, cap, frame_off};
-    return guard(e, strip_finish_impl, &a);
+    const int r = m2v_strip_finish_async(e, d_strip, cap);
+    return r < 0 ? r : m2v_strip_offsets(e, frame_off);
+}
+
+// headers + strips of all ranks -> the final stream.  d_all_off: [nranks][nf + 1] frame offsets in DEVICE memory; the layout
+// is computed there (k_strip_layout), the byte count comes back through the control word.
+static void strip_assemble_enqueue(m2v_enc *e, hipStream_t s, const Geom &g, uint32_t pf, size_t nf, int nranks, const void *const *strips,
+                                   const unsigned long long *d_all_off, uint8_t *d_out, size_t cap)
+{
+    const uint32_t gop = (pf & 0xFFu) + 1u;
+    const size_t nsegs = nf * (size_t)nranks;
+    e->d_segs.ensure(nsegs * sizeof(CopySeg) + 16);
+    e->d_frame_pos.ensure(nf + 1);
+    e->d_ctl.ensure(1);
+    StripSrc src{};
+    for (int r = 0; r < nranks; ++r) src.strip[r] = (const uint8_t *)strips[r];
+    e->chain_ev = nullptr;
+    hipLaunchKernelGGL(k_ctl_chain, dim3(1), dim3(1), 0, s, e->d_ctl.p, (unsigned long long)cap, 1);
+    Timer t(e, s, 3, (double)nf * g.ysz);
+    hipLaunchKernelGGL(k_strip_layout, dim3(1), dim3(kLayoutThreads), 0, s, d_all_off, nranks, (int)nf, gop, src, (CopySeg *)e->d_segs.p,
+                       e->d_frame_pos.p, e->d_ctl.p);
+    // every segment cut into `split` parts so that the launch has one to two thousand blocks whatever the number of ranks
+    const int split = (int)std::max<size_t>(1, std::min<size_t>(32, 2048 / std::max<size_t>(nsegs, 1)));
+    const unsigned blocks = (unsigned)(nsegs * (size_t)split + (nf + kCopyThreads - 1) / kCopyThreads + 1);
+    hipLaunchKernelGGL(k_strip_assemble, dim3(blocks), dim3(kCopyThreads), 0, s, (const CopySeg *)e->d_segs.p, (int)nsegs, split, g, (int)nf, gop,
+                       e->d_frame_pos.p, d_out, e->d_ctl.p);
+    HIPCHK(hipGetLastError());
+    t.stop();
 }
 
 struct StripAsmArgs { uint32_t xs, ys, pf; size_t n; int nranks; const void *const *strips; const unsigned long long *const *offs;
@@ -1394,60 +1494,31 @@ static int strip_assemble_impl(m2v_enc *e, void *argp)
 {
     auto *a = (StripAsmArgs *)argp;
     if (e->strip_active || e->state != m2v_enc::IDLE) return M2V_E_STATE;
+    if (a->nranks > kMaxStripRanks) { e->set_err("m2v_strip_assemble: at most %d strips", kMaxStripRanks); return M2V_E_PARAM; }
     hipStream_t s = a->s ? a->s : e->stream;
     const Geom g = make_geom(e, a->xs, a->ys);
     const uint32_t gop = (a->pf & 0xFFu) + 1u;
     const size_t nf = a->n;
-    // final layout: sequence headers, then per frame [GOP hdr] picture hdr, the strips top to bottom
-    std::vector<FrameJob> jobs(nf);
-    std::vector<unsigned long long> foff(nf + 1);
-    std::vector<CopySeg> segs;
+    // the byte count is known on the host (the caller holds the offsets): same arithmetic as k_strip_layout
     unsigned long long pos = kSeqHeaderBytes;
     for (size_t f = 0; f < nf; ++f) {
-        memset(&jobs[f], 0, sizeof(FrameJob));
-        jobs[f].i_frame = (int32_t)(f % gop);
-        jobs[f].n = (uint32_t)f;
-        foff[f] = pos;
-        pos += jobs[f].i_frame == 0 ? kGopHeaderBytes + 17u : 18u;
-        for (int r = 0; r < a->nranks; ++r) {
-            const unsigned long long len = a->offs[r][f + 1] - a->offs[r][f];
-            if (len) segs.push_back(CopySeg{(const uint8_t *)a->strips[r] + a->offs[r][f], pos, len});
-            pos += len;
-        }
+        pos += (f % gop) == 0 ? kGopHeaderBytes + 17u : 18u;
+        for (int r = 0; r < a->nranks; ++r) pos += a->offs[r][f + 1] - a->offs[r][f];
     }
-    foff[nf] = pos;
     const unsigned long long total = ((pos + 4) / 32ull + 1ull) * 32ull;       // end code + final word rule (RTL:2932-2937)
     if (total > a->cap) { e->set_err("output buffer too small"); return M2V_E_OVERFLOW; }
-    e->d_jobs.ensure(nf);
-    e->d_frame_off.ensure(nf + 1);
-    e->d_segs.ensure(segs.size() * sizeof(CopySeg) + 16);
-    // The three small tables go up from ONE pinned staging block with asynchronous copies on the caller's stream: the call
-    // neither blocks on a pageable copy nor synchronises the stream (the byte count is known on the host).  The staging is
-    // rewritten by the next call only after this call's copies have been consumed (ev_asm).
-    const size_t b_jobs = nf * sizeof(FrameJob), b_foff = (nf + 1) * sizeof(unsigned long long), b_segs = segs.size() * sizeof(CopySeg);
-    const size_t need = b_jobs + b_foff + b_segs + 64;
+    // The offsets go up from ONE pinned staging block with an asynchronous copy on the caller's stream: the call neither blocks
+    // on a pageable copy nor synchronises the stream.  The staging is rewritten by the next call only after this call's
+    // copy has been consumed (ev_asm).
+    const size_t b_off = (size_t)a->nranks * (nf + 1) * sizeof(unsigned long long);
     if (!e->ev_asm) HIPCHK(hipEventCreateWithFlags(&e->ev_asm, hipEventDisableTiming));
     else HIPCHK(hipEventSynchronize(e->ev_asm));
-    if (e->h_asm_cap < need) {
-        if (e->h_asm) (void)hipHostFree(e->h_asm);
-        e->h_asm = nullptr; e->h_asm_cap = 0;
-        HIPCHK(hipHostMalloc((void **)&e->h_asm, need * 2));
-        e->h_asm_cap = need * 2;
-    }
-    memcpy(e->h_asm, jobs.data(), b_jobs);
-    memcpy(e->h_asm + b_jobs, foff.data(), b_foff);
-    if (b_segs) memcpy(e->h_asm + b_jobs + b_foff, segs.data(), b_segs);
-    ctl_init(e, s, a->cap);
-    HIPCHK(hipMemcpyAsync(e->d_jobs.p, e->h_asm, b_jobs, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(e->d_frame_off.p, e->h_asm + b_jobs, b_foff, hipMemcpyHostToDevice, s));
-    if (b_segs) HIPCHK(hipMemcpyAsync(e->d_segs.p, e->h_asm + b_jobs + b_foff, b_segs, hipMemcpyHostToDevice, s));
+    ensure_pinned(e->h_asm, e->h_asm_cap, b_off);
+    for (int r = 0; r < a->nranks; ++r) memcpy(e->h_asm + (size_t)r * (nf + 1) * sizeof(unsigned long long), a->offs[r], (nf + 1) * sizeof(unsigned long long));
+    e->d_alloff.ensure((size_t)a->nranks * (nf + 1));
+    HIPCHK(hipMemcpyAsync(e->d_alloff.p, e->h_asm, b_off, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e->ev_asm, s));
-    if (!segs.empty())
-        hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)segs.size()), dim3(256), 0, s, (const CopySeg *)e->d_segs.p, a->d_out);
-    hipLaunchKernelGGL(k_headers, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, s, e->d_jobs.p, g, (int)nf, 1,
-                       e->d_frame_off.p, a->d_out, e->d_ctl.p);
-    hipLaunchKernelGGL(k_trailer, dim3(1), dim3(256), 0, s, a->d_out, pos, total);
-    HIPCHK(hipGetLastError());
+    strip_assemble_enqueue(e, s, g, a->pf, nf, a->nranks, a->strips, e->d_alloff.p, a->d_out, a->cap);
     if (a->bytes) *a->bytes = (size_t)total;            // known on the host: the stream is NOT synchronised here
     return M2V_OK;
 }
@@ -1461,6 +1532,235 @@ int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t 
                    (hipStream_t)hip_stream};
     return guard(e, strip_assemble_impl, &a);
 }
+
+// ---------------------------------------------------------------------------------------------
+// m2v_strip_encode: one call = one strip of one sequence, start to finish, with the exchange inside (no interpreter between
+// the GOP steps).  Per step:   edge rows + halo pack  (main stream)  -> event
+//                              send / recv with the two neighbours (comm stream, behind the event)     -> event
+//                              interior rows          (main stream, runs while the halo crosses xGMI)
+//                              neighbour rows into the reconstruction buffers (main stream, behind the comm event)
+// then the strip's slices, one all-gather of the per-frame sizes, the strips to the output rank, the final assembly there.
+// ---------------------------------------------------------------------------------------------
+struct StripEncodeArgs { m2v_comm *comm; int rank, world, dst; uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; uint8_t *d_out; size_t cap;
+                         size_t *bytes; hipStream_t s; };
+
+static int strip_encode_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripEncodeArgs *)argp;
+    using clk = std::chrono::steady_clock;
+    const int rank = a->rank, world = a->world;
+    const Geom full = make_geom(e, a->xs, a->ys);
+    if (world < 1 || world > kMaxStripRanks || world > full.mbh || rank < 0 || rank >= world || a->dst < 0 || a->dst >= world ||
+        (world > 1 && (!a->comm || a->comm->world != world))) {
+        e->set_err("m2v_strip_encode: bad rank / world / communicator");
+        return M2V_E_PARAM;
+    }
+    // contiguous strips, sizes differing by at most one row, the first mbh % world ranks get the extra row (parallel.partition_rows)
+    const int base = full.mbh / world, rem = full.mbh % world;
+    const int row0 = rank * base + std::min(rank, rem), row1 = row0 + base + (rank < rem ? 1 : 0);
+    StripBeginArgs b{a->xs, a->ys, a->pf, a->d_in, a->n, row0, row1, a->s};
+    int r = strip_begin_impl(e, &b);
+    if (r < 0) return r;
+    hipStream_t s = e->strip_stream;
+    const Geom &g = e->g;
+    const size_t nf = e->plan_nf;
+    int mh = 0;
+    for (auto &st : e->plan_steps) mh = std::max(mh, st.n_h);
+    const size_t halo_cap = (size_t)mh * (size_t)(3 * e->VL) * (size_t)g.W;
+    e->d_halo.ensure(4 * halo_cap + 64);
+    uint8_t *send_up = e->d_halo.p, *send_down = send_up + halo_cap, *recv_up = send_down + halo_cap, *recv_down = recv_up + halo_cap;
+    if (world > 1) {
+        if (!e->comm_stream) HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+        if (!e->ev_edges) HIPCHK(hipEventCreateWithFlags(&e->ev_edges, hipEventDisableTiming));
+        if (!e->ev_halo) HIPCHK(hipEventCreateWithFlags(&e->ev_halo, hipEventDisableTiming));
+    }
+    // profile: GPU events on the main stream around the exchange of every step (halo_total = edges packed .. neighbour rows there,
+    // halo_exposed = interior rows done .. neighbour rows there)
+    std::vector<hipEvent_t> marks;
+    auto mark = [&]() {
+        if (!e->profile) return;
+        hipEvent_t ev = pool_event(e);
+        e->chain_ev = nullptr;
+        HIPCHK(hipEventRecord(ev, s));
+        marks.push_back(ev);
+    };
+    const bool up = row0 > 0, down = row1 < g.mbh;
+    const auto t_loop = clk::now();
+    for (int j = 0; j < (int)e->plan_steps.size(); ++j) {
+        const int n_h = e->plan_steps[(size_t)j].n_h;
+        const bool xchg = world > 1 && n_h > 0 && (up || down);
+        if (xchg) {
+            StripStepArgs sa{j, send_up, send_down, nullptr, nullptr, 1};
+            if ((r = strip_step_impl(e, &sa)) < 0) return r;
+            mark();
+            HIPCHK(hipEventRecord(e->ev_edges, s));
+            HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_edges, 0));
+            const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)g.W;
+            a->comm->halo(rank, up ? send_up : nullptr, up ? recv_up : nullptr, down ? send_down : nullptr, down ? recv_down : nullptr, nbytes,
+                          e->comm_stream);
+            HIPCHK(hipEventRecord(e->ev_halo, e->comm_stream));
+            StripStepArgs si{j, nullptr, nullptr, nullptr, nullptr, 2};
+            if ((r = strip_step_impl(e, &si)) < 0) return r;
+            mark();
+            HIPCHK(hipStreamWaitEvent(s, e->ev_halo, 0));
+            mark();
+            StripStepArgs sh{j, nullptr, nullptr, up ? recv_up : nullptr, down ? recv_down : nullptr};
+            if ((r = strip_halo_in_impl(e, &sh)) < 0) return r;
+        } else {
+            StripStepArgs sa{j, nullptr, nullptr, nullptr, nullptr, 0};
+            if ((r = strip_step_impl(e, &sa)) < 0) return r;
+        }
+    }
+    e->strip_stats.steps = (int)e->plan_steps.size();
+    e->strip_stats.host_us_per_step = std::chrono::duration<double, std::micro>(clk::now() - t_loop).count() / std::max<size_t>(1, e->plan_steps.size());
+    hipEvent_t g0 = nullptr, g1 = nullptr;
+    if (e->profile) { g0 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g0, s)); }
+
+    // ---- this strip's slices; sizes; strips to the output rank; final assembly ----
+    const size_t strip_cap = nf * ((size_t)(row1 - row0) * g.mbw * 1216 + (size_t)(row1 - row0) * 8 + 64) + 256;     // worst case
+    e->d_strip_own.ensure(strip_cap);
+    const Geom gfull = full;
+    strip_finish_enqueue(e, e->d_strip_own.p, strip_cap);       // also closes the strip sequence
+    const void *strips[kMaxStripRanks] = {};
+    const unsigned long long *d_all = e->d_frame_off.p;
+    if (world > 1) {
+        e->d_alloff.ensure((size_t)world * (nf + 1));
+        a->comm->allgather_u64(rank, e->d_frame_off.p, e->d_alloff.p, nf + 1, s);
+        ensure_pinned(e->h_asm, e->h_asm_cap, (size_t)world * (nf + 1) * sizeof(unsigned long long));
+        HIPCHK(hipMemcpyAsync(e->h_asm, e->d_alloff.p, (size_t)world * (nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));                        // the sizes decide the receive counts: the one host wait
+        const StreamCtl *c = (const StreamCtl *)(e->h_strip + (nf + 1) * sizeof(unsigned long long));
+        if (c->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
+        size_t sizes[kMaxStripRanks] = {}, total_in = 0;
+        for (int k = 0; k < world; ++k) {
+            sizes[k] = (size_t)((const unsigned long long *)e->h_asm)[(size_t)k * (nf + 1) + nf];
+            if (k != a->dst) total_in += (sizes[k] + 255) & ~(size_t)255;
+        }
+        void *bufs[kMaxStripRanks] = {};
+        if (rank == a->dst) {
+            e->d_gather.ensure(total_in + 256);
+            size_t off = 0;
+            for (int k = 0; k < world; ++k) {
+                if (k == a->dst) { strips[k] = e->d_strip_own.p; continue; }
+                bufs[k] = e->d_gather.p + off;
+                strips[k] = bufs[k];
+                off += (sizes[k] + 255) & ~(size_t)255;
+            }
+        }
+        a->comm->gather(rank, a->dst, e->d_strip_own.p, sizes, bufs, s);
+        d_all = e->d_alloff.p;
+    } else {
+        strips[0] = e->d_strip_own.p;
+    }
+    size_t out_bytes = 0;
+    if (rank == a->dst) {
+        if (!a->d_out) { e->set_err("m2v_strip_encode: the output rank needs d_out"); return M2V_E_PARAM; }
+        strip_assemble_enqueue(e, s, gfull, a->pf, nf, world, strips, d_all, a->d_out, a->cap);
+        if (e->profile) { g1 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g1, s)); }
+        if (!e->st().h_ctl) HIPCHK(hipHostMalloc((void **)&e->st().h_ctl, 2 * sizeof(StreamCtl)));
+        HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
+    } else if (e->profile) { g1 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g1, s)); }
+    HIPCHK(hipStreamSynchronize(s));
+    if (world == 1) {
+        const StreamCtl *c = (const StreamCtl *)(e->h_strip + (nf + 1) * sizeof(unsigned long long));
+        if (c->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
+    }
+    if (rank == a->dst) {
+        if (e->st().h_ctl->overflow) { e->set_err("output buffer too small"); return M2V_E_OVERFLOW; }
+        out_bytes = (size_t)e->st().h_ctl->total_bytes;
+    }
+    if (e->profile) {
+        double tot = 0, exp = 0;
+        for (size_t k = 0; k + 3 <= marks.size(); k += 3) {
+            float m1 = 0, m2 = 0;
+            if (hipEventElapsedTime(&m1, marks[k], marks[k + 2]) == hipSuccess) tot += m1;
+            if (hipEventElapsedTime(&m2, marks[k + 1], marks[k + 2]) == hipSuccess) exp += m2;
+        }
+        float gm = 0;
+        if (g0 && g1 && hipEventElapsedTime(&gm, g0, g1) == hipSuccess) e->strip_stats.gather_ms = gm;
+        e->strip_stats.halo_total_ms = tot;
+        e->strip_stats.halo_exposed_ms = exp;
+    }
+    collect_timers(e);
+    if (a->bytes) *a->bytes = out_bytes;
+    return M2V_OK;
+}
+
+int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_rank, uint32_t xsize16, uint32_t ysize16,
+                     uint32_t pframes_count, const void *d_frames444, size_t nframes, void *d_out, size_t cap, size_t *out_bytes,
+                     void *hip_stream)
+{
+    if (!e || !d_frames444 || nframes == 0) return M2V_E_PARAM;
+    StripEncodeArgs a{comm, rank, world, dst_rank, xsize16, ysize16, pframes_count, (const uint8_t *)d_frames444, nframes, (uint8_t *)d_out, cap,
+                      out_bytes, (hipStream_t)hip_stream};
+    const int r = guard(e, strip_encode_impl, &a);
+    if (r < 0 && e->strip_active) strip_close(e);            // a failed sequence does not leave the handle in strip mode
+    return r;
+}
+
+int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_exposed_ms, double *gather_ms, double *host_us_per_step)
+{
+    if (!e) return M2V_E_PARAM;
+    if (halo_total_ms) *halo_total_ms = e->strip_stats.halo_total_ms;
+    if (halo_exposed_ms) *halo_exposed_ms = e->strip_stats.halo_exposed_ms;
+    if (gather_ms) *gather_ms = e->strip_stats.gather_ms;
+    if (host_us_per_step) *host_us_per_step = e->strip_stats.host_us_per_step;
+    return e->strip_stats.steps;
+}
+
+// ---- communicators (m2v_comm.hpp) ----
+
+int m2v_comm_unique_id(void *id, size_t cap)
+{
+    if (!id || cap < sizeof(ncclUniqueId)) return M2V_E_PARAM;
+    RcclApi &api = RcclApi::get();
+    if (!api.ok()) { t_comm_err = api.err; return M2V_E_NODEVICE; }
+    ncclUniqueId u;
+    const ncclResult_t r = api.GetUniqueId(&u);
+    if (r != ncclSuccess) { t_comm_err = std::string("ncclGetUniqueId: ") + api.GetErrorString(r); return M2V_E_HIP; }
+    memcpy(id, &u, sizeof u);
+    return (int)sizeof u;
+}
+
+m2v_comm *m2v_comm_init_rccl(const void *id, int rank, int world, int device, int *err)
+{
+    auto fail = [&](int code, const std::string &why) -> m2v_comm * { t_comm_err = why; if (err) *err = code; return nullptr; };
+    if (!id || world < 1 || world > kMaxStripRanks || rank < 0 || rank >= world) return fail(M2V_E_PARAM, "m2v_comm_init_rccl: bad rank / world");
+    if (hipSetDevice(device) != hipSuccess) return fail(M2V_E_NODEVICE, "m2v_comm_init_rccl: device ordinal out of range");
+    try {
+        ncclUniqueId u;
+        memcpy(&u, id, sizeof u);
+        m2v_comm *c = new RcclComm(u, rank, world);
+        if (err) *err = M2V_OK;
+        return c;
+    } catch (const std::exception &ex) {
+        return fail(M2V_E_HIP, ex.what());
+    }
+}
+
+m2v_comm *m2v_comm_init_local(int world, int *err)
+{
+    if (world < 1 || world > LocalComm::kMax) { t_comm_err = "m2v_comm_init_local: 1..16 ranks"; if (err) *err = M2V_E_PARAM; return nullptr; }
+    m2v_comm *c = new (std::nothrow) LocalComm(world);
+    if (err) *err = c ? M2V_OK : M2V_E_NOMEM;
+    return c;
+}
+
+void m2v_comm_destroy(m2v_comm *c) { delete c; }
+
+int m2v_comm_selftest(m2v_comm *c, int rank, const void *d_send, void *d_recv, size_t nbytes, void *hip_stream)
+{
+    if (!c || !d_send || !d_recv) return M2V_E_PARAM;
+    try {
+        c->loopback(rank, d_send, d_recv, nbytes, (hipStream_t)hip_stream);
+        return M2V_OK;
+    } catch (const std::exception &ex) {
+        t_comm_err = ex.what();
+        return M2V_E_HIP;
+    }
+}
+
+const char *m2v_comm_last_error(void) { return t_comm_err.c_str(); }
 
 int m2v_set_option(m2v_enc *e, const char *name, long long value)
 {

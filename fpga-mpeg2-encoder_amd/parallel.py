@@ -11,6 +11,9 @@ Two ways the path shards:
 
 `encode_strips` is written against a small engine interface so that the exchange logic is testable on CPU with the
 gloo backend (tests/test_parallel_gloo.py) and the kernels on one GPU with emulated ranks (tests/test_gpu_strips.py).
+It is the REFERENCE of the call order.  What a multi-GPU job runs is `encode_strips_native`: the same sequence of steps
+inside one C-ABI call (m2v_strip_encode), RCCL send / recv issued natively between the kernels, no interpreter between
+the GOP steps.
 """
 import numpy as np
 
@@ -97,11 +100,41 @@ class GpuStripEngine:
         return self.strip[:int(off[-1])], off.astype(np.int64)
 
     def assemble(self, strips, offs):
+        """-> the stream (device tensor).  Enqueued on the engine's stream, not synchronised: encode_strips() makes the
+        caller's current stream wait for it before returning."""
         total = 64 + sum(int(o[-1]) for o in offs) + self.nframes * 32 + 64
         out = self.torch.empty(total, dtype=self.torch.uint8, device=self.device)
         n = self.enc.strip_assemble([s.data_ptr() for s in strips], [np.asarray(o, np.uint64) for o in offs], self.nframes,
                                     out.data_ptr(), total, self.xs, self.ys, self.pf, self.stream)
         return out[:n]
+
+
+def _p2p(dist, sends, recvs):
+    """One batch of point-to-point transfers: sends / recvs = [(tensor, peer)].  RCCL takes device tensors as they are (and
+    orders the batch against the current stream); the gloo backend - CPU tests, and the 1-GPU test hook of bench.py -
+    moves host memory only, so device tensors are staged through the host around it.  Returns when the received
+    data is ordered on the current stream."""
+    import torch
+    staged = dist.get_backend() == "gloo"
+    ops, back = [], []
+    for t, peer in sends:
+        ops.append(dist.P2POp(dist.isend, t.cpu() if staged and t.is_cuda else t, peer))
+    for t, peer in recvs:
+        if staged and t.is_cuda:
+            h = torch.empty(t.shape, dtype=t.dtype)
+            back.append((t, h))
+            ops.append(dist.P2POp(dist.irecv, h, peer))
+        else:
+            ops.append(dist.P2POp(dist.irecv, t, peer))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    return reqs, back
+
+
+def _p2p_wait(reqs, back):
+    for req in reqs:
+        req.wait()
+    for t, h in back:
+        t.copy_(h)
 
 
 def encode_strips(engine, rank, world, dist=None, dst=0, timings=None):
@@ -114,7 +147,10 @@ def encode_strips(engine, rank, world, dist=None, dst=0, timings=None):
     if ctx is None:
         return _encode_strips(engine, rank, world, dist, dst, timings)
     with ctx:
-        return _encode_strips(engine, rank, world, dist, dst, timings)
+        out = _encode_strips(engine, rank, world, dist, dst, timings)
+    # the result was produced on the engine's stream: whatever the caller enqueues next on ITS stream comes after it
+    engine.torch.cuda.current_stream(engine.tstream.device).wait_stream(engine.tstream)
+    return out
 
 
 def _encode_strips(engine, rank, world, dist, dst, timings=None):
@@ -132,22 +168,21 @@ def _encode_strips(engine, rank, world, dist, dst, timings=None):
     split = hasattr(engine, "step_edges") and world > 1
     for j in range(steps):
         nbytes = engine.step_edges(j, send_up, send_down) if split else engine.step(j, send_up, send_down)
-        reqs = []
+        reqs, back = [], []
         if nbytes and world > 1:
-            ops = []
+            sends, recvs = [], []
             if rank > 0:                       # my top rows go up; the rows above my strip come down from rank-1
-                ops.append(dist.P2POp(dist.isend, send_up[:nbytes], rank - 1))
-                ops.append(dist.P2POp(dist.irecv, recv_up[:nbytes], rank - 1))
+                sends.append((send_up[:nbytes], rank - 1))
+                recvs.append((recv_up[:nbytes], rank - 1))
             if rank < world - 1:
-                ops.append(dist.P2POp(dist.isend, send_down[:nbytes], rank + 1))
-                ops.append(dist.P2POp(dist.irecv, recv_down[:nbytes], rank + 1))
+                sends.append((send_down[:nbytes], rank + 1))
+                recvs.append((recv_down[:nbytes], rank + 1))
             ma = mark()
-            reqs = dist.batch_isend_irecv(ops)
+            reqs, back = _p2p(dist, sends, recvs)
         if split:
             engine.step_interior(j)
         mb = mark() if reqs else None
-        for req in reqs:
-            req.wait()
+        _p2p_wait(reqs, back)
         if reqs:
             marks.append((ma, mb, mark()))
         if nbytes:
@@ -168,18 +203,30 @@ def _encode_strips(engine, rank, world, dist, dst, timings=None):
         return done(engine.assemble([strip], [off]))
     # sizes to everyone (tiny); then every strip goes to the output rank in ONE batch of point-to-point transfers of
     # exactly its size (xGMI is point-to-point: the 7 senders use 7 different links into `dst`, no padding to the longest)
-    off_t = torch.as_tensor(off, dtype=torch.int64, device=strip.device)
+    off_t = torch.as_tensor(np.asarray(off).astype(np.int64), dtype=torch.int64, device=strip.device if dist.get_backend() != "gloo" else "cpu")
     all_off = [torch.empty_like(off_t) for _ in range(world)]
     dist.all_gather(all_off, off_t)
     sizes = [int(o[-1]) for o in all_off]
     if rank != dst:
         if sizes[rank]:
-            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, strip[:sizes[rank]], dst)]):
-                req.wait()
+            _p2p_wait(*_p2p(dist, [(strip[:sizes[rank]], dst)], []))
         return done(None)
     bufs = [strip if r == dst else engine.alloc(sizes[r]) for r in range(world)]
-    ops = [dist.P2POp(dist.irecv, bufs[r][:sizes[r]], r) for r in range(world) if r != dst and sizes[r]]
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+    _p2p_wait(*_p2p(dist, [], [(bufs[r][:sizes[r]], r) for r in range(world) if r != dst and sizes[r]]))
     return done(engine.assemble([bufs[r][:sizes[r]] for r in range(world)], [o.cpu().numpy() for o in all_off]))
+
+
+def encode_strips_native(enc, comm, rank, world, clip, xsize16, ysize16, pframes_count, out=None, stream=0, dst=0):
+    """What a multi-GPU job runs: this rank's strip of the sequence through ONE native call (m2v_strip_encode) - the call
+    order of encode_strips() above with RCCL send / recv (or the in-process mailboxes of a local communicator) issued
+    from C++ between the kernels.  clip: device tensor [frames, 3, H, W]; out: device uint8 tensor on rank `dst`.
+    Returns the stream (a view of `out`) on rank `dst`, None elsewhere; the call has synchronised `stream` when it returns."""
+    n = enc.strip_encode(comm, rank, world, clip.data_ptr(), int(clip.shape[0]), xsize16, ysize16, pframes_count,
+                         out.data_ptr() if out is not None else None, int(out.numel()) if out is not None else 0, dst, stream)
+    return out[:n] if rank == dst and out is not None else None
+
+
+def strip_output_bound(nframes, W, H):
+    """A safe capacity for the assembled stream of `nframes` frames (the library reports M2V_E_OVERFLOW beyond it):
+    worst case 1216 bytes per macroblock + headers."""
+    return nframes * ((W // 16) * (H // 16) * 1216 + (H // 16) * 8 + 64) + 256

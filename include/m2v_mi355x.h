@@ -150,10 +150,51 @@ int m2v_strip_step_edges(m2v_enc *e, int step, void *d_send_up, void *d_send_dow
 int m2v_strip_step_interior(m2v_enc *e, int step);
 int m2v_strip_halo_in(m2v_enc *e, int step, const void *d_from_up, const void *d_from_down);
 int m2v_strip_finish(m2v_enc *e, void *d_strip, size_t cap, unsigned long long *frame_off);
+/* The same in two halves: _async enqueues the scans and the slice assembly and returns at once; m2v_strip_offsets waits for
+ * them (one event, pinned read-back) and hands out the nframes + 1 offsets.  m2v_strip_finish = both. */
+int m2v_strip_finish_async(m2v_enc *e, void *d_strip, size_t cap);
+int m2v_strip_offsets(m2v_enc *e, unsigned long long *frame_off);
 int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
                        size_t nframes, int nranks, const void *const *d_strips,
                        const unsigned long long *const *frame_off, void *d_out, size_t cap,
                        size_t *out_bytes, void *hip_stream);
+
+/*
+ * The exchange between the strips, behind one opaque communicator (csrc/m2v_comm.hpp).  Two kinds:
+ *   RCCL    one process per GPU (ncclGroupStart; ncclSend / ncclRecv x 2; ncclGroupEnd per GOP step over xGMI, one
+ *           ncclAllGather of the strip sizes and one group of sends into the output rank per sequence).  librccl is dlopen()ed
+ *           on first use.  Rank 0 calls m2v_comm_unique_id (128 bytes), the caller broadcasts them by whatever means it has
+ *           (torch.distributed, MPI, a file), every rank calls m2v_comm_init_rccl - a collective call, like ncclCommInitRank.
+ *   local   `world` handles inside ONE process, one host thread each (on one GPU or several): mailboxes of device pointers and
+ *           events, device-to-device copies.  One object shared by all the threads.  Runs the N-rank path on a 1-GPU box.
+ * m2v_comm_last_error(): why the last m2v_comm_* call on this thread failed.
+ */
+typedef struct m2v_comm m2v_comm;
+int       m2v_comm_unique_id(void *id, size_t cap);      /* returns 128, or a negative M2V_E_* (no librccl) */
+m2v_comm *m2v_comm_init_rccl(const void *id, int rank, int world, int device, int *err);
+m2v_comm *m2v_comm_init_local(int world, int *err);
+void      m2v_comm_destroy(m2v_comm *c);
+const char *m2v_comm_last_error(void);
+/* Self-test of a communicator: nbytes from d_send to d_recv (device memory) through the transport's own send / recv pair
+ * addressed to the calling rank itself (RCCL: one ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd), enqueued on hip_stream. */
+int       m2v_comm_selftest(m2v_comm *c, int rank, const void *d_send, void *d_recv, size_t nbytes, void *hip_stream);
+
+/*
+ * One strip of one sequence, start to finish, in ONE call: the loop that parallel.encode_strips() spells out in Python (begin,
+ * per GOP step edge rows -> exchange beside the interior rows -> neighbour rows in, finish, sizes, strips to `dst_rank`, final
+ * assembly there), natively and without an interpreter between the steps.  Rank r of `world` encodes macroblock rows
+ * [r * mbh / world ...) - the partition of parallel.partition_rows().  `comm` may be NULL iff world == 1.  On dst_rank the
+ * stream is left at d_out (device memory, capacity cap) and its length in *out_bytes; the other ranks may pass NULL / 0 and
+ * get *out_bytes = 0.  `hip_stream` (NULL = the handle's own) is synchronised before returning.  Collective: every rank
+ * of the communicator must make the call with the same sequence parameters.
+ */
+int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_rank, uint32_t xsize16, uint32_t ysize16,
+                     uint32_t pframes_count, const void *d_frames444, size_t nframes, void *d_out, size_t cap, size_t *out_bytes,
+                     void *hip_stream);
+/* Timings of the last m2v_strip_encode on this handle: host microseconds per GOP step (always), and with option "profile" the
+ * GPU-event times in ms: halo_total (edge rows packed .. neighbour rows there, summed over the steps), halo_exposed (interior
+ * rows done .. neighbour rows there), gather (sizes + strips to the output rank + final assembly).  Returns the step count. */
+int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_exposed_ms, double *gather_ms, double *host_us_per_step);
 
 /* Options: "batch_frames" (frames buffered before the GPU is kicked, default 96, at most 200: larger values are taken as 200),
  * "profile" (1 = time the per-kernel launches with HIP events),

@@ -1,0 +1,49 @@
+"""-m gpu: `python bench.py --gpus 2` on a 1-GPU box.  M2V_BENCH_SHARE_GPU=1 puts both ranks on GPU 0 and M2V_DIST_BACKEND=gloo
+replaces RCCL (which refuses two ranks on one device) - the launch path, the per-rank work, the barrier / max-over-ranks
+timing and, in strips mode, the halo exchange + gather + assembly and the whole-stream oracle check are the real ones."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(argv, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"M2V_BENCH_SHARE_GPU": "1", "M2V_DIST_BACKEND": "gloo"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return lines[0]
+
+
+def test_sequences_mode_two_ranks():
+    line = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0.2", "--no-cpu-baseline", "--gops", "2"])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["launched_by"] == "bench.py" and line["config"]["dist_backend"] == "gloo"
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_strips_mode_two_ranks_whole_stream_parity():
+    line = run_bench(["--gpus", "2", "--mode", "strips", "--steps", "2", "--warmup", "1", "--prewarm", "0", "--gops", "2"])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["strip_loop"] == "python"            # gloo between two processes on one GPU: the reference loop
+    assert line["parity_check"]["identical_to_oracle"] is True and line["parity_check"]["gops_compared"] == 2
+
+
+def test_strips_mode_one_rank_runs_the_native_loop():
+    line = run_bench(["--gpus", "1", "--mode", "strips", "--steps", "2", "--warmup", "1", "--prewarm", "0", "--gops", "2"])
+    assert line["n_gpus"] == 1 and line["config"]["strip_loop"] == "native"
+    assert line["parity_check"]["identical_to_oracle"] is True
+
+
+def test_config_c2_line():
+    line = run_bench(["--config", "c2", "--steps", "3", "--warmup", "1", "--prewarm", "0.2", "--gops", "64", "--no-e2e"])
+    assert line["config"]["frames"] == 64 and "I only" in line["metric"]
+    assert line["parity_check"]["identical_to_oracle"] is True
+    assert "k_mb<1,false>" in line["roofline"]["kernel"] and line["roofline"]["frac"] > 0

@@ -95,3 +95,103 @@ def test_encode_strips_world1_equals_resident():
         assert out.cpu().numpy().tobytes() == want
     finally:
         enc.close()
+
+
+# ---- the native loop: m2v_strip_encode, ranks = threads of this process talking through a local communicator ----
+def run_native_strips(M, d_clip, W, H, pf, VL, world, profile=False):
+    """`world` handles, one host thread each, all on GPU 0; every thread makes ONE call (m2v_strip_encode) - the GOP steps,
+    the halo exchange (mailboxes + device copies behind the same interface RCCL sits behind), the size all-gather, the
+    strips to rank 0 and the final assembly all happen inside it.  Returns (stream bytes, [strip_stats of every rank])."""
+    import threading
+    import torch
+    encs = [M.Mpeg2Encoder(7, 7, VL, 2) for _ in range(world)]
+    comm = M.StripComm.local(world) if world > 1 else None
+    out = torch.empty(M.parallel.strip_output_bound(int(d_clip.shape[0]), W, H), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    res, errs = [None] * world, []
+
+    def work(r):
+        try:
+            if profile:
+                encs[r].set_option("profile", 1)
+            res[r] = M.parallel.encode_strips_native(encs[r], comm, r, world, d_clip, W // 16, H // 16, pf, out if r == 0 else None)
+        except Exception as ex:  # noqa: BLE001
+            errs.append((r, ex))
+    try:
+        th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in th), "a rank is stuck in the exchange"
+        assert not errs, errs
+        stats = [e.strip_stats() for e in encs]
+        return res[0].cpu().numpy().tobytes(), stats
+    finally:
+        for e in encs:
+            e.close()
+        if comm is not None:
+            comm.close()
+
+
+@pytest.mark.parametrize("world,W,H,pf,VL", [(1, 96, 64, 2, 3), (2, 128, 96, 4, 3), (3, 96, 160, 2, 2), (4, 160, 128, 3, 1), (8, 64, 128, 1, 3)])
+def test_native_strip_loop_equals_oracle(world, W, H, pf, VL):
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    n = 2 * (pf + 1) + 1
+    clip = M.synth.clip(W, H, n, clip_index=70 + world)
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, 2)
+    d_clip = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
+    for _ in range(2):                                   # twice: the handles' and the communicator's state is reusable
+        got, stats = run_native_strips(M, d_clip, W, H, pf, VL, world)
+        assert got == want
+    assert all(s["steps"] == pf + 1 for s in stats)
+
+
+def test_native_strip_loop_config_c5_full_size_8_ranks():
+    """config c5 at its real size through the native loop: 2048x2048, one GOP of 1 I + 8 P, 8 ranks x 16 rows (threads on one
+    GPU, local communicator), byte-identical to the oracle; with option profile the per-step host time is reported."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    W = H = 2048
+    pf, n = 8, 9
+    d_clip = M.synth.clip_torch(W, H, n, clip_index=56, device="cuda:0", scene_len=5)
+    want = orc.encode(d_clip.cpu().numpy(), 128, 128, pf, 7, 7, 3, 2)
+    got, stats = run_native_strips(M, d_clip, W, H, pf, 3, 8, profile=True)
+    assert got == want
+    print("host us per GOP step, per rank:", [round(s["host_us_per_step"], 1) for s in stats])
+
+
+def test_rccl_communicator_on_one_gpu():
+    """What can be run of the RCCL transport on a 1-GPU box: librccl is found and dlopen()ed, a 1-rank communicator is
+    created from a fresh ncclUniqueId, and one ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd addressed to the rank itself
+    moves bytes on the device; m2v_strip_encode accepts the communicator (world = 1: nothing to exchange)."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    comm = M.StripComm.rccl(0, 1, 0)
+    try:
+        a = torch.arange(1 << 16, dtype=torch.int32, device="cuda:0").view(torch.uint8)
+        b = torch.zeros_like(a)
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        comm.selftest(0, a.data_ptr(), b.data_ptr(), a.numel(), s.cuda_stream)
+        s.synchronize()
+        assert torch.equal(a, b)
+        clip = M.synth.clip(96, 64, 5, clip_index=77)
+        d_clip = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
+        out = torch.empty(M.parallel.strip_output_bound(5, 96, 64), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        enc = M.Mpeg2Encoder(7, 7, 3, 2)
+        try:
+            got = M.parallel.encode_strips_native(enc, comm, 0, 1, d_clip, 6, 4, 2, out)
+            assert got.cpu().numpy().tobytes() == orc.encode(clip, 6, 4, 2, 7, 7, 3, 2)
+        finally:
+            enc.close()
+    finally:
+        comm.close()
