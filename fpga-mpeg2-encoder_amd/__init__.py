@@ -30,7 +30,7 @@ EXPORTS = [
     "m2v_kernel_stats", "m2v_debug_read", "m2v_last_error", "m2v_debug_table",
     "m2v_strip_begin", "m2v_strip_info", "m2v_strip_step", "m2v_strip_step_edges", "m2v_strip_step_interior", "m2v_strip_halo_in", "m2v_strip_finish", "m2v_strip_assemble",
     "m2v_strip_finish_async", "m2v_strip_offsets", "m2v_strip_encode", "m2v_strip_stats",
-    "m2v_comm_unique_id", "m2v_comm_init_rccl", "m2v_comm_init_local", "m2v_comm_destroy", "m2v_comm_last_error", "m2v_comm_selftest",
+    "m2v_comm_unique_id", "m2v_comm_init_rccl", "m2v_comm_init_local", "m2v_comm_init_solo", "m2v_comm_destroy", "m2v_comm_last_error", "m2v_comm_selftest",
 ]
 
 
@@ -88,7 +88,9 @@ def lib(debug=False):
         L.m2v_strip_offsets.argtypes = [vp, vp]
         L.m2v_strip_encode.argtypes = [vp, vp, ci, ci, ci, u32, u32, u32, vp, sz, vp, sz, ctypes.POINTER(sz), vp]
         dp = ctypes.POINTER(ctypes.c_double)
-        L.m2v_strip_stats.argtypes = [vp, dp, dp, dp, dp]
+        L.m2v_strip_stats.argtypes = [vp, dp, dp, dp, dp, dp]
+        L.m2v_comm_init_solo.restype = vp
+        L.m2v_comm_init_solo.argtypes = [ci, ctypes.POINTER(ci)]
         L.m2v_comm_unique_id.argtypes = [vp, sz]
         L.m2v_comm_init_rccl.restype = vp
         L.m2v_comm_init_rccl.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ci)]
@@ -263,9 +265,10 @@ class Mpeg2Encoder:
 
     def strip_stats(self):
         """-> dict of the last strip_encode: steps, host_us_per_step, and (option profile) halo_total / halo_exposed / gather in ms"""
-        v = [ctypes.c_double(0) for _ in range(4)]
+        v = [ctypes.c_double(0) for _ in range(5)]
         steps = self._chk(self._L.m2v_strip_stats(self._h, *[ctypes.byref(x) for x in v]), "m2v_strip_stats")
-        return {"steps": steps, "halo_total": v[0].value, "halo_exposed": v[1].value, "gather": v[2].value, "host_us_per_step": v[3].value}
+        return {"steps": steps, "halo_total": v[0].value, "halo_exposed": v[1].value, "gather": v[2].value, "host_us_per_step": v[3].value,
+                "comm_us_per_step": v[4].value, "host_us_per_step_outside_comm": v[3].value - v[4].value}
 
     def strip_assemble(self, strip_ptrs, frame_offs, nframes, d_out_ptr, cap, xsize16, ysize16, pframes_count, stream=0):
         n = len(strip_ptrs)
@@ -325,6 +328,16 @@ class StripComm:
         if not h:
             raise M2VError("m2v_comm_init_local failed (%d): %s" % (err.value, L.m2v_comm_last_error().decode()))
         return cls(h, "local", world)
+
+    @classmethod
+    def solo(cls, world):
+        """timing aid (tools/strip_solo.py): one rank of `world` alone on its GPU; the output is NOT a valid stream"""
+        L = lib()
+        err = ctypes.c_int(0)
+        h = L.m2v_comm_init_solo(world, ctypes.byref(err))
+        if not h:
+            raise M2VError("m2v_comm_init_solo failed (%d): %s" % (err.value, L.m2v_comm_last_error().decode()))
+        return cls(h, "solo", world)
 
     def selftest(self, rank, d_send_ptr, d_recv_ptr, nbytes, stream=0):
         r = lib().m2v_comm_selftest(self.handle, rank, d_send_ptr, d_recv_ptr, nbytes, stream)

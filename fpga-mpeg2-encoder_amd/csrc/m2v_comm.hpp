@@ -272,4 +272,36 @@ struct LocalComm final : m2v_comm {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// ONE rank of `world`, alone on its GPU, with nobody to talk to: the halo it "receives" is its own (a device copy of the same
+// size), everybody's sizes are its own, and the other ranks' strips are never sent.  The stream that comes out is NOT a valid
+// encoding (the neighbour rows are wrong) - this exists to TIME what one rank of an N-GPU job does per GOP step on a real
+// GPU (kernels of a 1/N strip, launch gaps, host time) when only one GPU is at hand: tools/strip_solo.py.
+// ---------------------------------------------------------------------------------------------
+struct SoloComm final : m2v_comm {
+    explicit SoloComm(int w) { world = w; }
+    const char *kind() const override { return "solo"; }
+    void halo(int r, const void *send_up, void *recv_up, const void *send_down, void *recv_down, size_t n, hipStream_t s) override
+    {
+        if (!n) return;
+        if (r > 0 && send_up && recv_up) M2V_COMM_HIP(hipMemcpyAsync(recv_up, send_up, n, hipMemcpyDeviceToDevice, s));
+        if (r < world - 1 && send_down && recv_down) M2V_COMM_HIP(hipMemcpyAsync(recv_down, send_down, n, hipMemcpyDeviceToDevice, s));
+    }
+    void allgather_u64(int, const unsigned long long *d_src, unsigned long long *d_all, size_t count, hipStream_t s) override
+    {
+        for (int k = 0; k < world; ++k)
+            M2V_COMM_HIP(hipMemcpyAsync(d_all + (size_t)k * count, d_src, count * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    }
+    void gather(int r, int dst, const void *d_strip, const size_t *sizes, void *const *bufs, hipStream_t s) override
+    {
+        if (r != dst) return;
+        for (int k = 0; k < world; ++k)       // the output rank "receives" copies of its own strip: the same bytes moved as in a real gather
+            if (k != dst && sizes[k]) M2V_COMM_HIP(hipMemcpyAsync(bufs[k], d_strip, sizes[k], hipMemcpyDeviceToDevice, s));
+    }
+    void loopback(int, const void *d_send, void *d_recv, size_t n, hipStream_t s) override
+    {
+        M2V_COMM_HIP(hipMemcpyAsync(d_recv, d_send, n, hipMemcpyDeviceToDevice, s));
+    }
+};
+
 }  // namespace m2v

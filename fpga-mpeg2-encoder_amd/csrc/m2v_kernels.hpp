@@ -136,6 +136,8 @@ constexpr int win_b_gap(int wrows) { return ((wrows * kWinStride - 32 + 63) / 64
 __host__ __device__ constexpr int s3_dy(int lane) { return (lane >> 1) & 15; }
 __host__ __device__ constexpr int s3_group(int lane) { return ((lane & 1) << 1) | (lane >> 5); }
 constexpr unsigned long long kS3Helpers = 0xFC000000FC000000ull;       // the lanes with s3_dy >= 13
+constexpr bool s3_helpers_match(int lane = 0) { return lane == 64 || ((((kS3Helpers >> lane) & 1ull) != 0) == (s3_dy(lane) > 12) && s3_helpers_match(lane + 1)); }
+static_assert(s3_helpers_match(), "kS3Helpers does not match s3_dy");
 constexpr int kS3Cur = 2 * (8 + 2 * 3) * 16;             // current luma rows (behind the two chroma windows)
 constexpr int kS3Win = kS3Cur + 256;                     // luma window, copy A
 constexpr int kS3Scratch = 1600 + 384 + 768 + 1536;      // the level buffer s_zig: unused until the quantiser
@@ -1872,7 +1874,7 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
                                                      int advance, uint32_t *__restrict__ out32)
 {
     __shared__ unsigned long long s_base;
-    __shared__ uint32_t s_wtot[16];
+    __shared__ unsigned long long s_wtot[16];
     const int tid = threadIdx.x;
     if (tid == 0) {
         // advance = this chunk continues the stream of the previous one in the same buffer: base = previous total
@@ -1911,20 +1913,22 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
         sum += slice_bytes[(size_t)f * g.mbh + g.row0 + r];
         if (r == 0) sum += header_bytes(f);
     }
-    // block scan on 32 bits (a chunk is < 2^32 bytes: m2v_set_option("batch_frames") caps it): inside a wavefront by DPP,
-    // then the 16 wavefront totals through LDS - one barrier
-    // instead of the twenty of a Hillis-Steele scan over 1024 threads
-    const uint32_t wscan = (uint32_t)wave_scan_incl((int)(uint32_t)sum);
+    // block scan of the 64-bit sums: inside a wavefront by DPP - which moves 32 bits, so the sum goes as three parts whose
+    // wavefront totals cannot wrap (bits 0-15, bits 16-31, the rest) and is put together again afterwards - then the 16
+    // wavefront totals through LDS: one barrier instead of the twenty of a Hillis-Steele scan over 1024 threads
+    const unsigned long long wscan = (unsigned long long)(uint32_t)wave_scan_incl((int)((uint32_t)sum & 0xFFFFu)) +
+                                     ((unsigned long long)(uint32_t)wave_scan_incl((int)(((uint32_t)sum >> 16) & 0xFFFFu)) << 16) +
+                                     ((unsigned long long)(uint32_t)wave_scan_incl((int)(uint32_t)(sum >> 32)) << 32);
     if ((tid & 63) == 63) s_wtot[tid >> 6] = wscan;
     __syncthreads();
-    uint32_t before = 0, grand = 0;
+    unsigned long long before = 0, grand = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-        const uint32_t t = s_wtot[w];
-        before += w < (tid >> 6) ? t : 0u;
+        const unsigned long long t = s_wtot[w];
+        before += w < (tid >> 6) ? t : 0ull;
         grand += t;
     }
-    const unsigned long long incl = (unsigned long long)(before + wscan);
+    const unsigned long long incl = before + wscan;
     // stream length and overflow: every thread derives them from the grand total (thread 1023 publishes them)
     const unsigned long long base = s_base, all_frames = grand;
     unsigned long long total = base + all_frames;

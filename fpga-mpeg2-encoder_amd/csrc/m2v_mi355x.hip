@@ -171,7 +171,7 @@ struct m2v_enc {
     DevBuf<uint8_t> d_halo, d_strip_own, d_gather;
     hipStream_t comm_stream = nullptr;    // send / recv with the neighbours, beside the interior rows on the main stream
     hipEvent_t ev_edges = nullptr, ev_halo = nullptr;
-    struct StripStats { double halo_total_ms = 0, halo_exposed_ms = 0, gather_ms = 0, host_us_per_step = 0; int steps = 0; } strip_stats;
+    struct StripStats { double halo_total_ms = 0, halo_exposed_ms = 0, gather_ms = 0, host_us_per_step = 0, comm_us_per_step = 0; int steps = 0; } strip_stats;
 
     // debug bookkeeping of the last resident encode
     size_t dbg_frames = 0;
@@ -254,13 +254,16 @@ void upload_tables_now()
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_dc_code), kDcSizeCode, sizeof kDcSizeCode));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_dc_len), kDcSizeLen, sizeof kDcSizeLen));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_ac_code), kAcCode, sizeof kAcCode));
-    static uint16_t ac2[2 * kAcRuns * kAcLevels];            // static: the copy below is synchronised at the end of this function
-    memset(ac2, 0, sizeof ac2);
+    // per-call staging (this function runs once per DEVICE, possibly on several threads at once: nothing shared, nothing static);
+    // the copies below are synchronised before it goes out of scope
+    std::vector<uint16_t> ac2v(2 * kAcRuns * kAcLevels, 0);
+    uint16_t *const ac2 = ac2v.data();
+    const size_t ac2_bytes = ac2v.size() * sizeof(uint16_t);
     for (int bank = 0; bank < 2; ++bank)
         for (int run = 0; run < 32; ++run)
             for (int lev = 1; lev <= 40; ++lev) ac2[(bank * kAcRuns + run) * kAcLevels + lev - 1] = kAcCode[run * 40 + lev - 1];
     ac2[kAcRuns * kAcLevels] = (1u << 8) | 1u;               // bank 1, run 0, level 1: '1' + sign
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_ac_code2), ac2, sizeof ac2));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_ac_code2), ac2, ac2_bytes));
     uint32_t recip[64];
     for (int i = 0; i < 64; ++i) recip[i] = ((1u << 21) + kIntraW[i] - 1u) / kIntraW[i];      // ceil(2^21 / W)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_intra_recip), recip, sizeof recip));
@@ -292,7 +295,6 @@ void upload_tables_now()
         // the reference pairs (w0,w1) (w2,w3) start at dword gq of window row dy', the pairs (w1,w2) (w3,w4) at gq + 1: one of the
         // two starts is even in copy A, the other in copy B (which holds dword j + 1 at index j); VECTOR_LEVEL 3 geometry
         const int dyi = s3_dy(lane), gq = s3_group(lane), gap = win_b_gap(16 + 4 * 3);
-        if ((int)((kS3Helpers >> lane) & 1u) != (dyi > 12)) throw std::logic_error("kS3Helpers does not match s3_dy");
         SearchLane &q = sl[lane];
         memset(&q, 0, sizeof q);
         // candidate j of the lane has dx = 4 gq - 8 + j
@@ -317,7 +319,12 @@ void upload_tables_now()
         }
     }
     // quad-major on the device (see MfmaLane): [quad][lane][4 dwords]
-    static uint32_t slq[sizeof(SearchLane) / 16][64][4], mlq[sizeof(MfmaLane) / 16][64][4];
+    typedef uint32_t Quad[64][4];
+    std::vector<uint32_t> slqv(sizeof(SearchLane) / 16 * 64 * 4), mlqv(sizeof(MfmaLane) / 16 * 64 * 4);
+    Quad *const slq = (Quad *)slqv.data(), *const mlq = (Quad *)mlqv.data();
+    const size_t slq_bytes = slqv.size() * 4, mlq_bytes = mlqv.size() * 4;
+    uint32_t dcl[12];
+    for (int i = 0; i < 12; ++i) dcl[i] = (uint32_t)kDcSizeCode[0][i] | ((uint32_t)kDcSizeLen[0][i] << 16);
     for (int lane = 0; lane < 64; ++lane) {
         for (size_t q = 0; q < sizeof(SearchLane) / 16; ++q) memcpy(slq[q][lane], (const uint8_t *)&sl[lane] + 16 * q, 16);
         for (size_t q = 0; q < sizeof(MfmaLane) / 16; ++q) memcpy(mlq[q][lane], (const uint8_t *)&ml[lane] + 16 * q, 16);
@@ -325,17 +332,15 @@ void upload_tables_now()
     for (int vl = 0; vl < 3; ++vl)
         for (int pf = 0; pf < 2; ++pf) {
             const size_t blk = ((size_t)(vl * 2 + pf) * kQuadsPerBlock) * 64 * 16;
-            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), slq, sizeof slq, blk + (size_t)kQuadSearch0 * 64 * 16));
-            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), mlq, sizeof mlq, blk + (size_t)kQuadMfma0 * 64 * 16));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), slq, slq_bytes, blk + (size_t)kQuadSearch0 * 64 * 16));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), mlq, mlq_bytes, blk + (size_t)kQuadMfma0 * 64 * 16));
             const size_t cst = blk + (size_t)kQuadConst0 * 64 * 16;
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dct32, sizeof dct32, cst + kConstDct32));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), kDctBasis, sizeof kDctBasis, cst + kConstDct));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dct_neg, sizeof dct_neg, cst + kConstDctNeg));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), kCbpCode, sizeof kCbpCode, cst + kConstCbp));
-            static uint32_t dcl[12];
-            for (int i = 0; i < 12; ++i) dcl[i] = (uint32_t)kDcSizeCode[0][i] | ((uint32_t)kDcSizeLen[0][i] << 16);
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dcl, sizeof dcl, cst + kConstDcLuma));
-            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), ac2, sizeof ac2, blk + (size_t)kQuadAc0 * 64 * 16));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), ac2, ac2_bytes, blk + (size_t)kQuadAc0 * 64 * 16));
         }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma_intra), mi, sizeof mi));
     HIPCHK(hipDeviceSynchronize());         // the copies read stack arrays: complete before they go out of scope
@@ -955,13 +960,19 @@ m2v_enc *m2v_create(int XL, int YL, int VECTOR_LEVEL, int Q_LEVEL, int device, i
         HIPCHK(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
         upload_tables(device);
         HIPCHK(hipDeviceSynchronize());
-    } catch (const HipError &h) {
-        const std::string why = std::string("m2v_create: ") + h.what + ": " + hipGetErrorString(h.e);
+    } catch (...) {                             // nothing may unwind through the C boundary
+        std::string why = "m2v_create: ";
+        int code = M2V_E_HIP;
+        try { throw; }
+        catch (const HipError &h) { why += std::string(h.what) + ": " + hipGetErrorString(h.e); if (h.e == hipErrorOutOfMemory) code = M2V_E_NOMEM; }
+        catch (const std::bad_alloc &) { why += "host allocation failed"; code = M2V_E_NOMEM; }
+        catch (const std::exception &ex) { why += ex.what(); }
+        catch (...) { why += "unknown failure"; }
         if (e->stream) (void)hipStreamDestroy(e->stream);
         if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
         if (e->up_stream) (void)hipStreamDestroy(e->up_stream);
         delete e;
-        return fail(M2V_E_HIP, why);
+        return fail(code, why);
     }
     if (err) *err = M2V_OK;
     return e;
@@ -1143,9 +1154,15 @@ static int push_frames_impl(m2v_enc *e, void *argp)
     // Frames that already sit in page-locked host memory (hipHostMalloc / hipHostRegister: capture buffers, pinned tensors)
     // cross PCIe straight from there; anything else is first copied into the stage's pinned buffer by a few threads (one core
     // moves ~25 GB/s, less than half of what the link takes).
-    hipPointerAttribute_t attr;
-    const bool pinned = e->direct_upload && hipPointerGetAttributes(&attr, a->frames) == hipSuccess && attr.type == hipMemoryTypeHost;
-    if (!pinned) (void)hipGetLastError();           // an ordinary pointer is "invalid value" to the query: not an error here
+    // The whole range must be page-locked, not just its first byte (a pointer near the end of a registered region): the
+    // first and the last byte are queried, and a range that is not pinned at both ends takes the staging copy.
+    auto page_locked = [](const void *p) {
+        hipPointerAttribute_t attr;
+        const bool yes = hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost;
+        if (!yes) (void)hipGetLastError();          // an ordinary pointer is "invalid value" to the query: not an error here
+        return yes;
+    };
+    const bool pinned = e->direct_upload && page_locked(a->frames) && page_locked(a->frames + a->n * fb - 1);
     bool direct_pending = false;
     for (size_t k = 0; k < a->n;) {
         m2v_enc::HostStage &h = e->st();
@@ -1475,7 +1492,7 @@ static void strip_assemble_enqueue(m2v_enc *e, hipStream_t s, const Geom &g, uin
     for (int r = 0; r < nranks; ++r) src.strip[r] = (const uint8_t *)strips[r];
     e->chain_ev = nullptr;
     hipLaunchKernelGGL(k_ctl_chain, dim3(1), dim3(1), 0, s, e->d_ctl.p, (unsigned long long)cap, 1);
-    Timer t(e, s, 3, (double)nf * g.ysz);
+    Timer t(e, s, 2, (double)nf * g.ysz);
     hipLaunchKernelGGL(k_strip_layout, dim3(1), dim3(kLayoutThreads), 0, s, d_all_off, nranks, (int)nf, gop, src, (CopySeg *)e->d_segs.p,
                        e->d_frame_pos.p, e->d_ctl.p);
     // every segment cut into `split` parts so that the launch has one to two thousand blocks whatever the number of ranks
@@ -1585,6 +1602,7 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         marks.push_back(ev);
     };
     const bool up = row0 > 0, down = row1 < g.mbh;
+    double us_in_comm = 0;                 // host time inside the communicator (a local communicator blocks there until the neighbour thread has posted)
     const auto t_loop = clk::now();
     for (int j = 0; j < (int)e->plan_steps.size(); ++j) {
         const int n_h = e->plan_steps[(size_t)j].n_h;
@@ -1596,8 +1614,10 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
             HIPCHK(hipEventRecord(e->ev_edges, s));
             HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_edges, 0));
             const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)g.W;
+            const auto t_c = clk::now();
             a->comm->halo(rank, up ? send_up : nullptr, up ? recv_up : nullptr, down ? send_down : nullptr, down ? recv_down : nullptr, nbytes,
                           e->comm_stream);
+            us_in_comm += std::chrono::duration<double, std::micro>(clk::now() - t_c).count();
             HIPCHK(hipEventRecord(e->ev_halo, e->comm_stream));
             StripStepArgs si{j, nullptr, nullptr, nullptr, nullptr, 2};
             if ((r = strip_step_impl(e, &si)) < 0) return r;
@@ -1613,14 +1633,15 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     }
     e->strip_stats.steps = (int)e->plan_steps.size();
     e->strip_stats.host_us_per_step = std::chrono::duration<double, std::micro>(clk::now() - t_loop).count() / std::max<size_t>(1, e->plan_steps.size());
+    e->strip_stats.comm_us_per_step = us_in_comm / std::max<size_t>(1, e->plan_steps.size());
     hipEvent_t g0 = nullptr, g1 = nullptr;
-    if (e->profile) { g0 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g0, s)); }
 
     // ---- this strip's slices; sizes; strips to the output rank; final assembly ----
     const size_t strip_cap = nf * ((size_t)(row1 - row0) * g.mbw * 1216 + (size_t)(row1 - row0) * 8 + 64) + 256;     // worst case
     e->d_strip_own.ensure(strip_cap);
     const Geom gfull = full;
     strip_finish_enqueue(e, e->d_strip_own.p, strip_cap);       // also closes the strip sequence
+    if (e->profile) { g0 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g0, s)); }     // from here: sizes, gather, final assembly
     const void *strips[kMaxStripRanks] = {};
     const unsigned long long *d_all = e->d_frame_off.p;
     if (world > 1) {
@@ -1698,9 +1719,11 @@ int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_ra
     return r;
 }
 
-int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_exposed_ms, double *gather_ms, double *host_us_per_step)
+int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_exposed_ms, double *gather_ms, double *host_us_per_step,
+                    double *comm_us_per_step)
 {
     if (!e) return M2V_E_PARAM;
+    if (comm_us_per_step) *comm_us_per_step = e->strip_stats.comm_us_per_step;
     if (halo_total_ms) *halo_total_ms = e->strip_stats.halo_total_ms;
     if (halo_exposed_ms) *halo_exposed_ms = e->strip_stats.halo_exposed_ms;
     if (gather_ms) *gather_ms = e->strip_stats.gather_ms;
@@ -1738,6 +1761,14 @@ m2v_comm *m2v_comm_init_rccl(const void *id, int rank, int world, int device, in
     }
 }
 
+m2v_comm *m2v_comm_init_solo(int world, int *err)
+{
+    if (world < 1 || world > kMaxStripRanks) { t_comm_err = "m2v_comm_init_solo: 1..16 ranks"; if (err) *err = M2V_E_PARAM; return nullptr; }
+    m2v_comm *c = new (std::nothrow) SoloComm(world);
+    if (err) *err = c ? M2V_OK : M2V_E_NOMEM;
+    return c;
+}
+
 m2v_comm *m2v_comm_init_local(int world, int *err)
 {
     if (world < 1 || world > LocalComm::kMax) { t_comm_err = "m2v_comm_init_local: 1..16 ranks"; if (err) *err = M2V_E_PARAM; return nullptr; }
@@ -1767,9 +1798,10 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
     if (!e || !name) return M2V_E_PARAM;
     if (!strcmp(name, "batch_frames")) {
         if (value < 1 || e->state != m2v_enc::IDLE) return M2V_E_PARAM;
-        // at most 200: the byte offsets inside one chunk are scanned in 32 bits (k_frame_scan), and 200 frames of the largest
-        // geometry at the worst-case 1216 bytes per macroblock stay below 2^32
-        e->batch_frames = (size_t)(value > 200 ? 200 : value);
+        // any chunk length: the byte offsets inside a chunk are scanned in 64 bits (k_frame_scan).  65536 is a sanity bound only
+        // (a chunk's frames are buffered on the device: 65536 frames of the largest geometry would be 824 GB)
+        if (value > 65536) { e->set_err("m2v_set_option: batch_frames is at most 65536"); return M2V_E_PARAM; }
+        e->batch_frames = (size_t)value;
         return M2V_OK;
     }
     if (!strcmp(name, "profile")) { e->profile = value != 0; return M2V_OK; }

@@ -173,6 +173,10 @@ typedef struct m2v_comm m2v_comm;
 int       m2v_comm_unique_id(void *id, size_t cap);      /* returns 128, or a negative M2V_E_* (no librccl) */
 m2v_comm *m2v_comm_init_rccl(const void *id, int rank, int world, int device, int *err);
 m2v_comm *m2v_comm_init_local(int world, int *err);
+/* Timing aid, NOT an encoder: one rank of `world` alone on its GPU; the halo it "receives" is its own rows, the sizes are its own,
+ * nothing is sent.  The resulting stream is not a valid encoding; tools/strip_solo.py uses it to time what one rank of an
+ * N-GPU job does per GOP step when only one GPU is at hand. */
+m2v_comm *m2v_comm_init_solo(int world, int *err);
 void      m2v_comm_destroy(m2v_comm *c);
 const char *m2v_comm_last_error(void);
 /* Self-test of a communicator: nbytes from d_send to d_recv (device memory) through the transport's own send / recv pair
@@ -191,12 +195,15 @@ int       m2v_comm_selftest(m2v_comm *c, int rank, const void *d_send, void *d_r
 int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_rank, uint32_t xsize16, uint32_t ysize16,
                      uint32_t pframes_count, const void *d_frames444, size_t nframes, void *d_out, size_t cap, size_t *out_bytes,
                      void *hip_stream);
-/* Timings of the last m2v_strip_encode on this handle: host microseconds per GOP step (always), and with option "profile" the
- * GPU-event times in ms: halo_total (edge rows packed .. neighbour rows there, summed over the steps), halo_exposed (interior
- * rows done .. neighbour rows there), gather (sizes + strips to the output rank + final assembly).  Returns the step count. */
-int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_exposed_ms, double *gather_ms, double *host_us_per_step);
+/* Timings of the last m2v_strip_encode on this handle: host microseconds per GOP step and how much of that was spent inside the
+ * communicator (RCCL: enqueueing; a local communicator blocks there until the neighbour thread has posted) - always - and, with
+ * option "profile", the GPU-event times in ms: halo_total (edge rows packed .. neighbour rows there, summed over the steps),
+ * halo_exposed (interior rows done .. neighbour rows there), gather (from the strip's own slices being assembled: sizes + strips
+ * to the output rank + final assembly).  Returns the step count. */
+int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_exposed_ms, double *gather_ms, double *host_us_per_step,
+                    double *comm_us_per_step);
 
-/* Options: "batch_frames" (frames buffered before the GPU is kicked, default 96, at most 200: larger values are taken as 200),
+/* Options: "batch_frames" (frames buffered before the GPU is kicked, default 96; 1 .. 65536, M2V_E_PARAM beyond),
  * "profile" (1 = time the per-kernel launches with HIP events),
  * "async" (default 1: the port path keeps two chunks in flight - while one chunk is uploaded, encoded and
  * read back, m2v_push_* fills the pinned staging of the next one; 0 = a chunk is complete when the push
@@ -220,7 +227,7 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value);
 
 /* Per-kernel statistics of the last m2v_encode_resident call with "profile" = 1.
  * kernel: 0 = macroblock kernel on P frames, 1 = macroblock kernel on I frames,
- * 2 = (unused), 3 = stream assembly (k_assemble), 4 = scans + headers.
+ * 2 = strip mode's final assembly (k_strip_layout + k_strip_assemble), 3 = slice assembly (k_assemble), 4 = scans.
  * Returns launches; *ms = summed duration, *units = luma pixels processed. */
 int m2v_kernel_stats(const m2v_enc *e, int kernel, double *ms, double *units);
 

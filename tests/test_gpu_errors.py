@@ -39,7 +39,9 @@ def test_overflow_reset_and_options():
         assert L.m2v_set_option(enc._h, b"no_such_option", 1) == -1
         assert L.m2v_set_option(enc._h, b"batch_frames", 2) == 0
         assert enc.encode(clip, 6, 4, 3) == want
-        assert L.m2v_set_option(enc._h, b"batch_frames", 100000) == 0   # taken as 200 (32-bit offsets inside a chunk, k_frame_scan)
+        assert L.m2v_set_option(enc._h, b"batch_frames", 100000) == -1  # beyond the sanity bound: refused, with a text
+        assert b"65536" in L.m2v_last_error(enc._h)
+        assert L.m2v_set_option(enc._h, b"batch_frames", 1000) == 0     # no 200-frame cap any more: offsets inside a chunk are 64-bit
         assert enc.encode(clip, 6, 4, 3) == want
         # zero frames: the sequence never starts (stop while idle does nothing, RTL:1090)
         assert enc.encode_resident(d_in.data_ptr(), 0, big.data_ptr(), big.numel(), 6, 4, 3) == 0

@@ -49,6 +49,17 @@ def test_degenerate_content(G, kind):
     assert G.compare_stages(f, 6, 4, 2, XL=4, YL=4) == []
 
 
+def test_one_chunk_of_600_frames(G):
+    """batch_frames used to be capped at 200 (32-bit offsets inside a chunk); k_frame_scan now scans 64-bit sums (as three
+    32-bit DPP scans), so one chunk can be any length: 600 frames = 9600 slices, more than the 8192 items the scan's threads
+    fetch in their first round trip"""
+    from oracle import m2v_oracle_ctypes as orc
+    f = G.M.synth.clip(64, 64, 600, clip_index=19, scene_len=7)
+    want = orc.encode(f, 4, 4, 2, XL=6, YL=6)
+    assert G.resident_encode(f, 4, 4, 2, XL=6, YL=6, batch_frames=600) == want
+    assert G.resident_encode(f, 4, 4, 2, XL=6, YL=6, batch_frames=250) == want
+
+
 def test_multi_gop_and_chunking(G):
     from oracle import m2v_oracle_ctypes as orc
     f = G.M.synth.clip(96, 64, 14, clip_index=9, scene_len=5)
