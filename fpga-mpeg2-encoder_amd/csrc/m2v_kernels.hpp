@@ -58,10 +58,15 @@ struct Geom {
     uint32_t magic_strip;    // floor(2^32 / strip_mbs), floor(2^32 / mbw): wave-uniform divisions on the scalar unit
     uint32_t magic_mbw;      // (geom_finish() fills the three after any change of the rows)
     uint32_t s16_off;        // word offset of the 64-byte slot class inside the compact-slot buffer (plan_chunk: macroblocks of the chunk * 32)
+    int rstride;             // macroblock rows between the launch's local rows: 1 normally; the EDGE launch of strip mode runs two local
+                             // rows, the strip's first and its last (row0 and row0 + rstride)
+    int edge_top, edge_bot;  // strip mode: the strip's first and last macroblock row (k_mb<.., EDGE> copies their outer rows of the
+                             // reconstruction into the halo buffers)
 };
 
 inline void geom_finish(Geom &g)
 {
+    if (g.rstride == 0) g.rstride = 1;
     g.strip_mbs = (uint32_t)((g.row1 - g.row0) * g.mbw);
     g.magic_strip = g.strip_mbs > 1 ? (uint32_t)(0x100000000ull / g.strip_mbs) : 0xFFFFFFFFu;
     g.magic_mbw = g.mbw > 1 ? (uint32_t)(0x100000000ull / (uint32_t)g.mbw) : 0xFFFFFFFFu;
@@ -75,6 +80,8 @@ struct FrameJob {           // one per frame of the chunk (device memory)
     uint32_t       n;       // frame number inside the sequence (time code, RTL:2685-2698)
     uint32_t       valid_beats;  // beats of real input in this frame; the rest is black (RTL:1048-1056)
     uint32_t       fidx;    // k_mb's copies in launch-list order: the frame's index in the chunk (0 in the per-frame array)
+    int32_t        hidx;    // strip mode: the frame's position in its GOP step's halo list (frames whose reconstruction is referenced later), -1 = none
+    int32_t        rhidx;   // ... and that of its reference frame in the previous step's list (where the neighbours' rows of it were received)
 };
 
 struct StreamCtl {          // device-resident stream bookkeeping, carried across chunks
@@ -733,11 +740,18 @@ __device__ u32x4_t d_lanetab[3][2][kQuadsPerBlock][64];
 // quantiser truncating toward zero with [-2048, 2047] saturation and mismatch control, blocks that are not coded are
 // not reconstructed.  The IDCT needs no change: for in-range coefficients its 18-bit row store never wraps and the
 // +-255 clip gives the same pixel after the final clip to 0..255.  Checked against the oracle's conformant mode.
-template <int VL, bool P, bool CONF = false, bool MFMA = false, bool FILL = false>
+// EDGE = the strip's first and last macroblock row in one launch (strip mode, m2v_strip_encode): besides everything else, the
+// outer 2 VL luma / VL chroma rows of the reconstruction also go to `halo_up` / `halo_down` - the buffers the neighbours
+// receive - in k_halo_pack's layout, so the step needs no pack kernel between the edge rows and the send; and the window rows
+// that lie in a neighbour's strip are read from `nb_up` / `nb_down`, the buffers the neighbours' rows of the reference frame
+// were received in, so there is no unpack kernel (and no launch gap) between the receive and the next step either.
+template <int VL, bool P, bool CONF = false, bool MFMA = false, bool FILL = false, bool EDGE = false>
 __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
                                            Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
                                            uint32_t *__restrict__ slots_small, uint32_t *__restrict__ slots,
-                                           int16_t *__restrict__ coef_dbg)
+                                           int16_t *__restrict__ coef_dbg, uint8_t *__restrict__ halo_up = nullptr,
+                                           uint8_t *__restrict__ halo_down = nullptr, const uint8_t *__restrict__ nb_up = nullptr,
+                                           const uint8_t *__restrict__ nb_down = nullptr)
 {
     constexpr int UR = VL, YR = 2 * VL;
     constexpr int WROWS = 16 + 2 * YR;         // luma window rows -YR .. 16+YR-1 (RTL:1446)
@@ -870,8 +884,19 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     const uint32_t li = udiv_magic(blk, g.strip_mbs, g.magic_strip);           // which frame of the launch list
     const FrameJob job = jobs[li];                 // `jobs` = the launch list as jobs: one dependent scalar load, not list -> job
     const int fidx = (int)job.fidx;
-    const int mb = g.row0 * g.mbw + (int)(blk - li * g.strip_mbs);
-    const int by = (int)udiv_magic((uint32_t)mb, (uint32_t)g.mbw, g.magic_mbw), bx = mb - by * g.mbw;
+    int mb, by, bx;
+    if constexpr (EDGE) {
+        // two local rows: the strip's first macroblock row and, rstride rows below, its last
+        const uint32_t local = blk - li * g.strip_mbs;
+        const uint32_t lrow = udiv_magic(local, (uint32_t)g.mbw, g.magic_mbw);
+        bx = (int)(local - lrow * (uint32_t)g.mbw);
+        by = g.row0 + (int)lrow * g.rstride;
+        mb = by * g.mbw + bx;
+    } else {
+        mb = g.row0 * g.mbw + (int)(blk - li * g.strip_mbs);
+        by = (int)udiv_magic((uint32_t)mb, (uint32_t)g.mbw, g.magic_mbw);
+        bx = mb - by * g.mbw;
+    }
     const int W = g.W;
     const int r = lane >> 2, c4 = lane & 3;
     // 1 = the macroblock has a neighbour on that side (left, right, up, down).  Sign-bit arithmetic, not compares: these
@@ -904,6 +929,36 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     }
     if constexpr (P) {
         const uint8_t *refY = job.ref, *refU = refY + g.ysz, *refV = refU + g.csz;
+        if constexpr (EDGE) {
+            // window rows above the strip's first / below its last macroblock row belong to a neighbour: they were received, for
+            // this frame's reference, at position rhidx of nb_up / nb_down ([YR rows of W luma][UR rows of cw U][UR of V] per
+            // frame, rows top to bottom); everything else as the clamped form below
+            const bool ext_u = nb_up != nullptr && by == g.edge_top, ext_d = nb_down != nullptr && by == g.edge_bot;     // wave-uniform
+            const uint32_t chunk = (uint32_t)(YR + UR) * (uint32_t)W, fb = (uint32_t)job.rhidx * chunk;
+#pragma unroll
+            for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass) {
+                const int i = pass * 64 + lane, row = i >> 3, k = i & 7;
+                int yy = 16 * by - YR + row, xx = 16 * bx - 8 + 4 * k;
+                yy = yy < 0 ? 0 : yy > g.H - 1 ? g.H - 1 : yy;
+                xx = xx < 0 ? 0 : xx > W - 4 ? W - 4 : xx;
+                const uint8_t *src = refY;
+                uint32_t off = __umul24((uint32_t)yy, (uint32_t)W) + (uint32_t)xx;
+                if (ext_u && row < YR) { src = nb_up; off = fb + (uint32_t)row * (uint32_t)W + (uint32_t)xx; }
+                if (ext_d && row >= YR + 16 && row < WROWS) { src = nb_down; off = fb + (uint32_t)(row - (YR + 16)) * (uint32_t)W + (uint32_t)xx; }
+                wv[pass] = *(const uint32_t *)(src + off);
+            }
+            const int cl = lane < CROWS * 4 ? lane : CROWS * 4 - 1, row = cl >> 2, k = cl & 3;
+            int yy = 8 * by - UR + row, xx = 8 * bx - 4 + 4 * k;
+            yy = yy < 0 ? 0 : yy > g.ch - 1 ? g.ch - 1 : yy;
+            xx = xx < 0 ? 0 : xx > g.cw - 4 ? g.cw - 4 : xx;
+            const uint8_t *su = refU, *sv = refV;
+            uint32_t coff = __umul24((uint32_t)yy, (uint32_t)g.cw) + (uint32_t)xx, voff = coff;
+            const uint32_t cbase = fb + (uint32_t)YR * (uint32_t)W + (uint32_t)xx, vstep = (uint32_t)UR * (uint32_t)g.cw;
+            if (ext_u && row < UR) { su = sv = nb_up; coff = cbase + (uint32_t)row * (uint32_t)g.cw; voff = coff + vstep; }
+            if (ext_d && row >= UR + 8) { su = sv = nb_down; coff = cbase + (uint32_t)(row - (UR + 8)) * (uint32_t)g.cw; voff = coff + vstep; }
+            wcu = *(const uint32_t *)(su + coff);
+            wcv = *(const uint32_t *)(sv + voff);
+        } else
         if (sgpr(in_l & in_r & in_u & in_d)) {
             // interior macroblock (wave-uniform test): the whole window lies inside the frame, no clamping, and the
             // passes differ by a constant row offset
@@ -1579,6 +1634,23 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             const uint32_t c0 = __umul24(k4p, (uint32_t)g.csz) + (k4r + (uint32_t)sgpr((int)(__umul24((uint32_t)(8 * by), (uint32_t)g.cw) + (uint32_t)(8 * bx))));
             const uint32_t coff = __umul24(kq4.x, (uint32_t)g.cw) + c0;
             *(gst32)(recU + coff) = v;
+        }
+        if constexpr (EDGE) {
+            // per frame of the step's halo list: [YR rows of W luma][UR rows of cw U][UR rows of cw V] (k_halo_pack's layout)
+            constexpr uint32_t YR2 = 2 * VL, UR2 = VL;
+            const uint32_t chunk = (YR2 + UR2) * (uint32_t)W, cw = (uint32_t)g.cw;
+            const uint32_t fbase = (uint32_t)job.hidx * chunk;
+            const uint32_t vy = *(LdsU32 *)(uintptr_t)kq0.z;                // the lane's four luma pixels of row r
+            const uint32_t vc = *(LdsU32 *)(uintptr_t)kq3.w;                // lanes < 32: four chroma pixels of row kq4.x, plane k4p
+            const uint32_t xl = (uint32_t)(16 * bx + 4 * c4), xc = (uint32_t)(8 * bx) + k4r;
+            if (halo_up != nullptr && by == g.edge_top) {                   // wave-uniform
+                if ((uint32_t)r < YR2) *(gst32)(halo_up + (fbase + (uint32_t)r * (uint32_t)W + xl)) = vy;
+                if (lane < 32 && kq4.x < UR2) *(gst32)(halo_up + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + kq4.x) * cw + xc)) = vc;
+            }
+            if (halo_down != nullptr && by == g.edge_bot) {
+                if ((uint32_t)r >= 16u - YR2) *(gst32)(halo_down + (fbase + ((uint32_t)r - (16u - YR2)) * (uint32_t)W + xl)) = vy;
+                if (lane < 32 && kq4.x >= 8u - UR2) *(gst32)(halo_down + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + (kq4.x - (8u - UR2))) * cw + xc)) = vc;
+            }
         }
     }
 }

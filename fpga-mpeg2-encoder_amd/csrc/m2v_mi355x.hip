@@ -170,7 +170,7 @@ struct m2v_enc {
     // m2v_strip_encode: the whole strip sequence in one call
     DevBuf<uint8_t> d_halo, d_strip_own, d_gather;
     hipStream_t comm_stream = nullptr;    // send / recv with the neighbours, beside the interior rows on the main stream
-    hipEvent_t ev_edges = nullptr, ev_halo = nullptr;
+    hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_interior = nullptr, ev_done = nullptr;
     struct StripStats { double halo_total_ms = 0, halo_exposed_ms = 0, gather_ms = 0, host_us_per_step = 0, comm_us_per_step = 0; int steps = 0; } strip_stats;
 
     // debug bookkeeping of the last resident encode
@@ -417,6 +417,31 @@ void collect_timers(m2v_enc *e)
     e->chain_ev = nullptr;
 }
 
+// strip mode, m2v_strip_encode: the strip's first and last macroblock row in ONE launch of the EDGE instantiation, which also
+// writes their outer rows of the reconstruction into the halo buffers (no pack kernel).  gg: row0 = first row, rstride = distance
+// to the last one, row1 - row0 = 1 or 2 local rows.
+template <bool P>
+void launch_mb_edges(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g, uint8_t *up, uint8_t *down,
+                     const uint8_t *nb_up, const uint8_t *nb_down)
+{
+    if (count <= 0) return;
+    const dim3 grid((unsigned)((size_t)count * (size_t)(g.row1 - g.row0) * g.mbw)), block(64);
+    Timer t(e, s, P ? 0 : 1, (double)count * (g.row1 - g.row0) * g.mbw * 256.0);
+    int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
+    const FrameJob *const jl = e->d_joblist.p + (d_list - e->d_lists.p);
+#define M2V_LAUNCH_EDGE(VLV) \
+    hipLaunchKernelGGL((k_mb<VLV, P, false, true, false, true>), grid, block, 0, s, jl, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
+                       e->d_slots_small.p, e->d_slots.p, dbg, up, down, nb_up, nb_down)
+    switch (e->VL) {
+        case 1: M2V_LAUNCH_EDGE(1); break;
+        case 2: M2V_LAUNCH_EDGE(2); break;
+        default: M2V_LAUNCH_EDGE(3); break;
+    }
+#undef M2V_LAUNCH_EDGE
+    HIPCHK(hipGetLastError());
+    t.stop();
+}
+
 template <bool P>
 void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g)
 {
@@ -484,6 +509,8 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
         jobs[k].ref = nullptr;
         jobs[k].rec = nullptr;
         jobs[k].fidx = 0;
+        jobs[k].hidx = -1;
+        jobs[k].rhidx = -1;
         if (k == 0 || jobs[k].i_frame == 0) seg_start.push_back((int)k);
     }
     const size_t nseg = seg_start.size();
@@ -558,8 +585,13 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
                 while (gnext <= group_of(sg)) cut[gnext++] = (int)lists.size() - off;      // the lists are in segment order
                 if (a + j >= b) continue;
                 const FrameJob &fj = jobs[a + j];
-                if ((pass == 0 && fj.i_frame == 0) || (pass == 1 && fj.i_frame != 0) || (pass == 2 && fj.rec != nullptr))
+                if ((pass == 0 && fj.i_frame == 0) || (pass == 1 && fj.i_frame != 0) || (pass == 2 && fj.rec != nullptr)) {
+                    if (pass == 2) {                                   // its place in the step's halo buffers; the next frame's reference
+                        jobs[a + j].hidx = (int32_t)((int)lists.size() - off);
+                        if (a + j + 1 < b) jobs[a + j + 1].rhidx = jobs[a + j].hidx;
+                    }
                     lists.push_back((int)(a + j));
+                }
             }
             const int cnt = (int)lists.size() - off;
             while (gnext <= m2v_enc::kMaxSplit) cut[gnext++] = cnt;
@@ -636,6 +668,23 @@ void run_step_rows(m2v_enc *e, hipStream_t s, size_t j, int r0, int r1)
     geom_finish(gg);
     launch_mb<false>(e, s, e->d_lists.p + st.off_i, st.n_i, gg);
     launch_mb<true>(e, s, e->d_lists.p + st.off_p, st.n_p, gg);
+}
+
+// strip mode: the strip's first and last macroblock row of GOP step j in one launch each for the I and the P frames of the step,
+// their halo rows written by the kernel itself (k_mb<.., EDGE>); up / down = the send buffers, null without a neighbour
+void run_step_edges_fused(m2v_enc *e, hipStream_t s, size_t j, uint8_t *up, uint8_t *down, const uint8_t *nb_up, const uint8_t *nb_down)
+{
+    const m2v_enc::Step &st = e->plan_steps[j];
+    Geom gg = e->g;
+    const int r0 = e->g.row0, r1 = e->g.row1, nrows = r1 - r0 >= 2 ? 2 : 1;
+    gg.row0 = r0;
+    gg.row1 = r0 + nrows;
+    gg.rstride = nrows == 2 ? r1 - 1 - r0 : 1;
+    gg.edge_top = r0;
+    gg.edge_bot = r1 - 1;
+    geom_finish(gg);
+    launch_mb_edges<false>(e, s, e->d_lists.p + st.off_i, st.n_i, gg, up, down, nullptr, nullptr);      // an I frame has no reference
+    launch_mb_edges<true>(e, s, e->d_lists.p + st.off_p, st.n_p, gg, up, down, nb_up, nb_down);
 }
 
 void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_stream, bool advance = false)
@@ -1011,6 +1060,8 @@ void m2v_destroy(m2v_enc *e)
     if (e->comm_stream) { (void)hipStreamSynchronize(e->comm_stream); (void)hipStreamDestroy(e->comm_stream); }
     if (e->ev_edges) (void)hipEventDestroy(e->ev_edges);
     if (e->ev_halo) (void)hipEventDestroy(e->ev_halo);
+    if (e->ev_interior) (void)hipEventDestroy(e->ev_interior);
+    if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     e->d_frame_pos.release(); e->d_alloff.release(); e->d_halo.release(); e->d_strip_own.release(); e->d_gather.release();
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     for (auto ev : e->ev_join) if (ev) (void)hipEventDestroy(ev);
@@ -1591,45 +1642,85 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         if (!e->ev_edges) HIPCHK(hipEventCreateWithFlags(&e->ev_edges, hipEventDisableTiming));
         if (!e->ev_halo) HIPCHK(hipEventCreateWithFlags(&e->ev_halo, hipEventDisableTiming));
     }
-    // profile: GPU events on the main stream around the exchange of every step (halo_total = edges packed .. neighbour rows there,
-    // halo_exposed = interior rows done .. neighbour rows there)
+    // profile: GPU events around the exchange of every step: halo_total = edge rows (and their halo) written .. neighbour rows and
+    // interior rows both there; halo_exposed = how much of that came after the interior rows were done
     std::vector<hipEvent_t> marks;
-    auto mark = [&]() {
+    auto mark = [&](hipStream_t on) {
         if (!e->profile) return;
         hipEvent_t ev = pool_event(e);
         e->chain_ev = nullptr;
-        HIPCHK(hipEventRecord(ev, s));
+        HIPCHK(hipEventRecord(ev, on));
         marks.push_back(ev);
     };
     const bool up = row0 > 0, down = row1 < g.mbh;
+    // The edge rows run as ONE launch of the instantiation that also fills the halo buffers (no pack kernel), the interior rows at
+    // the same time on a second stream: a strip of an 8-GPU job is ~20 000 wavefronts per step, 2.5 rounds of the wave slots -
+    // edge rows first and alone would hold the whole GPU for one macroblock lifetime at a third of its slots.
+    const bool fused = !e->conformant && e->dct_mfma && !e->keep_recon;
+    hipStream_t side = nullptr;
+    if (world > 1) {
+        if (!e->side[0]) HIPCHK(hipStreamCreateWithFlags(&e->side[0], hipStreamNonBlocking));
+        side = e->side[0];
+        if (!e->ev_done) HIPCHK(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+        if (!e->ev_interior) HIPCHK(hipEventCreateWithFlags(&e->ev_interior, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(e->ev_done, s));                  // the plan's uploads
+    }
     double us_in_comm = 0;                 // host time inside the communicator (a local communicator blocks there until the neighbour thread has posted)
     const auto t_loop = clk::now();
     for (int j = 0; j < (int)e->plan_steps.size(); ++j) {
         const int n_h = e->plan_steps[(size_t)j].n_h;
         const bool xchg = world > 1 && n_h > 0 && (up || down);
+        const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)g.W;
+        if (world > 1 && fused) {
+            // main stream:  EDGE(j) [reads the rows received in step j-1, writes the rows to send] -> send / recv(j)
+            // side stream:  interior(j)
+            // EDGE(j) and interior(j) both need ALL of step j-1 on this strip; the neighbours' rows only EDGE(j) - and it follows
+            // the receive in stream order.  Two launches, two event records, two waits and one exchange per step.
+            HIPCHK(hipStreamWaitEvent(side, j == 0 ? e->ev_done : e->ev_edges, 0));
+            if (j > 0) HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));
+            run_step_edges_fused(e, s, (size_t)j, xchg && up ? send_up : nullptr, xchg && down ? send_down : nullptr,
+                                 up ? recv_up : nullptr, down ? recv_down : nullptr);
+            mark(s);
+            HIPCHK(hipEventRecord(e->ev_edges, s));
+            run_step_rows(e, side, (size_t)j, row0 + 1, row1 - 1);
+            mark(side);
+            HIPCHK(hipEventRecord(e->ev_interior, side));
+            if (xchg) {
+                const auto t_c = clk::now();
+                a->comm->halo(rank, up ? send_up : nullptr, up ? recv_up : nullptr, down ? send_down : nullptr, down ? recv_down : nullptr, nbytes, s);
+                us_in_comm += std::chrono::duration<double, std::micro>(clk::now() - t_c).count();
+            }
+            mark(s);
+            if (j + 1 == (int)e->plan_steps.size()) HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));      // the scans follow on the main stream
+            continue;
+        }
         if (xchg) {
+            // the general form (option conformant / dct_mfma = 0 / the debug library's keep_recon): edge rows, pack kernel, exchange
+            // on a stream of its own beside the interior rows, unpack kernel
+            HIPCHK(hipStreamWaitEvent(side, e->ev_done, 0));    // the previous step, neighbour rows included
             StripStepArgs sa{j, send_up, send_down, nullptr, nullptr, 1};
             if ((r = strip_step_impl(e, &sa)) < 0) return r;
-            mark();
+            mark(s);
             HIPCHK(hipEventRecord(e->ev_edges, s));
+            run_step_rows(e, side, (size_t)j, row0 + 1, row1 - 1);
+            mark(side);
+            HIPCHK(hipEventRecord(e->ev_interior, side));
             HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_edges, 0));
-            const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)g.W;
             const auto t_c = clk::now();
             a->comm->halo(rank, up ? send_up : nullptr, up ? recv_up : nullptr, down ? send_down : nullptr, down ? recv_down : nullptr, nbytes,
                           e->comm_stream);
             us_in_comm += std::chrono::duration<double, std::micro>(clk::now() - t_c).count();
             HIPCHK(hipEventRecord(e->ev_halo, e->comm_stream));
-            StripStepArgs si{j, nullptr, nullptr, nullptr, nullptr, 2};
-            if ((r = strip_step_impl(e, &si)) < 0) return r;
-            mark();
             HIPCHK(hipStreamWaitEvent(s, e->ev_halo, 0));
-            mark();
+            HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));
+            mark(s);
             StripStepArgs sh{j, nullptr, nullptr, up ? recv_up : nullptr, down ? recv_down : nullptr};
             if ((r = strip_halo_in_impl(e, &sh)) < 0) return r;
         } else {
             StripStepArgs sa{j, nullptr, nullptr, nullptr, nullptr, 0};
             if ((r = strip_step_impl(e, &sa)) < 0) return r;
         }
+        if (world > 1) HIPCHK(hipEventRecord(e->ev_done, s));
     }
     e->strip_stats.steps = (int)e->plan_steps.size();
     e->strip_stats.host_us_per_step = std::chrono::duration<double, std::micro>(clk::now() - t_loop).count() / std::max<size_t>(1, e->plan_steps.size());
@@ -1692,10 +1783,10 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     }
     if (e->profile) {
         double tot = 0, exp = 0;
-        for (size_t k = 0; k + 3 <= marks.size(); k += 3) {
+        for (size_t k = 0; k + 3 <= marks.size(); k += 3) {       // per step: edges done (main), interior done (side), both + halo there (main)
             float m1 = 0, m2 = 0;
             if (hipEventElapsedTime(&m1, marks[k], marks[k + 2]) == hipSuccess) tot += m1;
-            if (hipEventElapsedTime(&m2, marks[k + 1], marks[k + 2]) == hipSuccess) exp += m2;
+            if (hipEventElapsedTime(&m2, marks[k + 1], marks[k + 2]) == hipSuccess && m2 > 0) exp += m2;
         }
         float gm = 0;
         if (g0 && g1 && hipEventElapsedTime(&gm, g0, g1) == hipSuccess) e->strip_stats.gather_ms = gm;

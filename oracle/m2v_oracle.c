@@ -14,6 +14,17 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Mutation switch (tests/test_oracle_mutants.py; oracle/Makefile target `mutants`).  The oracle is a hand restatement that
+ * nothing in this image can check against an executed RTL, so its guard is a SECOND, structurally different restatement
+ * (tests/rtl_stage_*.py, tests/rtl_module.py).  -DM2V_ORACLE_MUTANT=k builds this file with ONE deliberate mis-reading of
+ * an RTL quirk; the test asserts every such library is caught by the second restatement.  0 (the
+ * default, the only value the checker is ever built with) = the reading the parity tests rely on. */
+#ifndef M2V_ORACLE_MUTANT
+#define M2V_ORACLE_MUTANT 0
+#endif
+#define MUT(k) (M2V_ORACLE_MUTANT == (k))
+int m2v_oracle_mutant(void) { return M2V_ORACLE_MUTANT; }
+
 /* ------------------------------------------------------------------------------------------
  * geometry (RTL:55-72, 985-1006)
  * ---------------------------------------------------------------------------------------- */
@@ -136,7 +147,8 @@ static void bw_align(bitw_t *w)
  * zero-padded 32-byte word with o_last (RTL:2932-2937) */
 static size_t bw_finish(bitw_t *w)
 {
-    size_t words = (size_t)(w->nbits / 256) + 1;
+    size_t words = MUT(13) ? (size_t)((w->nbits + 255) / 256)      /* mutant 13: no extra word when the stream ends on a word boundary */
+                           : (size_t)(w->nbits / 256) + 1;
     size_t total = words * 32;
     size_t used = (size_t)((w->nbits + 7) >> 3);
     for (size_t i = used; i < total && i < w->cap; ++i) w->buf[i] = 0;
@@ -154,6 +166,9 @@ void m2v_oracle_subsample(const uint8_t *p, int W, int H, uint8_t *o)
             int h0 = mean2(p[(2 * j) * W + 2 * k], p[(2 * j) * W + 2 * k + 1]);
             int h1 = mean2(p[(2 * j + 1) * W + 2 * k], p[(2 * j + 1) * W + 2 * k + 1]);
             o[j * (W / 2) + k] = (uint8_t)mean2(h1, h0);
+            if (MUT(16))    /* mutant: one rounding over the four samples instead of the RTL's two stages (RTL:1086-1089, 1167-1170) */
+                o[j * (W / 2) + k] = (uint8_t)((p[(2 * j) * W + 2 * k] + p[(2 * j) * W + 2 * k + 1] + p[(2 * j + 1) * W + 2 * k] +
+                                                p[(2 * j + 1) * W + 2 * k + 1] + 2) >> 2);
         }
 }
 
@@ -188,13 +203,13 @@ void m2v_oracle_quant(const int32_t c[64], int inter, int Q, int16_t q[64])
             int32_t v = c[i * 8 + j];
             uint32_t a = (uint32_t)(v < 0 ? -v : v) & 0xFFFFu;          /* g_t3 is 16 bits, RTL:2068 */
             if (inter) {
-                a = ((a + 2u) & 0xFFFFu) >> (4 + Q);                   /* RTL:2070 */
+                a = ((a + (MUT(19) ? 0u : 2u)) & 0xFFFFu) >> (4 + Q);  /* RTL:2070 (mutant 19: no "+ 2") */
             } else if (i != 0 || j != 0) {
                 uint32_t w = M2V_INTRA_W[i][j];
                 a = ((a + ((w * ((3u << Q) + 2u)) >> 3)) >> Q) / w;    /* RTL:2072 */
                 a &= 0xFFFFu;
             } else {
-                a = (a >> 4) + ((a >> 3) & 1u);                        /* RTL:2074 */
+                a = (a >> 4) + (MUT(9) ? 0u : (a >> 3) & 1u);         /* RTL:2074 (mutant 9: truncation, no a[3] rounding) */
             }
             if (a > 2047u) a = 2047u;                                  /* RTL:2075 */
             q[i * 8 + j] = (int16_t)(v < 0 ? -(int32_t)a : (int32_t)a); /* RTL:2076 */
@@ -234,8 +249,9 @@ void m2v_oracle_dequant(const int16_t q[64], int inter, int Q, int16_t d[64])
                 t = sext((int32_t)((uint32_t)t << Q), 17);              /* RTL:2136 */
                 t = t < -2047 ? -2047 : t > 2047 ? 2047 : t;            /* RTL:2137 */
             } else if (i != 0 || j != 0) {
-                t = sext((int32_t)((uint32_t)t * M2V_INTRA_W[i][j]), 17); /* RTL:2139, modulo 2^17 */
-                if (Q >= 3) t = sext((int32_t)((uint32_t)t << (Q - 3)), 17); /* RTL:2141 */
+                t = sext((int32_t)((uint32_t)t * M2V_INTRA_W[i][j]), MUT(8) ? 32 : 17); /* RTL:2139, modulo 2^17 (mutant 8: no wrap) */
+                if (Q >= 3) t = sext((int32_t)((uint32_t)t << (Q - 3)), MUT(8) ? 32 : 17); /* RTL:2141 */
+                else if (MUT(17)) t = t / (1 << (3 - Q));               /* mutant 17: toward zero, as ISO 7.4.2.3 would */
                 else        t = t >> (3 - Q);                           /* RTL:2143, arithmetic */
                 t = t < -2047 ? -2047 : t > 2047 ? 2047 : t;            /* RTL:2144 */
             } else {
@@ -254,7 +270,7 @@ static inline int32_t mul32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a
 static inline int32_t add32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 static inline int32_t sub32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 
-static inline int32_t row_store(int32_t v, int conf) { return conf ? v : sext(v, 18); }   /* RTL:886, 2170: 18-bit register */
+static inline int32_t row_store(int32_t v, int conf) { return conf || MUT(7) ? v : sext(v, 18); }   /* RTL:886, 2170: 18-bit register (mutant 7: full width) */
 
 static void idct_row(const int16_t a[8], int32_t r[8], int conf)
 {
@@ -397,7 +413,7 @@ static int accumulate_sad13(const int col[16], int masked)
     for (int c = 0; c < 16; ++c)
         if (!over) {
             int s = diff + col[c];
-            over = s >> 12;
+            over = MUT(4) ? s >= 4095 : s >> 12;          /* mutant 4: the kill threshold one too low */
             diff = s & 0xFFF;
         }
     return (over << 12) | diff;
@@ -409,7 +425,7 @@ static void motion_stage(const geom_t *g, const uint8_t cy[256], const planes_t 
 {
     const int YR = g->YR, W = g->W, H = g->H;
     const int x0 = 16 * bx, y0 = 16 * by;
-    const int r4 = g_conformant ? 2 : 1;                  /* rounding of the four-sample mean: 1 = RTL:764 */
+    const int r4 = g_conformant || MUT(1) ? 2 : 1;        /* rounding of the four-sample mean: 1 = RTL:764 (mutant 1: the ISO + 2) */
 
     /* ---- full-pel search (RTL:1634-1715) ---- */
     int have = 0, best = 0, fy = 0, fx = 0;
@@ -426,10 +442,12 @@ static void motion_stage(const geom_t *g, const uint8_t cy[256], const planes_t 
                 col[c] = s;
             }
             int v = accumulate_sad13(col, 0);
+            if (MUT(3)) { v = 0; for (int c = 0; c < 16; ++c) v += col[c]; }     /* mutant 3: a large SAD never kills a candidate */
+            else
             if (v >> 12) continue;                               /* SAD >= 4096: candidate dead (RTL:1669-1670) */
             /* minimum (RTL:1675-1691); among equal minima the largest dy, then the largest dx
                survive (last-assignment-wins loops, RTL:1694-1710) */
-            if (!have || v <= best) { have = 1; best = v; fy = dy; fx = dx; }
+            if (!have || (MUT(5) ? v < best : v <= best)) { have = 1; best = v; fy = dy; fx = dx; }   /* mutant 5: the FIRST minimum wins */
         }
     /* no live candidate: f_mvy = f_mvx = 0 (RTL:1695, 1707) */
 
@@ -463,6 +481,8 @@ static void motion_stage(const geom_t *g, const uint8_t cy[256], const planes_t 
                          ((bx == g->max_x16 || fx ==  YR) && hx > 0) ||
                          ((by == 0          || fy == -YR) && hy < 0) ||
                          ((by == g->max_y16 || fy ==  YR) && hy > 0);
+            if (MUT(15))    /* mutant 15: half-pel candidates masked by the block position only, not by the search range */
+                masked = (bx == 0 && hx < 0) || (bx == g->max_x16 && hx > 0) || (by == 0 && hy < 0) || (by == g->max_y16 && hy > 0);
             int col[16];
             for (int c = 0; c < 16; ++c) {
                 int s = 0;
@@ -478,6 +498,7 @@ static void motion_stage(const geom_t *g, const uint8_t cy[256], const planes_t 
     uint32_t S = 0;
     for (int k = 0; k < 256; ++k) S += cy[k];
     int m = (int)((S >> 8) & 0xFF);
+    if (MUT(6)) S = 0;                                    /* mutant 6: the deviation sum starts from zero, not on top of the pixel sum */
     for (int c = 0; c < 16; ++c) {
         int s = 0;
         for (int r = 0; r < 16; ++r) s += absdiff(cy[r * 16 + c], m);
@@ -505,7 +526,7 @@ static void motion_stage(const geom_t *g, const uint8_t cy[256], const planes_t 
     /* ---- chroma prediction (RTL:1854-1888 integer part mv>>>2, RTL:1904-1916 half flag = bit 1) ---- */
     const int cw = W / 2, ch = H / 2;
     /* chroma vector in chroma half samples: RTL floor (mv >>> 1), ISO 7.6.3.7 truncation toward zero (mv / 2) */
-    const int cmvy = g_conformant ? mvy / 2 : mvy >> 1, cmvx = g_conformant ? mvx / 2 : mvx >> 1;
+    const int cmvy = g_conformant || MUT(2) ? mvy / 2 : mvy >> 1, cmvx = g_conformant || MUT(2) ? mvx / 2 : mvx >> 1;   /* mutant 2: the ISO division */
     int cy_i = cmvy >> 1, cx_i = cmvx >> 1;             /* floor */
     int fyh = cmvy & 1, fxh = cmvx & 1;
     for (int pl = 0; pl < 2; ++pl) {
@@ -634,7 +655,7 @@ typedef struct {
 static void put_ac(bitw_t *w, int v, int run)
 {
     int absv = v < 0 ? -v : v;
-    if (run < 32 && absv <= M2V_AC_MAX_LEVEL && M2V_AC_CODE[run][absv - 1].len) {
+    if (run < (MUT(11) ? 31 : 32) && absv <= M2V_AC_MAX_LEVEL && M2V_AC_CODE[run][absv - 1].len) {   /* mutant 11: run 31 escapes */
         const m2v_vlc *c = &M2V_AC_CODE[run][absv - 1];
         bw_put(w, c->code, c->len);
         bw_put(w, v < 0, 1);
@@ -648,6 +669,8 @@ static void put_ac(bitw_t *w, int v, int run)
 static void put_motion_delta(bitw_t *w, int mv, int prev)        /* RTL:2736-2748 */
 {
     int d = mv - prev;
+    if (MUT(21)) { if (d > 16) d -= 32; else if (d < -15) d += 32; }      /* mutant 21: the wrap window shifted by one */
+    else
     if (d > 15) d -= 32;
     else if (d < -16) d += 32;
     int a = d < 0 ? -d : d;
@@ -669,7 +692,7 @@ static void put_macroblock(bitw_t *w, slice_pred_t *sp, int i_frame, int inter, 
         bw_put(w, M2V_CBP_CODE[cbp].code, M2V_CBP_CODE[cbp].len);
         sp->prev_mvx = mvx;
         sp->prev_mvy = mvy;
-    } else {                                             /* RTL:2771-2774 */
+    } else if (!MUT(20)) {                               /* RTL:2771-2774 (mutant 20: an intra macroblock leaves the predictors alone) */
         sp->prev_mvx = 0;
         sp->prev_mvy = 0;
     }
@@ -679,12 +702,13 @@ static void put_macroblock(bitw_t *w, slice_pred_t *sp, int i_frame, int inter, 
         int comp = t < 4 ? 0 : t - 3;
         int val = zig[t][0];
         int diff_dc = val - sp->prev_dc[comp];
+        if (!(MUT(14) && inter))                         /* mutant 14: an inter macroblock leaves the DC predictors alone */
         sp->prev_dc[comp] = inter ? 0 : val;             /* updated for every tile (RTL:2786-2792) */
         int run = 0;
         if (inter) {                                     /* RTL:2795-2806 */
-            if (val == 0) run = 1;
+            if (val == 0) run = MUT(12) ? 0 : 1;         /* mutant 12: the first position does not count as a zero */
             else if (coded) {
-                if (val == 1 || val == -1) { bw_put(w, 1, 1); bw_put(w, val < 0, 1); }
+                if ((val == 1 || val == -1) && !MUT(10)) { bw_put(w, 1, 1); bw_put(w, val < 0, 1); }   /* mutant 10: no '1s' rule */
                 else put_ac(w, val, 0);
             }
         } else if (coded) {                              /* RTL:2807-2822 */

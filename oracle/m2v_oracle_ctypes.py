@@ -34,14 +34,13 @@ def build(force=False):
     return _LIB
 
 
-_lib = None
+_libs = {}
+_active = _LIB          # path of the library lib() talks to; only tests/test_oracle_mutants.py ever changes it
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        L = ctypes.CDLL(_LIB)
+def _load(path):
+    if path not in _libs:
+        L = ctypes.CDLL(path)
         L.m2v_oracle_encode.restype = ctypes.c_size_t
         L.m2v_oracle_encode.argtypes = [ctypes.POINTER(Params), ctypes.c_uint, ctypes.c_uint, ctypes.c_uint,
                                         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
@@ -56,8 +55,39 @@ def lib():
         for name in ("quant", "dequant"):
             getattr(L, "m2v_oracle_" + name).argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.m2v_oracle_subsample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
+
+
+class _Active:
+    """What lib() hands out: every attribute is looked up in the library that is active at the time of the call, so
+    modules that keep `L = orc.lib()` follow a switch made by use_library()."""
+
+    def __getattr__(self, name):
+        if _active == _LIB:
+            build()
+        return getattr(_load(_active), name)
+
+
+_proxy = _Active()
+
+
+def lib():
+    return _proxy
+
+
+def build_mutants():
+    """oracle/_mut/libm2v_oracle_mut<k>.so: the oracle compiled with ONE deliberate mis-reading each (m2v_oracle.c,
+    M2V_ORACLE_MUTANT).  Test-only.  -> {k: path}"""
+    subprocess.check_call(["make", "-s", "-j4", "-C", _HERE, "mutants"])
+    d = os.path.join(_HERE, "_mut")
+    return {int(f[len("libm2v_oracle_mut"):-3]): os.path.join(d, f) for f in sorted(os.listdir(d)) if f.startswith("libm2v_oracle_mut")}
+
+
+def use_library(path=None):
+    """Point lib() / encode() at another build of the oracle (a mutant); None = back to the real one."""
+    global _active
+    _active = path or _LIB
 
 
 def geometry(xsize16, ysize16, XL=7, YL=7, VL=3, Q=2):
