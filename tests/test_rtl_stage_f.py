@@ -7,6 +7,7 @@ import pytest
 
 import m2v_load
 from oracle import m2v_oracle_ctypes as orc
+import corner_clips as C
 from rtl_stage_f import stage_f
 
 M = m2v_load.load()
@@ -40,64 +41,6 @@ def _residual(levels_zz, inter, Q):
     return r.reshape(8, 8).astype(np.int64)
 
 
-def sad_threshold_clip(W, H, total):
-    """Two frames; the first is black (its reconstruction is exactly 0 / 128 / 128: tests/golden/kat_black), the second has
-    `total` as the pixel sum of every macroblock, the last of it in the macroblock's last column: EVERY full-pel candidate of
-    every macroblock then has a SAD of exactly `total`, reached only with the last column of the 16-clock accumulation.
-    total = 4095 is the largest SAD that keeps a candidate alive, 4096 the smallest that kills it (RTL:1669-1670)."""
-    clip = np.zeros((2, 3, H, W), np.uint8)
-    clip[:, 1:] = 128
-    mb = np.zeros((16, 16), np.int64)
-    flat = mb.reshape(-1)
-    left = total - 15                       # 15 sits in the last column, the rest is spread from the top left
-    k = 0
-    while left > 0:
-        if k % 16 != 15:
-            flat[k] = min(255, left)
-            left -= flat[k]
-        k += 1
-    mb[15, 15] = 15
-    assert mb.sum() == total and mb[:, :15].sum() < total
-    clip[1, 0] = np.tile(mb, (H // 16, W // 16)).astype(np.uint8)
-    return clip
-
-
-def sad_exact_clip(target):
-    """Two frames 64x64, VECTOR_LEVEL 1 (+-2).  The interior macroblock (1, 1) of the second frame is built against the oracle's
-    own reconstruction of the first so that its BEST full-pel candidate - at (dy, dx) = (-1, +1), not at the origin - has a SAD
-    of exactly `target`, while the half-pel position right of it matches far better: a candidate that survives (target <= 4095)
-    wins with its half-pel refinement, one that is killed (target >= 4096, RTL:1669-1670) leaves the vector at the origin.
-    The one construction where the kill threshold itself decides the stream."""
-    W = H = 64
-    by = bx = 1
-    dy0, dx0 = -1, 1
-    for slope in range(24, 40):
-        yy, xx = np.mgrid[0:H, 0:W]
-        tex = 20 + ((slope * xx + 7 * yy) % 140)
-        f0 = np.zeros((1, 3, H, W), np.uint8)
-        f0[0, 0] = tex.astype(np.uint8)
-        f0[0, 1:] = 128
-        _, d = orc.encode(f0, 4, 4, 0, 7, 7, 1, 2, dump=True)
-        rec = d["recon"][0][:W * H].reshape(H, W).astype(np.int64)
-        blk = lambda dy, dx: rec[16 * by + dy:16 * by + dy + 16, 16 * bx + dx:16 * bx + dx + 16]      # noqa: E731
-        cur = (blk(dy0, dx0) + blk(dy0, dx0 + 1) + 1) >> 1                  # the half-pel sample between dx0 and dx0 + 1
-        cands = [(dy, dx) for dy in range(-2, 3) for dx in range(-2, 3)]
-        # pixel (0, 0) is lifted above every reference sample it is compared with: every candidate's SAD then moves 1 : 1 with it
-        wo = {c: int(np.abs(cur - blk(*c)).sum() - abs(cur[0, 0] - blk(*c)[0, 0])) - int(blk(*c)[0, 0]) for c in cands}
-        best = min(wo, key=lambda c: wo[c])
-        c00 = target - wo[best]
-        top = max(int(blk(*c)[0, 0]) for c in cands)
-        if best != (dy0, dx0) or not (top <= c00 <= 255):
-            continue
-        cur = cur.copy()
-        cur[0, 0] = c00
-        assert min(int(np.abs(cur - blk(*c)).sum()) for c in cands) == target
-        clip = np.concatenate([f0, f0])
-        clip[1, 0, 16 * by:16 * by + 16, 16 * bx:16 * bx + 16] = cur.astype(np.uint8)
-        return clip
-    raise AssertionError("no texture slope gives a feasible construction")
-
-
 @pytest.mark.parametrize("W,H,n,pf,VL,Q,ci,kind", [(96, 80, 3, 2, 3, 2, 96, "clip"), (64, 96, 3, 2, 2, 1, 97, "clip"),
                                                     (80, 64, 3, 2, 1, 3, 98, "clip"), (64, 64, 2, 1, 3, 2, 0, "noise"),
                                                     (64, 64, 3, 2, 3, 2, 0, "checker"),
@@ -105,7 +48,7 @@ def sad_exact_clip(target):
                                                     (64, 64, 2, 1, 1, 2, 4095, "exact"), (64, 64, 2, 1, 1, 2, 4096, "exact")])
 def test_stage_f_emulation_equals_oracle(W, H, n, pf, VL, Q, ci, kind):
     clip = M.synth.clip(W, H, n, clip_index=ci, scene_len=7) if kind == "clip" else \
-        sad_threshold_clip(W, H, ci) if kind == "sad" else sad_exact_clip(ci) if kind == "exact" else M.synth.degenerate(kind, W, H, n)
+        C.sad_threshold_flat(W, H, ci) if kind == "sad" else C.sad_exact(ci) if kind == "exact" else M.synth.degenerate(kind, W, H, n)
     _, d = orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, Q, dump=True)
     rng = np.random.default_rng(ci + 1)
     UR, YR = VL, 2 * VL

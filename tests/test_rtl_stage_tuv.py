@@ -30,3 +30,16 @@ def test_clocked_model_equals_oracle(kind, W, H, n, pf, VL, Q):
     clip = M.synth.clip(W, H, n, clip_index=95, scene_len=2) if kind == "clip" else M.synth.degenerate(kind, W, H, n)
     data, d = orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, Q, dump=True)
     assert run_model(W, H, Q, pf, d, n) == data
+
+
+@pytest.mark.parametrize("make", ["lone_level_after_31_zeros", "stream_ending_on_a_word_boundary", "intra_between_inter_macroblocks",
+                                  "vector_delta_of_sixteen"])
+def test_clocked_model_equals_oracle_on_the_corner_clips(make):
+    """content built for one corner of the entropy coder each (tests/corner_clips.py): the last run with a table code, a stream
+    that ends on a word boundary, DC / vector predictors across alternating intra and inter macroblocks, a vector difference
+    at the wrap"""
+    import corner_clips as C
+    clip, pf, VL, Q = getattr(C, make)()
+    n, _, H, W = clip.shape
+    data, d = orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, Q, dump=True)
+    assert run_model(W, H, Q, pf, d, n) == data
