@@ -2,8 +2,8 @@
 //
 // Values are ISO/IEC 13818-2 tables B-9/B-10/B-12/B-13/B-14, the default intra matrix, the
 // zig-zag scan and the integer DCT basis the reference uses (RTL/mpeg2encoder.v:105-112,
-// 131-138, 156-163, 185-245, 258-739).  tests/test_tables_product.py checks every entry
-// against the oracle's independent copy and (when mounted) the RTL's `assign` lines.
+// 131-138, 156-163, 185-245, 258-739).  tests/test_abi.py::test_product_tables_match_oracle_tables checks every entry
+// against the oracle's independent copy (through m2v_debug_table), tests/test_tables_vs_rtl.py the oracle's against the RTL's `assign` lines.
 //
 // VLC entries are packed (len << 8) | code; `len` bits, MSB first.
 #pragma once

@@ -1,5 +1,5 @@
 """Every constant table of the oracle (and of the HIP path, which shares the values through
-tests/test_tables_product.py) against the live `assign` lines of the reference RTL.
+tests/test_abi.py::test_product_tables_match_oracle_tables) against the live `assign` lines of the reference RTL.
 
 Runs only where /root/reference is mounted (the build container); skipped on the GPU box.
 """

@@ -1,23 +1,24 @@
 #!/usr/bin/env python3
-"""Per-kernel averages of a rocprofv3 --pmc counter_collection.csv, encoder kernels only.
-FETCH_SIZE / WRITE_SIZE are in KiB per dispatch (rocprofv3); see MI355X_MICROARCH.md HBM section for
-the gfx950 caveats (FETCH_SIZE counts 64 B per 128-B request on wide streaming reads: x2 there;
-other access widths are uncalibrated)."""
-import csv
+"""Per-kernel, per-dispatch averages of rocprofv3 --pmc runs (encoder kernels only).
+    python tools/summarize_pmc.py DIR [DIR ...]      every *counter_collection.csv below the directories
+FETCH_SIZE / WRITE_SIZE come out in KiB per dispatch; on gfx950 FETCH_SIZE counts 64 B per 128-B request on wide streaming
+reads (x2 there, MI355X_MICROARCH.md HBM section; tools/profile_round.sh applies it and records what it measured)."""
 import collections
+import csv
+import glob
 import json
 import sys
 
-out = collections.OrderedDict()
-for path in sys.argv[1:]:
-    acc = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(path)):
-        if "m2v::" not in r["Kernel_Name"]:
-            continue
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        a = acc[(name, r["Counter_Name"])]
-        a[0] += 1
-        a[1] += float(r["Counter_Value"])
-    for (name, ctr), (n, tot) in sorted(acc.items()):
-        out.setdefault(name, {})[ctr] = {"dispatches": n, "avg_KiB_per_dispatch": round(tot / n, 1)}
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for d in sys.argv[1:]:
+    for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(path)):
+            if "m2v::" not in r["Kernel_Name"]:
+                continue
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            a = acc[name][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+out = {k: {c: round(v[1] / v[0], 1) for c, v in sorted(cs.items())} | {"dispatches": max(v[0] for v in cs.values())}
+       for k, cs in acc.items()}
 print(json.dumps(out, indent=1))
