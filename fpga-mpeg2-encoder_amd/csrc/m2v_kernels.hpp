@@ -711,7 +711,7 @@ struct LaneK {
     uint32_t xc4;                   // xc + 4
     uint32_t cp_rd;                 // &s_cp[0][lane >> 3][0]
     uint32_t a1;                    // pass-1 A operand of the matrix-core transform
-    uint32_t xrow;                  // &s_x[..] of the lane's first accumulator register
+    uint32_t xrow;                  // &s_t[..] of the lane's first accumulator register (dequantised coefficients, raster order)
     uint32_t zz2;                   // 2 * zig-zag position of the lane
     uint32_t col_rd, col_pred;      // &s_t[t][col], &s_pred[t][col] of the column pass
     uint32_t crec_rd;               // &s_pred[4 + pl][yc << 3 | half << 2] of the chroma store
@@ -784,9 +784,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     uint32_t *const s_winb = (uint32_t *)(lds + kOffWinB);                     // the same, one dword to the left
     uint32_t *const s_sym = (uint32_t *)(lds + 16);                            // VLC symbol list (<= 3 + 6 * 64 entries; [-1] is read), reuses R1
     uint8_t (*const s_pred)[64] = (uint8_t (*)[64])(lds + kOffPred);           // prediction, later reconstruction, tile layout
-    int16_t (*const s_x)[64] = (int16_t (*)[64])(lds + kOffX);                 // dequantised coefficients (stage K onwards)
     uint8_t (*const s_cp)[8][16] = (uint8_t (*)[8][16])(lds + kOffX);          // before that: signed current | prediction bytes per tile row
-    int32_t (*const s_t)[64] = (int32_t (*)[64])(lds + kOffT);                 // DCT phase 1, later IDCT row pass
+    int32_t (*const s_t)[64] = (int32_t (*)[64])(lds + kOffT);                 // DCT phase 1; then the dequantised coefficients (as int32: the row pass of
+                                                                               // the IDCT reads them without unpacking and works in place), then the bit buffer
     uint32_t *const s_bits = (uint32_t *)(lds + kOffT);                        // VLC bit segments (<= 1216 bytes), reuses s_t
     int16_t (*const s_zig)[64] = (int16_t (*)[64])(lds + kOffZig);             // quantised levels in zig-zag order
 
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         k.cp_rd = lds_off(&s_cp[0][di][0]);
         const int mg = lane >> 4, mc = lane & 15;
         k.a1 = lds_off(&s_cp[((mc >> 3) << 1) | (mg & 1)][mc & 7][8 * (mg >> 1)]);
-        k.xrow = lds_off(&s_x[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)]);
+        k.xrow = lds_off(&s_t[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)]);
         k.zz2 = 2u * c_zigzag[lane];
         const int ct = lane < 48 ? lane >> 3 : 5;               // column pass: 48 lanes
         k.col_rd = lds_off(&s_t[ct][lane & 7]);
@@ -1340,9 +1340,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         if constexpr (kMfmaLuma) {
             // the four luma tiles in accumulator layout: lane (g, c) owns rows 4g .. 4g+3 of column c of the 16x16 block,
             // i.e. four coefficients of tile 2 (g >> 1) + (c >> 3); their s_zig slots come from the lane table, their
-            // raster slots in s_x are 16 bytes apart
+            // raster slots in s_t are 32 bytes apart
             const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
-            int16_t *const xrow = (int16_t *)(__attribute__((address_space(3))) int16_t *)(uintptr_t)kq2.w;   // &s_x[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)]
+            int32_t *const xrow = (int32_t *)(__attribute__((address_space(3))) int32_t *)(uintptr_t)kq2.w;   // &s_t[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)]
             int nzor = 0, qv[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 for (int v = 0; v < 4; ++v) {
                     int x = (2 * qv[v] + sign_of(qv[v])) << Q;
                     x = clamp_vv(x, kn2047, k2047);
-                    xrow[v * 8] = (int16_t)x;
+                    xrow[v * 8] = x;
                 }
             }
             // coded flags of the four tiles: tile 2 ty + tx lives in lanes 32 ty + 16 h + 8 tx + (0 .. 7), h = 0, 1
@@ -1395,7 +1395,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 } else {
                     x = clamp_vv(x, kn2047, k2047);
                 }
-                s_x[t][lane] = (int16_t)x;
+                s_t[t][lane] = x;                       // behind this tile's phase-2 reads of s_t[t] (one wavefront: LDS operations execute in order)
             }
         }
     } else {
@@ -1405,7 +1405,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         if constexpr (kMfmaLuma) {
             const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
             const MfmaLaneIntra ml = c_mfma_intra[lane];
-            int16_t *const xrow = (int16_t *)(__attribute__((address_space(3))) int16_t *)(uintptr_t)kq2.w;
+            int32_t *const xrow = (int32_t *)(__attribute__((address_space(3))) int32_t *)(uintptr_t)kq2.w;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int wv = (int)((ml.wq >> (8 * v)) & 255u);
@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     } else {
                         x = 2 * q;
                     }
-                    xrow[v * 8] = (int16_t)x;
+                    xrow[v * 8] = x;
                 }
             }
         }
@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 } else {
                     x = 2 * q;
                 }
-                s_x[t][lane] = (int16_t)x;
+                s_t[t][lane] = x;                       // behind this tile's phase-2 reads of s_t[t] (one wavefront: LDS operations execute in order)
             }
         }
         cbp = 63;                                       // intra: every tile is coded (RTL:2461)
@@ -1475,6 +1475,69 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     M2V_WAVE_SYNC();
 
     M2V_STOP(5);            // ... up to the quantiser / inverse quantiser
+    // ---- stages H..R: Chen-Wang IDCT, reconstruction, store as next reference ------------------
+    if (need_rec) {
+        keep_alive(kq3); keep_alive(kq4);
+        if (lane < 48) {                                // rows: lane = tile*8 + row (RTL:2159-2189), in place
+            const int t = lane >> 3, row = lane & 7;
+            int a[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = s_t[t][row * 8 + k];
+            idct_row(a, o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s_t[t][row * 8 + k] = o[k];
+        }
+        M2V_WAVE_SYNC();
+        if (lane < 48) {                                // columns: lane = tile*8 + col (RTL:2238-2279)
+            typedef const __attribute__((address_space(3))) int32_t *LdsI32;
+            typedef __attribute__((address_space(3))) uint8_t *LdsW8;
+            int a[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = *(LdsI32)(uintptr_t)(kq3.y + (uint32_t)(k * 32));      // s_t[t][k * 8 + col]
+            idct_col(a, o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {               // add_clip_0_255 (RTL:786-795, 2352)
+                LdsW8 const pp = (LdsW8)(uintptr_t)(kq3.z + (uint32_t)(k * 8));                        // s_pred[t][k * 8 + col]
+                const int v = (int)*pp + o[k];
+                *pp = (uint8_t)(v > 255 ? 255 : v < 0 ? 0 : v);
+            }
+        }
+        M2V_WAVE_SYNC();
+        // scalar base + 32-bit lane offset (a generic pointer costs a 64-bit vector add per store); V sits csz bytes behind U
+        typedef __attribute__((address_space(1))) uint32_t *gst32;
+        uint8_t *recY = job.rec, *recU = recY + g.ysz;
+        {
+            const uint32_t v = *(LdsU32 *)(uintptr_t)kq0.z;                  // the lane's four pixels: s_pred[tile][ti] again
+            *(gst32)(recY + pix_off) = v;
+        }
+        if (lane < 32) {
+            // pl = lane >> 4, yc = (lane & 15) >> 1, half = lane & 1: s_pred[4 + pl][(yc << 3) | (half << 2)] goes to
+            // (8 by + yc) cw + 8 bx + 4 half + pl csz: two multiply-adds on the table's (yc, 4 half, pl)
+            const uint32_t v = *(LdsU32 *)(uintptr_t)kq3.w;
+            const uint32_t c0 = __umul24(k4p, (uint32_t)g.csz) + (k4r + (uint32_t)sgpr((int)(__umul24((uint32_t)(8 * by), (uint32_t)g.cw) + (uint32_t)(8 * bx))));
+            const uint32_t coff = __umul24(kq4.x, (uint32_t)g.cw) + c0;
+            *(gst32)(recU + coff) = v;
+        }
+        if constexpr (EDGE) {
+            // per frame of the step's halo list: [YR rows of W luma][UR rows of cw U][UR rows of cw V] (k_halo_pack's layout)
+            constexpr uint32_t YR2 = 2 * VL, UR2 = VL;
+            const uint32_t chunk = (YR2 + UR2) * (uint32_t)W, cw = (uint32_t)g.cw;
+            const uint32_t fbase = (uint32_t)job.hidx * chunk;
+            const uint32_t vy = *(LdsU32 *)(uintptr_t)kq0.z;                // the lane's four luma pixels of row r
+            const uint32_t vc = *(LdsU32 *)(uintptr_t)kq3.w;                // lanes < 32: four chroma pixels of row kq4.x, plane k4p
+            const uint32_t xl = (uint32_t)(16 * bx + 4 * c4), xc = (uint32_t)(8 * bx) + k4r;
+            if (halo_up != nullptr && by == g.edge_top) {                   // wave-uniform
+                if ((uint32_t)r < YR2) *(gst32)(halo_up + (fbase + (uint32_t)r * (uint32_t)W + xl)) = vy;
+                if (lane < 32 && kq4.x < UR2) *(gst32)(halo_up + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + kq4.x) * cw + xc)) = vc;
+            }
+            if (halo_down != nullptr && by == g.edge_bot) {
+                if ((uint32_t)r >= 16u - YR2) *(gst32)(halo_down + (fbase + ((uint32_t)r - (16u - YR2)) * (uint32_t)W + xl)) = vy;
+                if (lane < 32 && kq4.x >= 8u - UR2) *(gst32)(halo_down + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + (kq4.x - (8u - UR2))) * cw + xc)) = vc;
+            }
+        }
+    }
+
+    M2V_STOP(6);            // everything but the entropy coder
     // ---- stage T, coefficient part: run/level VLC of the six tiles (RTL:2777-2847) -----------------
     // Pass 1 (per tile, lane = zig-zag index): ballot the non-zero levels, rank them, and append
     // {run, level} / raw-code symbols to one compact list.  Pass 2 (once per macroblock): table lookup,
@@ -1590,69 +1653,6 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         }
     }
 
-    M2V_STOP(6);            // everything but the reconstruction loop
-    // ---- stages H..R: Chen-Wang IDCT, reconstruction, store as next reference ------------------
-    if (need_rec) {
-        keep_alive(kq3); keep_alive(kq4);
-        M2V_WAVE_SYNC();                                // s_t doubles as the bit buffer that was just copied out
-        if (lane < 48) {                                // rows: lane = tile*8 + row (RTL:2159-2189)
-            const int t = lane >> 3, row = lane & 7;
-            int a[8], o[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a[k] = s_x[t][row * 8 + k];
-            idct_row(a, o);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s_t[t][row * 8 + k] = o[k];
-        }
-        M2V_WAVE_SYNC();
-        if (lane < 48) {                                // columns: lane = tile*8 + col (RTL:2238-2279)
-            typedef const __attribute__((address_space(3))) int32_t *LdsI32;
-            typedef __attribute__((address_space(3))) uint8_t *LdsW8;
-            int a[8], o[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a[k] = *(LdsI32)(uintptr_t)(kq3.y + (uint32_t)(k * 32));      // s_t[t][k * 8 + col]
-            idct_col(a, o);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {               // add_clip_0_255 (RTL:786-795, 2352)
-                LdsW8 const pp = (LdsW8)(uintptr_t)(kq3.z + (uint32_t)(k * 8));                        // s_pred[t][k * 8 + col]
-                const int v = (int)*pp + o[k];
-                *pp = (uint8_t)(v > 255 ? 255 : v < 0 ? 0 : v);
-            }
-        }
-        M2V_WAVE_SYNC();
-        // scalar base + 32-bit lane offset (a generic pointer costs a 64-bit vector add per store); V sits csz bytes behind U
-        typedef __attribute__((address_space(1))) uint32_t *gst32;
-        uint8_t *recY = job.rec, *recU = recY + g.ysz;
-        {
-            const uint32_t v = *(LdsU32 *)(uintptr_t)kq0.z;                  // the lane's four pixels: s_pred[tile][ti] again
-            *(gst32)(recY + pix_off) = v;
-        }
-        if (lane < 32) {
-            // pl = lane >> 4, yc = (lane & 15) >> 1, half = lane & 1: s_pred[4 + pl][(yc << 3) | (half << 2)] goes to
-            // (8 by + yc) cw + 8 bx + 4 half + pl csz: two multiply-adds on the table's (yc, 4 half, pl)
-            const uint32_t v = *(LdsU32 *)(uintptr_t)kq3.w;
-            const uint32_t c0 = __umul24(k4p, (uint32_t)g.csz) + (k4r + (uint32_t)sgpr((int)(__umul24((uint32_t)(8 * by), (uint32_t)g.cw) + (uint32_t)(8 * bx))));
-            const uint32_t coff = __umul24(kq4.x, (uint32_t)g.cw) + c0;
-            *(gst32)(recU + coff) = v;
-        }
-        if constexpr (EDGE) {
-            // per frame of the step's halo list: [YR rows of W luma][UR rows of cw U][UR rows of cw V] (k_halo_pack's layout)
-            constexpr uint32_t YR2 = 2 * VL, UR2 = VL;
-            const uint32_t chunk = (YR2 + UR2) * (uint32_t)W, cw = (uint32_t)g.cw;
-            const uint32_t fbase = (uint32_t)job.hidx * chunk;
-            const uint32_t vy = *(LdsU32 *)(uintptr_t)kq0.z;                // the lane's four luma pixels of row r
-            const uint32_t vc = *(LdsU32 *)(uintptr_t)kq3.w;                // lanes < 32: four chroma pixels of row kq4.x, plane k4p
-            const uint32_t xl = (uint32_t)(16 * bx + 4 * c4), xc = (uint32_t)(8 * bx) + k4r;
-            if (halo_up != nullptr && by == g.edge_top) {                   // wave-uniform
-                if ((uint32_t)r < YR2) *(gst32)(halo_up + (fbase + (uint32_t)r * (uint32_t)W + xl)) = vy;
-                if (lane < 32 && kq4.x < UR2) *(gst32)(halo_up + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + kq4.x) * cw + xc)) = vc;
-            }
-            if (halo_down != nullptr && by == g.edge_bot) {
-                if ((uint32_t)r >= 16u - YR2) *(gst32)(halo_down + (fbase + ((uint32_t)r - (16u - YR2)) * (uint32_t)W + xl)) = vy;
-                if (lane < 32 && kq4.x >= 8u - UR2) *(gst32)(halo_down + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + (kq4.x - (8u - UR2))) * cw + xc)) = vc;
-            }
-        }
-    }
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ base = None
 rows = []
 for a in (0, 1, 2, 4, 8, 16, 31):
     d = json.load(open("%s/a%d.json" % (out, a)))
-    k = [v for n, v in d.items() if "k_mb<3, true" in n][0]
+    k = max((v for n, v in d.items() if "k_mb<3, true" in n), key=lambda v: v["SQ_WAVES"])
     w = k["SQ_WAVES"]
     cur = dict(valu=k["SQ_INSTS_VALU"] / w, salu=k["SQ_INSTS_SALU"] / w, lds=k["SQ_INSTS_LDS"] / w, act=4 * k["SQ_ACTIVE_INST_VALU"] / w,
                ldsc=k["SQ_LDS_IDX_ACTIVE"] / w, conf=k["SQ_LDS_BANK_CONFLICT"] / w)

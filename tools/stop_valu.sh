@@ -15,12 +15,12 @@ python3 - "$OUT" <<'PY'
 import json, sys
 out = sys.argv[1]
 names = {1: "loads, 4:2:0, window staging", 2: "full-pel search", 3: "half-pel, decision, prediction", 4: "forward transform", 5: "quantiser + inverse quantiser",
-         6: "run/level VLC, slot store", 0: "IDCT, reconstruction"}
+         6: "IDCT, reconstruction", 0: "run/level VLC, slot store"}
 prev = dict(valu=0, salu=0, lds=0, act=0, ldsc=0, conf=0)
 rows = []
 for n in (1, 2, 3, 4, 5, 6, 0):
     d = json.load(open("%s/s%d.json" % (out, n)))
-    k = [v for kk, v in d.items() if "k_mb<3, true" in kk][0]
+    k = max((v for kk, v in d.items() if "k_mb<3, true" in kk), key=lambda v: v["SQ_WAVES"])   # not the one-wave FILL instantiation
     w = k["SQ_WAVES"]
     cur = dict(valu=k["SQ_INSTS_VALU"] / w, salu=k["SQ_INSTS_SALU"] / w, lds=k["SQ_INSTS_LDS"] / w, act=4 * k["SQ_ACTIVE_INST_VALU"] / w,
                ldsc=k["SQ_LDS_IDX_ACTIVE"] / w, conf=k["SQ_LDS_BANK_CONFLICT"] / w)
