@@ -147,7 +147,7 @@ constexpr bool s3_helpers_match(int lane = 0) { return lane == 64 || ((((kS3Help
 static_assert(s3_helpers_match(), "kS3Helpers does not match s3_dy");
 constexpr int kS3Cur = 2 * (8 + 2 * 3) * 16;             // current luma rows (behind the two chroma windows)
 constexpr int kS3Win = kS3Cur + 256;                     // luma window, copy A
-constexpr int kS3Scratch = 1600 + 384 + 768 + 1536;      // the level buffer s_zig: unused until the quantiser
+constexpr int kS3Scratch = 1600 + 384 + 1536;            // the level buffer s_zig: unused until the quantiser
 constexpr int kS3Flush = kS3Scratch;                     // running sums [t][group][k], 8 bytes each
 constexpr int kS3Rep = kS3Flush + 3 * 4 * 4 * 8;         // macroblock rows 13 14 15 13 14 15 ... (12 x 16 bytes) for the helpers
 static_assert((kS3Rep - kS3Cur) % 256 == 128, "a step reads one row of each in the same instruction: 32 banks apart");
@@ -774,8 +774,14 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     constexpr int kWinBGap = win_b_gap(WROWS);                                 // dwords from A to B: >= window, = 32 mod 64
     constexpr int kOffWinB = kOffWin + kWinBGap * 4;
     constexpr int kR1 = 1600;
-    static_assert(!P || (kOffWin % 8 == 0 && kOffWinB + kWinBytes <= 1600 + 384 + 768 + 1536), "window copies may run over s_pred, s_x, s_t only");
-    constexpr int kOffPred = kR1, kOffX = kOffPred + 384, kOffT = kOffX + 768, kOffZig = kOffT + 1536;
+    // The transform's input tiles s_cp (signed current | prediction bytes, 768 bytes) live INSIDE R1: they are written when the
+    // prediction is formed - after the luma window's last read, beside the chroma windows and the current rows, which end below
+    // byte 704 - and are dead before the symbol list is written.  4 288 bytes per wavefront: the I-frame kernel (56 VGPRs) fits
+    // nine wavefronts per SIMD, the P-frame kernel stays at the eight its 64 VGPRs allow.
+    constexpr int kOffCp = 704;
+    static_assert(2 * kCwinBytes + 256 <= kOffCp && kOffCp + 768 <= kR1, "s_cp behind the chroma windows and the current rows, inside R1");
+    constexpr int kOffPred = kR1, kOffT = kOffPred + 384, kOffZig = kOffT + 1536;
+    static_assert(!P || (kOffWin % 8 == 0 && kOffWinB + kWinBytes <= kOffZig), "window copies may run over s_pred and s_t only");
     constexpr int kLdsBytes = kOffZig + 768;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];   // static base: every DS access uses an immediate offset
     uint32_t (*const s_cwin)[CROWS * 4] = (uint32_t (*)[CROWS * 4])lds;       // chroma windows: 16 bytes/row = cols 8bx-4 .. 8bx+11
@@ -784,7 +790,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     uint32_t *const s_winb = (uint32_t *)(lds + kOffWinB);                     // the same, one dword to the left
     uint32_t *const s_sym = (uint32_t *)(lds + 16);                            // VLC symbol list (<= 3 + 6 * 64 entries; [-1] is read), reuses R1
     uint8_t (*const s_pred)[64] = (uint8_t (*)[64])(lds + kOffPred);           // prediction, later reconstruction, tile layout
-    uint8_t (*const s_cp)[8][16] = (uint8_t (*)[8][16])(lds + kOffX);          // before that: signed current | prediction bytes per tile row
+    uint8_t (*const s_cp)[8][16] = (uint8_t (*)[8][16])(lds + kOffCp);         // signed current | prediction bytes per tile row: the transform's input
     int32_t (*const s_t)[64] = (int32_t (*)[64])(lds + kOffT);                 // DCT phase 1; then the dequantised coefficients (as int32: the row pass of
                                                                                // the IDCT reads them without unpacking and works in place), then the bit buffer
     uint32_t *const s_bits = (uint32_t *)(lds + kOffT);                        // VLC bit segments (<= 1216 bytes), reuses s_t
