@@ -1668,12 +1668,12 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 __global__ __launch_bounds__(128) void k_slice_scan(const FrameJob *__restrict__ jobs, Geom g,
                                                     const uint32_t *__restrict__ mbinfo, const MbAux *__restrict__ mbaux,
                                                     uint32_t *__restrict__ mb_len, uint32_t *__restrict__ mb_bitoff,
-                                                    uint32_t *__restrict__ slice_bytes, MbDepRec *__restrict__ mbdep)
+                                                    uint32_t *__restrict__ slice_bytes, MbDepRec *__restrict__ mbdep, int f0)
 {
     __shared__ uint32_t s[128];
     const int tid = threadIdx.x;
     const int rows = g.row1 - g.row0;
-    const int f = blockIdx.x / rows, by = g.row0 + (int)(blockIdx.x % rows);      // blockIdx = frame * rows + local row
+    const int f = f0 + (int)(blockIdx.x / rows), by = g.row0 + (int)(blockIdx.x % rows);      // blockIdx = (frame - f0) * rows + local row
     const size_t base = ((size_t)f * g.mbh + by) * g.mbw;
     uint32_t len = 0;
     if (tid < g.mbw) {
@@ -1911,8 +1911,15 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
         for (int k = tid; k < nw; k += kAsmThreads) {
             const uint32_t gk = c0 + (uint32_t)k;
             const uint32_t be = __builtin_bswap32(s_img[k]);
-            if (gk == 0 || gk == nout - 1) { if (be) atomicOr(&out32[w0 + gk], be); }
-            else out32[w0 + gk] = be;
+            if (gk == 0 || gk == nout - 1) {
+                // a slice is byte aligned, not word aligned: of its first and its last word only the bytes that are its own are
+                // written, one by one (the others belong to the previous / next slice or to headers).  No atomics and nothing to
+                // clear beforehand.
+                const int j0 = gk == 0 ? sh >> 3 : 0;
+                const int j1 = gk == nout - 1 ? (int)((((uint32_t)sh + total + 7u) >> 3) - 1u) & 3 : 3;      // last byte of the slice inside this word
+                uint8_t *const o8 = (uint8_t *)&out32[w0 + gk];
+                for (int j = j0; j <= j1; ++j) o8[j] = (uint8_t)(be >> (8 * j));
+            } else out32[w0 + gk] = be;
         }
         __syncthreads();                                   // the image is reused by the next pass
     }
@@ -1954,6 +1961,9 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
     __shared__ unsigned long long s_base;
     __shared__ unsigned long long s_wtot[16];
     const int tid = threadIdx.x;
+    // requested with everything else: this single workgroup is pure latency, and these were a round trip of their own after the scan
+    const unsigned long long c_prior = ctl->prior_bytes, c_cap = ctl->cap_bytes;
+    const uint32_t c_ov = ctl->overflow;
     if (tid == 0) {
         // advance = this chunk continues the stream of the previous one in the same buffer: base = previous total
         unsigned long long b = ctl->base_bytes;
@@ -2012,14 +2022,13 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
     unsigned long long total = base + all_frames;
     if (last) {
         total += 4;                                           // sequence_end_code (RTL:2621-2628)
-        const unsigned long long all = ctl->prior_bytes + total;
-        total = (all / 32ull + 1ull) * 32ull - ctl->prior_bytes;       // final word always leaves (RTL:2932-2937)
+        const unsigned long long all = c_prior + total;
+        total = (all / 32ull + 1ull) * 32ull - c_prior;                // final word always leaves (RTL:2932-2937)
     }
-    const bool ov = total > ctl->cap_bytes || ctl->overflow;
-    // k_assemble writes the inner dwords of a slice with plain stores and ORs its first and last dword into place (slices
-    // and headers are byte aligned, not dword aligned): only those boundary dwords have to be cleared beforehand, not
-    // the whole stream.  None of them can hold bytes of the previous chunk: at least a 17-byte picture header lies between
-    // `base` and the first slice.  The tail (end code + padding of the final 32-byte word) is cleared as a whole.
+    const bool ov = total > c_cap || c_ov;
+    // k_assemble writes every byte of every slice and header itself (whole dwords inside a slice, single bytes in its first and
+    // last word), so nothing of the stream has to be cleared beforehand except the tail: end code + padding of the final
+    // 32-byte word.
     unsigned long long run = incl - sum;
     auto place = [&](int f, int r, uint32_t sb, uint32_t hb) {
         if (r == 0) {
@@ -2027,10 +2036,6 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
             run += hb;
         }
         slice_off[(size_t)f * g.mbh + g.row0 + r] = run;
-        if (!ov) {
-            out32[(base + run) >> 2] = 0u;
-            if (sb) out32[(base + run + sb - 1u) >> 2] = 0u;
-        }
         run += sb;
     };
     {

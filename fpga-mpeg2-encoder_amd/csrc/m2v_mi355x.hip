@@ -153,6 +153,8 @@ struct m2v_enc {
     // plan of the chunk being encoded (plan_chunk -> run_step* -> finish_chunk)
     struct Step { int off_i, n_i, off_p, n_p, off_h, n_h; int cut_i[kMaxSplit + 1], cut_p[kMaxSplit + 1]; };   // cut_*[k]: first list entry of segment group k
     int plan_groups = 1;                  // groups the launch lists of the current plan are cut into
+    int plan_gf[kMaxSplit + 1] = {};      // chunk-frame index where each group's frames start (its GOP segments are consecutive frames)
+    bool slice_scan_done = false;         // the groups ran k_slice_scan on their own streams (encode_chunk): finish_chunk skips it
     std::vector<Step> plan_steps;
     size_t plan_nf = 0;
     bool strip_active = false;            // between m2v_strip_begin and m2v_strip_finish
@@ -574,6 +576,9 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
     const int groups = (int)std::max<size_t>(1, std::min<size_t>({(size_t)e->split_streams, nseg, (size_t)m2v_enc::kMaxSplit}));
     e->plan_groups = groups;
     auto group_of = [&](size_t sg) { return (int)(sg * (size_t)groups / nseg); };
+    for (int k = 0; k <= m2v_enc::kMaxSplit; ++k) e->plan_gf[k] = (int)nf;
+    for (size_t sg = nseg; sg-- > 0;) e->plan_gf[group_of(sg)] = seg_start[sg];       // first segment of every group (descending: the first one wins)
+    e->slice_scan_done = false;
     for (size_t j = 0; j < maxlen; ++j) {
         m2v_enc::Step st{};
         for (int pass = 0; pass < 3; ++pass) {
@@ -694,8 +699,10 @@ void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_s
     const size_t rows = (size_t)(g.row1 - g.row0);
     {
         Timer t(e, s, 4, (double)nf * g.ysz);
-        hipLaunchKernelGGL(k_slice_scan, dim3((unsigned)(nf * rows)), dim3(128), 0, s, e->d_jobs.p, g, e->d_mbinfo.p,
-                           e->d_mbaux.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_bytes.p, e->d_mbdep.p);
+        if (!e->slice_scan_done)
+            hipLaunchKernelGGL(k_slice_scan, dim3((unsigned)(nf * rows)), dim3(128), 0, s, e->d_jobs.p, g, e->d_mbinfo.p,
+                               e->d_mbaux.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_bytes.p, e->d_mbdep.p, 0);
+        e->slice_scan_done = false;
         // offsets of every frame and slice, stream length, and the boundary dwords k_assemble ORs into cleared
         hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(1024), 0, s, e->d_jobs.p, g, (int)nf, first ? 1 : 0, last ? 1 : 0,
                            e->d_slice_bytes.p, e->d_slice_off.p, e->d_frame_off.p, e->d_ctl.p, advance ? 1 : 0,
@@ -741,6 +748,18 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
                 launch_mb<true>(e, sk, e->d_lists.p + st.off_p + st.cut_p[k], st.cut_p[k + 1] - st.cut_p[k], e->g);
             }
         }
+        // every group scans its own slices right behind its last macroblock kernel (nothing in k_slice_scan looks beyond a
+        // slice): the group that finishes first does it while the others still encode; only k_frame_scan and k_assemble need all
+        const size_t rows = (size_t)(e->g.row1 - e->g.row0);
+        for (int k = 0; k < G; ++k) {
+            hipStream_t sk = k == 0 ? s : e->side[k - 1];
+            const int fa = e->plan_gf[k], fb = e->plan_gf[k + 1];
+            if (fb > fa)
+                hipLaunchKernelGGL(k_slice_scan, dim3((unsigned)((size_t)(fb - fa) * rows)), dim3(128), 0, sk, e->d_jobs.p, e->g, e->d_mbinfo.p,
+                                   e->d_mbaux.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_bytes.p, e->d_mbdep.p, fa);
+        }
+        HIPCHK(hipGetLastError());
+        e->slice_scan_done = true;
         for (int k = 1; k < G; ++k) {
             HIPCHK(hipEventRecord(e->ev_join[k - 1], e->side[k - 1]));
             HIPCHK(hipStreamWaitEvent(s, e->ev_join[k - 1], 0));
