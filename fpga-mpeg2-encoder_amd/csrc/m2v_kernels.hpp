@@ -1341,7 +1341,6 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         for (int t = 0; t < 6; ++t) s_zig[t][lane] = 0;
         cbp = inter ? 0 : 63;
     } else if (inter) {
-        const int k2047 = vgpr_const(2047), kn2047 = vgpr_const(-2047);
         const int qneg = sgpr(-(((1 << (4 + Q)) - 5) << 12));      // MINUS the bias of a negative value (it multiplies the sign mask)
         if constexpr (kMfmaLuma) {
             // the four luma tiles in accumulator layout: lane (g, c) owns rows 4g .. 4g+3 of column c of the 16x16 block,
@@ -1362,9 +1361,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             if (need_rec) {                     // one test for the four coefficients
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    int x = (2 * qv[v] + sign_of(qv[v])) << Q;
-                    x = clamp_vv(x, kn2047, k2047);
-                    xrow[v * 8] = x;
+                    // RTL:2134-2137 clamps to +-2047; the clamp cannot bind here: |q| <= 16322 >> (4 + Q), so (2 |q| + 1) << Q <= 2044
+                    // for every Q_LEVEL (tests/test_host_logic.py::test_inverse_quantisers_never_reach_their_clamps)
+                    xrow[v * 8] = (2 * qv[v] + sign_of(qv[v])) << Q;
                 }
             }
             // coded flags of the four tiles: tile 2 ty + tx lives in lanes 32 ty + 16 h + 8 tx + (0 .. 7), h = 0, 1
@@ -1398,16 +1397,13 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     const bool coded = ballot(q != 0) != 0ull;
                     const bool even = (__popcll(ballot(x & 1)) & 1) == 0;
                     if (coded && even && lane == 63) x ^= 1;
-                } else {
-                    x = clamp_vv(x, kn2047, k2047);
-                }
+                }                                       // (the reference's +-2047 clamp cannot bind: see the luma tiles above)
                 s_t[t][lane] = x;                       // behind this tile's phase-2 reads of s_t[t] (one wavefront: LDS operations execute in order)
             }
         }
     } else {
         if constexpr (P) { wq = c_intra_w[lane]; wrecip = c_intra_recip[lane]; }
         const uint32_t qoff = __umul24((uint32_t)wq, (3u << Q) + 2u) >> 3;
-        const int k2047 = vgpr_const(2047), kn2047 = vgpr_const(-2047);
         if constexpr (kMfmaLuma) {
             const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
             const MfmaLaneIntra ml = c_mfma_intra[lane];
@@ -1422,16 +1418,18 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
                 if (!is_dc) a = __umul24((a + qo) >> Q, ml.recip[v]) >> 21;
                 else        a = (a + 8u) >> 4;
-                if (a > 2047u) a = 2047u;
+                // RTL:2075 clamps to 2047 here and RTL:2139-2144 keeps the inverse quantiser's product in 17 bits and clamps it to +-2047:
+                // an intra block is pixel - 128, so |C| <= 8192, the level is at most 512 (DC) / 272 (AC) and |level * W| < 2^14 - none
+                // of the three can bind (tests/test_host_logic.py::test_inverse_quantisers_never_reach_their_clamps).  The conformant
+                // build keeps its own saturation.
                 const int q = (int)(a ^ (uint32_t)sg) - sg;
                 *(int16_t *)((uint8_t *)&s_zig[0][0] + zo[v]) = (int16_t)q;
                 if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + (zo[v] >> 1)] = (int16_t)q;
                 if (need_rec) {
                     int x;
                     if (!is_dc) {
-                        x = sext(__mul24(q, wv), 17);
-                        x = Q >= 3 ? sext((int)((uint32_t)x << (Q - 3)), 17) : (x >> (3 - Q));
-                        x = clamp_vv(x, kn2047, k2047);
+                        x = __mul24(q, wv);
+                        x = Q >= 3 ? x << (Q - 3) : x >> (3 - Q);
                     } else {
                         x = 2 * q;
                     }
@@ -1449,7 +1447,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
             if (lane != 0) a = __umul24((a + qoff) >> Q, wrecip) >> 21;             // exact "/ W" (n < 2^14, recip < 2^19), RTL:2072
             else           a = (a + 8u) >> 4;                                       // (a >> 4) + bit 3, RTL:2074
-            if (a > 2047u) a = 2047u;
+            if constexpr (CONF) { if (a > 2047u) a = 2047u; }                       // RTL:2075; cannot bind (see the luma tiles)
             const int q = (int)(a ^ (uint32_t)sg) - sg;
             *(LdsW16)(uintptr_t)(lds_off(&s_zig[t][0]) + kq3.x) = (uint16_t)q;      // s_zig[t][zz]
             if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
@@ -1467,9 +1465,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     const bool even = (__popcll(ballot(x & 1)) & 1) == 0;      // mismatch control (7.4.4)
                     if (even && lane == 63) x ^= 1;
                 } else if (lane != 0) {
-                    x = sext(__mul24(q, wq), 17);       // 17-bit temporary (RTL:2093, 2139)
-                    x = Q >= 3 ? sext((int)((uint32_t)x << (Q - 3)), 17) : (x >> (3 - Q));
-                    x = clamp_vv(x, kn2047, k2047);
+                    x = __mul24(q, wq);                 // the 17-bit temporary of RTL:2093 / 2139 and the +-2047 clamp of RTL:2144 cannot bind
+                    x = Q >= 3 ? x << (Q - 3) : x >> (3 - Q);
                 } else {
                     x = 2 * q;
                 }

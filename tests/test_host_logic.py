@@ -93,3 +93,35 @@ def test_inter_quantiser_never_reaches_its_clamp():
         x_ref = np.clip((2 * q_ref + np.sign(q_ref)) << Q, -2047, 2047)
         x_new = np.clip((2 * q_new + np.clip(q_new, -1, 1)) << Q, -2047, 2047)
         assert np.array_equal(x_ref, x_new)
+
+
+def test_inverse_quantisers_never_reach_their_clamps():
+    """The kernels drop three saturations of the RTL that no real input can reach (the oracle keeps them: it is also fed arbitrary
+    levels by the unit tests):
+    * non-intra inverse quantiser, RTL:2134-2137: |C| <= 16320 gives |q| <= 16322 >> (4 + Q), and (2 |q| + 1) << Q <= 2047;
+    * intra quantiser, RTL:2075, and intra inverse quantiser, RTL:2139-2144 (17-bit product, +-2047): an intra block is
+      pixel - 128, so |C| <= 8192 (the bound below), and over EVERY weight of the matrix, every Q_LEVEL and every |C| up to it the
+      level stays below 2047, the product level * W below 2^16 and the shifted product within +-2047."""
+    for Q in (1, 2, 3, 4):
+        qmax = (16320 + 2) >> (4 + Q)
+        assert ((2 * qmax + 1) << Q) <= 2047, Q
+    D = np.array([M.lib().m2v_debug_table(0, i, j) for i in range(8) for j in range(8)]).reshape(8, 8)
+    worst = 0
+    for i in range(8):
+        for j in range(8):
+            x = 128 * np.sign(np.outer(D[i], D[j]))          # pixel - 128 lies in [-128, 127]: 128 bounds it
+            worst = max(worst, (abs(int(D[i] @ x @ D[j])) + 2048) >> 12)
+    assert worst <= 8193
+    C = np.arange(0, worst + 1, dtype=np.int64)
+    assert (((C + 8) >> 4) <= 2047).all()                    # DC, RTL:2074
+    for w in sorted(set(INTRA_W) | set(range(8, 84))):
+        for Q in (1, 2, 3, 4):
+            off = (w * ((3 << Q) + 2)) >> 3
+            q = ((C + off) >> Q) // w                        # RTL:2072
+            assert q.max() <= 2047
+            prod = q * w
+            assert prod.max() < (1 << 16)                    # the 17-bit signed temporary of RTL:2093 cannot wrap
+            x = prod << (Q - 3) if Q >= 3 else prod >> (3 - Q)
+            assert x.max() < (1 << 16) and x.max() <= 2047, (w, Q)
+            xn = (-prod) << (Q - 3) if Q >= 3 else (-prod) >> (3 - Q)       # negative levels: arithmetic shift floors (RTL:2143)
+            assert xn.min() >= -2047
