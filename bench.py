@@ -174,12 +174,10 @@ def end_to_end(M, clip_np, want_bytes):
     n = clip_np.shape[0]
     gop = PFRAMES + 1 if PFRAMES else 16          # frames per push (config c2: every frame is a GOP; 16 at a time)
 
-    def run(frames, best_of=4, deferred=False):
+    def run(frames, best_of=4):
         enc = M.Mpeg2Encoder(XL, YL, VL, Q)
         try:
             enc.set_option("batch_frames", 2 * gop)
-            if deferred:
-                enc.set_option("direct_upload", 2)
             best, data = 1e9, b""
             for _ in range(best_of):
                 t0 = time.perf_counter()
@@ -198,14 +196,9 @@ def end_to_end(M, clip_np, want_bytes):
     t_page, d_page = run(clip_np)
     pinned = torch.from_numpy(clip_np).pin_memory().numpy()
     t_pin, d_pin = run(pinned)
-    t_def, d_def = run(pinned, deferred=True)
     px = n * W * H
     return {"value": round(px / t_pin * 1e-6, 1), "unit": "MPixels/s", "frames": n, "best_of": 4,
-            "input_GBps": round(px * 3 / t_pin * 1e-9, 2),
-            "identical_to_resident_stream": d_pin == want_bytes and d_page == want_bytes and d_def == want_bytes,
-            "deferred_upload": {"value": round(px / t_def * 1e-6, 1), "input_GBps": round(px * 3 / t_def * 1e-9, 2),
-                                "path": "the same with option direct_upload = 2: m2v_push_frames returns once the upload is queued (the caller keeps "
-                                        "the frames untouched until its next push), so uploads follow each other on the link"},
+            "input_GBps": round(px * 3 / t_pin * 1e-9, 2), "identical_to_resident_stream": d_pin == want_bytes and d_page == want_bytes,
             "path": "m2v_push_frames -> m2v_pull, frames in page-locked host memory uploaded straight from the caller's buffer "
                     "(hipMemcpyAsync on an upload stream), stream bytes back to the host; chunk k+1 uploads while chunk k encodes, "
                     "batch_frames=%d" % (2 * gop),

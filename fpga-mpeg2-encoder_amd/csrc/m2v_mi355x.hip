@@ -115,10 +115,7 @@ struct m2v_enc {
                                   // path.  Same results; kept by the rocprofv3 number (profiles/r02_mfma_*: 138.3 vs 140.3 us per launch)
     bool conformant = false;      // option "conformant": ISO reconstruction loop instead of the RTL's (NOT byte-identical to the reference)
     int copy_threads = 8;         // option "copy_threads": threads that copy m2v_push_frames input into pinned memory
-    int direct_upload = 1;        // option "direct_upload": 1 = page-locked caller memory is uploaded without the staging copy and the call
-                                  // returns when its frames have left; 2 = the call returns as soon as the upload is QUEUED, and the wait moves
-                                  // to the start of the next call on this handle (the caller keeps the frames untouched until then)
-    bool upload_in_flight = false;
+    bool direct_upload = true;    // option "direct_upload": page-locked caller memory is uploaded without the staging copy
     int split_streams = 2;        // GOP segments of a chunk run as this many independent groups on as many streams (encode_chunk)
     static constexpr int kMaxSplit = 8;
     hipStream_t side[kMaxSplit - 1] = {};            // group 0 runs on the caller's stream
@@ -979,15 +976,10 @@ void do_stop(m2v_enc *e)
     e->state = m2v_enc::ENDED;
 }
 
-int guard(m2v_enc *e, int (*fn)(m2v_enc *, void *), void *arg, bool wait_upload = true)
+int guard(m2v_enc *e, int (*fn)(m2v_enc *, void *), void *arg)
 {
     try {
         if (e->device >= 0) HIPCHK(hipSetDevice(e->device));
-        if (e->upload_in_flight && wait_upload) {   // option direct_upload = 2: the previous push's frames leave before this call does anything
-                                                    // (every entry point but m2v_pull, which only collects finished chunks)
-            e->upload_in_flight = false;
-            HIPCHK(hipStreamSynchronize(e->up_stream));
-        }
         return fn(e, arg);
     } catch (const HipError &h) {
         e->set_err("%s: %s", h.what, hipGetErrorString(h.e));
@@ -1109,7 +1101,6 @@ int m2v_reset(m2v_enc *e)
     for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
     if (e->strip_stream && e->strip_stream != e->stream) (void)hipStreamSynchronize(e->strip_stream);
     for (auto &h : e->hs) { h.stage = 0; h.uploaded = 0; }
-    e->upload_in_flight = false;
     e->pending.clear();
     e->state = m2v_enc::IDLE;
     e->buffered = 0; e->beat_pos = 0; e->frames_total = 0; e->persist_slot = -1;
@@ -1261,10 +1252,7 @@ static int push_frames_impl(m2v_enc *e, void *argp)
         k += take;
         if (e->buffered == e->batch_frames) flush_buffered(e, false);
     }
-    if (direct_pending) {
-        if (e->direct_upload == 2) e->upload_in_flight = true;             // deferred: the next call on this handle waits for it first
-        else HIPCHK(hipStreamSynchronize(e->up_stream));                   // the caller may reuse its buffer when this returns
-    }
+    if (direct_pending) HIPCHK(hipStreamSynchronize(e->up_stream));     // the caller may reuse its buffer when this returns
     progress(e, false);
     return M2V_OK;
 }
@@ -1303,7 +1291,7 @@ long long m2v_pull(m2v_enc *e, uint8_t *dst, size_t cap, int *last)
     if (!e || (!dst && cap)) return M2V_E_PARAM;
     if (last) *last = 0;
     if (!e->pending.empty()) {
-        const int r = guard(e, pull_progress_impl, nullptr, /*wait_upload=*/false);
+        const int r = guard(e, pull_progress_impl, nullptr);
         if (r < 0) return r;
     }
     const size_t avail = e->fifo.size() - e->fifo_rd;
@@ -1939,11 +1927,7 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
         return M2V_OK;
     }
     if (!strcmp(name, "dct_mfma")) { e->dct_mfma = value != 0; return M2V_OK; }
-    if (!strcmp(name, "direct_upload")) {
-        if (value < 0 || value > 2) return M2V_E_PARAM;
-        e->direct_upload = (int)value;
-        return M2V_OK;
-    }
+    if (!strcmp(name, "direct_upload")) { e->direct_upload = value != 0; return M2V_OK; }
     if (!strcmp(name, "copy_threads")) { if (value < 1 || value > 64) return M2V_E_PARAM; e->copy_threads = (int)value; return M2V_OK; }
     if (kDebug) {       // libm2v_mi355x_dbg.so only (-DM2V_DEBUG): the shipped library does not know these names
         if (!strcmp(name, "keep_recon")) { e->keep_recon = value != 0; return M2V_OK; }

@@ -211,10 +211,7 @@ int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_expose
  * "copy_threads" (default 8: threads m2v_push_frames uses to copy large inputs into pinned memory),
  * "direct_upload" (default 1: frames handed to m2v_push_frames in page-locked host memory - hipHostMalloc / hipHostRegister -
  * are uploaded straight from the caller's buffer, without the copy into the handle's pinned staging; the call returns when
- * the upload of its frames has completed, the encoding continues asynchronously.  2 = the same, but the call returns as soon as
- * the upload is QUEUED: the caller must leave those frames untouched until its next m2v_push_* / m2v_sequence_stop / m2v_reset call
- * on this handle has returned (m2v_pull does not count) - a capture ring's contract; uploads then follow each other on the link
- * without the caller's turn-around time in between.  0 = always through the staging copy),
+ * the upload of its frames has completed, the encoding continues asynchronously),
  * "split_streams" (default 2; 1..8 = the closed GOPs of a chunk are encoded as this many independent groups on as many
  * HIP streams, so that the partially filled tail of one group's launch overlaps with another group's next launch;
  * 1 = a single stream; ignored while "profile" is on, which times every launch with in-band events on one stream),

@@ -282,35 +282,3 @@ def test_page_locked_frames_are_uploaded_directly_and_mix_with_beats():
                 assert b"".join(out) == want, "batch_frames=%d direct_upload=%d" % (batch, direct)
             finally:
                 enc.close()
-
-
-def test_deferred_direct_upload_keeps_the_frames_until_the_next_push():
-    """option direct_upload = 2: m2v_push_frames returns once the upload of page-locked frames is QUEUED; the frames must stay
-    untouched until the next push / stop on the handle has returned (m2v_pull in between does not wait for them).  Two pinned
-    buffers used alternately, each trashed right after the call that FOLLOWS its own push: the bytes are the oracle's."""
-    import torch
-    import m2v_load
-    from oracle import m2v_oracle_ctypes as orc
-    M = m2v_load.load()
-    W, H, n, pf = 256, 192, 12, 3
-    clip = M.synth.clip(W, H, n, clip_index=78, scene_len=5)
-    want = orc.encode(clip, W // 16, H // 16, pf, 6, 6, 3, 2)
-    for batch in (4, 6, 96):
-        enc = M.Mpeg2Encoder(6, 6, 3, 2)
-        try:
-            enc.set_option("batch_frames", batch)
-            enc.set_option("direct_upload", 2)
-            bufs = [torch.empty((2, 3, H, W), dtype=torch.uint8).pin_memory().numpy() for _ in range(2)]
-            out = []
-            for i, k in enumerate(range(0, n, 2)):
-                b = bufs[i & 1]
-                b[:] = clip[k:k + 2]
-                enc.push_frames(W // 16, H // 16, pf, b)       # returns with the upload of b in flight; waits for the other buffer's first
-                bufs[(i & 1) ^ 1][:] = 0xA5                    # the PREVIOUS push's frames have left by now: free to overwrite
-                out.append(enc.pull()[0])                      # does not wait for the upload
-            enc.sequence_stop()
-            out.append(enc.pull_all())
-            assert b"".join(out) == want, "batch_frames=%d" % batch
-            assert enc._L.m2v_set_option(enc._h, b"direct_upload", 3) == -1
-        finally:
-            enc.close()
