@@ -37,3 +37,23 @@ def test_time_code_field_follows_the_frame_number():
     assert bench.gop_time_code(24) == (0x00080000 | (1 << 13) | 0x40).to_bytes(4, "big")
     assert bench.gop_time_code(1440) == (0x00080000 | (1 << 20) | 0x40).to_bytes(4, "big")
     assert bench.gop_time_code(86400) == (0x00080000 | (1 << 26) | 0x40).to_bytes(4, "big")
+
+
+def test_traffic_carries_the_tree_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from separate PMC passes (profiles/pmc_traffic.json); the line says which tree they measured and
+    whether the kernel source has changed since (`traffic_stale`)."""
+    import hashlib
+    import json
+    import os
+    head, ksha = bench.source_shas()
+    src = os.path.join(bench.ROOT, "fpga-mpeg2-encoder_amd", "csrc", "m2v_kernels.hpp")
+    assert ksha == hashlib.sha256(open(src, "rb").read()).hexdigest()
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic("k_mb_p_bytes_per_launch") == {"traffic": None}            # no file: null, nothing invented
+    monkeypatch.setattr(bench, "source_shas", lambda: (head, ksha))
+    for recorded, stale in ((ksha, False), ("0" * 64, True), (None, True)):
+        (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps({"k_mb_p_bytes_per_launch": 136489472, "head": "abc", "kernel_sha": recorded}))
+        t = bench.pmc_traffic("k_mb_p_bytes_per_launch")
+        assert t["traffic"] == 136489472 and t["traffic_stale"] is stale and t["traffic_measured_at"]["head"] == "abc"
+        assert bench.pmc_traffic("k_mb_i_c2_bytes_per_launch") == {"traffic": None}     # a key the passes did not measure
