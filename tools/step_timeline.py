@@ -29,3 +29,9 @@ for s, e, n, q in step:
         busy += e - max(s, cur_end)
         cur_end = e
 print("time with at least one encoder kernel running: %.1f us; gaps: %.1f us" % (busy / 1e3, (step[-1][1] - t0 - busy) / 1e3))
+if b < len(rows):
+    print("from this step's last kernel to the next step's first: %.1f us (host: end-of-call wait, the caller, the next call's plan)" % ((rows[b][0] - step[-1][1]) / 1e3))
+    other = [r for r in csv.DictReader(open(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]))
+             if step[-1][1] <= int(r["Start_Timestamp"]) <= rows[b][0] and "m2v::" not in r["Kernel_Name"]]
+    for r in other:
+        print("    in between: %s %.1f us" % (r["Kernel_Name"][:60], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
