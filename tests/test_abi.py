@@ -78,3 +78,28 @@ def test_product_tables_match_oracle_tables(L):
         for lvl in range(1, 41):
             c, n = pair(O.m2v_oracle_tab_ac, run, lvl)
             assert L.m2v_debug_table(6, run, lvl) == ((n << 8) | c if n else 0)
+
+
+def test_communicator_constructors_validate_without_a_gpu(L):
+    """m2v_comm_*: the in-process communicators are plain host objects (creating one needs no GPU); bad arguments give NULL, a code and
+    a text; the RCCL one refuses a bad rank before it touches the device."""
+    err = ctypes.c_int(0)
+    for bad in (0, -1, 17):
+        assert not L.m2v_comm_init_local(bad, ctypes.byref(err)) and err.value == -1
+        assert b"1..16" in L.m2v_comm_last_error()
+        assert not L.m2v_comm_init_solo(bad, ctypes.byref(err)) and err.value == -1
+    for world in (1, 2, 8, 16):
+        c = L.m2v_comm_init_local(world, ctypes.byref(err))
+        assert c and err.value == 0
+        L.m2v_comm_destroy(c)
+        c = L.m2v_comm_init_solo(world, ctypes.byref(err))
+        assert c and err.value == 0
+        L.m2v_comm_destroy(c)
+    ident = ctypes.create_string_buffer(128)
+    for rank, world in ((2, 2), (-1, 2), (0, 0), (0, 17)):
+        assert not L.m2v_comm_init_rccl(ident, rank, world, 0, ctypes.byref(err)) and err.value == -1
+    assert not L.m2v_comm_init_rccl(None, 0, 1, 0, ctypes.byref(err)) and err.value == -1
+    assert L.m2v_comm_unique_id(ident, 64) == -1                  # the buffer must hold a ncclUniqueId (128 bytes)
+    assert L.m2v_comm_selftest(None, 0, None, None, 0, None) == -1
+    assert L.m2v_strip_encode(None, None, 0, 1, 0, 4, 4, 0, None, 0, None, 0, None, None) == -1
+    L.m2v_comm_destroy(None)                                      # like free(NULL)

@@ -165,3 +165,37 @@ def test_config_c4_eight_handles_from_eight_threads():
     for t in range(T):
         assert got[t] is not None, "thread %d died" % t
         assert got[t] == want[t], "sequence %d" % t
+
+
+def test_strip_encode_refuses_bad_ranks_and_leaves_the_handle_usable():
+    """m2v_strip_encode: no communicator for more than one rank, a communicator of another size, more ranks than macroblock rows,
+    an output rank without a buffer - each refused with a code and a text, and the handle encodes normally afterwards."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    clip = M.synth.clip(96, 64, 5, clip_index=131)
+    want = orc.encode(clip, 6, 4, 2, 6, 6, 3, 2)
+    d_in = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
+    out = torch.empty(1 << 20, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    enc = M.Mpeg2Encoder(6, 6, 3, 2)
+    c3 = M.StripComm.local(3)
+    L, n = enc._L, ctypes.c_size_t(0)
+
+    def call(comm, rank, world, dst, d_out, cap):
+        return L.m2v_strip_encode(enc._h, comm, rank, world, dst, 6, 4, 2, d_in.data_ptr(), 5, d_out, cap, ctypes.byref(n), None)
+    try:
+        assert call(None, 0, 2, 0, out.data_ptr(), out.numel()) == -1 and b"communicator" in L.m2v_last_error(enc._h)
+        assert call(c3.handle, 0, 2, 0, out.data_ptr(), out.numel()) == -1            # a communicator of three for a world of two
+        assert call(None, 0, 5, 0, out.data_ptr(), out.numel()) == -1                 # four macroblock rows cannot make five strips
+        assert call(None, 1, 1, 0, out.data_ptr(), out.numel()) == -1                 # rank outside the world
+        assert call(None, 0, 1, 0, None, 0) == -1 and b"d_out" in L.m2v_last_error(enc._h)
+        assert call(None, 0, 1, 0, out.data_ptr(), 64) == -6                          # M2V_E_OVERFLOW: the stream does not fit
+        assert not enc.busy
+        assert call(None, 0, 1, 0, out.data_ptr(), out.numel()) == 0
+        assert out[:n.value].cpu().numpy().tobytes() == want
+        assert enc.encode(clip, 6, 4, 2) == want                                      # and the port path after it
+    finally:
+        c3.close()
+        enc.close()
