@@ -580,7 +580,7 @@ def main():
             dom, dom_name, dom_launches, dom_ms, tkey = "I", "k_mb<1,false> (I-frame macroblock kernel, no search)", li, msi, "k_mb_i_c2_bytes_per_launch"
             alg_bytes = nframes * 3.0 * W * H
         achieved = alg_bytes / (dom_ms * 1e-3) * 1e-9 if dom_ms > 0 else 0.0
-        traffic = pmc_traffic(tkey)
+        traffic = pmc_traffic(tkey) if PFRAMES > 0 and args.gops == GOPS or PFRAMES == 0 and nframes == 256 else {"traffic": None}   # measured for these launches
         workload = ("c3: 1920x1152 yuv444p, %d closed GOPs of 1 I + %d P frames (%d frames), VECTOR_LEVEL=3 Q_LEVEL=2 XL=YL=7, "
                     "one independent sequence per GPU (c4 for N > 1), no data-path collective" % (args.gops, PFRAMES, nframes)) if PFRAMES else \
                    ("c2: 640x480 yuv444p, %d I frames (i_pframes_count = 0), Q_LEVEL=2 XL=YL=7, one independent sequence per GPU, "
