@@ -84,21 +84,27 @@ def lib(debug=False):
         L.m2v_strip_halo_in.argtypes = [vp, ci, vp, vp]
         L.m2v_strip_finish.argtypes = [vp, vp, sz, vp]
         L.m2v_strip_assemble.argtypes = [vp, u32, u32, u32, sz, ci, vp, vp, vp, sz, ctypes.POINTER(sz), vp]
-        L.m2v_strip_finish_async.argtypes = [vp, vp, sz]
-        L.m2v_strip_offsets.argtypes = [vp, vp]
-        L.m2v_strip_encode.argtypes = [vp, vp, ci, ci, ci, u32, u32, u32, vp, sz, vp, sz, ctypes.POINTER(sz), vp]
-        dp = ctypes.POINTER(ctypes.c_double)
-        L.m2v_strip_stats.argtypes = [vp, dp, dp, dp, dp, dp]
-        L.m2v_comm_init_solo.restype = vp
-        L.m2v_comm_init_solo.argtypes = [ci, ctypes.POINTER(ci)]
-        L.m2v_comm_unique_id.argtypes = [vp, sz]
-        L.m2v_comm_init_rccl.restype = vp
-        L.m2v_comm_init_rccl.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ci)]
-        L.m2v_comm_init_local.restype = vp
-        L.m2v_comm_init_local.argtypes = [ci, ctypes.POINTER(ci)]
-        L.m2v_comm_destroy.argtypes = [vp]
-        L.m2v_comm_last_error.restype = ctypes.c_char_p
-        L.m2v_comm_selftest.argtypes = [vp, ci, vp, vp, sz, vp]
+        try:
+            L.m2v_strip_finish_async.argtypes = [vp, vp, sz]
+            L.m2v_strip_offsets.argtypes = [vp, vp]
+            L.m2v_strip_encode.argtypes = [vp, vp, ci, ci, ci, u32, u32, u32, vp, sz, vp, sz, ctypes.POINTER(sz), vp]
+            dp = ctypes.POINTER(ctypes.c_double)
+            L.m2v_strip_stats.argtypes = [vp, dp, dp, dp, dp, dp]
+            L.m2v_comm_init_solo.restype = vp
+            L.m2v_comm_init_solo.argtypes = [ci, ctypes.POINTER(ci)]
+            L.m2v_comm_unique_id.argtypes = [vp, sz]
+            L.m2v_comm_init_rccl.restype = vp
+            L.m2v_comm_init_rccl.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ci)]
+            L.m2v_comm_init_local.restype = vp
+            L.m2v_comm_init_local.argtypes = [ci, ctypes.POINTER(ci)]
+            L.m2v_comm_destroy.argtypes = [vp]
+            L.m2v_comm_last_error.restype = ctypes.c_char_p
+            L.m2v_comm_selftest.argtypes = [vp, ci, vp, vp, sz, vp]
+        except AttributeError:
+            # an OLDER build handed in through M2V_LIB for a same-box A/B (tools/ab.sh) may lack the newer entry points; the library of
+            # this tree must have every one of them (tests/test_abi.py)
+            if not os.environ.get("M2V_LIB"):
+                raise
         _libs[path] = L
     return _libs[path]
 

@@ -1020,8 +1020,8 @@ extern "C" {
 
 const char *m2v_version(void)
 {
-    return kDebug ? "m2v_mi355x 0.2-debug (gfx950, wave64, one wavefront per macroblock; M2V_DEBUG: level dump, keep_recon, ablate)"
-                  : "m2v_mi355x 0.2 (gfx950, wave64, one wavefront per macroblock)";
+    return kDebug ? "m2v_mi355x 0.3-debug (gfx950, wave64, one wavefront per macroblock; M2V_DEBUG: level dump, keep_recon, ablate)"
+                  : "m2v_mi355x 0.3 (gfx950, wave64, one wavefront per macroblock)";
 }
 
 m2v_enc *m2v_create(int XL, int YL, int VECTOR_LEVEL, int Q_LEVEL, int device, int *err)
