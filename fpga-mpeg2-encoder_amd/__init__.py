@@ -26,7 +26,8 @@ _libs = {}
 
 EXPORTS = [
     "m2v_version", "m2v_create", "m2v_destroy", "m2v_reset", "m2v_push_beats", "m2v_push_packed", "m2v_push_frames",
-    "m2v_sequence_stop", "m2v_busy", "m2v_pull", "m2v_geometry", "m2v_encode_resident", "m2v_set_option",
+    "m2v_sequence_stop", "m2v_busy", "m2v_pull", "m2v_geometry", "m2v_encode_resident", "m2v_encode_resident_begin",
+    "m2v_encode_resident_end", "m2v_set_option",
     "m2v_kernel_stats", "m2v_debug_read", "m2v_last_error", "m2v_debug_table",
     "m2v_strip_begin", "m2v_strip_info", "m2v_strip_step", "m2v_strip_step_edges", "m2v_strip_step_interior", "m2v_strip_halo_in", "m2v_strip_finish", "m2v_strip_assemble",
     "m2v_strip_finish_async", "m2v_strip_offsets", "m2v_strip_encode", "m2v_strip_stats",
@@ -69,6 +70,8 @@ def lib(debug=False):
         L.m2v_pull.argtypes = [vp, vp, sz, ctypes.POINTER(ci)]
         L.m2v_geometry.argtypes = [vp, u32, u32, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.m2v_encode_resident.argtypes = [vp, u32, u32, u32, vp, sz, vp, sz, ctypes.POINTER(sz), vp]
+        L.m2v_encode_resident_begin.argtypes = [vp, u32, u32, u32, vp, sz, vp, sz, vp]
+        L.m2v_encode_resident_end.argtypes = [vp, ctypes.POINTER(sz)]
         L.m2v_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_longlong]
         L.m2v_kernel_stats.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.m2v_debug_read.restype = ctypes.c_longlong
@@ -226,6 +229,16 @@ class Mpeg2Encoder:
         n = ctypes.c_size_t(0)
         self._chk(self._L.m2v_encode_resident(self._h, xsize16, ysize16, pframes_count, d_frames_ptr, nframes,
                                               d_out_ptr, cap, ctypes.byref(n), stream), "m2v_encode_resident")
+        return n.value
+
+    def encode_resident_begin(self, d_frames_ptr, nframes, d_out_ptr, cap, xsize16, ysize16, pframes_count, stream=0):
+        """enqueue a whole sequence and return; encode_resident_end() waits for it and returns the byte count"""
+        self._chk(self._L.m2v_encode_resident_begin(self._h, xsize16, ysize16, pframes_count, d_frames_ptr, nframes, d_out_ptr, cap,
+                                                    stream), "m2v_encode_resident_begin")
+
+    def encode_resident_end(self):
+        n = ctypes.c_size_t(0)
+        self._chk(self._L.m2v_encode_resident_end(self._h, ctypes.byref(n)), "m2v_encode_resident_end")
         return n.value
 
     # ---- strip mode (config c5): see include/m2v_mi355x.h ----

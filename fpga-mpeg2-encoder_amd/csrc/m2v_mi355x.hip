@@ -160,6 +160,9 @@ struct m2v_enc {
     const void *dev_jobs_p = nullptr, *dev_lists_p = nullptr, *dev_joblist_p = nullptr;
     int plan_groups = 1;                  // groups the launch lists of the current plan are cut into
     int plan_gf[kMaxSplit + 1] = {};      // chunk-frame index where each group's frames start (its GOP segments are consecutive frames)
+    bool resident_inflight = false;       // between m2v_encode_resident_begin and m2v_encode_resident_end
+    bool resident_empty = false;          // ... of a sequence without frames
+    hipStream_t resident_stream = nullptr;
     bool slice_scan_done = false;         // the groups ran k_slice_scan on their own streams (encode_chunk): finish_chunk skips it
     std::vector<Step> plan_steps;
     size_t plan_nf = 0;
@@ -1117,6 +1120,7 @@ int m2v_reset(m2v_enc *e)
     if (e->strip_stream && e->strip_stream != e->stream) (void)hipStreamSynchronize(e->strip_stream);
     for (auto &h : e->hs) { h.stage = 0; h.uploaded = 0; }
     e->dev_jobs.clear(); e->dev_lists.clear(); e->dev_jobs_p = nullptr;
+    e->resident_inflight = false; e->resident_empty = false;
     e->pending.clear();
     e->state = m2v_enc::IDLE;
     e->buffered = 0; e->beat_pos = 0; e->frames_total = 0; e->persist_slot = -1;
@@ -1151,6 +1155,7 @@ static int push_beats_impl(m2v_enc *e, void *argp)
 {
     auto *a = (PushBeatsArgs *)argp;
     if (e->strip_active) { e->set_err("m2v_push_*: a strip sequence is open (m2v_strip_finish or m2v_reset first)"); return M2V_E_STATE; }
+    if (e->resident_inflight) { e->set_err("m2v_push_*: a resident sequence is in flight (m2v_encode_resident_end first)"); return M2V_E_STATE; }
     if (e->state == m2v_enc::ENDED) return M2V_OK;              // dropped while the sequence ends (RTL:1045-1058)
     size_t i = 0;
     if (a->n == 0) {
@@ -1229,6 +1234,7 @@ static int push_frames_impl(m2v_enc *e, void *argp)
 {
     auto *a = (PushFramesArgs *)argp;
     if (e->strip_active) { e->set_err("m2v_push_*: a strip sequence is open (m2v_strip_finish or m2v_reset first)"); return M2V_E_STATE; }
+    if (e->resident_inflight) { e->set_err("m2v_push_*: a resident sequence is in flight (m2v_encode_resident_end first)"); return M2V_E_STATE; }
     if (e->state == m2v_enc::ENDED || a->n == 0) return M2V_OK;
     if (e->state == m2v_enc::IDLE) start_sequence(e, a->xs, a->ys, a->pf);
     const Geom &g = e->g;
@@ -1328,13 +1334,28 @@ long long m2v_pull(m2v_enc *e, uint8_t *dst, size_t cap, int *last)
     return (long long)n;
 }
 
-struct ResidentArgs { uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; uint8_t *d_out; size_t cap; size_t *bytes; hipStream_t s; };
+struct ResidentArgs { uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; uint8_t *d_out; size_t cap; size_t *bytes; hipStream_t s; bool async = false; };
+
+// The resident entry in two halves: everything enqueued (m2v_encode_resident_begin), then the one wait and the byte count
+// (m2v_encode_resident_end).  m2v_encode_resident is both, back to back.
+static int resident_end_impl(m2v_enc *e, void *argp)
+{
+    auto *bytes = (size_t *)argp;
+    if (!e->resident_inflight) { e->set_err("m2v_encode_resident_end: nothing in flight"); return M2V_E_STATE; }
+    e->resident_inflight = false;
+    HIPCHK(hipStreamSynchronize(e->resident_stream));
+    collect_timers(e);
+    if (e->st().h_ctl->overflow) { e->set_err("output buffer too small"); return M2V_E_OVERFLOW; }
+    if (bytes) *bytes = (size_t)e->st().h_ctl->total_bytes;
+    return M2V_OK;
+}
 
 static int resident_impl(m2v_enc *e, void *argp)
 {
     auto *a = (ResidentArgs *)argp;
-    if (e->state != m2v_enc::IDLE || e->strip_active) { e->set_err("m2v_encode_resident: encoder busy"); return M2V_E_STATE; }
-    if (a->n == 0) { if (a->bytes) *a->bytes = 0; return M2V_OK; }   // no beat: the sequence never starts
+    if (e->state != m2v_enc::IDLE || e->strip_active || e->resident_inflight) { e->set_err("m2v_encode_resident: encoder busy"); return M2V_E_STATE; }
+    if (a->n == 0) { if (a->bytes) *a->bytes = 0; e->resident_empty = true; return M2V_OK; }   // no beat: the sequence never starts
+    e->resident_empty = false;
     hipStream_t s = a->s ? a->s : e->stream;
     e->g = make_geom(e, a->xs, a->ys);
     e->pframes = a->pf & 0xFFu;
@@ -1358,11 +1379,10 @@ static int resident_impl(m2v_enc *e, void *argp)
         if (!last) HIPCHK(hipStreamSynchronize(s));    // the per-chunk work buffers are reused
     }
     HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    collect_timers(e);
-    if (e->st().h_ctl->overflow) { e->set_err("output buffer too small"); return M2V_E_OVERFLOW; }
-    if (a->bytes) *a->bytes = (size_t)e->st().h_ctl->total_bytes;
-    return M2V_OK;
+    e->resident_inflight = true;
+    e->resident_stream = s;
+    if (a->async) return M2V_OK;
+    return resident_end_impl(e, a->bytes);
 }
 
 int m2v_encode_resident(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const void *d_frames444,
@@ -1374,6 +1394,22 @@ int m2v_encode_resident(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t
     return guard(e, resident_impl, &a);
 }
 
+int m2v_encode_resident_begin(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const void *d_frames444,
+                              size_t nframes, void *d_out, size_t cap, void *hip_stream)
+{
+    if (!e || (nframes && (!d_frames444 || !d_out))) return M2V_E_PARAM;
+    ResidentArgs a{xsize16, ysize16, pframes_count, (const uint8_t *)d_frames444, nframes, (uint8_t *)d_out, cap, nullptr,
+                   (hipStream_t)hip_stream, true};
+    return guard(e, resident_impl, &a);
+}
+
+int m2v_encode_resident_end(m2v_enc *e, size_t *out_bytes)
+{
+    if (!e) return M2V_E_PARAM;
+    if (e->resident_empty && !e->resident_inflight) { e->resident_empty = false; if (out_bytes) *out_bytes = 0; return M2V_OK; }
+    return guard(e, resident_end_impl, out_bytes);
+}
+
 // ---------------------------------------------------------------------------------------------
 // strip mode (BASELINE config c5): this handle encodes macroblock rows [row0,row1) of every frame
 // ---------------------------------------------------------------------------------------------
@@ -1382,7 +1418,7 @@ struct StripBeginArgs { uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; int 
 static int strip_begin_impl(m2v_enc *e, void *argp)
 {
     auto *a = (StripBeginArgs *)argp;
-    if (e->state != m2v_enc::IDLE || e->strip_active) { e->set_err("m2v_strip_begin: encoder busy"); return M2V_E_STATE; }
+    if (e->state != m2v_enc::IDLE || e->strip_active || e->resident_inflight) { e->set_err("m2v_strip_begin: encoder busy"); return M2V_E_STATE; }
     Geom g = make_geom(e, a->xs, a->ys);
     if (a->n == 0 || a->row0 < 0 || a->row1 > g.mbh || a->row0 >= a->row1) { e->set_err("m2v_strip_begin: bad rows / no frames"); return M2V_E_PARAM; }
     g.row0 = a->row0; g.row1 = a->row1; g.strip = 1;

@@ -113,6 +113,17 @@ int m2v_geometry(const m2v_enc *e, uint32_t xsize16, uint32_t ysize16, int *widt
 int m2v_encode_resident(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
                         const void *d_frames444, size_t nframes, void *d_out, size_t cap,
                         size_t *out_bytes, void *hip_stream);
+/*
+ * The same in two halves, for callers that keep more than one sequence in flight (several handles, each with its own work
+ * buffers and streams: the stream assembly of one sequence then runs beside the first macroblock kernels of the next instead of
+ * leaving the GPU to drain).  _begin enqueues the whole sequence on `hip_stream` and returns without waiting; _end waits for that
+ * stream and hands out the byte count.  Between the two the handle accepts no other call but m2v_reset / m2v_destroy, and the
+ * input and output buffers belong to the encoder.  (A sequence longer than "batch_frames" is still encoded chunk by chunk, with a
+ * wait between the chunks inside _begin.)
+ */
+int m2v_encode_resident_begin(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
+                              const void *d_frames444, size_t nframes, void *d_out, size_t cap, void *hip_stream);
+int m2v_encode_resident_end(m2v_enc *e, size_t *out_bytes);
 
 /*
  * Strip mode (BASELINE config c5; no RTL counterpart — the RTL has one reference BRAM): several

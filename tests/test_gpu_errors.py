@@ -199,3 +199,48 @@ def test_strip_encode_refuses_bad_ranks_and_leaves_the_handle_usable():
     finally:
         c3.close()
         enc.close()
+
+
+def test_resident_begin_end_two_handles_taking_turns():
+    """m2v_encode_resident_begin / _end: two handles keep two sequences in flight (what bench.py's timed loop does); the bytes are
+    the oracle's for both, every time; between the two halves the handle refuses everything else."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    clips = [M.synth.clip(160, 96, 7, clip_index=140 + k, scene_len=4) for k in range(2)]
+    wants = [orc.encode(c, 10, 6, 2, 6, 6, 3, 2) for c in clips]
+    d_in = [torch.from_numpy(np.ascontiguousarray(c)).to("cuda:0") for c in clips]
+    d_out = [torch.zeros(1 << 20, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+    encs = [M.Mpeg2Encoder(6, 6, 3, 2) for _ in range(2)]
+    L = encs[0]._L
+    try:
+        assert L.m2v_encode_resident_end(encs[0]._h, None) == -4                      # nothing in flight
+        busy = [False, False]
+        for i in range(9):
+            h = i % 2
+            if busy[h]:
+                n = encs[h].encode_resident_end()
+                assert d_out[h][:n].cpu().numpy().tobytes() == wants[h], "step %d" % i
+                d_out[h].zero_()
+                torch.cuda.synchronize()
+            encs[h].encode_resident_begin(d_in[h].data_ptr(), 7, d_out[h].data_ptr(), d_out[h].numel(), 10, 6, 2)
+            busy[h] = True
+            # in flight: nothing else is accepted
+            n0 = ctypes.c_size_t(0)
+            assert L.m2v_encode_resident(encs[h]._h, 10, 6, 2, d_in[h].data_ptr(), 7, d_out[h].data_ptr(), d_out[h].numel(), ctypes.byref(n0), None) == -4
+            assert L.m2v_push_frames(encs[h]._h, 10, 6, 2, clips[h].ctypes.data, 1) == -4
+        for h in range(2):
+            n = encs[h].encode_resident_end()
+            assert d_out[h][:n].cpu().numpy().tobytes() == wants[h]
+            assert encs[h].encode(clips[h], 10, 6, 2) == wants[h]                      # the port path afterwards
+        # an empty sequence, and a reset while one is in flight
+        encs[0].encode_resident_begin(d_in[0].data_ptr(), 0, d_out[0].data_ptr(), d_out[0].numel(), 10, 6, 2)
+        assert encs[0].encode_resident_end() == 0
+        encs[0].encode_resident_begin(d_in[0].data_ptr(), 7, d_out[0].data_ptr(), d_out[0].numel(), 10, 6, 2)
+        assert L.m2v_reset(encs[0]._h) == 0
+        assert encs[0].encode(clips[0], 10, 6, 2) == wants[0]
+    finally:
+        for e in encs:
+            e.close()
