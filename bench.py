@@ -3,7 +3,10 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input: a 1920x1152 yuv444p clip
 of 10 closed GOPs (1 I + 8 P frames each, VECTOR_LEVEL=3, Q_LEVEL=2, XL=YL=7) resident in HBM,
-encoded to the final MPEG-2 elementary stream in HBM through the C-ABI (m2v_encode_resident).
+encoded to the final MPEG-2 elementary stream in HBM through the C-ABI.  The timed loop keeps two such
+sequences in flight on two encoder handles (m2v_encode_resident_begin / _end): the stream assembly of one
+runs beside the first macroblock kernels of the next.  `one_synchronous_call_per_step` in the line is
+the same K steps as one blocking m2v_encode_resident call after the other (what rounds 1 and 2 timed).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode sequences|strips] [--config c3|c2]
 
@@ -520,14 +523,20 @@ def main():
     nh = max(1, args.inflight)
     d_outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(nh)]
     d_out = d_outs[0]
-    encs = [M.Mpeg2Encoder(XL, YL, VL, Q, device=local_rank, debug=bool(args.ablate)) for _ in range(nh)]   # --ablate needs the -DM2V_DEBUG library
-    enc = encs[0]
-    for h in encs:
+    # `enc`: the handle of the synchronous calls (warm-up, the comparison figure, the profiled pass), library defaults: the GOPs of a
+    # sequence as two groups on two streams.  `encs`: the handles that take turns in the timed loop; with two sequences in flight the
+    # sequences themselves are what overlaps, so each runs on ONE stream (measured: 2 in flight x 1 stream 191.0, 2 x 2 181.5,
+    # 3 x 1 189.3, 1 x 2 184.4 GPixel/s on one box)
+    enc = M.Mpeg2Encoder(XL, YL, VL, Q, device=local_rank, debug=bool(args.ablate))       # --ablate needs the -DM2V_DEBUG library
+    encs = [enc] if nh == 1 else [M.Mpeg2Encoder(XL, YL, VL, Q, device=local_rank, debug=bool(args.ablate)) for _ in range(nh)]
+    for h in set(encs + [enc]):
         h.set_option("batch_frames", nframes)
         if args.ablate:
             h.set_option("ablate", args.ablate)
         if args.split >= 0:
             h.set_option("split_streams", args.split)
+        elif h is not enc:
+            h.set_option("split_streams", 1)
     stream = torch.cuda.current_stream().cuda_stream
     torch.cuda.synchronize()                   # the clip is there: the handles' own streams do not wait for torch's
 
@@ -581,6 +590,9 @@ def main():
     # under way at a time
     dt, nbytes = timed(args.steps)
     # the same K steps as one synchronous call after the other on one handle: the figure rounds 1 and 2 reported as `value`
+    if nh > 1:
+        for _ in range(max(3, args.warmup)):   # this handle has not run yet: its work buffers are allocated by its first call
+            step()
     dt_sync, nbytes_sync = timed(args.steps, lambda k: [step() for _ in range(k)][-1]) if nh > 1 else (dt, nbytes)
     assert nbytes_sync == nbytes
     # second pass, same K steps, for the per-kernel numbers: option "profile" brackets every launch with HIP events on the
@@ -646,7 +658,8 @@ def main():
             "profiled_pass": {"value": round(world * args.steps * pixels_per_step / dt_prof * 1e-6, 2),
                               "ms_per_step": round(dt_prof / args.steps * 1e3, 3), "steps": args.steps,
                               "streams": 1, "in_band_event_timers": True},
-            "streams": args.split if args.split >= 0 else 2,
+            "streams": {"per_sequence_in_the_timed_loop": args.split if args.split >= 0 else (1 if nh > 1 else 2),
+                        "per_sequence_in_a_synchronous_call": args.split if args.split >= 0 else 2},
         }
         if dom == "P":
             # secondary "operation roofline" of SURVEY.md 8(d): the search alone is (2*6+1)^2 + 9 = 178 byte absolute
@@ -672,7 +685,7 @@ def main():
                 out["end_to_end"] = end_to_end(M, clip_np, gpu_bytes)
         print(json.dumps(out))
         sys.stdout.flush()
-    for h in encs:
+    for h in set(encs + [enc]):
         h.close()
     if dist is not None:
         dist.barrier()
