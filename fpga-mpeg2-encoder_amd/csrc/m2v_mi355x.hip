@@ -956,6 +956,8 @@ void flush_buffered(m2v_enc *e, bool last)
 
 void start_sequence(m2v_enc *e, uint32_t xs, uint32_t ys, uint32_t pf)
 {
+    if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    if (!e->up_stream) HIPCHK(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
     e->g = make_geom(e, xs, ys);            // latched on the first beat (RTL:1060-1065)
     e->pframes = pf & 0xFFu;
     e->state = m2v_enc::DURING;
@@ -1042,8 +1044,10 @@ m2v_enc *m2v_create(int XL, int YL, int VECTOR_LEVEL, int Q_LEVEL, int device, i
     try {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
+        // the port path's upload and read-back streams are created with its first sequence (start_sequence): HIP spreads a process's
+        // streams over a handful of hardware queues in creation order, and a handle that only ever runs the resident entry should not
+        // push its own two GOP-group streams - or another handle's - onto the same queue (three handles with three streams each did
+        // exactly that: the two groups of one handle serialised, 1.08 -> 1.20 ms per step)
         upload_tables(device);
         HIPCHK(hipDeviceSynchronize());
     } catch (...) {                             // nothing may unwind through the C boundary
