@@ -12,7 +12,7 @@ echo "pytest(mfma on) rc=$?"; tail -3 $OUT/pytest_mfma.log
 for V in 0 1; do
   M2V_DCT_MFMA=$V rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw$V -o s -- python3 bench.py --split 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_rocprof_$V.log 2>&1
   python3 tools/summarize_rocprof.py $OUT/raw$V/s_kernel_stats.csv $OUT/kernel_stats_$V.csv; rm -rf $OUT/raw$V
-  M2V_DCT_MFMA=$V rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_I8 --output-format csv -d $OUT/p$V -o p -- python3 bench.py --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
+  M2V_DCT_MFMA=$V rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_I8 --output-format csv -d $OUT/p$V -o p -- python3 bench.py --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
   python3 tools/summarize_pmc.py $OUT/p$V > $OUT/pmc_$V.json; rm -rf $OUT/p$V
 done
 for i in 1 2 3; do

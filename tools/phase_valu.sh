@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=${1:-gpurun_out/phase}
 mkdir -p $OUT
 for A in 0 1 2 4 8 16 31; do
-  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $OUT/a$A -o p -- python3 bench.py --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline --ablate $A > $OUT/a$A.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $OUT/a$A -o p -- python3 bench.py --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline --ablate $A > $OUT/a$A.log 2>&1
   python3 tools/summarize_pmc.py $OUT/a$A > $OUT/a$A.json
   rm -rf $OUT/a$A
 done

@@ -7,7 +7,7 @@ OUT=${1:-gpurun_out/stops}
 mkdir -p $OUT
 for N in 1 2 3 4 5 6 0; do
   A=$((N * 256))
-  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $OUT/s$N -o p -- python3 bench.py --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline --ablate $A > $OUT/s$N.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $OUT/s$N -o p -- python3 bench.py --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline --ablate $A > $OUT/s$N.log 2>&1
   python3 tools/summarize_pmc.py $OUT/s$N > $OUT/s$N.json
   rm -rf $OUT/s$N
 done
