@@ -38,6 +38,9 @@ struct m2v_comm {
     virtual void gather(int rank, int dst, const void *d_strip, const size_t *sizes, void *const *bufs, hipStream_t s) = 0;
     // self-test: nbytes from d_send to d_recv through the transport's own send / recv pair addressed to this very rank
     virtual void loopback(int rank, const void *d_send, void *d_recv, size_t nbytes, hipStream_t s) = 0;
+    // a rank has failed: ranks blocked in (or arriving at) an exchange give up with an error instead of waiting for it (in-process
+    // communicator; RCCL has no cheap equivalent - a failed rank of a multi-process job takes the job down, bench.py's launcher does that)
+    virtual void abort() {}
     virtual const char *kind() const = 0;
 };
 
@@ -174,6 +177,18 @@ struct LocalComm final : m2v_comm {
     std::vector<unsigned long long> stage[kMax];
     int bar_count = 0;
     unsigned long long bar_gen = 0;
+    bool aborted = false;               // (under mu)
+
+    void abort() override
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        aborted = true;
+        cv.notify_all();
+    }
+    void check(const std::unique_lock<std::mutex> &) const
+    {
+        if (aborted) throw CommError("local exchange: another rank of this communicator has failed");
+    }
 
     explicit LocalComm(int w) { world = w; }
     ~LocalComm() override
@@ -188,14 +203,17 @@ struct LocalComm final : m2v_comm {
     {
         std::unique_lock<std::mutex> lk(mu);
         const unsigned long long gen = bar_gen;
+        check(lk);
         if (++bar_count == world) { bar_count = 0; ++bar_gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return bar_gen != gen; });
+        else cv.wait(lk, [&] { return bar_gen != gen || aborted; });
+        check(lk);
     }
     // sender: the bytes at ptr are final once everything enqueued on `s` so far has run
     void post(Slot &sl, const void *ptr, size_t n, hipStream_t s)
     {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !sl.full && !sl.taken; });
+        cv.wait(lk, [&] { return (!sl.full && !sl.taken) || aborted; });
+        check(lk);
         if (!sl.ready) {
             M2V_COMM_HIP(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
             M2V_COMM_HIP(hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
@@ -210,7 +228,8 @@ struct LocalComm final : m2v_comm {
         const void *src;
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return sl.full; });
+            cv.wait(lk, [&] { return sl.full || aborted; });
+            check(lk);
             if (sl.n != n) throw CommError("local exchange: the two sides disagree about the size");
             src = sl.ptr;
         }
@@ -225,7 +244,8 @@ struct LocalComm final : m2v_comm {
     void release(Slot &sl, hipStream_t s)
     {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return sl.taken; });
+        cv.wait(lk, [&] { return sl.taken || aborted; });
+        check(lk);
         M2V_COMM_HIP(hipStreamWaitEvent(s, sl.consumed, 0));
         sl.taken = false;
         cv.notify_all();

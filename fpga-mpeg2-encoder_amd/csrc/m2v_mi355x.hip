@@ -1701,6 +1701,7 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         e->set_err("m2v_strip_encode: bad rank / world / communicator");
         return M2V_E_PARAM;
     }
+    if (rank == a->dst && !a->d_out) { e->set_err("m2v_strip_encode: the output rank needs d_out"); return M2V_E_PARAM; }     // before anything collective
     // contiguous strips, sizes differing by at most one row, the first mbh % world ranks get the extra row (parallel.partition_rows)
     const int base = full.mbh / world, rem = full.mbh % world;
     const int row0 = rank * base + std::min(rank, rem), row1 = row0 + base + (rank < rem ? 1 : 0);
@@ -1715,8 +1716,11 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     const size_t halo_cap = (size_t)mh * (size_t)(3 * e->VL) * (size_t)g.W;
     e->d_halo.ensure(4 * halo_cap + 64);
     uint8_t *send_up = e->d_halo.p, *send_down = send_up + halo_cap, *recv_up = send_down + halo_cap, *recv_down = recv_up + halo_cap;
+    const bool fused = !e->conformant && e->dct_mfma && !e->keep_recon;
     if (world > 1) {
-        if (!e->comm_stream) HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+        // (the general form's exchange stream only when that form runs: every stream a process creates moves the others around the
+        // handful of hardware queues)
+        if (!fused && !e->comm_stream) HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
         if (!e->ev_edges) HIPCHK(hipEventCreateWithFlags(&e->ev_edges, hipEventDisableTiming));
         if (!e->ev_halo) HIPCHK(hipEventCreateWithFlags(&e->ev_halo, hipEventDisableTiming));
     }
@@ -1734,7 +1738,6 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     // The edge rows run as ONE launch of the instantiation that also fills the halo buffers (no pack kernel), the interior rows at
     // the same time on a second stream: a strip of an 8-GPU job is ~20 000 wavefronts per step, 2.5 rounds of the wave slots -
     // edge rows first and alone would hold the whole GPU for one macroblock lifetime at a third of its slots.
-    const bool fused = !e->conformant && e->dct_mfma && !e->keep_recon;
     hipStream_t side = nullptr;
     if (world > 1) {
         if (!e->side[0]) HIPCHK(hipStreamCreateWithFlags(&e->side[0], hipStreamNonBlocking));
@@ -1819,8 +1822,8 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         ensure_pinned(e->h_asm, e->h_asm_cap, (size_t)world * (nf + 1) * sizeof(unsigned long long));
         HIPCHK(hipMemcpyAsync(e->h_asm, e->d_alloff.p, (size_t)world * (nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));                        // the sizes decide the receive counts: the one host wait
-        const StreamCtl *c = (const StreamCtl *)(e->h_strip + (nf + 1) * sizeof(unsigned long long));
-        if (c->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
+        // (an overflow of this strip's buffer - impossible with the worst-case size above - is reported at the end: the other ranks
+        // are waiting in the gather, and a rank that left now would leave them there)
         size_t sizes[kMaxStripRanks] = {}, total_in = 0;
         for (int k = 0; k < world; ++k) {
             sizes[k] = (size_t)((const unsigned long long *)e->h_asm)[(size_t)k * (nf + 1) + nf];
@@ -1844,14 +1847,13 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     }
     size_t out_bytes = 0;
     if (rank == a->dst) {
-        if (!a->d_out) { e->set_err("m2v_strip_encode: the output rank needs d_out"); return M2V_E_PARAM; }
         strip_assemble_enqueue(e, s, gfull, a->pf, nf, world, strips, d_all, a->d_out, a->cap);
         if (e->profile) { g1 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g1, s)); }
         if (!e->st().h_ctl) HIPCHK(hipHostMalloc((void **)&e->st().h_ctl, 2 * sizeof(StreamCtl)));
         HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
     } else if (e->profile) { g1 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g1, s)); }
     HIPCHK(hipStreamSynchronize(s));
-    if (world == 1) {
+    {
         const StreamCtl *c = (const StreamCtl *)(e->h_strip + (nf + 1) * sizeof(unsigned long long));
         if (c->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
     }
@@ -1885,6 +1887,7 @@ int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_ra
                       out_bytes, (hipStream_t)hip_stream};
     const int r = guard(e, strip_encode_impl, &a);
     if (r < 0 && e->strip_active) strip_close(e);            // a failed sequence does not leave the handle in strip mode
+    if (r < 0 && comm) comm->abort();                         // ... and the other ranks of an in-process communicator do not wait for it for ever
     return r;
 }
 

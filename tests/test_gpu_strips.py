@@ -200,3 +200,46 @@ def test_rccl_communicator_on_one_gpu():
             enc.close()
     finally:
         comm.close()
+
+
+def test_a_failing_rank_does_not_leave_the_others_waiting():
+    """three ranks (threads) on an in-process communicator; rank 1 makes a call that is refused (no output buffer on the output
+    rank's position is fine for 0 and 2 - rank 1 claims to BE the output rank without one): the communicator is aborted and
+    the two ranks that are already waiting for rank 1's rows come back with an error instead of hanging."""
+    import ctypes
+    import threading
+    import torch
+    import m2v_load
+    M = m2v_load.load()
+    W, H, pf, n = 96, 96, 2, 6
+    d_clip = torch.from_numpy(np.ascontiguousarray(M.synth.clip(W, H, n, clip_index=90))).to("cuda:0")
+    out = torch.empty(M.parallel.strip_output_bound(n, W, H), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    encs = [M.Mpeg2Encoder(7, 7, 3, 2) for _ in range(3)]
+    comm = M.StripComm.local(3)
+    rc, msg = [None] * 3, [None] * 3
+
+    def work(r):
+        nb = ctypes.c_size_t(0)
+        dst = 1 if r == 1 else 0                       # rank 1: "I am the output rank", but hands in no buffer
+        rc[r] = encs[r]._L.m2v_strip_encode(encs[r]._h, comm.handle, r, 3, dst, W // 16, H // 16, pf, d_clip.data_ptr(), n,
+                                            out.data_ptr() if r == 0 else None, out.numel() if r == 0 else 0, ctypes.byref(nb), None)
+        msg[r] = encs[r]._L.m2v_last_error(encs[r]._h)
+    try:
+        th = [threading.Thread(target=work, args=(r,)) for r in (0, 2)]
+        for t in th:
+            t.start()
+        import time
+        time.sleep(0.5)                                # ranks 0 and 2 are inside the exchange of the first step by now
+        work(1)
+        for t in th:
+            t.join(timeout=60)
+        assert not any(t.is_alive() for t in th), "a rank is still waiting for the one that failed"
+        assert rc[1] == -1 and b"d_out" in msg[1]
+        assert rc[0] < 0 and rc[2] < 0 and b"another rank" in msg[0] + msg[2]
+        for e in encs:                                 # the handles are usable afterwards
+            assert not e.busy and e.encode(d_clip[:2].cpu().numpy(), W // 16, H // 16, pf)
+    finally:
+        for e in encs:
+            e.close()
+        comm.close()

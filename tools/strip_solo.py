@@ -57,6 +57,7 @@ def main():
                 print(json.dumps({"world": world, "rank": rank, "ms_per_sequence": round(dt * 1e3, 3),
                                   "speedup_vs_one_rank": round(base / dt, 2) if base else None,
                                   "ideal": world, "host_us_per_gop_step": round(st["host_us_per_step"], 1),
+                                  "of_which_inside_the_communicator": round(st["comm_us_per_step"], 1),
                                   "halo_ms": {"total": round(st["halo_total"], 3), "exposed": round(st["halo_exposed"], 3)},
                                   "sizes_gather_assembly_ms": round(st["gather"], 3), "kernel_ms": ks}))
                 sys.stdout.flush()
