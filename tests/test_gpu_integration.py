@@ -57,3 +57,29 @@ def test_hip_stream_through_the_independent_decoder(W, H, n, pf, VL, Q, ci):
         assert dec.psnr(out.frames[f][0], clip[f, 0]) > 28.0
     iso = dec.decode(es, quirks=False)                                   # a standard decoder: parses, stays close
     assert all(dec.psnr(iso.frames[f][0], clip[f, 0]) > 26.0 for f in range(n))
+
+
+@pytest.mark.parametrize("nranks,W,H,pf", [(1, 96, 64, 2), (3, 160, 96, 3), (4, 128, 128, 8)])
+def test_plain_c_caller_encodes_one_sequence_as_strips(tmp_path, nranks, W, H, pf):
+    """integration/strip_caller.c (gcc, C99, pthreads; include/m2v_mi355x.h + hipMalloc for its own buffers): one thread per rank,
+    every rank ONE m2v_strip_encode call on an in-process communicator - the C form of BASELINE config c5 (INTEGRATION.md
+    section 5).  The stream rank 0 writes is the oracle's."""
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    M.build()
+    libdir = os.path.join(ROOT, "fpga-mpeg2-encoder_amd")
+    exe = str(tmp_path / "strip_caller")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+           os.path.join(ROOT, "integration", "strip_caller.c"), "-L" + libdir, "-lm2v_mi355x", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    n = 2 * (pf + 1) + 1
+    clip = M.synth.clip(W, H, n, clip_index=135 + nranks, scene_len=5)
+    (tmp_path / "in.yuv").write_bytes(clip.tobytes())
+    out = tmp_path / "out.m2v"
+    r = subprocess.run([exe, str(tmp_path / "in.yuv"), str(W), str(H), str(pf), str(nranks), str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "%d strips" % nranks in r.stdout
+    assert out.read_bytes() == orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
