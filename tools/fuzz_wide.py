@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ad-hoc wide-frame differential run (HIP path vs oracle): widths up to the XL=7 maximum (128 macroblocks per slice: the
 largest slice tables of k_slice_scan / k_assemble), every content kind of tests/test_gpu_fuzz.py, both interfaces.
-usage (GPU box): python tools/fuzz_wide.py [cases]"""
+usage (GPU box): python tools/fuzz_wide.py [cases] [seed]"""
 import os
 import sys
 
@@ -14,7 +14,7 @@ from oracle import m2v_oracle_ctypes as orc
 from test_gpu_fuzz import make_content
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-rng = np.random.default_rng(4242)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 bad = 0
 for case in range(n_cases):
     W = 16 * int(rng.choice([128, 127, 120, 97, 64]))
