@@ -197,8 +197,19 @@ def end_to_end(M, clip_np, want_bytes):
         return best, data
 
     t_page, d_page = run(clip_np)
-    pinned = torch.from_numpy(clip_np).pin_memory().numpy()
+    pinned_t = torch.from_numpy(clip_np).pin_memory()
+    pinned = pinned_t.numpy()
     t_pin, d_pin = run(pinned)
+    # what the link gives a plain copy of the same page-locked bytes on this box (the bound the path can be held against)
+    dev_t = torch.empty_like(pinned_t, device="cuda")
+    dev_t.copy_(pinned_t, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        dev_t.copy_(pinned_t, non_blocking=True)
+    torch.cuda.synchronize()
+    h2d = 4 * pinned_t.numel() / (time.perf_counter() - t0)
+    del dev_t
     px = n * W * H
     return {"value": round(px / t_pin * 1e-6, 1), "unit": "MPixels/s", "frames": n, "best_of": 4,
             "input_GBps": round(px * 3 / t_pin * 1e-9, 2), "identical_to_resident_stream": d_pin == want_bytes and d_page == want_bytes,
@@ -207,7 +218,8 @@ def end_to_end(M, clip_np, want_bytes):
                     "batch_frames=%d" % (2 * gop),
             "pageable_source": {"value": round(px / t_page * 1e-6, 1), "input_GBps": round(px * 3 / t_page * 1e-9, 2),
                                 "path": "the same from a plain numpy array: copied into the handle's pinned staging by 8 threads first"},
-            "pcie_bound_MPixels": round(63e9 / 3 * 1e-6, 0)}
+            "pcie_bound_MPixels": round(63e9 / 3 * 1e-6, 0),
+            "h2d_copy_measured_GBps": round(h2d * 1e-9, 1), "fraction_of_measured_h2d": round(px * 3 / t_pin / h2d, 3)}
 
 
 def hbm_copy_rate(torch, dev):
