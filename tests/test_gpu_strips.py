@@ -98,13 +98,13 @@ def test_encode_strips_world1_equals_resident():
 
 
 # ---- the native loop: m2v_strip_encode, ranks = threads of this process talking through a local communicator ----
-def run_native_strips(M, d_clip, W, H, pf, VL, world, profile=False, general=False):
+def run_native_strips(M, d_clip, W, H, pf, VL, world, profile=False, general=False, Q=2):
     """`world` handles, one host thread each, all on GPU 0; every thread makes ONE call (m2v_strip_encode) - the GOP steps,
     the halo exchange (mailboxes + device copies behind the same interface RCCL sits behind), the size all-gather, the
     strips to rank 0 and the final assembly all happen inside it.  Returns (stream bytes, [strip_stats of every rank])."""
     import threading
     import torch
-    encs = [M.Mpeg2Encoder(7, 7, VL, 2) for _ in range(world)]
+    encs = [M.Mpeg2Encoder(7, 7, VL, Q) for _ in range(world)]
     if general:          # the general form of the step (pack / unpack kernels, exchange on its own stream): what option conformant
         for e in encs:   # and dct_mfma = 0 run instead of the fused edge-row kernel
             e.set_option("dct_mfma", 0)
