@@ -573,11 +573,31 @@ __host__ __device__ constexpr uint32_t sym_raw(uint32_t len, uint32_t code, bool
 
 // Pass 1 of the coefficient VLC for one coded tile (lane = zig-zag index): rank the non-zero levels, append their
 // {position, level} symbols and the end_of_block code to the macroblock's symbol list.  The run of a level is formed in pass 2
-// from the position of the symbol before it (a raw symbol = block start).  Trimmed for instruction count (a non-intra
-// macroblock runs this five times): the list position is kept in BYTES (no shifts), and instead of narrowing EXEC to the
-// non-zero lanes (s_and_saveexec, s_cbranch_execz, s_or per tile) the zero lanes store to a dump word in front of the list;
-// the end-of-block symbol is stored by all lanes.  sym_base = LDS byte address of the list, eob = the end-of-block symbol in a
+// from the position of the symbol before it (a raw symbol = block start).  Trimmed for VECTOR instruction count (a non-intra
+// macroblock runs this five times): the list position is kept in BYTES (no shifts); only the non-zero lanes store, EXEC
+// narrowed by scalar moves (vlc_store_symbols).  sym_base = LDS byte address of the list, eob = the end-of-block symbol in a
 // register; returns the new byte length.  First the non-intra form: every position counts and there is no DC code.
+// The stores of pass 1: the lanes of `mask` (the non-zero levels) put their symbol into their slot of the list, and the
+// end_of_block symbol '10' (RTL:2835) ends up behind the last of them.  EXEC is narrowed by scalar moves around the stores: the
+// vector ALU is the unit this kernel is bound by, and the round-2 form (zero lanes redirected to a dump word by a v_cndmask, the
+// end code's wave-uniform address moved to a vector register, the dump address re-materialised) cost three vector instructions
+// per tile.  Every storing lane first puts the end code BEHIND its own slot, then its symbol INTO its slot: LDS operations of a
+// wavefront execute in order, so every end code but the last is overwritten by the next lane's symbol.  MAY_BE_EMPTY (intra
+// tiles: the mask leaves out lane 0, the DC, and there may be no AC level at all, but the end code is unconditional): lane 0,
+// whose slot is the first one, puts an end code INTO it beforehand, where the first level - if there is one - overwrites it.
+template <bool MAY_BE_EMPTY>
+__device__ __forceinline__ void vlc_store_symbols(uint32_t slot, uint32_t sym, uint32_t eob, unsigned long long mask)
+{
+    unsigned long long saved;
+    if constexpr (MAY_BE_EMPTY)
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %1, %3\n\t"
+                     "s_mov_b64 exec, %4\n\tds_write_b32 %1, %3 offset:4\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(slot), "v"(sym), "v"(eob), "s"(mask) : "memory");
+    else
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\tds_write_b32 %1, %3 offset:4\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(slot), "v"(sym), "v"(eob), "s"(mask) : "memory");
+}
+
 __device__ __forceinline__ uint32_t vlc_tile_symbols_inter(const int16_t *zig, uint32_t sym_base, int lane, uint32_t lane_pos, uint32_t nsym4, uint32_t eob)
 {
     typedef __attribute__((address_space(3))) uint32_t *LdsW;
@@ -585,12 +605,8 @@ __device__ __forceinline__ uint32_t vlc_tile_symbols_inter(const int16_t *zig, u
     const unsigned long long mask = ballot(v != 0);
     const uint32_t end4 = (uint32_t)sgpr((int)(nsym4 + 4u * (uint32_t)__builtin_popcountll(mask)));
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    // zero lanes -> the dump word; one v_cndmask on the compare's mask (left to the compiler this becomes an EXEC region again)
     const uint32_t slot = (rank << 2) + (uint32_t)sgpr((int)(sym_base + nsym4));
-    uint32_t at;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(at) : "v"(sym_base - 8u), "v"(slot), "s"(mask));
-    *(LdsW)(uintptr_t)at = lane_pos | ((uint32_t)v & 0xFFFFu);
-    *(LdsW)(uintptr_t)(sym_base + end4) = eob;      // end_of_block '10' (RTL:2835) behind the last level
+    vlc_store_symbols<false>(slot, lane_pos | ((uint32_t)v & 0xFFFFu), eob, mask);     // a coded non-intra tile has at least one level
     return (uint32_t)sgpr((int)(end4 + 4u));
 }
 
@@ -612,10 +628,7 @@ __device__ __forceinline__ uint32_t vlc_tile_symbols_intra(const int16_t *zig, u
     const uint32_t end4 = (uint32_t)sgpr((int)(nsym4 + 4u * (uint32_t)__builtin_popcountll(mask)));
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     const uint32_t slot = (rank << 2) + (uint32_t)sgpr((int)(sym_base + nsym4));
-    uint32_t at;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(at) : "v"(sym_base - 8u), "v"(slot), "s"(mask));
-    *(LdsW)(uintptr_t)at = lane_pos | ((uint32_t)v & 0xFFFFu);
-    *(LdsW)(uintptr_t)(sym_base + end4) = eob;      // an intra block may have no AC level at all: the end code is unconditional
+    vlc_store_symbols<true>(slot, lane_pos | ((uint32_t)v & 0xFFFFu), eob, mask);
     return (uint32_t)sgpr((int)(end4 + 4u));
 }
 
@@ -1655,7 +1668,6 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             mbaux[mbidx] = aux;
         }
     }
-
 }
 
 // ----------------------------------------------------------------------------------------------
