@@ -51,12 +51,22 @@ def cpu_baseline(frames_np):
                 sample="%s of the benchmark clip, oracle/m2v_oracle.c, %.1f s" % (what, dt))
 
 
-def source_shas():
-    """What the running tree is: git HEAD (if this is a checkout) and the sha256 of the kernel source.  profiles/pmc_traffic.json
-    carries the same two values for the tree its PMC passes ran on (tools/profile_round.sh)."""
+def kernel_source_sha(path):
+    """sha256 of the kernel source as the compiler sees it: comments dropped, runs of white space collapsed - a reworded comment does
+    not make the counter passes stale (tools/make_pmc_traffic.py computes the same)"""
     import hashlib
+    import re
+    text = open(path, encoding="utf-8").read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return hashlib.sha256(" ".join(text.split()).encode()).hexdigest()
+
+
+def source_shas():
+    """What the running tree is: git HEAD (if this is a checkout) and the sha256 of the kernel source (kernel_source_sha).  profiles/pmc_traffic.json
+    carries the same two values for the tree its PMC passes ran on (tools/profile_round.sh)."""
     import subprocess
-    ksha = hashlib.sha256(open(os.path.join(ROOT, "fpga-mpeg2-encoder_amd", "csrc", "m2v_kernels.hpp"), "rb").read()).hexdigest()
+    ksha = kernel_source_sha(os.path.join(ROOT, "fpga-mpeg2-encoder_amd", "csrc", "m2v_kernels.hpp"))
     try:
         head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
     except Exception:  # noqa: BLE001

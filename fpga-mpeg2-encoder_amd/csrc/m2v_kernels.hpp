@@ -789,8 +789,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     constexpr int kR1 = 1600;
     // The transform's input tiles s_cp (signed current | prediction bytes, 768 bytes) live INSIDE R1: they are written when the
     // prediction is formed - after the luma window's last read, beside the chroma windows and the current rows, which end below
-    // byte 704 - and are dead before the symbol list is written.  4 288 bytes per wavefront: the I-frame kernel (56 VGPRs) fits
-    // nine wavefronts per SIMD, the P-frame kernel stays at the eight its 64 VGPRs allow.
+    // byte 704 - and are dead before the symbol list is written.  4 288 bytes per wavefront (5 056 before round 3); eight wavefronts per SIMD -
+    // the hardware's limit - with the 64 VGPRs of the P-frame kernel.
     constexpr int kOffCp = 704;
     static_assert(2 * kCwinBytes + 256 <= kOffCp && kOffCp + 768 <= kR1, "s_cp behind the chroma windows and the current rows, inside R1");
     constexpr int kOffPred = kR1, kOffT = kOffPred + 384, kOffZig = kOffT + 1536;

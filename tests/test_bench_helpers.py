@@ -47,7 +47,12 @@ def test_traffic_carries_the_tree_it_was_measured_on(tmp_path, monkeypatch):
     import os
     head, ksha = bench.source_shas()
     src = os.path.join(bench.ROOT, "fpga-mpeg2-encoder_amd", "csrc", "m2v_kernels.hpp")
-    assert ksha == hashlib.sha256(open(src, "rb").read()).hexdigest()
+    assert ksha == bench.kernel_source_sha(src)
+    # comments and white space do not count, code does
+    text = open(src, encoding="utf-8").read()
+    (tmp_path / "a.hpp").write_text(text + "\n// a reworded comment\n   /* and\n another */\n")
+    (tmp_path / "b.hpp").write_text(text + "\nint x;\n")
+    assert bench.kernel_source_sha(str(tmp_path / "a.hpp")) == ksha != bench.kernel_source_sha(str(tmp_path / "b.hpp"))
     (tmp_path / "profiles").mkdir()
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.pmc_traffic("k_mb_p_bytes_per_launch") == {"traffic": None}            # no file: null, nothing invented

@@ -6,6 +6,7 @@ in: the GPU box has no .git) and the sha256 of the kernel source.  bench.py comp
 "traffic_stale" when they differ.
     python tools/make_pmc_traffic.py <c3 pmc_hbm.json> <c2 pmc_hbm.json or -> <git head or -> > pmc_traffic.json"""
 import hashlib
+import re
 import json
 import os
 import sys
@@ -22,7 +23,15 @@ def kernel(d, needle):
 c3 = json.load(open(sys.argv[1]))
 c2 = json.load(open(sys.argv[2])) if len(sys.argv) > 2 and sys.argv[2] != "-" and os.path.exists(sys.argv[2]) else {}
 head = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None
-ksha = hashlib.sha256(open(os.path.join(ROOT, "fpga-mpeg2-encoder_amd", "csrc", "m2v_kernels.hpp"), "rb").read()).hexdigest()
+def kernel_source_sha(path):
+    """the same as bench.py's: comments dropped, white space collapsed"""
+    text = open(path, encoding="utf-8").read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return hashlib.sha256(" ".join(text.split()).encode()).hexdigest()
+
+
+ksha = kernel_source_sha(os.path.join(ROOT, "fpga-mpeg2-encoder_amd", "csrc", "m2v_kernels.hpp"))
 out = {"head": head, "kernel_sha": ksha,
        "source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py --split 1 --steps 1 "
                  "--warmup 1` (c3: one launch = 10 P frames of 1920x1152; c2: `--gops 128`, one launch = 128 I frames of 640x480, doubled for bench.py's 256), KiB per dispatch; "
