@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Where the host-memory-to-host-memory time of bench.py's end_to_end leg goes: the same calls (one GOP per m2v_push_frames from
+page-locked memory, m2v_pull after each, m2v_sequence_stop, drain), timed per kind of call.  usage (GPU box): python tools/e2e_breakdown.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+import m2v_load
+
+M = m2v_load.load()
+W, H, PF, n = 1920, 1152, 8, 90
+gop = PF + 1
+clip = M.synth.clip_torch(W, H, n, clip_index=0, device="cuda:0").cpu()
+pinned_t = clip.pin_memory()
+frames = pinned_t.numpy()
+enc = M.Mpeg2Encoder(7, 7, 3, 2)
+enc.set_option("batch_frames", 2 * gop)
+for rep in range(4):
+    t = {"push": 0.0, "pull": 0.0, "stop": 0.0, "drain": 0.0}
+    t0 = time.perf_counter()
+    out = []
+    for k in range(0, n, gop):
+        a = time.perf_counter()
+        enc.push_frames(W // 16, H // 16, PF, frames[k:k + gop])
+        b = time.perf_counter()
+        out.append(enc.pull(1 << 24)[0])
+        c = time.perf_counter()
+        t["push"] += b - a
+        t["pull"] += c - b
+    a = time.perf_counter()
+    enc.sequence_stop()
+    b = time.perf_counter()
+    out.append(enc.pull_all())
+    c = time.perf_counter()
+    t["stop"], t["drain"] = b - a, c - b
+    total = c - t0
+    print("total %.2f ms (%.1f GB/s of input)  " % (total * 1e3, n * W * H * 3 / total * 1e-9) + "  ".join("%s %.2f" % (k, v * 1e3) for k, v in t.items()),
+          " bytes", sum(len(o) for o in out))
+dev = torch.empty_like(pinned_t, device="cuda")
+dev.copy_(pinned_t, non_blocking=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+dev.copy_(pinned_t, non_blocking=True)
+torch.cuda.synchronize()
+print("plain pinned copy of the clip: %.2f ms" % ((time.perf_counter() - t0) * 1e3))
+enc.close()
