@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Ad-hoc concurrency run: several host threads at once on ONE GPU, each with handles of its own - blocking resident calls, two
+handles taking turns with m2v_encode_resident_begin / _end, the port path (push / pull), and strip mode with an in-process
+communicator (whose ranks are further threads) - created, used and closed while the others run.  Every stream is checked against
+the oracle (computed beforehand, single-threaded).  usage (GPU box): python tools/stress_threads.py [threads] [rounds] [seed]"""
+import os
+import sys
+import threading
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np
+import torch
+
+import gpu_util as G
+from oracle import m2v_oracle_ctypes as orc
+from test_gpu_strips import run_native_strips
+
+M = G.M
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 5)
+
+cases = []
+for _ in range(10):
+    W, H = 16 * int(rng.integers(4, 24)), 16 * int(rng.integers(4, 12))
+    n, pf = int(rng.integers(2, 12)), int(rng.choice([0, 2, 8]))
+    VL, Q = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+    clip = M.synth.clip(W, H, n, clip_index=int(rng.integers(0, 1000)), scene_len=int(rng.integers(3, 9)))
+    cases.append((W, H, n, pf, VL, Q, clip, orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, Q)))
+torch.cuda.synchronize()
+bad, done, lock = [], [0], threading.Lock()
+
+
+def resident(encs, c):
+    W, H, n, pf, VL, Q, clip, want = c
+    d = torch.from_numpy(np.ascontiguousarray(clip)).cuda()
+    outs = [torch.empty(n * W * H * 3 + 65536, dtype=torch.uint8, device="cuda") for _ in encs]
+    torch.cuda.synchronize()
+    got = []
+    for h, (e, o) in enumerate(zip(encs, outs)):
+        e.encode_resident_begin(d.data_ptr(), n, o.data_ptr(), o.numel(), W // 16, H // 16, pf, 0)
+    for e, o in zip(encs, outs):
+        nb = e.encode_resident_end()
+        got.append(o[:nb].cpu().numpy().tobytes())
+    return all(g == want for g in got)
+
+
+def worker(t):
+    r = np.random.default_rng(1000 + t)
+    for it in range(R):
+        c = cases[int(r.integers(0, len(cases)))]
+        W, H, n, pf, VL, Q, clip, want = c
+        kind = int(r.integers(0, 4))
+        try:
+            if kind == 0:
+                ok = G.resident_encode(clip, W // 16, H // 16, pf, 7, 7, VL, Q, batch_frames=int(r.choice([2, 96]))) == want
+            elif kind == 1:
+                encs = [M.Mpeg2Encoder(7, 7, VL, Q) for _ in range(2)]
+                try:
+                    for e in encs:
+                        e.set_option("split_streams", int(r.integers(1, 4)))
+                    ok = resident(encs, c) and resident(encs, c)
+                finally:
+                    for e in encs:
+                        e.close()
+            elif kind == 2:
+                e = M.Mpeg2Encoder(7, 7, VL, Q)
+                try:
+                    e.set_option("batch_frames", int(r.choice([1, 3, 96])))
+                    ok = e.encode(clip, W // 16, H // 16, pf) == want
+                finally:
+                    e.close()
+            else:
+                world = int(r.integers(1, min(5, H // 16) + 1))
+                d = torch.from_numpy(np.ascontiguousarray(clip)).cuda()
+                torch.cuda.synchronize()
+                ok = run_native_strips(M, d, W, H, pf, VL, world, general=bool(r.integers(0, 2)), Q=Q)[0] == want
+        except Exception as ex:  # noqa: BLE001
+            ok = False
+            print("thread %d round %d kind %d: %r" % (t, it, kind, ex), flush=True)
+        with lock:
+            done[0] += 1
+            if not ok:
+                bad.append((t, it, kind, W, H, n, pf, VL, Q))
+
+
+th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+for x in th:
+    x.start()
+for x in th:
+    x.join(timeout=900)
+stuck = [i for i, x in enumerate(th) if x.is_alive()]
+print("sequences checked: %d, mismatches: %d %s, stuck threads: %s" % (done[0], len(bad), bad[:8], stuck), flush=True)
+os._exit(1 if bad or stuck else 0)
