@@ -47,3 +47,36 @@ dev.copy_(pinned_t, non_blocking=True)
 torch.cuda.synchronize()
 print("plain pinned copy of the clip: %.2f ms" % ((time.perf_counter() - t0) * 1e3))
 enc.close()
+
+# two callers at once (two threads, a handle and a page-locked clip each): what the link gives when one caller's turn-around
+# is covered by the other's upload
+import threading
+
+clips = [pinned_t, clip.clone().pin_memory()]
+encs = [M.Mpeg2Encoder(7, 7, 3, 2) for _ in range(2)]
+for e in encs:
+    e.set_option("batch_frames", 2 * gop)
+
+
+def one(e, fr, res, i):
+    out = []
+    for k in range(0, n, gop):
+        e.push_frames(W // 16, H // 16, PF, fr[k:k + gop])
+        out.append(e.pull(1 << 24)[0])
+    e.sequence_stop()
+    out.append(e.pull_all())
+    res[i] = sum(len(o) for o in out)
+
+
+for rep in range(4):
+    res = [0, 0]
+    th = [threading.Thread(target=one, args=(encs[i], clips[i].numpy(), res, i)) for i in range(2)]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    print("two callers: %.2f ms for 2 x %d frames = %.1f GB/s of input, %.1f GPixel/s  bytes %s" % (dt * 1e3, n, 2 * n * W * H * 3 / dt * 1e-9, 2 * n * W * H / dt * 1e-9, res))
+for e in encs:
+    e.close()
