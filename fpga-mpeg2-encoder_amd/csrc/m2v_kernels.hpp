@@ -715,7 +715,7 @@ __device__ __forceinline__ void search_rows13(uint32_t cur, uint32_t cur12, uint
 // its only source), so the values cannot drift from the LDS map they describe.
 struct LaneK {
     // quads 0, 1: requested with the pixels; quad 2 onwards: before the half-pel phase (registers)
-    uint32_t win_st;                // LDS address of s_win[(lane >> 3) kWS + (lane & 7)]
+    uint32_t win_st;                // LDS address of s_win[(lane >> 2) kWS + 2 (lane & 3)]: the lane's 8 bytes of a 16-row window pass
     uint32_t hp;                    // LDS address of s_win[r kWS + c4]: the lane part of the half-pel neighbourhood
     uint32_t pred_st, cp_st;        // &s_pred[tile][ti], &s_cp[tile][r & 7][(c4 & 1) << 2]
     uint32_t cpc_st;                // &s_cp[4][r >> 1][2 c4]
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     auto lane_consts = [&]() {
         LaneK k{};
         const int r = lane >> 2, c4 = lane & 3;
-        k.win_st = lds_off(&s_win[(lane >> 3) * kWS + (lane & 7)]);
+        k.win_st = lds_off(&s_win[(lane >> 2) * kWS + 2 * (lane & 3)]);
         k.hp = lds_off(&s_win[r * kWS + c4]);
         const int tile = ((r >> 3) << 1) | (c4 >> 1), ti = ((r & 7) << 3) | ((c4 & 1) << 2);
         k.pred_st = lds_off(&s_pred[tile][ti]);
@@ -926,17 +926,26 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 
     // ---- stages A..E: current macroblock; 4:4:4 -> 4:2:0 with two-stage rounding -------------
     // (RTL:1086-1089 horizontal mean2, RTL:1167-1170 vertical mean2 of the two means)
-    // Every global load of the macroblock (3 current rows, 4 window row groups, 2 chroma windows) is issued
+    // Every global load of the macroblock (3 current rows, 2 luma window passes, the chroma windows) is issued
     // back to back through explicit global-address-space pointers and waited for once: the wavefront pays ONE
     // memory round trip.  Window samples outside the frame can never be selected (RTL:1642-1645), so their
     // addresses are clamped into the frame instead of being branched around.
+    // The windows arrive 8 bytes per lane: a luma pass is 16 rows x 32 bytes (lane = row, 8-byte column), both chroma windows are
+    // one pass (lane = plane, row, half of the 16 bytes).  An interior macroblock - 95 % of a frame - needs one dwordx2 load per pass: three
+    // vector loads instead of six (vector memory instructions are the second thing this kernel is sensitive to:
+    // profiles/r03_experiments.txt item 8); at the frame border, where the two dwords are clamped separately, it is two loads per pass.
     typedef const __attribute__((address_space(1))) uint32_t *gld32;
     const uint8_t *inY = job.in, *inU = inY + g.ysz, *inV = inU + g.ysz;
     const uint32_t pix_off = __umul24((uint32_t)(16 * by + r), (uint32_t)W) + (uint32_t)(16 * bx + 4 * c4);   // rows, W < 2^12
     uint32_t cur4 = *(gld32)(inY + pix_off);
     uint32_t u4 = *(gld32)(inU + pix_off);
     uint32_t v4 = *(gld32)(inV + pix_off);
-    uint32_t wv[P ? (WROWS * 8 + 63) / 64 : 1], wcu = 0, wcv = 0;
+    constexpr int kWinPasses = (WROWS + 15) / 16;
+    typedef const __attribute__((address_space(1))) u32x2_t *gld64;
+    u32x2_t wwin[P ? kWinPasses : 1], wc = {0, 0};
+    const int wrow = lane >> 2, wcp = lane & 3;                                  // luma window pass: row, 8-byte column
+    const int cpl = lane >> 5, crow0 = (lane & 31) >> 1, chalf = lane & 1;       // chroma windows: plane, row, half
+    const int crow = crow0 < CROWS ? crow0 : CROWS - 1;
     SearchLane sl{};                             // the lane's search addresses: loaded with the pixels, one memory round trip
     if constexpr (P && VL == 3) {
         const u32x4_t s0 = M2V_QUAD(kQuadSearch0, SearchLane, even), s1 = M2V_QUAD(kQuadSearch0, SearchLane, plus);
@@ -955,56 +964,59 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             const bool ext_u = nb_up != nullptr && by == g.edge_top, ext_d = nb_down != nullptr && by == g.edge_bot;     // wave-uniform
             const uint32_t chunk = (uint32_t)(YR + UR) * (uint32_t)W, fb = (uint32_t)job.rhidx * chunk;
 #pragma unroll
-            for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass) {
-                const int i = pass * 64 + lane, row = i >> 3, k = i & 7;
-                int yy = 16 * by - YR + row, xx = 16 * bx - 8 + 4 * k;
+            for (int pass = 0; pass < kWinPasses; ++pass) {
+                const int row = pass * 16 + wrow;
+                int yy = 16 * by - YR + row, x0 = 16 * bx - 8 + 8 * wcp, x1 = x0 + 4;
                 yy = yy < 0 ? 0 : yy > g.H - 1 ? g.H - 1 : yy;
-                xx = xx < 0 ? 0 : xx > W - 4 ? W - 4 : xx;
+                x0 = x0 < 0 ? 0 : x0 > W - 4 ? W - 4 : x0;
+                x1 = x1 < 0 ? 0 : x1 > W - 4 ? W - 4 : x1;
                 const uint8_t *src = refY;
-                uint32_t off = __umul24((uint32_t)yy, (uint32_t)W) + (uint32_t)xx;
-                if (ext_u && row < YR) { src = nb_up; off = fb + (uint32_t)row * (uint32_t)W + (uint32_t)xx; }
-                if (ext_d && row >= YR + 16 && row < WROWS) { src = nb_down; off = fb + (uint32_t)(row - (YR + 16)) * (uint32_t)W + (uint32_t)xx; }
-                wv[pass] = *(const uint32_t *)(src + off);
+                uint32_t off = __umul24((uint32_t)yy, (uint32_t)W);
+                if (ext_u && row < YR) { src = nb_up; off = fb + (uint32_t)row * (uint32_t)W; }
+                if (ext_d && row >= YR + 16 && row < WROWS) { src = nb_down; off = fb + (uint32_t)(row - (YR + 16)) * (uint32_t)W; }
+                wwin[pass].x = *(const uint32_t *)(src + (off + (uint32_t)x0));
+                wwin[pass].y = *(const uint32_t *)(src + (off + (uint32_t)x1));
             }
-            const int cl = lane < CROWS * 4 ? lane : CROWS * 4 - 1, row = cl >> 2, k = cl & 3;
-            int yy = 8 * by - UR + row, xx = 8 * bx - 4 + 4 * k;
+            int yy = 8 * by - UR + crow, x0 = 8 * bx - 4 + 8 * chalf, x1 = x0 + 4;
             yy = yy < 0 ? 0 : yy > g.ch - 1 ? g.ch - 1 : yy;
-            xx = xx < 0 ? 0 : xx > g.cw - 4 ? g.cw - 4 : xx;
-            const uint8_t *su = refU, *sv = refV;
-            uint32_t coff = __umul24((uint32_t)yy, (uint32_t)g.cw) + (uint32_t)xx, voff = coff;
-            const uint32_t cbase = fb + (uint32_t)YR * (uint32_t)W + (uint32_t)xx, vstep = (uint32_t)UR * (uint32_t)g.cw;
-            if (ext_u && row < UR) { su = sv = nb_up; coff = cbase + (uint32_t)row * (uint32_t)g.cw; voff = coff + vstep; }
-            if (ext_d && row >= UR + 8) { su = sv = nb_down; coff = cbase + (uint32_t)(row - (UR + 8)) * (uint32_t)g.cw; voff = coff + vstep; }
-            wcu = *(const uint32_t *)(su + coff);
-            wcv = *(const uint32_t *)(sv + voff);
+            x0 = x0 < 0 ? 0 : x0 > g.cw - 4 ? g.cw - 4 : x0;
+            x1 = x1 < 0 ? 0 : x1 > g.cw - 4 ? g.cw - 4 : x1;
+            const uint8_t *sc = refU;
+            uint32_t coff = __umul24((uint32_t)yy, (uint32_t)g.cw) + __umul24((uint32_t)cpl, g.csz);       // V sits csz bytes behind U
+            const uint32_t cbase = fb + (uint32_t)YR * (uint32_t)W + __umul24((uint32_t)cpl, (uint32_t)UR * (uint32_t)g.cw);   // and UR rows behind it in a halo chunk
+            if (ext_u && crow < UR) { sc = nb_up; coff = cbase + (uint32_t)crow * (uint32_t)g.cw; }
+            if (ext_d && crow >= UR + 8) { sc = nb_down; coff = cbase + (uint32_t)(crow - (UR + 8)) * (uint32_t)g.cw; }
+            wc.x = *(const uint32_t *)(sc + (coff + (uint32_t)x0));
+            wc.y = *(const uint32_t *)(sc + (coff + (uint32_t)x1));
         } else
         if (sgpr(in_l & in_r & in_u & in_d)) {
             // interior macroblock (wave-uniform test): the whole window lies inside the frame, no clamping, and the
             // passes differ by a constant row offset
-            const uint32_t w0 = __umul24((uint32_t)(16 * by - YR + (lane >> 3)), (uint32_t)W) + (uint32_t)(16 * bx - 8 + 4 * (lane & 7));
+            // (the last pass reaches past the window - at most to row 16 by + 31 - YR -, still inside the frame: there is a macroblock row below)
+            const uint32_t w0 = __umul24((uint32_t)(16 * by - YR + wrow), (uint32_t)W) + (uint32_t)(16 * bx - 8 + 8 * wcp);
 #pragma unroll
-            for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass)
-                wv[pass] = *(gld32)(refY + (w0 + (uint32_t)(pass * 8) * (uint32_t)W));
-            const int cl = lane < CROWS * 4 ? lane : CROWS * 4 - 1;
-            const uint32_t coff = __umul24((uint32_t)(8 * by - UR + (cl >> 2)), (uint32_t)g.cw) + (uint32_t)(8 * bx - 4 + 4 * (cl & 3));
-            wcu = *(gld32)(refU + coff);
-            wcv = *(gld32)(refV + coff);
+            for (int pass = 0; pass < kWinPasses; ++pass)
+                wwin[pass] = *(gld64)(refY + (w0 + (uint32_t)(pass * 16) * (uint32_t)W));
+            const uint32_t coff = __umul24((uint32_t)(8 * by - UR + crow), (uint32_t)g.cw) + (uint32_t)(8 * bx - 4 + 8 * chalf) + __umul24((uint32_t)cpl, g.csz);
+            wc = *(gld64)(refU + coff);                     // (4-byte aligned: the chroma window starts at column 8 bx - 4)
         } else {
 #pragma unroll
-            for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass) {
-                const int i = pass * 64 + lane, row = i >> 3, k = i & 7;
-                int yy = 16 * by - YR + row, xx = 16 * bx - 8 + 4 * k;
+            for (int pass = 0; pass < kWinPasses; ++pass) {
+                int yy = 16 * by - YR + pass * 16 + wrow, x0 = 16 * bx - 8 + 8 * wcp, x1 = x0 + 4;
                 yy = yy < 0 ? 0 : yy > g.H - 1 ? g.H - 1 : yy;
-                xx = xx < 0 ? 0 : xx > W - 4 ? W - 4 : xx;
-                wv[pass] = *(gld32)(refY + (__umul24((uint32_t)yy, (uint32_t)W) + (uint32_t)xx));   // 32-bit offset from a uniform base
+                x0 = x0 < 0 ? 0 : x0 > W - 4 ? W - 4 : x0;
+                x1 = x1 < 0 ? 0 : x1 > W - 4 ? W - 4 : x1;
+                const uint32_t off = __umul24((uint32_t)yy, (uint32_t)W);                          // 32-bit offsets from a uniform base
+                wwin[pass].x = *(gld32)(refY + (off + (uint32_t)x0));
+                wwin[pass].y = *(gld32)(refY + (off + (uint32_t)x1));
             }
-            const int cl = lane < CROWS * 4 ? lane : CROWS * 4 - 1, row = cl >> 2, k = cl & 3;
-            int yy = 8 * by - UR + row, xx = 8 * bx - 4 + 4 * k;
+            int yy = 8 * by - UR + crow, x0 = 8 * bx - 4 + 8 * chalf, x1 = x0 + 4;
             yy = yy < 0 ? 0 : yy > g.ch - 1 ? g.ch - 1 : yy;
-            xx = xx < 0 ? 0 : xx > g.cw - 4 ? g.cw - 4 : xx;
-            const uint32_t coff = __umul24((uint32_t)yy, (uint32_t)g.cw) + (uint32_t)xx;
-            wcu = *(gld32)(refU + coff);
-            wcv = *(gld32)(refV + coff);
+            x0 = x0 < 0 ? 0 : x0 > g.cw - 4 ? g.cw - 4 : x0;
+            x1 = x1 < 0 ? 0 : x1 > g.cw - 4 ? g.cw - 4 : x1;
+            const uint32_t coff = __umul24((uint32_t)yy, (uint32_t)g.cw) + __umul24((uint32_t)cpl, g.csz);
+            wc.x = *(gld32)(refU + (coff + (uint32_t)x0));
+            wc.y = *(gld32)(refU + (coff + (uint32_t)x1));
         }
     }
     if (sgpr((int)((job.valid_beats - (g.ysz >> 2)) >> 31))) {    // a frame cut short by i_sequence_stop: wave-uniform, almost never
@@ -1038,19 +1050,19 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 
     if constexpr (P) {
         // ---- stages X..Z: reference window of recon(f-1) into LDS (RTL:1350-1425, 1612-1629) --
+        typedef __attribute__((address_space(3))) u32x2_t *LdsW64;
 #pragma unroll
-        for (int pass = 0; pass < (WROWS * 8 + 63) / 64; ++pass)
-            if ((pass + 1) * 64 <= WROWS * 8 || lane < WROWS * 8 - pass * 64) {
-                // s_win[(pass * 8 + (lane >> 3)) * kWS + (lane & 7)] and the same element of copy B, one dword to the left
-                // (column 0 lands in padding): the lane's address from the table, everything else an immediate
+        for (int pass = 0; pass < kWinPasses; ++pass)
+            if ((pass + 1) * 16 <= WROWS || lane < (WROWS - pass * 16) * 4) {
+                // s_win[(pass * 16 + (lane >> 2)) * kWS + 2 (lane & 3)] (8-byte aligned: one ds_write_b64) and the same two elements of copy
+                // B, one dword to the left (column 0 lands in padding): the lane's address from the table, everything else an immediate
                 typedef __attribute__((address_space(3))) uint32_t *LdsW;
-                *(LdsW)(uintptr_t)(kq0.x + (uint32_t)(pass * 8 * kWS * 4)) = wv[pass];
-                *(LdsW)(uintptr_t)(kq0.x + (uint32_t)(pass * 8 * kWS * 4 + kWinBGap * 4 - 4)) = wv[pass];
+                *(LdsW64)(uintptr_t)(kq0.x + (uint32_t)(pass * 16 * kWS * 4)) = wwin[pass];
+                *(LdsW)(uintptr_t)(kq0.x + (uint32_t)(pass * 16 * kWS * 4 + kWinBGap * 4 - 4)) = wwin[pass].x;
+                *(LdsW)(uintptr_t)(kq0.x + (uint32_t)(pass * 16 * kWS * 4 + kWinBGap * 4)) = wwin[pass].y;
             }
-        if (lane < CROWS * 4) {
-            s_cwin[0][lane] = wcu;
-            s_cwin[1][lane] = wcv;
-        }
+        if (crow0 < CROWS)                      // s_cwin[plane][row * 4 + 2 * half]: (lane & 31) * 8 bytes into the plane's window
+            *(LdsW64)(uintptr_t)(lds_off(&s_cwin[0][0]) + (uint32_t)cpl * (uint32_t)kCwinBytes + (uint32_t)(lane & 31) * 8u) = wc;
         M2V_WAVE_SYNC();
         M2V_STOP(1);        // loads, chroma subsampling, window staging
 
