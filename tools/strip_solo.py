@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--world", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--gops", type=int, default=10)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--split", type=int, default=-1, help="option split_streams of the handle (GOP groups on a stream each; default: the library's)")
     args = ap.parse_args()
     import torch
     import m2v_load
@@ -36,6 +37,8 @@ def main():
     for world in args.world:
         for rank in sorted({0, world // 2}):                      # the output rank (one neighbour + final assembly) and an inner rank
             enc = M.Mpeg2Encoder(7, 7, 3, 2)
+            if args.split >= 0:
+                enc.set_option("split_streams", args.split)
             comm = M.StripComm.solo(world) if world > 1 else None
             try:
                 run = lambda: M.parallel.encode_strips_native(enc, comm, rank, world, clip, 128, 128, pf, out if rank == 0 else None)   # noqa: E731
@@ -54,7 +57,7 @@ def main():
                 ks = {name: round(enc.kernel_stats(k)[1], 3) for k, name in ((0, "k_mb_P"), (1, "k_mb_I"), (4, "scans"), (3, "k_assemble"), (2, "final_assembly"))}
                 if world == 1:
                     base = dt
-                print(json.dumps({"world": world, "rank": rank, "ms_per_sequence": round(dt * 1e3, 3),
+                print(json.dumps({"world": world, "rank": rank, "split_streams": args.split if args.split >= 0 else "default", "ms_per_sequence": round(dt * 1e3, 3),
                                   "speedup_vs_one_rank": round(base / dt, 2) if base else None,
                                   "ideal": world, "host_us_per_gop_step": round(st["host_us_per_step"], 1),
                                   "of_which_inside_the_communicator": round(st["comm_us_per_step"], 1),
