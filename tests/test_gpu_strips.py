@@ -98,13 +98,16 @@ def test_encode_strips_world1_equals_resident():
 
 
 # ---- the native loop: m2v_strip_encode, ranks = threads of this process talking through a local communicator ----
-def run_native_strips(M, d_clip, W, H, pf, VL, world, profile=False, general=False, Q=2):
+def run_native_strips(M, d_clip, W, H, pf, VL, world, profile=False, general=False, Q=2, conformant=False):
     """`world` handles, one host thread each, all on GPU 0; every thread makes ONE call (m2v_strip_encode) - the GOP steps,
     the halo exchange (mailboxes + device copies behind the same interface RCCL sits behind), the size all-gather, the
     strips to rank 0 and the final assembly all happen inside it.  Returns (stream bytes, [strip_stats of every rank])."""
     import threading
     import torch
     encs = [M.Mpeg2Encoder(7, 7, VL, Q) for _ in range(world)]
+    if conformant:       # option conformant (NOT the reference's arithmetic): the general form of the step, checked against the oracle's conformant mode
+        for e in encs:
+            e.set_option("conformant", 1)
     if general:          # the general form of the step (pack / unpack kernels, exchange on its own stream): what option conformant
         for e in encs:   # and dct_mfma = 0 run instead of the fused edge-row kernel
             e.set_option("dct_mfma", 0)
@@ -243,3 +246,21 @@ def test_a_failing_rank_does_not_leave_the_others_waiting():
         for e in encs:
             e.close()
         comm.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_native_strip_loop_in_conformant_mode(world):
+    """option conformant (ISO reconstruction loop, clearly non-parity) through strip mode: the halo rows are the conformant
+    reconstruction's, the stream equals the oracle's conformant mode."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    W, H, pf, VL, n = 160, 128, 3, 3, 9
+    clip = M.synth.clip(W, H, n, clip_index=91, scene_len=4)
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, 2, conformant=True)
+    assert want != orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, 2)
+    d_clip = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
+    got, _ = run_native_strips(M, d_clip, W, H, pf, VL, world, conformant=True)
+    assert got == want
+
