@@ -83,3 +83,28 @@ def test_plain_c_caller_encodes_one_sequence_as_strips(tmp_path, nranks, W, H, p
     assert r.returncode == 0, r.stdout + r.stderr
     assert "%d strips" % nranks in r.stdout
     assert out.read_bytes() == orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
+
+
+def test_plain_c_caller_keeps_two_sequences_in_flight(tmp_path):
+    """integration/pipeline_caller.c (gcc, C99): m2v_encode_resident_begin / _end on two handles taking turns - the submission form
+    bench.py's timed loop uses - from plain C.  Seven sequences of the same clip: every stream identical, and the oracle's."""
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    M.build()
+    libdir = os.path.join(ROOT, "fpga-mpeg2-encoder_amd")
+    exe = str(tmp_path / "pipeline_caller")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+           os.path.join(ROOT, "integration", "pipeline_caller.c"), "-L" + libdir, "-lm2v_mi355x", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    W, H, pf, n = 320, 192, 4, 23
+    clip = M.synth.clip(W, H, n, clip_index=140, scene_len=6)
+    (tmp_path / "in.yuv").write_bytes(clip.tobytes())
+    out = tmp_path / "out.m2v"
+    r = subprocess.run([exe, str(tmp_path / "in.yuv"), str(W), str(H), str(pf), "7", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "7 sequences" in r.stdout and "all identical" in r.stdout
+    assert out.read_bytes() == orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
+
