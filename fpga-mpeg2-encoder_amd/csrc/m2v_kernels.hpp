@@ -147,7 +147,11 @@ constexpr bool s3_helpers_match(int lane = 0) { return lane == 64 || ((((kS3Help
 static_assert(s3_helpers_match(), "kS3Helpers does not match s3_dy");
 constexpr int kS3Cur = 2 * (8 + 2 * 3) * 16;             // current luma rows (behind the two chroma windows)
 constexpr int kS3Win = kS3Cur + 256;                     // luma window, copy A
-constexpr int kS3Scratch = 1600 + 384 + 1536;            // the level buffer s_zig: unused until the quantiser
+constexpr int kS3Scratch = 1600 + 384 + 1536;            // the end of the transform tiles and the level buffer s_zig: unused until the transform
+// dwords between the six tiles of s_t: 64 of data + 8 of padding.  With 64 the tiles start on the same bank: the quantiser's stores of the four
+// luma tiles (accumulator layout) were 4-way conflicted and the column pass of the IDCT 6-way; with 72 both are conflict-free (the row pass,
+// 16 bytes per lane, costs the same either way).  Same box, ms per step: 64 1.149 / 1.162, 68 1.145, 72 1.141 / 1.154, 76 1.153, 80 1.153.
+constexpr int kTileStride = 72;
 constexpr int kS3Flush = kS3Scratch;                     // running sums [t][group][k], 8 bytes each
 constexpr int kS3Rep = kS3Flush + 3 * 4 * 4 * 8;         // macroblock rows 13 14 15 13 14 15 ... (12 x 16 bytes) for the helpers
 static_assert((kS3Rep - kS3Cur) % 256 == 128, "a step reads one row of each in the same instruction: 32 banks apart");
@@ -793,8 +797,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // the hardware's limit - with the 64 VGPRs of the P-frame kernel.
     constexpr int kOffCp = 704;
     static_assert(2 * kCwinBytes + 256 <= kOffCp && kOffCp + 768 <= kR1, "s_cp behind the chroma windows and the current rows, inside R1");
-    constexpr int kOffPred = kR1, kOffT = kOffPred + 384, kOffZig = kOffT + 1536;
-    static_assert(!P || (kOffWin % 8 == 0 && kOffWinB + kWinBytes <= kOffZig), "window copies may run over s_pred and s_t only");
+    constexpr int kOffPred = kR1, kOffT = kOffPred + 384, kOffZig = kOffT + 6 * kTileStride * 4;
+    static_assert(!P || (kOffWin % 8 == 0 && kOffWinB + kWinBytes <= kS3Scratch && kS3Scratch <= kOffZig), "window copies may run over s_pred and s_t only, and end in front of the search's scratch");
     constexpr int kLdsBytes = kOffZig + 768;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];   // static base: every DS access uses an immediate offset
     uint32_t (*const s_cwin)[CROWS * 4] = (uint32_t (*)[CROWS * 4])lds;       // chroma windows: 16 bytes/row = cols 8bx-4 .. 8bx+11
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     uint32_t *const s_sym = (uint32_t *)(lds + 16);                            // VLC symbol list (<= 3 + 6 * 64 entries; [-1] is read), reuses R1
     uint8_t (*const s_pred)[64] = (uint8_t (*)[64])(lds + kOffPred);           // prediction, later reconstruction, tile layout
     uint8_t (*const s_cp)[8][16] = (uint8_t (*)[8][16])(lds + kOffCp);         // signed current | prediction bytes per tile row: the transform's input
-    int32_t (*const s_t)[64] = (int32_t (*)[64])(lds + kOffT);                 // DCT phase 1; then the dequantised coefficients (as int32: the row pass of
+    int32_t (*const s_t)[kTileStride] = (int32_t (*)[kTileStride])(lds + kOffT);                 // DCT phase 1; then the dequantised coefficients (as int32: the row pass of
                                                                                // the IDCT reads them without unpacking and works in place), then the bit buffer
     uint32_t *const s_bits = (uint32_t *)(lds + kOffT);                        // VLC bit segments (<= 1216 bytes), reuses s_t
     int16_t (*const s_zig)[64] = (int16_t (*)[64])(lds + kOffZig);             // quantised levels in zig-zag order
@@ -1028,7 +1032,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     }
     s_cur[lane] = cur4;
     if constexpr (P && VL == 3) {               // full-pel search with helper lanes: their copy of rows 13..15, the zeroed sum cells
-        static_assert(2 * kCwinBytes == kS3Cur && kOffWin == kS3Win && kOffZig == kS3Scratch && kS3Zero + 8 <= kLdsBytes, "c_search holds these offsets");
+        static_assert(2 * kCwinBytes == kS3Cur && kOffWin == kS3Win && kOffT + 6 * 64 * 4 == kS3Scratch && kS3Zero + 8 <= kLdsBytes, "c_search holds these offsets");
         if (lane >= 52) {
             uint32_t *const rep = (uint32_t *)(lds + kS3Rep) + (lane - 52);
             rep[0] = cur4; rep[12] = cur4; rep[24] = cur4; rep[36] = cur4;
