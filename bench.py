@@ -306,9 +306,12 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
     if os.environ.get("M2V_STRIP_LOOP") == "python" or (world > 1 and backend != "nccl"):
         loop, why = "python", "M2V_STRIP_LOOP=python" if os.environ.get("M2V_STRIP_LOOP") == "python" else "backend %s" % backend
     elif world > 1:
+        # (StripComm.rccl is collective: a failure to make the id on rank 0 reaches every rank through its broadcast and all of them
+        # land in the except branch together; a rank stuck in ncclCommInitRank because another one never arrived ends its process
+        # after init_timeout, and the launcher tears the job down.  The vote below runs after every rank has returned from it.)
         ok = 1
         try:
-            comm = M.StripComm.rccl(rank, world, local_rank, dist)
+            comm = M.StripComm.rccl(rank, world, local_rank, dist, init_timeout=float(os.environ.get("M2V_RCCL_INIT_TIMEOUT", "180")))
         except Exception as ex:  # noqa: BLE001
             ok, why = 0, "m2v_comm_init_rccl: %s" % ex
         t = torch.tensor([ok], dtype=torch.int64, device=dev)
@@ -454,23 +457,49 @@ def launch_ranks(nranks, argv):
             sys.stdout.buffer.flush()
     t = threading.Thread(target=relay, daemon=True)
     t.start()
-    deadline = None
-    while live:
-        for r in list(live):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            live.discard(r)
-            if rc != 0:
-                worst = worst or rc
-                if deadline is None:
-                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks in 20 s\n" % (r, rc))
-                    deadline = time.time() + 20.0
-        if deadline is not None and time.time() > deadline:
-            for r in live:
-                procs[r].terminate()
-            deadline = time.time() + 1e9
-        time.sleep(0.05)
+    # A failed rank ends the job: the others get 20 s to finish on their own, then SIGTERM, and - a rank blocked in an RCCL
+    # collective or a driver call may ignore that - SIGKILL 10 s later.  The same clean-up runs when the launcher itself is
+    # interrupted or terminated, so no rank is left behind holding a GPU.  Children are ended by their exact PIDs.
+    import signal
+
+    def on_term(signum, frame):
+        raise KeyboardInterrupt
+    old_term = signal.signal(signal.SIGTERM, on_term)
+    grace, grace_kill = (float(x) for x in os.environ.get("M2V_BENCH_GRACE", "20,10").split(","))
+    deadline, stage = None, 0          # stage 0: waiting, 1: SIGTERM sent, 2: SIGKILL sent
+    try:
+        while live:
+            for r in list(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0:
+                    worst = worst or rc
+                    if deadline is None:
+                        sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks in %.0f s\n" % (r, rc, grace))
+                        deadline = time.time() + grace
+            if deadline is not None and time.time() > deadline and stage < 2:
+                for r in live:
+                    (procs[r].terminate if stage == 0 else procs[r].kill)()
+                stage += 1
+                deadline = time.time() + grace_kill
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        worst = worst or 130
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        t_kill = time.time() + grace_kill
+        while time.time() < t_kill and any(pr.poll() is None for pr in procs):
+            time.sleep(0.05)
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        for pr in procs:
+            pr.wait()
+    finally:
+        signal.signal(signal.SIGTERM, old_term)
     t.join(timeout=10.0)
     return worst
 
@@ -483,6 +512,13 @@ def dry_launch(args, rank, world):
     backend = os.environ.get("M2V_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if os.environ.get("M2V_BENCH_TEST_FAIL_RANK") == str(rank):        # tests/test_bench_launch.py: a rank that dies early
         return 3
+    if os.environ.get("M2V_BENCH_TEST_DEAF_RANK") == str(rank):        # ... and one that is stuck and ignores SIGTERM
+        import signal
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        with open(os.environ["M2V_BENCH_TEST_PIDFILE"], "w") as f:
+            f.write(str(os.getpid()))
+        time.sleep(600)
+        return 0
     seen, total = 1, 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

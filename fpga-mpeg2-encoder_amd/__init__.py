@@ -7,6 +7,8 @@ fallback: without the built library or without a GPU every entry point raises.
 """
 import ctypes
 import os
+import sys
+import threading
 
 import numpy as np
 
@@ -318,23 +320,41 @@ class StripComm:
         self.handle, self.kind, self.world = handle, kind, world
 
     @classmethod
-    def rccl(cls, rank, world, device, dist=None):
+    def rccl(cls, rank, world, device, dist=None, init_timeout=None):
         """Collective over `dist` (an initialised torch.distributed of any backend, used ONLY to hand rank 0's ncclUniqueId to
-        the others); afterwards the data path talks to librccl directly."""
+        the others); afterwards the data path talks to librccl directly.
+
+        Rank 0 broadcasts (status, id) whatever happened: when librccl cannot produce an id there, EVERY rank raises here,
+        together, and nobody is left waiting in the broadcast.  ncclCommInitRank itself blocks until all ranks have arrived; a rank
+        that cannot get there (its own librccl missing) would leave the others inside it, so with `init_timeout` (seconds) a rank
+        still inside after that long ends its process with exit code 70 - a launcher that watches its ranks (bench.py) then tears
+        the job down instead of hanging."""
         L = lib()
-        ident = None
+        status, ident = 128, None
         if rank == 0:
             buf = ctypes.create_string_buffer(128)
-            r = L.m2v_comm_unique_id(buf, 128)
-            if r != 128:
-                raise M2VError("m2v_comm_unique_id failed (%d): %s" % (r, L.m2v_comm_last_error().decode()))
-            ident = buf.raw
+            status = L.m2v_comm_unique_id(buf, 128)
+            ident = buf.raw if status == 128 else L.m2v_comm_last_error().decode()
         if world > 1:
-            box = [ident]
+            box = [(status, ident)]
             dist.broadcast_object_list(box, src=0)
-            ident = box[0]
+            status, ident = box[0]
+        if status != 128:
+            raise M2VError("m2v_comm_unique_id failed on rank 0 (%d): %s" % (status, ident))
         err = ctypes.c_int(0)
-        h = L.m2v_comm_init_rccl(ident, rank, world, device, ctypes.byref(err))
+        done = threading.Event()
+        if init_timeout:
+            def watchdog():
+                if not done.wait(init_timeout):
+                    sys.stderr.write("m2v: rank %d still inside m2v_comm_init_rccl after %.0f s (another rank never arrived?): giving up\n"
+                                     % (rank, init_timeout))
+                    sys.stderr.flush()
+                    os._exit(70)
+            threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            h = L.m2v_comm_init_rccl(ident, rank, world, device, ctypes.byref(err))
+        finally:
+            done.set()
         if not h:
             raise M2VError("m2v_comm_init_rccl failed (%d): %s" % (err.value, L.m2v_comm_last_error().decode()))
         return cls(h, "rccl", world)

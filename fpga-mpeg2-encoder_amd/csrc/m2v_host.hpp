@@ -1,0 +1,272 @@
+// m2v_host.hpp — internals shared by the host translation units of libm2v_mi355x.so (not installed; the ABI is include/m2v_mi355x.h).
+//
+//   m2v_launch.hip    the ONLY unit that includes the device code (m2v_kernels.hpp): constant-table upload and one plain C++ launch
+//                     function per kernel (device globals live in the code object of the unit that defines them, so every launch
+//                     has to come from there)
+//   m2v_core.hip      handle life cycle, options, geometry (RTL:985-1006), the chunk plan (GOP segments, reconstruction slots, launch
+//                     lists) and its execution: plan_chunk -> run_step* -> finish_chunk
+//   m2v_port.hip      the port path: beats in (RTL:1027-1095), 32-byte words out (RTL:2961-2994), double-buffered staging
+//   m2v_resident.hip  whole sequences resident in HBM (what bench.py times), one or several per call
+//   m2v_strips.hip    strip mode (BASELINE config c5) and the communicators of m2v_comm.hpp
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/m2v_mi355x.h"
+#include "m2v_types.hpp"
+
+namespace m2v {
+
+struct HipError { hipError_t e; const char *what; };
+
+#define HIPCHK(expr)                                                        \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) throw ::m2v::HipError{_e, #expr};             \
+    } while (0)
+
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    void ensure(size_t count)
+    {
+        if (count <= n) return;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct KStat { int launches = 0; double ms = 0, units = 0; };
+
+
+struct TimedLaunch { hipEvent_t a, b; int kernel; double units; };
+
+}  // namespace m2v
+
+using namespace m2v;      // (an internal header: every unit that includes it is part of the library)
+
+struct m2v_enc {
+    // module parameters (RTL:11-14)
+    int XL, YL, VL, Q;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // options
+    size_t batch_frames = 96;
+    bool profile = false;
+    int ablate = 0;               // profiling aid, see Geom::ablate
+    bool keep_recon = false;      // debug: every frame keeps its own reconstruction buffer, levels are dumped
+
+    // sequence state (RTL:1017-1022)
+    enum State { IDLE, DURING, ENDED } state = IDLE;
+    Geom g{};
+    uint32_t pframes = 0;
+    size_t frames_total = 0;      // frames of this sequence handed to the GPU so far
+    bool first_chunk = true;
+
+    // Host staging, double buffered: while the GPU works on the chunk submitted from one stage the caller
+    // fills the other one.  Each stage owns everything the host and the device touch asynchronously:
+    // the pinned frames, the pinned launch plan, the control read-back, the chunk's stream buffer.
+    struct HostStage {
+        uint8_t *h_in = nullptr;              // pinned planar 4:4:4 frames of the chunk being filled
+        size_t h_in_cap = 0;                  // bytes
+        StreamCtl *h_ctl = nullptr;           // pinned: [0] read-back, [1] initial values
+        FrameJob *h_jobs = nullptr;           // pinned staging of the per-frame jobs
+        size_t h_jobs_cap = 0;
+        FrameJob *h_joblist = nullptr;        // pinned staging of the jobs in launch-list order
+        int *h_lists = nullptr;               // pinned staging of the launch lists
+        size_t h_lists_cap = 0;
+        uint8_t *h_out = nullptr;             // pinned read-back buffer
+        size_t h_out_cap = 0;
+        DevBuf<uint8_t> d_in;                 // the chunk's frames on the device: the upload of chunk k+1 (up_stream) runs
+                                              // while the kernels of chunk k read the other stage's buffer
+        DevBuf<uint8_t> d_out;                // chunk output when it goes to the host
+        hipEvent_t ev_ctl = nullptr, ev_out = nullptr, ev_up = nullptr;
+        size_t uploaded = 0;                  // leading frames of the chunk being filled that are already in d_in (page-locked
+                                              // caller memory goes to the device directly, without the pinned staging copy)
+        int stage = 0;                        // 0 free, 1 encode submitted, 2 stream read-back submitted
+        bool last = false;
+        size_t bytes = 0;
+    } hs[2];
+    int cur = 0;                  // stage being filled by m2v_push_*
+    HostStage &st() { return hs[cur]; }
+    std::deque<int> pending;      // submitted stages, oldest first
+    bool dct_mfma = true;         // option "dct_mfma": luma DCT through the matrix cores (k_mb<.., MFMA = true>); 0 = integer VALU / LDS
+                                  // path.  Same results; kept by the rocprofv3 number (profiles/r02_mfma_*: 138.3 vs 140.3 us per launch)
+    bool conformant = false;      // option "conformant": ISO reconstruction loop instead of the RTL's (NOT byte-identical to the reference)
+    int copy_threads = 8;         // option "copy_threads": threads that copy m2v_push_frames input into pinned memory
+    bool direct_upload = true;    // option "direct_upload": page-locked caller memory is uploaded without the staging copy
+    int split_streams = 2;        // GOP segments of a chunk run as this many independent groups on as many streams (encode_chunk)
+    static constexpr int kMaxSplit = 8;
+    hipStream_t side[kMaxSplit - 1] = {};            // group 0 runs on the caller's stream
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSplit - 1] = {};
+    hipStream_t up_stream = nullptr;     // host -> device uploads of the port path
+    bool async = true;            // option "async": 0 = every chunk is completed before m2v_push_* returns
+    hipStream_t copy_stream = nullptr;   // stream read-back, concurrent with the next chunk's kernels
+    size_t buffered = 0;          // complete frames waiting in st().h_in
+    size_t beat_pos = 0;          // beats received of the frame in progress
+    uint32_t last_frame_valid_beats = 0;   // for a black-filled last frame
+
+    // host output FIFO (32-byte words are handed out by m2v_pull)
+    std::vector<uint8_t> fifo;
+    size_t fifo_rd = 0;
+    bool end_pending = false;     // the data in the FIFO ends with the o_last word
+
+    // device buffers
+    DevBuf<int16_t> d_coef;               // debug only: quantised levels
+    DevBuf<MbAux> d_mbaux;
+    DevBuf<MbDepRec> d_mbdep;             // neighbour-dependent codes of every macroblock (k_slice_scan -> k_assemble)
+    DevBuf<uint32_t> d_slots;             // per-macroblock VLC bit segments (kSlotWords each), used on overflow only
+    DevBuf<uint32_t> d_slots_small;       // compact 128-byte slots (kSmallSlotWords each): the common case
+    DevBuf<uint32_t> d_mbinfo, d_mblen, d_mboff, d_slice_bytes;
+    DevBuf<unsigned long long> d_slice_off, d_frame_off;
+    DevBuf<FrameJob> d_jobs;
+    DevBuf<int> d_lists;
+    DevBuf<FrameJob> d_joblist;           // the jobs again, in launch-list order (k_mb reads its frame's job with ONE dependent scalar load)
+    DevBuf<StreamCtl> d_ctl;
+    std::vector<uint8_t *> rec_pool;      // reconstruction buffers (4:2:0 planar), each ysz + 2*csz
+    size_t rec_bytes = 0;
+    size_t rec_pool_bytes = 0;            // allocation size of every buffer in rec_pool
+    int persist_slot = -1;                // slot holding recon of the last encoded frame (GOP continues)
+    unsigned long long stream_bytes = 0;  // bytes of the current sequence already moved to the FIFO
+
+    // plan of the chunk being encoded (plan_chunk -> run_step* -> finish_chunk)
+    struct Step { int off_i, n_i, off_p, n_p, off_h, n_h; int cut_i[kMaxSplit + 1], cut_p[kMaxSplit + 1]; };   // cut_*[k]: first list entry of segment group k
+    // what d_jobs / d_lists / d_joblist hold: a caller that encodes sequence after sequence of one shape from the same buffers (the
+    // resident entry in a loop) gets the same plan every time, and three small host-to-device copies in front of the first kernel
+    // of every call are ~25 us of latency the GPU spends idle
+    std::vector<FrameJob> dev_jobs;
+    std::vector<int> dev_lists;
+    const void *dev_jobs_p = nullptr, *dev_lists_p = nullptr, *dev_joblist_p = nullptr;
+    int plan_groups = 1;                  // groups the launch lists of the current plan are cut into
+    int plan_gf[kMaxSplit + 1] = {};      // chunk-frame index where each group's frames start (its GOP segments are consecutive frames)
+    bool resident_inflight = false;       // between m2v_encode_resident_begin and m2v_encode_resident_end
+    bool resident_empty = false;          // ... of a sequence without frames
+    hipStream_t resident_stream = nullptr;
+    bool slice_scan_done = false;         // the groups ran k_slice_scan on their own streams (encode_chunk): finish_chunk skips it
+    std::vector<Step> plan_steps;
+    size_t plan_nf = 0;
+    bool strip_active = false;            // between m2v_strip_begin and m2v_strip_finish
+    hipStream_t strip_stream = nullptr;
+    DevBuf<uint8_t> d_segs;               // CopySeg table of the strip assembly (written by k_strip_layout)
+    DevBuf<unsigned long long> d_frame_pos;   // where every frame's headers start in the assembled stream (k_strip_layout)
+    DevBuf<unsigned long long> d_alloff;  // [ranks][frames + 1] frame offsets of every rank's strip
+    uint8_t *h_asm = nullptr;             // pinned staging of the offsets (m2v_strip_assemble: up; m2v_strip_encode: the all-gathered sizes down)
+    size_t h_asm_cap = 0;
+    hipEvent_t ev_asm = nullptr;          // the staging may be rewritten once this has been reached
+    uint8_t *h_strip = nullptr;           // pinned: this strip's frame offsets + control word (m2v_strip_finish_async -> m2v_strip_offsets)
+    size_t h_strip_cap = 0;
+    size_t strip_nf = 0;
+    hipEvent_t ev_strip = nullptr;
+    // m2v_strip_encode: the whole strip sequence in one call
+    DevBuf<uint8_t> d_halo, d_strip_own, d_gather;
+    hipStream_t comm_stream = nullptr;    // send / recv with the neighbours, beside the interior rows on the main stream
+    hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_interior = nullptr, ev_done = nullptr;
+    struct StripStats { double halo_total_ms = 0, halo_exposed_ms = 0, gather_ms = 0, host_us_per_step = 0, comm_us_per_step = 0; int steps = 0; } strip_stats;
+
+    // debug bookkeeping of the last resident encode
+    size_t dbg_frames = 0;
+    std::vector<int> dbg_rec_slot;
+
+    // profiling
+    KStat stats[5];
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> ev_pool;      // timing events, reused from step to step
+    size_t ev_used = 0;
+    hipEvent_t chain_ev = nullptr;        // stop event of the previous timer while nothing else was enqueued after it
+    hipStream_t chain_stream = nullptr;
+
+    void set_err(const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+    }
+};
+
+namespace m2v {
+
+// ---- m2v_core.hip ----
+Geom make_geom(const m2v_enc *e, uint32_t xs, uint32_t ys);
+hipEvent_t pool_event(m2v_enc *e);
+void collect_timers(m2v_enc *e);
+void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool last, uint32_t last_valid_beats);
+void run_step(m2v_enc *e, hipStream_t s, size_t j);
+void run_step_rows(m2v_enc *e, hipStream_t s, size_t j, int r0, int r1);
+void run_step_edges_fused(m2v_enc *e, hipStream_t s, size_t j, uint8_t *up, uint8_t *down, const uint8_t *nb_up, const uint8_t *nb_down);
+void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_stream, bool advance = false);
+void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool first, bool last, uint32_t last_valid_beats,
+                  uint8_t *d_stream, bool advance = false);
+// pinned host memory of at least `bytes`, kept with the handle
+void ensure_pinned(uint8_t *&p, size_t &cap, size_t bytes);
+// every C-ABI entry runs its body through this: selects the handle's device, turns exceptions into M2V_E_* + the handle's error text
+int guard(m2v_enc *e, int (*fn)(m2v_enc *, void *), void *arg);
+
+// HIP-event timers of option "profile": events come from a pool that lives as long as the handle, and a timer
+// that starts right where the previous one stopped (same stream, nothing enqueued in between) reuses that
+// event, so a step of n back-to-back launches costs n + 1 event records and no create / destroy.
+struct Timer {
+    m2v_enc *e; hipStream_t s; int kernel; double units; hipEvent_t a = nullptr, b = nullptr;
+    Timer(m2v_enc *e_, hipStream_t s_, int k, double u) : e(e_), s(s_), kernel(k), units(u)
+    {
+        if (e->profile) {
+            if (e->chain_ev && e->chain_stream == s) a = e->chain_ev;
+            else { a = pool_event(e); HIPCHK(hipEventRecord(a, s)); }
+            e->chain_ev = nullptr;
+        }
+    }
+    void stop()
+    {
+        if (e->profile) {
+            b = pool_event(e);
+            HIPCHK(hipEventRecord(b, s));
+            e->timed.push_back(TimedLaunch{a, b, kernel, units});
+            e->chain_ev = b;
+            e->chain_stream = s;
+        }
+    }
+};
+
+// ---- m2v_launch.hip: everything that touches device code ----
+// The constant tables live in each device's copy of the code object: uploaded once per device, whichever thread creates the first
+// handle there (config c4 creates 8 handles from 8 threads).
+void upload_tables(int device);
+template <bool P> void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g);
+template <bool P> void launch_mb_edges(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g, uint8_t *up, uint8_t *down,
+                                       const uint8_t *nb_up, const uint8_t *nb_down);
+extern template void launch_mb<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &);
+extern template void launch_mb<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &);
+extern template void launch_mb_edges<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *);
+extern template void launch_mb_edges<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *);
+// start of a chunk: the bytes of the sequence that precede it are the previous chunk's prior + total (still in *ctl: one stream, in
+// order); only the padding rule needs them.  A one-thread kernel, not a host-to-device copy (a copy engine round trip in front of
+// the first kernel)
+void launch_ctl_chain(m2v_enc *e, hipStream_t s, unsigned long long cap, bool first);
+// neighbour-dependent codes + bit offsets of the slices of frames [f0, f1) of the chunk (one block per slice)
+void launch_slice_scan(m2v_enc *e, hipStream_t s, const Geom &g, int f0, int f1);
+void launch_frame_scan(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, bool advance, uint8_t *d_stream);
+void launch_assemble(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, uint8_t *d_stream);
+void launch_halo_pack(m2v_enc *e, hipStream_t s, const int *d_list, int count, uint8_t *up, uint8_t *down);
+void launch_halo_unpack(m2v_enc *e, hipStream_t s, const int *d_list, int count, const uint8_t *from_up, const uint8_t *from_down);
+// strip mode, output rank: where every (frame, rank) piece goes + the copy itself, headers and trailer (k_strip_layout, k_strip_assemble)
+void launch_strip_assemble(m2v_enc *e, hipStream_t s, const Geom &g, uint32_t gop, size_t nf, int nranks, const StripSrc &src,
+                           const unsigned long long *d_all_off, uint8_t *d_out);
+int debug_table(int which, int i, int j);
+
+}  // namespace m2v

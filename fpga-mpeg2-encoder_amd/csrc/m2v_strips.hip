@@ -1,0 +1,551 @@
+// m2v_strips.hip — strip mode (BASELINE config c5): a handle encodes the macroblock rows [row0, row1) of every
+// frame; slices are independent (RTL:2704-2715) and strips meet only in the +-2 VECTOR_LEVEL luma / +-VECTOR_LEVEL chroma rows of the
+// previous reconstruction (window geometry RTL:1446-1448), which the communicators of m2v_comm.hpp move between the GPUs.
+#include <chrono>
+#include <new>
+
+#include "m2v_host.hpp"
+#include "m2v_comm.hpp"
+
+static thread_local std::string t_comm_err;          // why the last m2v_comm_* constructor on this thread failed
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+// strip mode (BASELINE config c5): this handle encodes macroblock rows [row0,row1) of every frame
+// ---------------------------------------------------------------------------------------------
+struct StripBeginArgs { uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; int row0, row1; hipStream_t s; };
+
+static int strip_begin_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripBeginArgs *)argp;
+    if (e->state != m2v_enc::IDLE || e->strip_active || e->resident_inflight) { e->set_err("m2v_strip_begin: encoder busy"); return M2V_E_STATE; }
+    Geom g = make_geom(e, a->xs, a->ys);
+    if (a->n == 0 || a->row0 < 0 || a->row1 > g.mbh || a->row0 >= a->row1) { e->set_err("m2v_strip_begin: bad rows / no frames"); return M2V_E_PARAM; }
+    g.row0 = a->row0; g.row1 = a->row1; g.strip = 1;
+    geom_finish(g);
+    e->g = g;
+    e->pframes = a->pf & 0xFFu;
+    e->frames_total = 0;
+    e->persist_slot = -1;
+    for (auto &st : e->stats) st = KStat{};
+    e->strip_stream = a->s ? a->s : e->stream;
+    plan_chunk(e, e->strip_stream, a->d_in, a->n, true, g.ysz / 4);
+    e->strip_active = true;
+    return M2V_OK;
+}
+
+int m2v_strip_begin(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const void *d_frames444,
+                    size_t nframes, int row0, int row1, void *hip_stream)
+{
+    if (!e || !d_frames444) return M2V_E_PARAM;
+    StripBeginArgs a{xsize16, ysize16, pframes_count, (const uint8_t *)d_frames444, nframes, row0, row1, (hipStream_t)hip_stream};
+    return guard(e, strip_begin_impl, &a);
+}
+
+int m2v_strip_info(const m2v_enc *e, int *steps, size_t *halo_bytes_per_direction)
+{
+    if (!e || !e->strip_active) return M2V_E_STATE;
+    int mh = 0;
+    for (auto &st : e->plan_steps) mh = std::max(mh, st.n_h);
+    if (steps) *steps = (int)e->plan_steps.size();
+    if (halo_bytes_per_direction) *halo_bytes_per_direction = (size_t)mh * (size_t)(3 * e->VL) * (size_t)e->g.W;   // (YR + UR) * W per frame
+    return M2V_OK;
+}
+
+struct StripStepArgs { int j; uint8_t *up, *down; const uint8_t *from_up, *from_down; int part = 0; };   // part: 0 whole strip, 1 edge rows + halo pack, 2 interior rows
+
+static int strip_step_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripStepArgs *)argp;
+    if (!e->strip_active || a->j < 0 || a->j >= (int)e->plan_steps.size()) return M2V_E_STATE;
+    const m2v_enc::Step &st = e->plan_steps[a->j];
+    const int r0 = e->g.row0, r1 = e->g.row1;
+    if (a->part == 0) {
+        run_step(e, e->strip_stream, (size_t)a->j);
+    } else if (a->part == 1) {                              // the rows the neighbours need: first and last of the strip
+        run_step_rows(e, e->strip_stream, (size_t)a->j, r0, r0 + 1);
+        if (r1 - r0 >= 2) run_step_rows(e, e->strip_stream, (size_t)a->j, r1 - 1, r1);
+    } else {                                                // everything in between; no halo is packed here
+        run_step_rows(e, e->strip_stream, (size_t)a->j, r0 + 1, r1 - 1);
+        return st.n_h;
+    }
+    if (st.n_h > 0 && (a->up || a->down)) {
+        e->chain_ev = nullptr;
+        launch_halo_pack(e, e->strip_stream, e->d_lists.p + st.off_h, st.n_h, e->g.row0 > 0 ? a->up : nullptr, e->g.row1 < e->g.mbh ? a->down : nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    return st.n_h;
+}
+
+int m2v_strip_step(m2v_enc *e, int step, void *d_send_up, void *d_send_down)
+{
+    if (!e) return M2V_E_PARAM;
+    StripStepArgs a{step, (uint8_t *)d_send_up, (uint8_t *)d_send_down, nullptr, nullptr, 0};
+    return guard(e, strip_step_impl, &a);
+}
+
+int m2v_strip_step_edges(m2v_enc *e, int step, void *d_send_up, void *d_send_down)
+{
+    if (!e) return M2V_E_PARAM;
+    StripStepArgs a{step, (uint8_t *)d_send_up, (uint8_t *)d_send_down, nullptr, nullptr, 1};
+    return guard(e, strip_step_impl, &a);
+}
+
+int m2v_strip_step_interior(m2v_enc *e, int step)
+{
+    if (!e) return M2V_E_PARAM;
+    StripStepArgs a{step, nullptr, nullptr, nullptr, nullptr, 2};
+    return guard(e, strip_step_impl, &a);
+}
+
+static int strip_halo_in_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripStepArgs *)argp;
+    if (!e->strip_active || a->j < 0 || a->j >= (int)e->plan_steps.size()) return M2V_E_STATE;
+    const m2v_enc::Step &st = e->plan_steps[a->j];
+    if (st.n_h > 0 && (a->from_up || a->from_down)) {
+        e->chain_ev = nullptr;
+        launch_halo_unpack(e, e->strip_stream, e->d_lists.p + st.off_h, st.n_h, e->g.row0 > 0 ? a->from_up : nullptr,
+                           e->g.row1 < e->g.mbh ? a->from_down : nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    return M2V_OK;
+}
+
+int m2v_strip_halo_in(m2v_enc *e, int step, const void *d_from_up, const void *d_from_down)
+{
+    if (!e) return M2V_E_PARAM;
+    StripStepArgs a{step, nullptr, nullptr, (const uint8_t *)d_from_up, (const uint8_t *)d_from_down};
+    return guard(e, strip_halo_in_impl, &a);
+}
+
+// end of a strip sequence: back to the full frame
+static void strip_close(m2v_enc *e)
+{
+    e->strip_active = false;
+    Geom full = e->g; full.row0 = 0; full.row1 = full.mbh; full.strip = 0;
+    geom_finish(full);
+    e->g = full;
+}
+
+
+// scans + slice assembly of this strip into d_strip; the frame offsets stay on the device (d_frame_off) and are also
+// copied to pinned host memory behind ev_strip: NOTHING is synchronised here
+static void strip_finish_enqueue(m2v_enc *e, uint8_t *d_strip, size_t cap)
+{
+    hipStream_t s = e->strip_stream;
+    const size_t nf = e->plan_nf;
+    e->chain_ev = nullptr;
+    e->d_ctl.ensure(1);
+    launch_ctl_chain(e, s, (unsigned long long)cap, true);
+    finish_chunk(e, s, false, false, d_strip);
+    ensure_pinned(e->h_strip, e->h_strip_cap, (nf + 1) * sizeof(unsigned long long) + sizeof(StreamCtl));
+    HIPCHK(hipMemcpyAsync(e->h_strip, e->d_frame_off.p, (nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(e->h_strip + (nf + 1) * sizeof(unsigned long long), e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
+    if (!e->ev_strip) HIPCHK(hipEventCreateWithFlags(&e->ev_strip, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->ev_strip, s));
+    e->strip_nf = nf;
+    strip_close(e);
+}
+
+struct StripFinishArgs { uint8_t *d_strip; size_t cap; unsigned long long *frame_off; };
+
+static int strip_finish_async_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripFinishArgs *)argp;
+    if (!e->strip_active) return M2V_E_STATE;
+    e->d_ctl.ensure(1);
+    strip_finish_enqueue(e, a->d_strip, a->cap);
+    return M2V_OK;
+}
+
+static int strip_offsets_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripFinishArgs *)argp;
+    if (!e->ev_strip || e->strip_nf == 0) { e->set_err("m2v_strip_offsets: no finished strip"); return M2V_E_STATE; }
+    HIPCHK(hipEventSynchronize(e->ev_strip));           // the one wait of a strip sequence: its sizes are needed on the host
+    collect_timers(e);
+    memcpy(a->frame_off, e->h_strip, (e->strip_nf + 1) * sizeof(unsigned long long));
+    const StreamCtl *c = (const StreamCtl *)(e->h_strip + (e->strip_nf + 1) * sizeof(unsigned long long));
+    if (c->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
+    return M2V_OK;
+}
+
+int m2v_strip_finish_async(m2v_enc *e, void *d_strip, size_t cap)
+{
+    if (!e || !d_strip) return M2V_E_PARAM;
+    StripFinishArgs a{(uint8_t *)d_strip, cap, nullptr};
+    return guard(e, strip_finish_async_impl, &a);
+}
+
+int m2v_strip_offsets(m2v_enc *e, unsigned long long *frame_off)
+{
+    if (!e || !frame_off) return M2V_E_PARAM;
+    StripFinishArgs a{nullptr, 0, frame_off};
+    return guard(e, strip_offsets_impl, &a);
+}
+
+int m2v_strip_finish(m2v_enc *e, void *d_strip, size_t cap, unsigned long long *frame_off)
+{
+    const int r = m2v_strip_finish_async(e, d_strip, cap);
+    return r < 0 ? r : m2v_strip_offsets(e, frame_off);
+}
+
+// headers + strips of all ranks -> the final stream.  d_all_off: [nranks][nf + 1] frame offsets in DEVICE memory; the layout
+// is computed there (k_strip_layout), the byte count comes back through the control word.
+static void strip_assemble_enqueue(m2v_enc *e, hipStream_t s, const Geom &g, uint32_t pf, size_t nf, int nranks, const void *const *strips,
+                                   const unsigned long long *d_all_off, uint8_t *d_out, size_t cap)
+{
+    const uint32_t gop = (pf & 0xFFu) + 1u;
+    const size_t nsegs = nf * (size_t)nranks;
+    e->d_segs.ensure(nsegs * sizeof(CopySeg) + 16);
+    e->d_frame_pos.ensure(nf + 1);
+    e->d_ctl.ensure(1);
+    StripSrc src{};
+    for (int r = 0; r < nranks; ++r) src.strip[r] = (const uint8_t *)strips[r];
+    e->chain_ev = nullptr;
+    launch_ctl_chain(e, s, (unsigned long long)cap, true);
+    Timer t(e, s, 2, (double)nf * g.ysz);
+    launch_strip_assemble(e, s, g, gop, nf, nranks, src, d_all_off, d_out);
+    HIPCHK(hipGetLastError());
+    t.stop();
+}
+
+struct StripAsmArgs { uint32_t xs, ys, pf; size_t n; int nranks; const void *const *strips; const unsigned long long *const *offs;
+                      uint8_t *d_out; size_t cap; size_t *bytes; hipStream_t s; };
+
+static int strip_assemble_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripAsmArgs *)argp;
+    if (e->strip_active || e->resident_inflight || e->state != m2v_enc::IDLE) { e->set_err("m2v_strip_assemble: encoder busy"); return M2V_E_STATE; }
+    if (((uintptr_t)a->d_out & 15u) != 0) { e->set_err("m2v_strip_assemble: d_out must be 16-byte aligned"); return M2V_E_PARAM; }
+    if (a->nranks > kMaxStripRanks) { e->set_err("m2v_strip_assemble: at most %d strips", kMaxStripRanks); return M2V_E_PARAM; }
+    for (int r = 0; r < a->nranks; ++r)
+        if (((uintptr_t)a->strips[r] & 3u) != 0) { e->set_err("m2v_strip_assemble: d_strips[%d] must be 4-byte aligned", r); return M2V_E_PARAM; }
+    hipStream_t s = a->s ? a->s : e->stream;
+    const Geom g = make_geom(e, a->xs, a->ys);
+    const uint32_t gop = (a->pf & 0xFFu) + 1u;
+    const size_t nf = a->n;
+    // the byte count is known on the host (the caller holds the offsets): same arithmetic as k_strip_layout
+    unsigned long long pos = kSeqHeaderBytes;
+    for (size_t f = 0; f < nf; ++f) {
+        pos += (f % gop) == 0 ? kGopHeaderBytes + 17u : 18u;
+        for (int r = 0; r < a->nranks; ++r) pos += a->offs[r][f + 1] - a->offs[r][f];
+    }
+    const unsigned long long total = ((pos + 4) / 32ull + 1ull) * 32ull;       // end code + final word rule (RTL:2932-2937)
+    if (total > a->cap) { e->set_err("output buffer too small"); return M2V_E_OVERFLOW; }
+    // The offsets go up from ONE pinned staging block with an asynchronous copy on the caller's stream: the call neither blocks
+    // on a pageable copy nor synchronises the stream.  The staging is rewritten by the next call only after this call's
+    // copy has been consumed (ev_asm).
+    const size_t b_off = (size_t)a->nranks * (nf + 1) * sizeof(unsigned long long);
+    if (!e->ev_asm) HIPCHK(hipEventCreateWithFlags(&e->ev_asm, hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(e->ev_asm));
+    ensure_pinned(e->h_asm, e->h_asm_cap, b_off);
+    for (int r = 0; r < a->nranks; ++r) memcpy(e->h_asm + (size_t)r * (nf + 1) * sizeof(unsigned long long), a->offs[r], (nf + 1) * sizeof(unsigned long long));
+    e->d_alloff.ensure((size_t)a->nranks * (nf + 1));
+    HIPCHK(hipMemcpyAsync(e->d_alloff.p, e->h_asm, b_off, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(e->ev_asm, s));
+    strip_assemble_enqueue(e, s, g, a->pf, nf, a->nranks, a->strips, e->d_alloff.p, a->d_out, a->cap);
+    if (a->bytes) *a->bytes = (size_t)total;            // known on the host: the stream is NOT synchronised here
+    return M2V_OK;
+}
+
+int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, size_t nframes, int nranks,
+                       const void *const *d_strips, const unsigned long long *const *frame_off, void *d_out, size_t cap,
+                       size_t *out_bytes, void *hip_stream)
+{
+    if (!e || !d_strips || !frame_off || !d_out || nranks < 1 || nframes == 0) return M2V_E_PARAM;
+    StripAsmArgs a{xsize16, ysize16, pframes_count, nframes, nranks, d_strips, frame_off, (uint8_t *)d_out, cap, out_bytes,
+                   (hipStream_t)hip_stream};
+    return guard(e, strip_assemble_impl, &a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// m2v_strip_encode: one call = one strip of one sequence, start to finish, with the exchange inside (no interpreter between
+// the GOP steps).  Per step:   edge rows + halo pack  (main stream)  -> event
+//                              send / recv with the two neighbours (comm stream, behind the event)     -> event
+//                              interior rows          (main stream, runs while the halo crosses xGMI)
+//                              neighbour rows into the reconstruction buffers (main stream, behind the comm event)
+// then the strip's slices, one all-gather of the per-frame sizes, the strips to the output rank, the final assembly there.
+// ---------------------------------------------------------------------------------------------
+struct StripEncodeArgs { m2v_comm *comm; int rank, world, dst; uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; uint8_t *d_out; size_t cap;
+                         size_t *bytes; hipStream_t s; };
+
+static int strip_encode_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripEncodeArgs *)argp;
+    using clk = std::chrono::steady_clock;
+    const int rank = a->rank, world = a->world;
+    const Geom full = make_geom(e, a->xs, a->ys);
+    if (world < 1 || world > kMaxStripRanks || world > full.mbh || rank < 0 || rank >= world || a->dst < 0 || a->dst >= world ||
+        (world > 1 && (!a->comm || a->comm->world != world))) {
+        e->set_err("m2v_strip_encode: bad rank / world / communicator");
+        return M2V_E_PARAM;
+    }
+    if (rank == a->dst && !a->d_out) { e->set_err("m2v_strip_encode: the output rank needs d_out"); return M2V_E_PARAM; }     // before anything collective
+    if (rank == a->dst && ((uintptr_t)a->d_out & 15u) != 0) { e->set_err("m2v_strip_encode: d_out must be 16-byte aligned"); return M2V_E_PARAM; }
+    // contiguous strips, sizes differing by at most one row, the first mbh % world ranks get the extra row (parallel.partition_rows)
+    const int base = full.mbh / world, rem = full.mbh % world;
+    const int row0 = rank * base + std::min(rank, rem), row1 = row0 + base + (rank < rem ? 1 : 0);
+    StripBeginArgs b{a->xs, a->ys, a->pf, a->d_in, a->n, row0, row1, a->s};
+    int r = strip_begin_impl(e, &b);
+    if (r < 0) return r;
+    hipStream_t s = e->strip_stream;
+    const Geom &g = e->g;
+    const size_t nf = e->plan_nf;
+    int mh = 0;
+    for (auto &st : e->plan_steps) mh = std::max(mh, st.n_h);
+    const size_t halo_cap = (size_t)mh * (size_t)(3 * e->VL) * (size_t)g.W;
+    e->d_halo.ensure(4 * halo_cap + 64);
+    uint8_t *send_up = e->d_halo.p, *send_down = send_up + halo_cap, *recv_up = send_down + halo_cap, *recv_down = recv_up + halo_cap;
+    const bool fused = !e->conformant && e->dct_mfma && !e->keep_recon;
+    if (world > 1) {
+        // (the general form's exchange stream only when that form runs: every stream a process creates moves the others around the
+        // handful of hardware queues)
+        if (!fused && !e->comm_stream) HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+        if (!e->ev_edges) HIPCHK(hipEventCreateWithFlags(&e->ev_edges, hipEventDisableTiming));
+        if (!e->ev_halo) HIPCHK(hipEventCreateWithFlags(&e->ev_halo, hipEventDisableTiming));
+    }
+    // profile: GPU events around the exchange of every step: halo_total = edge rows (and their halo) written .. neighbour rows and
+    // interior rows both there; halo_exposed = how much of that came after the interior rows were done
+    std::vector<hipEvent_t> marks;
+    auto mark = [&](hipStream_t on) {
+        if (!e->profile) return;
+        hipEvent_t ev = pool_event(e);
+        e->chain_ev = nullptr;
+        HIPCHK(hipEventRecord(ev, on));
+        marks.push_back(ev);
+    };
+    const bool up = row0 > 0, down = row1 < g.mbh;
+    // The edge rows run as ONE launch of the instantiation that also fills the halo buffers (no pack kernel), the interior rows at
+    // the same time on a second stream: a strip of an 8-GPU job is ~20 000 wavefronts per step, 2.5 rounds of the wave slots -
+    // edge rows first and alone would hold the whole GPU for one macroblock lifetime at a third of its slots.
+    hipStream_t side = nullptr;
+    if (world > 1) {
+        if (!e->side[0]) HIPCHK(hipStreamCreateWithFlags(&e->side[0], hipStreamNonBlocking));
+        side = e->side[0];
+        if (!e->ev_done) HIPCHK(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+        if (!e->ev_interior) HIPCHK(hipEventCreateWithFlags(&e->ev_interior, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(e->ev_done, s));                  // the plan's uploads
+    }
+    double us_in_comm = 0;                 // host time inside the communicator (a local communicator blocks there until the neighbour thread has posted)
+    const auto t_loop = clk::now();
+    for (int j = 0; j < (int)e->plan_steps.size(); ++j) {
+        const int n_h = e->plan_steps[(size_t)j].n_h;
+        const bool xchg = world > 1 && n_h > 0 && (up || down);
+        const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)g.W;
+        if (world > 1 && fused) {
+            // main stream:  EDGE(j) [reads the rows received in step j-1, writes the rows to send] -> send / recv(j)
+            // side stream:  interior(j)
+            // EDGE(j) and interior(j) both need ALL of step j-1 on this strip; the neighbours' rows only EDGE(j) - and it follows
+            // the receive in stream order.  Two launches, two event records, two waits and one exchange per step.
+            HIPCHK(hipStreamWaitEvent(side, j == 0 ? e->ev_done : e->ev_edges, 0));
+            if (j > 0) HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));
+            run_step_edges_fused(e, s, (size_t)j, xchg && up ? send_up : nullptr, xchg && down ? send_down : nullptr,
+                                 up ? recv_up : nullptr, down ? recv_down : nullptr);
+            mark(s);
+            HIPCHK(hipEventRecord(e->ev_edges, s));
+            run_step_rows(e, side, (size_t)j, row0 + 1, row1 - 1);
+            mark(side);
+            HIPCHK(hipEventRecord(e->ev_interior, side));
+            if (xchg) {
+                const auto t_c = clk::now();
+                a->comm->halo(rank, up ? send_up : nullptr, up ? recv_up : nullptr, down ? send_down : nullptr, down ? recv_down : nullptr, nbytes, s);
+                us_in_comm += std::chrono::duration<double, std::micro>(clk::now() - t_c).count();
+            }
+            mark(s);
+            if (j + 1 == (int)e->plan_steps.size()) HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));      // the scans follow on the main stream
+            continue;
+        }
+        if (xchg) {
+            // the general form (option conformant / dct_mfma = 0 / the debug library's keep_recon): edge rows, pack kernel, exchange
+            // on a stream of its own beside the interior rows, unpack kernel
+            HIPCHK(hipStreamWaitEvent(side, e->ev_done, 0));    // the previous step, neighbour rows included
+            StripStepArgs sa{j, send_up, send_down, nullptr, nullptr, 1};
+            if ((r = strip_step_impl(e, &sa)) < 0) return r;
+            mark(s);
+            HIPCHK(hipEventRecord(e->ev_edges, s));
+            run_step_rows(e, side, (size_t)j, row0 + 1, row1 - 1);
+            mark(side);
+            HIPCHK(hipEventRecord(e->ev_interior, side));
+            HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_edges, 0));
+            const auto t_c = clk::now();
+            a->comm->halo(rank, up ? send_up : nullptr, up ? recv_up : nullptr, down ? send_down : nullptr, down ? recv_down : nullptr, nbytes,
+                          e->comm_stream);
+            us_in_comm += std::chrono::duration<double, std::micro>(clk::now() - t_c).count();
+            HIPCHK(hipEventRecord(e->ev_halo, e->comm_stream));
+            HIPCHK(hipStreamWaitEvent(s, e->ev_halo, 0));
+            HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));
+            mark(s);
+            StripStepArgs sh{j, nullptr, nullptr, up ? recv_up : nullptr, down ? recv_down : nullptr};
+            if ((r = strip_halo_in_impl(e, &sh)) < 0) return r;
+        } else {
+            StripStepArgs sa{j, nullptr, nullptr, nullptr, nullptr, 0};
+            if ((r = strip_step_impl(e, &sa)) < 0) return r;
+        }
+        if (world > 1) HIPCHK(hipEventRecord(e->ev_done, s));
+    }
+    e->strip_stats.steps = (int)e->plan_steps.size();
+    e->strip_stats.host_us_per_step = std::chrono::duration<double, std::micro>(clk::now() - t_loop).count() / std::max<size_t>(1, e->plan_steps.size());
+    e->strip_stats.comm_us_per_step = us_in_comm / std::max<size_t>(1, e->plan_steps.size());
+    hipEvent_t g0 = nullptr, g1 = nullptr;
+
+    // ---- this strip's slices; sizes; strips to the output rank; final assembly ----
+    const size_t strip_cap = nf * ((size_t)(row1 - row0) * g.mbw * 1216 + (size_t)(row1 - row0) * 8 + 64) + 256;     // worst case
+    e->d_strip_own.ensure(strip_cap);
+    const Geom gfull = full;
+    strip_finish_enqueue(e, e->d_strip_own.p, strip_cap);       // also closes the strip sequence
+    if (e->profile) { g0 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g0, s)); }     // from here: sizes, gather, final assembly
+    const void *strips[kMaxStripRanks] = {};
+    const unsigned long long *d_all = e->d_frame_off.p;
+    if (world > 1) {
+        e->d_alloff.ensure((size_t)world * (nf + 1));
+        a->comm->allgather_u64(rank, e->d_frame_off.p, e->d_alloff.p, nf + 1, s);
+        ensure_pinned(e->h_asm, e->h_asm_cap, (size_t)world * (nf + 1) * sizeof(unsigned long long));
+        HIPCHK(hipMemcpyAsync(e->h_asm, e->d_alloff.p, (size_t)world * (nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));                        // the sizes decide the receive counts: the one host wait
+        // (an overflow of this strip's buffer - impossible with the worst-case size above - is reported at the end: the other ranks
+        // are waiting in the gather, and a rank that left now would leave them there)
+        size_t sizes[kMaxStripRanks] = {}, total_in = 0;
+        for (int k = 0; k < world; ++k) {
+            sizes[k] = (size_t)((const unsigned long long *)e->h_asm)[(size_t)k * (nf + 1) + nf];
+            if (k != a->dst) total_in += (sizes[k] + 255) & ~(size_t)255;
+        }
+        void *bufs[kMaxStripRanks] = {};
+        if (rank == a->dst) {
+            e->d_gather.ensure(total_in + 256);
+            size_t off = 0;
+            for (int k = 0; k < world; ++k) {
+                if (k == a->dst) { strips[k] = e->d_strip_own.p; continue; }
+                bufs[k] = e->d_gather.p + off;
+                strips[k] = bufs[k];
+                off += (sizes[k] + 255) & ~(size_t)255;
+            }
+        }
+        a->comm->gather(rank, a->dst, e->d_strip_own.p, sizes, bufs, s);
+        d_all = e->d_alloff.p;
+    } else {
+        strips[0] = e->d_strip_own.p;
+    }
+    size_t out_bytes = 0;
+    if (rank == a->dst) {
+        strip_assemble_enqueue(e, s, gfull, a->pf, nf, world, strips, d_all, a->d_out, a->cap);
+        if (e->profile) { g1 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g1, s)); }
+        if (!e->st().h_ctl) HIPCHK(hipHostMalloc((void **)&e->st().h_ctl, 2 * sizeof(StreamCtl)));
+        HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
+    } else if (e->profile) { g1 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g1, s)); }
+    HIPCHK(hipStreamSynchronize(s));
+    {
+        const StreamCtl *c = (const StreamCtl *)(e->h_strip + (nf + 1) * sizeof(unsigned long long));
+        if (c->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
+    }
+    if (rank == a->dst) {
+        if (e->st().h_ctl->overflow) { e->set_err("output buffer too small"); return M2V_E_OVERFLOW; }
+        out_bytes = (size_t)e->st().h_ctl->total_bytes;
+    }
+    if (e->profile) {
+        double tot = 0, exp = 0;
+        for (size_t k = 0; k + 3 <= marks.size(); k += 3) {       // per step: edges done (main), interior done (side), both + halo there (main)
+            float m1 = 0, m2 = 0;
+            if (hipEventElapsedTime(&m1, marks[k], marks[k + 2]) == hipSuccess) tot += m1;
+            if (hipEventElapsedTime(&m2, marks[k + 1], marks[k + 2]) == hipSuccess && m2 > 0) exp += m2;
+        }
+        float gm = 0;
+        if (g0 && g1 && hipEventElapsedTime(&gm, g0, g1) == hipSuccess) e->strip_stats.gather_ms = gm;
+        e->strip_stats.halo_total_ms = tot;
+        e->strip_stats.halo_exposed_ms = exp;
+    }
+    collect_timers(e);
+    if (a->bytes) *a->bytes = out_bytes;
+    return M2V_OK;
+}
+
+int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_rank, uint32_t xsize16, uint32_t ysize16,
+                     uint32_t pframes_count, const void *d_frames444, size_t nframes, void *d_out, size_t cap, size_t *out_bytes,
+                     void *hip_stream)
+{
+    if (!e || !d_frames444 || nframes == 0) return M2V_E_PARAM;
+    StripEncodeArgs a{comm, rank, world, dst_rank, xsize16, ysize16, pframes_count, (const uint8_t *)d_frames444, nframes, (uint8_t *)d_out, cap,
+                      out_bytes, (hipStream_t)hip_stream};
+    const int r = guard(e, strip_encode_impl, &a);
+    if (r < 0 && e->strip_active) strip_close(e);            // a failed sequence does not leave the handle in strip mode
+    if (r < 0 && comm) comm->abort();                         // ... and the other ranks of an in-process communicator do not wait for it for ever
+    return r;
+}
+
+int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_exposed_ms, double *gather_ms, double *host_us_per_step,
+                    double *comm_us_per_step)
+{
+    if (!e) return M2V_E_PARAM;
+    if (comm_us_per_step) *comm_us_per_step = e->strip_stats.comm_us_per_step;
+    if (halo_total_ms) *halo_total_ms = e->strip_stats.halo_total_ms;
+    if (halo_exposed_ms) *halo_exposed_ms = e->strip_stats.halo_exposed_ms;
+    if (gather_ms) *gather_ms = e->strip_stats.gather_ms;
+    if (host_us_per_step) *host_us_per_step = e->strip_stats.host_us_per_step;
+    return e->strip_stats.steps;
+}
+
+// ---- communicators (m2v_comm.hpp) ----
+
+int m2v_comm_unique_id(void *id, size_t cap)
+{
+    if (!id || cap < sizeof(ncclUniqueId)) return M2V_E_PARAM;
+    RcclApi &api = RcclApi::get();
+    if (!api.ok()) { t_comm_err = api.err; return M2V_E_NODEVICE; }
+    ncclUniqueId u;
+    const ncclResult_t r = api.GetUniqueId(&u);
+    if (r != ncclSuccess) { t_comm_err = std::string("ncclGetUniqueId: ") + api.GetErrorString(r); return M2V_E_HIP; }
+    memcpy(id, &u, sizeof u);
+    return (int)sizeof u;
+}
+
+m2v_comm *m2v_comm_init_rccl(const void *id, int rank, int world, int device, int *err)
+{
+    auto fail = [&](int code, const std::string &why) -> m2v_comm * { t_comm_err = why; if (err) *err = code; return nullptr; };
+    if (!id || world < 1 || world > kMaxStripRanks || rank < 0 || rank >= world) return fail(M2V_E_PARAM, "m2v_comm_init_rccl: bad rank / world");
+    if (hipSetDevice(device) != hipSuccess) return fail(M2V_E_NODEVICE, "m2v_comm_init_rccl: device ordinal out of range");
+    try {
+        ncclUniqueId u;
+        memcpy(&u, id, sizeof u);
+        m2v_comm *c = new RcclComm(u, rank, world);
+        if (err) *err = M2V_OK;
+        return c;
+    } catch (const std::exception &ex) {
+        return fail(M2V_E_HIP, ex.what());
+    }
+}
+
+m2v_comm *m2v_comm_init_solo(int world, int *err)
+{
+    if (world < 1 || world > kMaxStripRanks) { t_comm_err = "m2v_comm_init_solo: 1..16 ranks"; if (err) *err = M2V_E_PARAM; return nullptr; }
+    m2v_comm *c = new (std::nothrow) SoloComm(world);
+    if (err) *err = c ? M2V_OK : M2V_E_NOMEM;
+    return c;
+}
+
+m2v_comm *m2v_comm_init_local(int world, int *err)
+{
+    if (world < 1 || world > LocalComm::kMax) { t_comm_err = "m2v_comm_init_local: 1..16 ranks"; if (err) *err = M2V_E_PARAM; return nullptr; }
+    m2v_comm *c = new (std::nothrow) LocalComm(world);
+    if (err) *err = c ? M2V_OK : M2V_E_NOMEM;
+    return c;
+}
+
+void m2v_comm_destroy(m2v_comm *c) { delete c; }
+
+int m2v_comm_selftest(m2v_comm *c, int rank, const void *d_send, void *d_recv, size_t nbytes, void *hip_stream)
+{
+    if (!c || !d_send || !d_recv) return M2V_E_PARAM;
+    try {
+        c->loopback(rank, d_send, d_recv, nbytes, (hipStream_t)hip_stream);
+        return M2V_OK;
+    } catch (const std::exception &ex) {
+        t_comm_err = ex.what();
+        return M2V_E_HIP;
+    }
+}
+
+const char *m2v_comm_last_error(void) { return t_comm_err.c_str(); }
+
+}  // extern "C"

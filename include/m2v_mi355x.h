@@ -117,8 +117,9 @@ int m2v_encode_resident(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t
  * The same in two halves, for callers that keep more than one sequence in flight (several handles, each with its own work
  * buffers and streams: the stream assembly of one sequence then runs beside the first macroblock kernels of the next instead of
  * leaving the GPU to drain).  _begin enqueues the whole sequence on `hip_stream` and returns without waiting; _end waits for that
- * stream and hands out the byte count.  Between the two the handle accepts no other call but m2v_reset / m2v_destroy, and the
- * input and output buffers belong to the encoder.  (A sequence longer than "batch_frames" is still encoded chunk by chunk, with a
+ * stream and hands out the byte count.  Between the two the handle accepts no other call but m2v_reset / m2v_destroy (both wait
+ * for the sequence first, on whichever stream it was given; everything else answers M2V_E_STATE), and the input and output buffers
+ * belong to the encoder.  (A sequence longer than "batch_frames" is still encoded chunk by chunk, with a
  * wait between the chunks inside _begin.)
  */
 int m2v_encode_resident_begin(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
@@ -149,6 +150,9 @@ int m2v_encode_resident_end(m2v_enc *e, size_t *out_bytes);
  *                                                *out_bytes is valid at return, the bytes in stream order)
  * Everything is enqueued on the stream given to m2v_strip_begin (NULL = the handle's own stream).
  * Buffers are device pointers except frame_off (host).
+ * Alignment (m2v_strip_assemble and the output rank of m2v_strip_encode move the strips with 16-byte stores and read them as
+ * aligned dwords): d_out 16-byte aligned, every d_strips[r] 4-byte aligned with a capacity that is a multiple of 4 (the dword
+ * that holds a strip's last byte is read whole); M2V_E_PARAM otherwise.  hipMalloc'ed buffers satisfy both.
  */
 int m2v_strip_begin(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
                     const void *d_frames444, size_t nframes, int row0, int row1, void *hip_stream);

@@ -56,3 +56,41 @@ def test_a_dying_rank_takes_the_job_down():
     """rank 1 fails before the rendezvous: the parent reports a non-zero code instead of waiting for ever"""
     r, lines = run(["--gpus", "2", "--dry-launch"], {"M2V_DIST_BACKEND": "gloo", "M2V_BENCH_TEST_FAIL_RANK": "1"}, timeout=120)
     assert r.returncode != 0
+
+
+def _alive(pid):
+    try:
+        with open("/proc/%d/stat" % pid) as f:
+            return f.read().rsplit(")", 1)[1].split()[0] != "Z"      # a zombie nobody has reaped yet is not running
+    except OSError:
+        return False
+
+
+def test_a_rank_that_ignores_sigterm_is_killed(tmp_path):
+    """rank 1 fails, rank 0 is stuck (as in a collective the failed rank never joins) and ignores SIGTERM: the launcher escalates
+    to SIGKILL instead of looping for ever (round-3 advisor), and the stuck process is really gone afterwards"""
+    pidfile = str(tmp_path / "deaf.pid")
+    r, _ = run(["--gpus", "2", "--dry-launch"], {"M2V_DIST_BACKEND": "gloo", "M2V_BENCH_TEST_FAIL_RANK": "1", "M2V_BENCH_TEST_DEAF_RANK": "0",
+                                                 "M2V_BENCH_TEST_PIDFILE": pidfile, "M2V_BENCH_GRACE": "2,2"}, timeout=120)
+    assert r.returncode != 0
+    assert not _alive(int(open(pidfile).read()))
+
+
+def test_terminating_the_launcher_ends_its_ranks(tmp_path):
+    """SIGTERM to `bench.py --gpus 2` itself: no rank is left behind holding a GPU"""
+    import signal
+    import time
+    pidfile = str(tmp_path / "deaf.pid")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"M2V_DIST_BACKEND": "gloo", "M2V_BENCH_TEST_DEAF_RANK": "1", "M2V_BENCH_TEST_PIDFILE": pidfile, "M2V_BENCH_GRACE": "2,2"})
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env, cwd=ROOT,
+                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    t0 = time.time()
+    while not os.path.exists(pidfile) and time.time() - t0 < 90:
+        time.sleep(0.1)
+    assert os.path.exists(pidfile), "the ranks never started"
+    time.sleep(0.3)
+    pid = int(open(pidfile).read())
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) != 0
+    assert not _alive(pid)

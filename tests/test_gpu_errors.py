@@ -244,3 +244,45 @@ def test_resident_begin_end_two_handles_taking_turns():
     finally:
         for e in encs:
             e.close()
+
+
+def test_destroy_and_reset_wait_for_a_sequence_on_a_caller_stream():
+    """m2v_encode_resident_begin on a CALLER's stream: the scans, the assembly and the control read-back are queued there, not on the
+    handle's stream.  m2v_reset must wait for them before the next call rewrites the work buffers, m2v_destroy before it frees them
+    (round-3 advisor).  A long clip keeps the GPU busy for milliseconds after _begin returns; the stream of the sequence enqueued
+    right after the reset is the oracle's, and destroying a handle in flight leaves the process and the GPU in working order."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    big = M.synth.clip(640, 480, 36, clip_index=150)
+    small = M.synth.clip(96, 64, 4, clip_index=151)
+    want_small = orc.encode(small, 6, 4, 3, 6, 6, 3, 2)
+    d_big = torch.from_numpy(np.ascontiguousarray(big)).to("cuda:0")
+    d_small = torch.from_numpy(np.ascontiguousarray(small)).to("cuda:0")
+    d_out = torch.zeros(8 << 20, dtype=torch.uint8, device="cuda:0")
+    mine = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    enc = M.Mpeg2Encoder(6, 6, 3, 2)
+    L = enc._L
+    try:
+        enc.encode_resident_begin(d_big.data_ptr(), 36, d_out.data_ptr(), d_out.numel(), 40, 30, 8, stream=mine.cuda_stream)
+        assert L.m2v_set_option(enc._h, b"split_streams", 1) == -4         # planned with the current options: not while in flight
+        assert L.m2v_reset(enc._h) == 0
+        assert mine.query(), "m2v_reset returned while the sequence was still running on the caller's stream"
+        n = enc.encode_resident(d_small.data_ptr(), 4, d_out.data_ptr(), d_out.numel(), 6, 4, 3)
+        assert d_out[:n].cpu().numpy().tobytes() == want_small
+        # a stray _end after a SYNCHRONOUS empty sequence has nothing to answer
+        assert enc.encode_resident(d_small.data_ptr(), 0, d_out.data_ptr(), d_out.numel(), 6, 4, 3) == 0
+        assert L.m2v_encode_resident_end(enc._h, None) == -4
+        enc.encode_resident_begin(d_big.data_ptr(), 36, d_out.data_ptr(), d_out.numel(), 40, 30, 8, stream=mine.cuda_stream)
+    finally:
+        enc.close()                                                         # m2v_destroy with the sequence in flight
+    assert mine.query(), "m2v_destroy returned while the sequence was still running on the caller's stream"
+    torch.cuda.synchronize()
+    enc = M.Mpeg2Encoder(6, 6, 3, 2)
+    try:
+        n = enc.encode_resident(d_small.data_ptr(), 4, d_out.data_ptr(), d_out.numel(), 6, 4, 3)
+        assert d_out[:n].cpu().numpy().tobytes() == want_small
+    finally:
+        enc.close()

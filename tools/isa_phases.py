@@ -13,9 +13,9 @@ SRC = os.path.join(ROOT, "fpga-mpeg2-encoder_amd", "csrc")
 want = sys.argv[1] if len(sys.argv) > 1 else "k_mbILi3ELb1"
 tmp = tempfile.mkdtemp()
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fwrapv", "-fPIC",
-                       "-gline-tables-only", "-c", os.path.join(SRC, "m2v_mi355x.hip"), "-save-temps", "-o", "x.o"],
+                       "-gline-tables-only", "-c", os.path.join(SRC, "m2v_launch.hip"), "-save-temps", "-o", "x.o"],
                       cwd=tmp, stderr=subprocess.DEVNULL)
-s = open(os.path.join(tmp, "m2v_mi355x-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+s = open(os.path.join(tmp, "m2v_launch-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 name = [m for m in re.findall(r"^(_Z\w+):", s, re.M) if want in m][0]
 i = s.index(name + ":")
 body = s[i:s.index("s_endpgm", i)].split("\n")
