@@ -348,6 +348,8 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    graph_stats = enc.strip_graph_stats() if loop == "native" else None      # the timed steps: one recorded hipGraph launch each?
+    host_us_timed = enc.strip_stats().get("host_us_per_step") if loop == "native" else None
     # one more pass with per-launch HIP events (option profile) and the exchange bracketed by events on the engine's stream
     enc.set_option("profile", 1)
     timings = {}
@@ -385,6 +387,7 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
                        "stream_bytes": int(out.numel()) if out is not None else None,
                        "baseline": "FPGA Kintex-7 268 MPixels/s (README.md:22)",
                        "strip_loop": loop, "strip_loop_why": why, "dist_backend": backend,
+                       "strip_graph": graph_stats,
                        "launched_by": os.environ.get("M2V_BENCH_LAUNCHED_BY", "caller")},
             "roofline": {"bound": "hbm", "kernel": "k_mb<3,true> on rank 0's strip (%d macroblock rows), P-frame launches of one step" % (rows[1] - rows[0]),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -394,6 +397,7 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
             "exchange_ms_per_step": {"halo_exposed": round(timings.get("halo_exposed", 0.0), 3), "halo_total": round(timings.get("halo_total", 0.0), 3),
                                      "gather_and_assembly": round(timings.get("gather", 0.0), 3),
                                      "host_us_per_gop_step": round(host_us, 1) if host_us is not None else None,
+                                     "host_us_per_gop_step_in_the_timed_steps": round(host_us_timed, 1) if host_us_timed is not None else None,
                                      "host_us_per_gop_step_outside_the_communicator": round(host_out, 1) if host_out is not None else None,
                                      "note": "max over ranks; halo_exposed = stream time spent waiting for neighbour rows after the "
                                              "interior rows were done, halo_total = from edge rows packed to neighbour rows there"},
@@ -715,6 +719,24 @@ def main():
     pixels_per_step = nframes * W * H
     value = world * args.steps * pixels_per_step / dt * 1e-6
 
+    rank_parity = None
+    if world > 1:
+        # N > 1: every rank checks the first GOP of ITS sequence (its own seed) against the oracle - a few seconds of CPU per rank,
+        # after the timed regions - and the ranks agree on the verdict.  (The whole-stream check of all GOPs is the N = 1 line's.)
+        from oracle import m2v_oracle_ctypes as orc
+        if rank == 0:
+            orc.build()
+        dist.barrier()
+        mine = d_out[:nbytes].cpu().numpy().tobytes()
+        ref = orc.encode(clip[:gop].cpu().numpy(), XS16, YS16, PFRAMES, XL, YL, VL, Q)
+        head, gops, _ = split_gops(mine)
+        rhead, rgops, _ = split_gops(ref)
+        ok = int(len(gops) == args.gops and head == rhead and len(rgops) == 1 and gops[0] == rgops[0])
+        t = torch.tensor([ok], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        rank_parity = {"ranks_checked": world, "gops_compared_per_rank": 1, "identical_to_oracle": bool(int(t.item())),
+                       "note": "every rank: sequence headers + first GOP of its own sequence against oracle/m2v_oracle.c"}
+
     if rank == 0:
         # dominant kernel: k_mb<3,true> (P-frame macroblock kernel); for the I-only config c2 it is k_mb<1,false>.
         # Statistics of the LAST step.
@@ -784,6 +806,8 @@ def main():
                                   "note": "256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz; the macroblock kernel is VALU-issue bound "
                                           "(VALUBusy 100 %), the SADs are ~21 % of its VALU cycles at 66 % lane efficiency"}
         out["roofline"]["timed_in"] = "profiled_pass (one stream, HIP events around every launch on the launch stream)"
+        if rank_parity is not None:
+            out["parity_check"] = rank_parity
         if world == 1 and not args.no_cpu_baseline:
             clip_np = clip.cpu().numpy()
             gpu_bytes = d_out[:nbytes].cpu().numpy().tobytes()

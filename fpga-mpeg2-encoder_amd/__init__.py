@@ -34,6 +34,7 @@ EXPORTS = [
     "m2v_strip_begin", "m2v_strip_info", "m2v_strip_step", "m2v_strip_step_edges", "m2v_strip_step_interior", "m2v_strip_halo_in", "m2v_strip_finish", "m2v_strip_assemble",
     "m2v_strip_finish_async", "m2v_strip_offsets", "m2v_strip_encode", "m2v_strip_stats",
     "m2v_comm_unique_id", "m2v_comm_init_rccl", "m2v_comm_init_local", "m2v_comm_init_solo", "m2v_comm_destroy", "m2v_comm_last_error", "m2v_comm_selftest",
+    "m2v_comm_init_solo_rccl", "m2v_comm_selftest_captured", "m2v_strip_graph_stats",
 ]
 
 
@@ -105,6 +106,11 @@ def lib(debug=False):
             L.m2v_comm_destroy.argtypes = [vp]
             L.m2v_comm_last_error.restype = ctypes.c_char_p
             L.m2v_comm_selftest.argtypes = [vp, ci, vp, vp, sz, vp]
+            L.m2v_comm_init_solo_rccl.restype = vp
+            L.m2v_comm_init_solo_rccl.argtypes = [ci, ctypes.POINTER(ci)]
+            L.m2v_comm_selftest_captured.argtypes = [vp, ci, vp, vp, sz, vp, ci]
+            ip = ctypes.POINTER(ci)
+            L.m2v_strip_graph_stats.argtypes = [vp, ip, ip, ip]
         except AttributeError:
             # an OLDER build handed in through M2V_LIB for a same-box A/B (tools/ab.sh) may lack the newer entry points; the library of
             # this tree must have every one of them (tests/test_abi.py)
@@ -291,6 +297,13 @@ class Mpeg2Encoder:
         return {"steps": steps, "halo_total": v[0].value, "halo_exposed": v[1].value, "gather": v[2].value, "host_us_per_step": v[3].value,
                 "comm_us_per_step": v[4].value, "host_us_per_step_outside_comm": v[3].value - v[4].value}
 
+    def strip_graph_stats(self):
+        """-> dict: was the last strip_encode launched as a recorded hipGraph, how many recordings / launches so far, and whether
+        recording has failed on this handle (the sequence is then enqueued call by call)"""
+        v = [ctypes.c_int(0) for _ in range(3)]
+        broken = self._chk(self._L.m2v_strip_graph_stats(self._h, *[ctypes.byref(x) for x in v]), "m2v_strip_graph_stats")
+        return {"last_call_was_graph": bool(v[0].value), "recordings": v[1].value, "launches": v[2].value, "broken": bool(broken)}
+
     def strip_assemble(self, strip_ptrs, frame_offs, nframes, d_out_ptr, cap, xsize16, ysize16, pframes_count, stream=0):
         n = len(strip_ptrs)
         ptrs = (ctypes.c_void_p * n)(*strip_ptrs)
@@ -369,19 +382,26 @@ class StripComm:
         return cls(h, "local", world)
 
     @classmethod
-    def solo(cls, world):
-        """timing aid (tools/strip_solo.py): one rank of `world` alone on its GPU; the output is NOT a valid stream"""
+    def solo(cls, world, rccl=False):
+        """timing aid (tools/strip_solo.py): one rank of `world` alone on its GPU; the output is NOT a valid stream.
+        rccl=True: the rows travel through a 1-rank RCCL communicator (ncclSend / ncclRecv to itself) instead of device copies"""
         L = lib()
         err = ctypes.c_int(0)
-        h = L.m2v_comm_init_solo(world, ctypes.byref(err))
+        h = (L.m2v_comm_init_solo_rccl if rccl else L.m2v_comm_init_solo)(world, ctypes.byref(err))
         if not h:
-            raise M2VError("m2v_comm_init_solo failed (%d): %s" % (err.value, L.m2v_comm_last_error().decode()))
-        return cls(h, "solo", world)
+            raise M2VError("m2v_comm_init_solo%s failed (%d): %s" % ("_rccl" if rccl else "", err.value, L.m2v_comm_last_error().decode()))
+        return cls(h, "solo-rccl" if rccl else "solo", world)
 
     def selftest(self, rank, d_send_ptr, d_recv_ptr, nbytes, stream=0):
         r = lib().m2v_comm_selftest(self.handle, rank, d_send_ptr, d_recv_ptr, nbytes, stream)
         if r < 0:
             raise M2VError("m2v_comm_selftest failed (%d): %s" % (r, lib().m2v_comm_last_error().decode()))
+
+    def selftest_captured(self, rank, d_send_ptr, d_recv_ptr, nbytes, stream=0, launches=2):
+        """the same pair recorded into a hipGraph and launched `launches` times (can this transport be part of a recorded strip sequence?)"""
+        r = lib().m2v_comm_selftest_captured(self.handle, rank, d_send_ptr, d_recv_ptr, nbytes, stream, launches)
+        if r < 0:
+            raise M2VError("m2v_comm_selftest_captured failed (%d): %s" % (r, lib().m2v_comm_last_error().decode()))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -41,6 +41,9 @@ struct m2v_comm {
     // a rank has failed: ranks blocked in (or arriving at) an exchange give up with an error instead of waiting for it (in-process
     // communicator; RCCL has no cheap equivalent - a failed rank of a multi-process job takes the job down, bench.py's launcher does that)
     virtual void abort() {}
+    // true when every call above only ENQUEUES on the stream it is given, so that a whole strip sequence can be recorded into a
+    // hipGraph (m2v_strip_encode) - false for the in-process communicator, whose calls block on the other threads
+    virtual bool capturable() const { return false; }
     virtual const char *kind() const = 0;
 };
 
@@ -116,6 +119,7 @@ struct RcclComm final : m2v_comm {
     }
     ~RcclComm() override { if (comm) (void)api.CommDestroy(comm); }
     const char *kind() const override { return "rccl"; }
+    bool capturable() const override { return true; }
     void chk(ncclResult_t r, const char *what) const
     {
         if (r != ncclSuccess) throw CommError(std::string(what) + ": " + api.GetErrorString(r));
@@ -167,9 +171,13 @@ struct LocalComm final : m2v_comm {
     struct Slot {
         const void *ptr = nullptr;
         size_t n = 0;
+        int dev = -1;                   // the sender's device
+        // `ready` is recorded by the sender on its stream and `consumed` by the receiver on its own: with the two handles on
+        // different GPUs an event must belong to the device of the stream that records it, so each side creates its own
         hipEvent_t ready = nullptr, consumed = nullptr;
         bool full = false, taken = false;
     };
+    bool peer_on[kMax][kMax] = {};      // (under mu) hipDeviceEnablePeerAccess done for [reader][owner]
     std::mutex mu;
     std::condition_variable cv;
     Slot halo_slot[kMax][2];            // [sender][0 = to the rank above, 1 = to the rank below]
@@ -214,10 +222,8 @@ struct LocalComm final : m2v_comm {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return (!sl.full && !sl.taken) || aborted; });
         check(lk);
-        if (!sl.ready) {
-            M2V_COMM_HIP(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
-            M2V_COMM_HIP(hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
-        }
+        if (!sl.ready) M2V_COMM_HIP(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+        M2V_COMM_HIP(hipGetDevice(&sl.dev));
         M2V_COMM_HIP(hipEventRecord(sl.ready, s));
         sl.ptr = ptr; sl.n = n; sl.full = true;
         cv.notify_all();
@@ -226,15 +232,32 @@ struct LocalComm final : m2v_comm {
     void take(Slot &sl, void *dst, size_t n, hipStream_t s)
     {
         const void *src;
+        int mine = -1, theirs = -1;
+        M2V_COMM_HIP(hipGetDevice(&mine));
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return sl.full || aborted; });
             check(lk);
             if (sl.n != n) throw CommError("local exchange: the two sides disagree about the size");
             src = sl.ptr;
+            theirs = sl.dev;
+            if (!sl.consumed) M2V_COMM_HIP(hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));    // on the receiver's device
+            // two GPUs: direct access over xGMI where the devices offer it (the copy below works without, through a staging hop)
+            if (theirs != mine && mine >= 0 && theirs >= 0 && mine < kMax && theirs < kMax && !peer_on[mine][theirs]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, mine, theirs) == hipSuccess && can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(theirs, 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) throw CommError(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
+                }
+                (void)hipGetLastError();
+                peer_on[mine][theirs] = true;
+            }
         }
         M2V_COMM_HIP(hipStreamWaitEvent(s, sl.ready, 0));
-        if (n) M2V_COMM_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
+        if (n) {
+            if (theirs == mine) M2V_COMM_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
+            else M2V_COMM_HIP(hipMemcpyPeerAsync(dst, mine, src, theirs, n, s));
+        }
         M2V_COMM_HIP(hipEventRecord(sl.consumed, s));
         std::unique_lock<std::mutex> lk(mu);
         sl.full = false; sl.taken = true;
@@ -299,16 +322,55 @@ struct LocalComm final : m2v_comm {
 // GPU (kernels of a 1/N strip, launch gaps, host time) when only one GPU is at hand: tools/strip_solo.py.
 // ---------------------------------------------------------------------------------------------
 struct SoloComm final : m2v_comm {
-    explicit SoloComm(int w) { world = w; }
-    const char *kind() const override { return "solo"; }
+    // with_rccl: the rows travel through a 1-rank RCCL communicator as ncclSend / ncclRecv pairs addressed to this very rank inside
+    // ncclGroupStart / ncclGroupEnd - the call pattern of RcclComm::halo, RCCL's own kernels on the stream - so that one GPU can
+    // show what RCCL costs per GOP step and that it can be recorded into a hipGraph.  Otherwise plain device copies.
+    RcclComm *self = nullptr;
+    SoloComm(int w, bool with_rccl)
+    {
+        world = w;
+        if (with_rccl) {
+            RcclApi &api = RcclApi::get();
+            if (!api.ok()) throw CommError(api.err);
+            ncclUniqueId id;
+            const ncclResult_t r = api.GetUniqueId(&id);
+            if (r != ncclSuccess) throw CommError(std::string("ncclGetUniqueId: ") + api.GetErrorString(r));
+            self = new RcclComm(id, 0, 1);
+        }
+    }
+    ~SoloComm() override { delete self; }
+    const char *kind() const override { return self ? "solo-rccl" : "solo"; }
+    bool capturable() const override { return true; }
     void halo(int r, const void *send_up, void *recv_up, const void *send_down, void *recv_down, size_t n, hipStream_t s) override
     {
         if (!n) return;
-        if (r > 0 && send_up && recv_up) M2V_COMM_HIP(hipMemcpyAsync(recv_up, send_up, n, hipMemcpyDeviceToDevice, s));
-        if (r < world - 1 && send_down && recv_down) M2V_COMM_HIP(hipMemcpyAsync(recv_down, send_down, n, hipMemcpyDeviceToDevice, s));
+        const bool up = r > 0 && send_up && recv_up, down = r < world - 1 && send_down && recv_down;
+        if (self) {
+            // sends and receives to oneself pair up in the order they were issued
+            RcclApi &api = self->api;
+            self->chk(api.GroupStart(), "ncclGroupStart");
+            if (up) {
+                self->chk(api.Send(send_up, n, ncclUint8, 0, self->comm, s), "ncclSend(self, up)");
+                self->chk(api.Recv(recv_up, n, ncclUint8, 0, self->comm, s), "ncclRecv(self, up)");
+            }
+            if (down) {
+                self->chk(api.Send(send_down, n, ncclUint8, 0, self->comm, s), "ncclSend(self, down)");
+                self->chk(api.Recv(recv_down, n, ncclUint8, 0, self->comm, s), "ncclRecv(self, down)");
+            }
+            self->chk(api.GroupEnd(), "ncclGroupEnd");
+            return;
+        }
+        if (up) M2V_COMM_HIP(hipMemcpyAsync(recv_up, send_up, n, hipMemcpyDeviceToDevice, s));
+        if (down) M2V_COMM_HIP(hipMemcpyAsync(recv_down, send_down, n, hipMemcpyDeviceToDevice, s));
     }
     void allgather_u64(int, const unsigned long long *d_src, unsigned long long *d_all, size_t count, hipStream_t s) override
     {
+        if (self) {                             // the collective itself on the 1-rank communicator (into row 0), the other rows copied
+            self->allgather_u64(0, d_src, d_all, count, s);
+            for (int k = 1; k < world; ++k)
+                M2V_COMM_HIP(hipMemcpyAsync(d_all + (size_t)k * count, d_all, count * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+            return;
+        }
         for (int k = 0; k < world; ++k)
             M2V_COMM_HIP(hipMemcpyAsync(d_all + (size_t)k * count, d_src, count * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
     }
@@ -320,6 +382,7 @@ struct SoloComm final : m2v_comm {
     }
     void loopback(int, const void *d_send, void *d_recv, size_t n, hipStream_t s) override
     {
+        if (self) { self->loopback(0, d_send, d_recv, n, s); return; }
         M2V_COMM_HIP(hipMemcpyAsync(d_recv, d_send, n, hipMemcpyDeviceToDevice, s));
     }
 };

@@ -119,6 +119,7 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
     if (need_any_rec) {
         if (e->rec_pool_bytes < e->rec_bytes) {       // geometry grew since the pool was allocated (new sequence)
             if (e->persist_slot >= 0) throw HipError{hipErrorInvalidValue, "reference lost on geometry change"};
+            ++alloc_generation();
             for (auto p : e->rec_pool) (void)hipFree(p);
             e->rec_pool.clear();
             e->rec_pool_bytes = e->rec_bytes;
@@ -364,6 +365,7 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
 void ensure_pinned(uint8_t *&p, size_t &cap, size_t bytes)
 {
     if (cap >= bytes) return;
+    ++alloc_generation();
     if (p) (void)hipHostFree(p);
     p = nullptr; cap = 0;
     HIPCHK(hipHostMalloc((void **)&p, bytes * 2));
@@ -482,6 +484,7 @@ void m2v_destroy(m2v_enc *e)
     if (e->ev_interior) (void)hipEventDestroy(e->ev_interior);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     e->d_frame_pos.release(); e->d_alloff.release(); e->d_halo.release(); e->d_strip_own.release(); e->d_gather.release();
+    if (e->strip_graph.exec) (void)hipGraphExecDestroy(e->strip_graph.exec);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     for (auto ev : e->ev_join) if (ev) (void)hipEventDestroy(ev);
     for (auto sd : e->side) if (sd) (void)hipStreamDestroy(sd);
@@ -561,6 +564,7 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
         return M2V_OK;
     }
     if (!strcmp(name, "dct_mfma")) { e->dct_mfma = value != 0; return M2V_OK; }
+    if (!strcmp(name, "strip_graph")) { e->strip_graph_opt = value != 0; return M2V_OK; }
     if (!strcmp(name, "direct_upload")) { e->direct_upload = value != 0; return M2V_OK; }
     if (!strcmp(name, "copy_threads")) { if (value < 1 || value > 64) return M2V_E_PARAM; e->copy_threads = (int)value; return M2V_OK; }
     if (kDebug) {       // libm2v_mi355x_dbg.so only (-DM2V_DEBUG): the shipped library does not know these names

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -33,6 +34,14 @@ struct HipError { hipError_t e; const char *what; };
     } while (0)
 
 
+// Bumped whenever device or pinned memory of any handle is (re)allocated or freed: a recorded hipGraph holds raw pointers, and a
+// graph recorded under an older generation is recorded again instead of launched (m2v_strip_encode).
+inline std::atomic<unsigned long long> &alloc_generation()
+{
+    static std::atomic<unsigned long long> gen{0};
+    return gen;
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -40,12 +49,13 @@ struct DevBuf {
     void ensure(size_t count)
     {
         if (count <= n) return;
+        ++alloc_generation();
         if (p) (void)hipFree(p);
         p = nullptr; n = 0;
         HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
         n = count;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p) { ++alloc_generation(); (void)hipFree(p); } p = nullptr; n = 0; }
 };
 
 struct KStat { int launches = 0; double ms = 0, units = 0; };
@@ -175,7 +185,16 @@ struct m2v_enc {
     DevBuf<uint8_t> d_halo, d_strip_own, d_gather;
     hipStream_t comm_stream = nullptr;    // send / recv with the neighbours, beside the interior rows on the main stream
     hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_interior = nullptr, ev_done = nullptr;
-    struct StripStats { double halo_total_ms = 0, halo_exposed_ms = 0, gather_ms = 0, host_us_per_step = 0, comm_us_per_step = 0; int steps = 0; } strip_stats;
+    // m2v_strip_encode as a recorded hipGraph (option "strip_graph"): everything one call enqueues before its one host wait
+    struct StripGraph {
+        hipGraphExec_t exec = nullptr;
+        std::vector<unsigned long long> key;       // what the recording depends on (shape, ranks, buffers' generation)
+        std::vector<unsigned long long> seen;      // the key of the previous call: a shape is recorded when it comes a second time
+        bool broken = false;                       // recording failed once on this handle: not tried again
+        int launches = 0, captures = 0;
+    } strip_graph;
+    bool strip_graph_opt = true;
+    struct StripStats { double halo_total_ms = 0, halo_exposed_ms = 0, gather_ms = 0, host_us_per_step = 0, comm_us_per_step = 0; int steps = 0; int graph = 0; } strip_stats;
 
     // debug bookkeeping of the last resident encode
     size_t dbg_frames = 0;

@@ -263,14 +263,150 @@ int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t 
 
 // ---------------------------------------------------------------------------------------------
 // m2v_strip_encode: one call = one strip of one sequence, start to finish, with the exchange inside (no interpreter between
-// the GOP steps).  Per step:   edge rows + halo pack  (main stream)  -> event
-//                              send / recv with the two neighbours (comm stream, behind the event)     -> event
-//                              interior rows          (main stream, runs while the halo crosses xGMI)
-//                              neighbour rows into the reconstruction buffers (main stream, behind the comm event)
-// then the strip's slices, one all-gather of the per-frame sizes, the strips to the output rank, the final assembly there.
+// the GOP steps).  Per step (the usual form; the general form of options conformant / dct_mfma = 0 uses pack / unpack kernels
+// and a stream of its own for the exchange):
+//      main stream:  EDGE(j) [first and last macroblock row: reads the rows received in step j-1, writes the rows to send]
+//                    -> send / recv(j) with the two neighbours
+//      side stream:  interior(j), beside both
+// then the strip's slices and one all-gather of the per-frame sizes.  All of that is the SEQUENCE: it depends on nothing the
+// host has to look at, so it is enqueued in one go - or, from the second call of the same shape on, launched as ONE recorded
+// hipGraph (option "strip_graph"): a strip of an 8-GPU job is ~24 us of GPU work per GOP step, less than the ~31 us the host
+// needs to issue a step's launches, event records and waits one by one (profiles/r03_strip_solo.jsonl).  Then the one host
+// wait (the sizes decide the receive counts), the strips to the output rank, the final assembly there.
+//
+// Failures: a rank whose local work fails (a launch or a copy refused) keeps the collective call order - it goes on exchanging,
+// with whatever is in its buffers - and marks its row of the all-gathered sizes; every rank then sees the mark after the same
+// call, skips the gather and returns an error.  Nobody is left waiting inside RCCL for a rank that has gone home.
 // ---------------------------------------------------------------------------------------------
 struct StripEncodeArgs { m2v_comm *comm; int rank, world, dst; uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; uint8_t *d_out; size_t cap;
                          size_t *bytes; hipStream_t s; };
+
+// frames of GOP step j whose reconstruction a later frame references (= the frames of the step's halo list): GOPs longer than j + 1
+static int halo_frames_of_step(size_t nf, uint32_t gop, int j)
+{
+    int n = 0;
+    for (size_t a = 0; a < nf; a += gop)
+        if ((size_t)j + 1 < std::min<size_t>(gop, nf - a)) ++n;
+    return n;
+}
+
+constexpr unsigned long long kStripPoison = ~0ull;         // a failed rank's "size" in the all-gathered table
+
+struct StripSeq {
+    m2v_comm *comm; int rank, world, row0, row1; bool up, down, fused;
+    uint8_t *send_up, *send_down, *recv_up, *recv_down;
+    size_t strip_cap;
+    uint32_t gop;
+    size_t nf;
+    int steps;
+};
+
+// Enqueues the sequence on s (and the handle's side / comm streams, forked from and joined back into s by events): no allocation,
+// no synchronisation, no host state of the handle changed - this is what is recorded into the graph.  `fail` (direct mode only):
+// see above; local work is skipped once it is set, the exchanges are not.
+static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q, bool recording, int &fail, std::string &fail_text,
+                                   std::vector<hipEvent_t> *marks, double *us_in_comm)
+{
+    using clk = std::chrono::steady_clock;
+    const Geom &g = e->g;
+    auto local = [&](auto &&fn) {
+        if (fail) return;
+        if (recording) { fn(); return; }                    // a failure while recording abandons the recording, nothing has run yet
+        try { fn(); }
+        catch (const HipError &h) {
+            fail = h.e == hipErrorOutOfMemory ? M2V_E_NOMEM : M2V_E_HIP;
+            fail_text = std::string(h.what) + ": " + hipGetErrorString(h.e);
+            (void)hipGetLastError();
+        }
+    };
+    auto mark = [&](hipStream_t on) {
+        if (!marks || fail) return;
+        hipEvent_t ev = pool_event(e);
+        e->chain_ev = nullptr;
+        HIPCHK(hipEventRecord(ev, on));
+        marks->push_back(ev);
+    };
+    auto exchange = [&](size_t nbytes, hipStream_t on) {
+        const auto t_c = clk::now();
+        q.comm->halo(q.rank, q.up ? q.send_up : nullptr, q.up ? q.recv_up : nullptr, q.down ? q.send_down : nullptr, q.down ? q.recv_down : nullptr,
+                     nbytes, on);
+        if (us_in_comm) *us_in_comm += std::chrono::duration<double, std::micro>(clk::now() - t_c).count();
+    };
+    hipStream_t side = q.world > 1 ? e->side[0] : nullptr;
+    if (q.world > 1) local([&] { HIPCHK(hipEventRecord(e->ev_done, s)); });          // the plan's uploads
+    for (int j = 0; j < q.steps; ++j) {
+        const int n_h = halo_frames_of_step(q.nf, q.gop, j);
+        const bool xchg = q.world > 1 && n_h > 0 && (q.up || q.down);
+        const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)g.W;
+        if (q.world > 1 && q.fused) {
+            // EDGE(j) and interior(j) both need ALL of step j-1 on this strip; the neighbours' rows only EDGE(j) - and it follows
+            // the receive in stream order.  Two launches, two event records, two waits and one exchange per step.
+            local([&] {
+                HIPCHK(hipStreamWaitEvent(side, j == 0 ? e->ev_done : e->ev_edges, 0));
+                if (j > 0) HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));
+                run_step_edges_fused(e, s, (size_t)j, xchg && q.up ? q.send_up : nullptr, xchg && q.down ? q.send_down : nullptr,
+                                     q.up ? q.recv_up : nullptr, q.down ? q.recv_down : nullptr);
+                mark(s);
+                HIPCHK(hipEventRecord(e->ev_edges, s));
+                run_step_rows(e, side, (size_t)j, q.row0 + 1, q.row1 - 1);
+                mark(side);
+                HIPCHK(hipEventRecord(e->ev_interior, side));
+            });
+            if (xchg) exchange(nbytes, s);
+            local([&] {
+                mark(s);
+                if (j + 1 == q.steps) HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));      // the scans follow on the main stream
+            });
+            continue;
+        }
+        if (xchg) {
+            // the general form (option conformant / dct_mfma = 0 / the debug library's keep_recon): edge rows, pack kernel, exchange
+            // on a stream of its own beside the interior rows, unpack kernel
+            local([&] {
+                HIPCHK(hipStreamWaitEvent(side, e->ev_done, 0));    // the previous step, neighbour rows included
+                run_step_rows(e, s, (size_t)j, q.row0, q.row0 + 1);
+                if (q.row1 - q.row0 >= 2) run_step_rows(e, s, (size_t)j, q.row1 - 1, q.row1);
+                e->chain_ev = nullptr;
+                launch_halo_pack(e, s, e->d_lists.p + e->plan_steps[(size_t)j].off_h, n_h, q.up ? q.send_up : nullptr, q.down ? q.send_down : nullptr);
+                HIPCHK(hipGetLastError());
+                mark(s);
+                HIPCHK(hipEventRecord(e->ev_edges, s));
+                run_step_rows(e, side, (size_t)j, q.row0 + 1, q.row1 - 1);
+                mark(side);
+                HIPCHK(hipEventRecord(e->ev_interior, side));
+                HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_edges, 0));
+            });
+            exchange(nbytes, fail ? s : e->comm_stream);
+            local([&] {
+                HIPCHK(hipEventRecord(e->ev_halo, e->comm_stream));
+                HIPCHK(hipStreamWaitEvent(s, e->ev_halo, 0));
+                HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));
+                mark(s);
+                e->chain_ev = nullptr;
+                launch_halo_unpack(e, s, e->d_lists.p + e->plan_steps[(size_t)j].off_h, n_h, q.up ? q.recv_up : nullptr, q.down ? q.recv_down : nullptr);
+                HIPCHK(hipGetLastError());
+            });
+        } else {
+            local([&] { run_step(e, s, (size_t)j); });
+        }
+        if (q.world > 1) local([&] { HIPCHK(hipEventRecord(e->ev_done, s)); });
+    }
+    // ---- this strip's slices, their sizes; everybody's sizes ----
+    local([&] {
+        e->chain_ev = nullptr;
+        launch_ctl_chain(e, s, (unsigned long long)q.strip_cap, true);
+        finish_chunk(e, s, false, false, e->d_strip_own.p);
+        e->frames_total -= q.nf;                            // (host state is the caller's business: a recorded sequence is replayed without this code)
+        HIPCHK(hipMemcpyAsync(e->h_strip, e->d_frame_off.p, (q.nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->h_strip + (q.nf + 1) * sizeof(unsigned long long), e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
+    });
+    if (q.world > 1) {
+        if (fail) (void)hipMemsetAsync(e->d_frame_off.p, 0xFF, (q.nf + 1) * sizeof(unsigned long long), s);        // the mark
+        q.comm->allgather_u64(q.rank, e->d_frame_off.p, e->d_alloff.p, q.nf + 1, s);
+        const hipError_t ce = hipMemcpyAsync(e->h_asm, e->d_alloff.p, (size_t)q.world * (q.nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+        if (ce != hipSuccess && !fail) throw HipError{ce, "hipMemcpyAsync(all-gathered sizes)"};
+    }
+}
 
 static int strip_encode_impl(m2v_enc *e, void *argp)
 {
@@ -285,152 +421,190 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     }
     if (rank == a->dst && !a->d_out) { e->set_err("m2v_strip_encode: the output rank needs d_out"); return M2V_E_PARAM; }     // before anything collective
     if (rank == a->dst && ((uintptr_t)a->d_out & 15u) != 0) { e->set_err("m2v_strip_encode: d_out must be 16-byte aligned"); return M2V_E_PARAM; }
+    if (e->state != m2v_enc::IDLE || e->strip_active || e->resident_inflight) { e->set_err("m2v_strip_encode: encoder busy"); return M2V_E_STATE; }
     // contiguous strips, sizes differing by at most one row, the first mbh % world ranks get the extra row (parallel.partition_rows)
     const int base = full.mbh / world, rem = full.mbh % world;
     const int row0 = rank * base + std::min(rank, rem), row1 = row0 + base + (rank < rem ? 1 : 0);
-    StripBeginArgs b{a->xs, a->ys, a->pf, a->d_in, a->n, row0, row1, a->s};
-    int r = strip_begin_impl(e, &b);
-    if (r < 0) return r;
-    hipStream_t s = e->strip_stream;
-    const Geom &g = e->g;
-    const size_t nf = e->plan_nf;
-    int mh = 0;
-    for (auto &st : e->plan_steps) mh = std::max(mh, st.n_h);
-    const size_t halo_cap = (size_t)mh * (size_t)(3 * e->VL) * (size_t)g.W;
+    const size_t nf = a->n;
+    const uint32_t gop = (a->pf & 0xFFu) + 1u;
+
+    // ---- plan and buffers.  Everything up to here was the same on every rank; from here on a failure is this rank's alone and
+    //      must not break the collective call order (see the head of this section) ----
+    int fail = 0;
+    std::string fail_text;
+    auto local = [&](auto &&fn) {
+        if (fail) return;
+        try { fn(); }
+        catch (const HipError &h) {
+            fail = h.e == hipErrorOutOfMemory ? M2V_E_NOMEM : M2V_E_HIP;
+            fail_text = std::string(h.what) + ": " + hipGetErrorString(h.e);
+            (void)hipGetLastError();
+        }
+    };
+    StripSeq q{};
+    q.comm = a->comm; q.rank = rank; q.world = world; q.row0 = row0; q.row1 = row1;
+    q.up = row0 > 0; q.down = row1 < full.mbh;
+    q.fused = !e->conformant && e->dct_mfma && !e->keep_recon;
+    q.gop = gop; q.nf = nf;
+    q.steps = (int)std::min<size_t>(gop, nf);
+    q.strip_cap = nf * ((size_t)(row1 - row0) * full.mbw * 1216 + (size_t)(row1 - row0) * 8 + 64) + 256;     // worst case
+    const size_t halo_cap = (size_t)halo_frames_of_step(nf, gop, 0) * (size_t)(3 * e->VL) * (size_t)full.W;
+    // the buffers an exchange touches come first: with them a rank can keep the call order whatever else fails
     e->d_halo.ensure(4 * halo_cap + 64);
-    uint8_t *send_up = e->d_halo.p, *send_down = send_up + halo_cap, *recv_up = send_down + halo_cap, *recv_down = recv_up + halo_cap;
-    const bool fused = !e->conformant && e->dct_mfma && !e->keep_recon;
+    e->d_frame_off.ensure(nf + 1);
     if (world > 1) {
-        // (the general form's exchange stream only when that form runs: every stream a process creates moves the others around the
-        // handful of hardware queues)
-        if (!fused && !e->comm_stream) HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
-        if (!e->ev_edges) HIPCHK(hipEventCreateWithFlags(&e->ev_edges, hipEventDisableTiming));
-        if (!e->ev_halo) HIPCHK(hipEventCreateWithFlags(&e->ev_halo, hipEventDisableTiming));
+        e->d_alloff.ensure((size_t)world * (nf + 1));
+        ensure_pinned(e->h_asm, e->h_asm_cap, (size_t)world * (nf + 1) * sizeof(unsigned long long));
     }
+    q.send_up = e->d_halo.p; q.send_down = q.send_up + halo_cap; q.recv_up = q.send_down + halo_cap; q.recv_down = q.recv_up + halo_cap;
+    int r = M2V_OK;
+    local([&] {
+        StripBeginArgs b{a->xs, a->ys, a->pf, a->d_in, a->n, row0, row1, a->s};
+        r = strip_begin_impl(e, &b);
+    });
+    if (r < 0) return r;                                    // (parameters: the same answer on every rank)
+    hipStream_t s = e->strip_active ? e->strip_stream : (a->s ? a->s : e->stream);
+    local([&] {
+        if ((int)e->plan_steps.size() != q.steps) throw HipError{hipErrorInvalidValue, "strip plan and step count disagree"};
+        for (int j = 0; j < q.steps; ++j)
+            if (e->plan_steps[(size_t)j].n_h != halo_frames_of_step(nf, gop, j)) throw HipError{hipErrorInvalidValue, "strip plan and halo list disagree"};
+        e->d_strip_own.ensure(q.strip_cap);
+        ensure_pinned(e->h_strip, e->h_strip_cap, (nf + 1) * sizeof(unsigned long long) + sizeof(StreamCtl));
+        e->d_ctl.ensure(1);
+        if (world > 1) {
+            // (the general form's exchange stream only when that form runs: every stream a process creates moves the others around the
+            // handful of hardware queues)
+            if (!q.fused && !e->comm_stream) HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+            if (!e->ev_edges) HIPCHK(hipEventCreateWithFlags(&e->ev_edges, hipEventDisableTiming));
+            if (!e->ev_halo) HIPCHK(hipEventCreateWithFlags(&e->ev_halo, hipEventDisableTiming));
+            // The edge rows run as ONE launch of the instantiation that also fills the halo buffers (no pack kernel), the interior rows at
+            // the same time on a second stream: a strip of an 8-GPU job is ~20 000 wavefronts per step, 2.5 rounds of the wave slots -
+            // edge rows first and alone would hold the whole GPU for one macroblock lifetime at a third of its slots.
+            if (!e->side[0]) HIPCHK(hipStreamCreateWithFlags(&e->side[0], hipStreamNonBlocking));
+            if (!e->ev_done) HIPCHK(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+            if (!e->ev_interior) HIPCHK(hipEventCreateWithFlags(&e->ev_interior, hipEventDisableTiming));
+        }
+    });
+
+    // ---- the sequence: recorded graph, or call by call ----
     // profile: GPU events around the exchange of every step: halo_total = edge rows (and their halo) written .. neighbour rows and
     // interior rows both there; halo_exposed = how much of that came after the interior rows were done
     std::vector<hipEvent_t> marks;
-    auto mark = [&](hipStream_t on) {
-        if (!e->profile) return;
-        hipEvent_t ev = pool_event(e);
-        e->chain_ev = nullptr;
-        HIPCHK(hipEventRecord(ev, on));
-        marks.push_back(ev);
-    };
-    const bool up = row0 > 0, down = row1 < g.mbh;
-    // The edge rows run as ONE launch of the instantiation that also fills the halo buffers (no pack kernel), the interior rows at
-    // the same time on a second stream: a strip of an 8-GPU job is ~20 000 wavefronts per step, 2.5 rounds of the wave slots -
-    // edge rows first and alone would hold the whole GPU for one macroblock lifetime at a third of its slots.
-    hipStream_t side = nullptr;
-    if (world > 1) {
-        if (!e->side[0]) HIPCHK(hipStreamCreateWithFlags(&e->side[0], hipStreamNonBlocking));
-        side = e->side[0];
-        if (!e->ev_done) HIPCHK(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
-        if (!e->ev_interior) HIPCHK(hipEventCreateWithFlags(&e->ev_interior, hipEventDisableTiming));
-        HIPCHK(hipEventRecord(e->ev_done, s));                  // the plan's uploads
-    }
     double us_in_comm = 0;                 // host time inside the communicator (a local communicator blocks there until the neighbour thread has posted)
     const auto t_loop = clk::now();
-    for (int j = 0; j < (int)e->plan_steps.size(); ++j) {
-        const int n_h = e->plan_steps[(size_t)j].n_h;
-        const bool xchg = world > 1 && n_h > 0 && (up || down);
-        const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)g.W;
-        if (world > 1 && fused) {
-            // main stream:  EDGE(j) [reads the rows received in step j-1, writes the rows to send] -> send / recv(j)
-            // side stream:  interior(j)
-            // EDGE(j) and interior(j) both need ALL of step j-1 on this strip; the neighbours' rows only EDGE(j) - and it follows
-            // the receive in stream order.  Two launches, two event records, two waits and one exchange per step.
-            HIPCHK(hipStreamWaitEvent(side, j == 0 ? e->ev_done : e->ev_edges, 0));
-            if (j > 0) HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));
-            run_step_edges_fused(e, s, (size_t)j, xchg && up ? send_up : nullptr, xchg && down ? send_down : nullptr,
-                                 up ? recv_up : nullptr, down ? recv_down : nullptr);
-            mark(s);
-            HIPCHK(hipEventRecord(e->ev_edges, s));
-            run_step_rows(e, side, (size_t)j, row0 + 1, row1 - 1);
-            mark(side);
-            HIPCHK(hipEventRecord(e->ev_interior, side));
-            if (xchg) {
-                const auto t_c = clk::now();
-                a->comm->halo(rank, up ? send_up : nullptr, up ? recv_up : nullptr, down ? send_down : nullptr, down ? recv_down : nullptr, nbytes, s);
-                us_in_comm += std::chrono::duration<double, std::micro>(clk::now() - t_c).count();
+    m2v_enc::StripGraph &sg = e->strip_graph;
+    int graph_used = 0;
+    // (the general form - options conformant / dct_mfma = 0 - is enqueued call by call: it issues the exchange on a stream of its own,
+    // and RCCL 2.26 crashes when its send / recv group is recorded on a stream that joined the recording through an event)
+    const bool graph_ok = e->strip_graph_opt && !sg.broken && !fail && !e->profile && (world == 1 || q.fused) && (!a->comm || a->comm->capturable());
+    if (graph_ok) {
+        const std::vector<unsigned long long> key = {alloc_generation().load(), (unsigned long long)full.W, (unsigned long long)full.H, (unsigned long long)full.Q,
+            (unsigned long long)row0, (unsigned long long)row1, (unsigned long long)nf, (unsigned long long)gop, (unsigned long long)rank,
+            (unsigned long long)world, (unsigned long long)(uintptr_t)a->comm, (unsigned long long)q.fused, (unsigned long long)e->VL,
+            (unsigned long long)e->conformant, (unsigned long long)e->dct_mfma};
+        if (sg.exec && sg.key == key) graph_used = 1;
+        else if (sg.seen == key) {
+            // the second call of this shape: record.  (Not the first: RCCL sets up its connections to a peer inside the first send /
+            // recv that uses them, which is no business of a recording, and a one-off call would pay for a graph it never launches.)
+            if (sg.exec) { (void)hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            bool began = false;
+            try {
+                HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+                began = true;
+                int none = 0;
+                std::string none_text;
+                strip_enqueue_sequence(e, s, q, true, none, none_text, nullptr, nullptr);
+                began = false;
+                HIPCHK(hipStreamEndCapture(s, &graph));
+                HIPCHK(hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                sg.key = key;
+                sg.captures++;
+                graph_used = 1;
+            } catch (const std::exception &ex) {            // a communicator that cannot be recorded after all
+                if (began) { (void)hipStreamEndCapture(s, &graph); }
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+                if (sg.exec) { (void)hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }
+                sg.broken = true;
+                e->set_err("strip_graph: recording failed (%s); the sequence is enqueued call by call from now on", ex.what());
+            } catch (const HipError &h) {
+                if (began) { (void)hipStreamEndCapture(s, &graph); }
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+                if (sg.exec) { (void)hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }
+                sg.broken = true;
+                e->set_err("strip_graph: recording failed (%s: %s); the sequence is enqueued call by call from now on", h.what, hipGetErrorString(h.e));
             }
-            mark(s);
-            if (j + 1 == (int)e->plan_steps.size()) HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));      // the scans follow on the main stream
-            continue;
         }
-        if (xchg) {
-            // the general form (option conformant / dct_mfma = 0 / the debug library's keep_recon): edge rows, pack kernel, exchange
-            // on a stream of its own beside the interior rows, unpack kernel
-            HIPCHK(hipStreamWaitEvent(side, e->ev_done, 0));    // the previous step, neighbour rows included
-            StripStepArgs sa{j, send_up, send_down, nullptr, nullptr, 1};
-            if ((r = strip_step_impl(e, &sa)) < 0) return r;
-            mark(s);
-            HIPCHK(hipEventRecord(e->ev_edges, s));
-            run_step_rows(e, side, (size_t)j, row0 + 1, row1 - 1);
-            mark(side);
-            HIPCHK(hipEventRecord(e->ev_interior, side));
-            HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_edges, 0));
-            const auto t_c = clk::now();
-            a->comm->halo(rank, up ? send_up : nullptr, up ? recv_up : nullptr, down ? send_down : nullptr, down ? recv_down : nullptr, nbytes,
-                          e->comm_stream);
-            us_in_comm += std::chrono::duration<double, std::micro>(clk::now() - t_c).count();
-            HIPCHK(hipEventRecord(e->ev_halo, e->comm_stream));
-            HIPCHK(hipStreamWaitEvent(s, e->ev_halo, 0));
-            HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));
-            mark(s);
-            StripStepArgs sh{j, nullptr, nullptr, up ? recv_up : nullptr, down ? recv_down : nullptr};
-            if ((r = strip_halo_in_impl(e, &sh)) < 0) return r;
-        } else {
-            StripStepArgs sa{j, nullptr, nullptr, nullptr, nullptr, 0};
-            if ((r = strip_step_impl(e, &sa)) < 0) return r;
-        }
-        if (world > 1) HIPCHK(hipEventRecord(e->ev_done, s));
+        sg.seen = key;
     }
-    e->strip_stats.steps = (int)e->plan_steps.size();
-    e->strip_stats.host_us_per_step = std::chrono::duration<double, std::micro>(clk::now() - t_loop).count() / std::max<size_t>(1, e->plan_steps.size());
-    e->strip_stats.comm_us_per_step = us_in_comm / std::max<size_t>(1, e->plan_steps.size());
+    if (graph_used) {
+        HIPCHK(hipGraphLaunch(sg.exec, s));
+        sg.launches++;
+    } else {
+        strip_enqueue_sequence(e, s, q, false, fail, fail_text, e->profile ? &marks : nullptr, &us_in_comm);
+    }
+    // host state the sequence leaves behind, recorded or not
+    if (e->strip_active) {
+        e->frames_total += nf;
+        e->strip_nf = nf;
+        strip_close(e);
+    }
+    e->strip_stats.steps = q.steps;
+    e->strip_stats.graph = graph_used;
+    e->strip_stats.host_us_per_step = std::chrono::duration<double, std::micro>(clk::now() - t_loop).count() / std::max(1, q.steps);
+    e->strip_stats.comm_us_per_step = us_in_comm / std::max(1, q.steps);
     hipEvent_t g0 = nullptr, g1 = nullptr;
+    if (e->profile && !fail) { g0 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g0, s)); }     // from here: gather, final assembly
 
-    // ---- this strip's slices; sizes; strips to the output rank; final assembly ----
-    const size_t strip_cap = nf * ((size_t)(row1 - row0) * g.mbw * 1216 + (size_t)(row1 - row0) * 8 + 64) + 256;     // worst case
-    e->d_strip_own.ensure(strip_cap);
-    const Geom gfull = full;
-    strip_finish_enqueue(e, e->d_strip_own.p, strip_cap);       // also closes the strip sequence
-    if (e->profile) { g0 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g0, s)); }     // from here: sizes, gather, final assembly
+    // ---- the one host wait; strips to the output rank; final assembly ----
     const void *strips[kMaxStripRanks] = {};
     const unsigned long long *d_all = e->d_frame_off.p;
+    int failed_rank = fail ? rank : -1;
     if (world > 1) {
-        e->d_alloff.ensure((size_t)world * (nf + 1));
-        a->comm->allgather_u64(rank, e->d_frame_off.p, e->d_alloff.p, nf + 1, s);
-        ensure_pinned(e->h_asm, e->h_asm_cap, (size_t)world * (nf + 1) * sizeof(unsigned long long));
-        HIPCHK(hipMemcpyAsync(e->h_asm, e->d_alloff.p, (size_t)world * (nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));                        // the sizes decide the receive counts: the one host wait
-        // (an overflow of this strip's buffer - impossible with the worst-case size above - is reported at the end: the other ranks
-        // are waiting in the gather, and a rank that left now would leave them there)
-        size_t sizes[kMaxStripRanks] = {}, total_in = 0;
-        for (int k = 0; k < world; ++k) {
-            sizes[k] = (size_t)((const unsigned long long *)e->h_asm)[(size_t)k * (nf + 1) + nf];
-            if (k != a->dst) total_in += (sizes[k] + 255) & ~(size_t)255;
-        }
-        void *bufs[kMaxStripRanks] = {};
-        if (rank == a->dst) {
-            e->d_gather.ensure(total_in + 256);
-            size_t off = 0;
+        const hipError_t se = hipStreamSynchronize(s);      // the sizes decide the receive counts
+        if (se != hipSuccess && !fail) throw HipError{se, "hipStreamSynchronize(strip sequence)"};
+        const unsigned long long *all = (const unsigned long long *)e->h_asm;
+        for (int k = 0; k < world && failed_rank < 0; ++k)
+            if (all[(size_t)k * (nf + 1) + nf] == kStripPoison) failed_rank = k;
+        if (failed_rank < 0) {
+            // (an overflow of this strip's buffer - impossible with the worst-case size above - is reported at the end: the other ranks
+            // are waiting in the gather, and a rank that left now would leave them there)
+            size_t sizes[kMaxStripRanks] = {}, total_in = 0;
             for (int k = 0; k < world; ++k) {
-                if (k == a->dst) { strips[k] = e->d_strip_own.p; continue; }
-                bufs[k] = e->d_gather.p + off;
-                strips[k] = bufs[k];
-                off += (sizes[k] + 255) & ~(size_t)255;
+                sizes[k] = (size_t)all[(size_t)k * (nf + 1) + nf];
+                if (k != a->dst) total_in += (sizes[k] + 255) & ~(size_t)255;
             }
+            void *bufs[kMaxStripRanks] = {};
+            if (rank == a->dst) {
+                local([&] { e->d_gather.ensure(total_in + 256); });
+                size_t off = 0;
+                for (int k = 0; k < world; ++k) {
+                    if (k == a->dst) { strips[k] = e->d_strip_own.p; continue; }
+                    bufs[k] = e->d_gather.p + off;
+                    strips[k] = bufs[k];
+                    off += (sizes[k] + 255) & ~(size_t)255;
+                }
+            }
+            if (fail) throw HipError{hipErrorOutOfMemory, "no room for the other ranks' strips on the output rank"};     // (they are already sending: nothing to keep in order any more)
+            a->comm->gather(rank, a->dst, e->d_strip_own.p, sizes, bufs, s);
+            d_all = e->d_alloff.p;
         }
-        a->comm->gather(rank, a->dst, e->d_strip_own.p, sizes, bufs, s);
-        d_all = e->d_alloff.p;
     } else {
         strips[0] = e->d_strip_own.p;
     }
+    if (failed_rank >= 0) {
+        (void)hipStreamSynchronize(s);
+        collect_timers(e);
+        if (fail) { e->set_err("m2v_strip_encode: %s", fail_text.c_str()); return fail; }
+        e->set_err("m2v_strip_encode: rank %d of the job failed", failed_rank);
+        return M2V_E_HIP;
+    }
     size_t out_bytes = 0;
     if (rank == a->dst) {
-        strip_assemble_enqueue(e, s, gfull, a->pf, nf, world, strips, d_all, a->d_out, a->cap);
+        strip_assemble_enqueue(e, s, full, a->pf, nf, world, strips, d_all, a->d_out, a->cap);
         if (e->profile) { g1 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g1, s)); }
         if (!e->st().h_ctl) HIPCHK(hipHostMalloc((void **)&e->st().h_ctl, 2 * sizeof(StreamCtl)));
         HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
@@ -486,6 +660,15 @@ int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_expose
     return e->strip_stats.steps;
 }
 
+int m2v_strip_graph_stats(const m2v_enc *e, int *last_call_was_graph, int *recordings, int *launches)
+{
+    if (!e) return M2V_E_PARAM;
+    if (last_call_was_graph) *last_call_was_graph = e->strip_stats.graph;
+    if (recordings) *recordings = e->strip_graph.captures;
+    if (launches) *launches = e->strip_graph.launches;
+    return e->strip_graph.broken ? 1 : 0;
+}
+
 // ---- communicators (m2v_comm.hpp) ----
 
 int m2v_comm_unique_id(void *id, size_t cap)
@@ -516,13 +699,25 @@ m2v_comm *m2v_comm_init_rccl(const void *id, int rank, int world, int device, in
     }
 }
 
-m2v_comm *m2v_comm_init_solo(int world, int *err)
+static m2v_comm *init_solo(int world, bool with_rccl, int *err)
 {
     if (world < 1 || world > kMaxStripRanks) { t_comm_err = "m2v_comm_init_solo: 1..16 ranks"; if (err) *err = M2V_E_PARAM; return nullptr; }
-    m2v_comm *c = new (std::nothrow) SoloComm(world);
-    if (err) *err = c ? M2V_OK : M2V_E_NOMEM;
-    return c;
+    try {
+        m2v_comm *c = new SoloComm(world, with_rccl);
+        if (err) *err = M2V_OK;
+        return c;
+    } catch (const std::bad_alloc &) {
+        t_comm_err = "host allocation failed";
+        if (err) *err = M2V_E_NOMEM;
+    } catch (const std::exception &ex) {
+        t_comm_err = ex.what();
+        if (err) *err = M2V_E_HIP;
+    }
+    return nullptr;
 }
+
+m2v_comm *m2v_comm_init_solo(int world, int *err) { return init_solo(world, false, err); }
+m2v_comm *m2v_comm_init_solo_rccl(int world, int *err) { return init_solo(world, true, err); }
 
 m2v_comm *m2v_comm_init_local(int world, int *err)
 {
@@ -544,6 +739,41 @@ int m2v_comm_selftest(m2v_comm *c, int rank, const void *d_send, void *d_recv, s
         t_comm_err = ex.what();
         return M2V_E_HIP;
     }
+}
+
+// The same pair recorded into a hipGraph and launched `launches` times: whether this transport can be part of the recorded strip
+// sequence of m2v_strip_encode.  The stream is synchronised before returning.
+int m2v_comm_selftest_captured(m2v_comm *c, int rank, const void *d_send, void *d_recv, size_t nbytes, void *hip_stream, int launches)
+{
+    if (!c || !d_send || !d_recv || launches < 1) return M2V_E_PARAM;
+    if (!c->capturable()) { t_comm_err = std::string("a '") + c->kind() + "' communicator blocks on other threads: it cannot be recorded"; return M2V_E_STATE; }
+    hipStream_t s = (hipStream_t)hip_stream, own = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int r = M2V_OK;
+    bool began = false;
+    try {
+        if (!s) { M2V_COMM_HIP(hipStreamCreateWithFlags(&own, hipStreamNonBlocking)); s = own; }
+        c->loopback(rank, d_send, d_recv, nbytes, s);           // connections are set up by the first use, outside any recording
+        M2V_COMM_HIP(hipStreamSynchronize(s));
+        M2V_COMM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        began = true;
+        c->loopback(rank, d_send, d_recv, nbytes, s);
+        began = false;
+        M2V_COMM_HIP(hipStreamEndCapture(s, &graph));
+        M2V_COMM_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (int k = 0; k < launches; ++k) M2V_COMM_HIP(hipGraphLaunch(exec, s));
+        M2V_COMM_HIP(hipStreamSynchronize(s));
+    } catch (const std::exception &ex) {
+        if (began) (void)hipStreamEndCapture(s, &graph);
+        (void)hipGetLastError();
+        t_comm_err = ex.what();
+        r = M2V_E_HIP;
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (own) (void)hipStreamDestroy(own);
+    return r;
 }
 
 const char *m2v_comm_last_error(void) { return t_comm_err.c_str(); }

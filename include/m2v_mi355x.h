@@ -192,11 +192,18 @@ m2v_comm *m2v_comm_init_local(int world, int *err);
  * nothing is sent.  The resulting stream is not a valid encoding; tools/strip_solo.py uses it to time what one rank of an
  * N-GPU job does per GOP step when only one GPU is at hand. */
 m2v_comm *m2v_comm_init_solo(int world, int *err);
+/* The same with the rows travelling through a 1-rank RCCL communicator: ncclGroupStart; ncclSend / ncclRecv addressed to the rank
+ * itself; ncclGroupEnd - RCCL's call pattern and RCCL's kernels on the stream, with one GPU. */
+m2v_comm *m2v_comm_init_solo_rccl(int world, int *err);
 void      m2v_comm_destroy(m2v_comm *c);
 const char *m2v_comm_last_error(void);
 /* Self-test of a communicator: nbytes from d_send to d_recv (device memory) through the transport's own send / recv pair
  * addressed to the calling rank itself (RCCL: one ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd), enqueued on hip_stream. */
 int       m2v_comm_selftest(m2v_comm *c, int rank, const void *d_send, void *d_recv, size_t nbytes, void *hip_stream);
+/* The same pair once directly, then recorded into a hipGraph (stream capture) and launched `launches` times; the stream is
+ * synchronised before returning.  M2V_E_STATE for a communicator that cannot be recorded (the in-process one blocks on other
+ * threads).  This is the check that a transport can take part in the recorded sequence of m2v_strip_encode. */
+int       m2v_comm_selftest_captured(m2v_comm *c, int rank, const void *d_send, void *d_recv, size_t nbytes, void *hip_stream, int launches);
 
 /*
  * One strip of one sequence, start to finish, in ONE call: the loop that parallel.encode_strips() spells out in Python (begin,
@@ -206,6 +213,11 @@ int       m2v_comm_selftest(m2v_comm *c, int rank, const void *d_send, void *d_r
  * stream is left at d_out (device memory, capacity cap) and its length in *out_bytes; the other ranks may pass NULL / 0 and
  * get *out_bytes = 0.  `hip_stream` (NULL = the handle's own) is synchronised before returning.  Collective: every rank
  * of the communicator must make the call with the same sequence parameters.
+ * Everything a call enqueues before its one host wait - the GOP steps with their exchanges, the strip's slices, the all-gather of
+ * the sizes - is recorded into a hipGraph when the same shape comes a second time, and launched as one graph from then on
+ * (option "strip_graph", default 1; RCCL and solo communicators; not with option "profile" or an in-process communicator).
+ * A rank whose own work fails keeps the collective call order and marks its sizes; every rank then returns an error from the
+ * same call instead of waiting for it inside an exchange.
  */
 int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_rank, uint32_t xsize16, uint32_t ysize16,
                      uint32_t pframes_count, const void *d_frames444, size_t nframes, void *d_out, size_t cap, size_t *out_bytes,
@@ -217,6 +229,10 @@ int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_ra
  * to the output rank + final assembly).  Returns the step count. */
 int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_exposed_ms, double *gather_ms, double *host_us_per_step,
                     double *comm_us_per_step);
+
+/* The recorded-graph side of m2v_strip_encode on this handle: whether the last call was launched as a graph, recordings and graph
+ * launches so far.  Returns 1 if recording has failed on this handle (the sequence is then enqueued call by call), else 0. */
+int m2v_strip_graph_stats(const m2v_enc *e, int *last_call_was_graph, int *recordings, int *launches);
 
 /* Options: "batch_frames" (frames buffered before the GPU is kicked, default 96; 1 .. 65536, M2V_E_PARAM beyond),
  * "profile" (1 = time the per-kernel launches with HIP events),
@@ -233,6 +249,7 @@ int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_expose
  * "dct_mfma" (default 1: the four luma tiles' 2-D DCT runs on the matrix cores as two chained i8 GEMMs,
  * B16 . Z . B16^T with the 19-bit intermediate in three byte limbs; 0 = every tile on the integer v_dot4 / v_mad_i32_i24
  * path through LDS.  Bit-identical results either way; the default is the faster one under rocprofv3),
+ * "strip_graph" (default 1: m2v_strip_encode launches its sequence as a recorded hipGraph, see there; 0 = always call by call),
  * "conformant" (default 0 = the reference's arithmetic, byte-identical to the RTL.  1 = NOT the reference's
  * behaviour: the reconstruction loop follows ISO/IEC 13818-2 where the RTL deviates from it - four-sample average
  * rounded with +2, 4:2:0 chroma vector = mv / 2 toward zero, inverse quantiser truncating toward zero with

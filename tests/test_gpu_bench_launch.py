@@ -27,6 +27,7 @@ def test_sequences_mode_two_ranks():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
     assert line["config"]["launched_by"] == "bench.py" and line["config"]["dist_backend"] == "gloo"
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert line["parity_check"]["ranks_checked"] == 2 and line["parity_check"]["identical_to_oracle"] is True     # every rank, its own clip
 
 
 def test_strips_mode_two_ranks_whole_stream_parity():

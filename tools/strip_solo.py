@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--world", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--gops", type=int, default=10)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--rccl", type=int, default=0, help="1: the rows go through a 1-rank RCCL communicator (ncclSend / ncclRecv to itself) instead of device copies")
+    ap.add_argument("--graph", type=int, nargs="+", default=[0, 1], help="option strip_graph: 0 = the sequence call by call, 1 = one recorded hipGraph launch")
     ap.add_argument("--split", type=int, default=-1, help="option split_streams of the handle (GOP groups on a stream each; default: the library's)")
     args = ap.parse_args()
     import torch
@@ -34,12 +36,13 @@ def main():
     out = torch.empty(M.parallel.strip_output_bound(n, W, H), dtype=torch.uint8, device="cuda:0")
     torch.cuda.synchronize()
     base = None
-    for world in args.world:
+    for world, graph in [(w, gph) for w in args.world for gph in args.graph]:
         for rank in sorted({0, world // 2}):                      # the output rank (one neighbour + final assembly) and an inner rank
             enc = M.Mpeg2Encoder(7, 7, 3, 2)
+            enc.set_option("strip_graph", graph)
             if args.split >= 0:
                 enc.set_option("split_streams", args.split)
-            comm = M.StripComm.solo(world) if world > 1 else None
+            comm = M.StripComm.solo(world, rccl=bool(args.rccl)) if world > 1 else None
             try:
                 run = lambda: M.parallel.encode_strips_native(enc, comm, rank, world, clip, 128, 128, pf, out if rank == 0 else None)   # noqa: E731
                 t0 = time.perf_counter()
@@ -51,15 +54,19 @@ def main():
                     run()
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / args.steps
+                host_timed = enc.strip_stats()["host_us_per_step"]
+                gst = enc.strip_graph_stats()
                 enc.set_option("profile", 1)
                 run(); run()
                 st = enc.strip_stats()
                 ks = {name: round(enc.kernel_stats(k)[1], 3) for k, name in ((0, "k_mb_P"), (1, "k_mb_I"), (4, "scans"), (3, "k_assemble"), (2, "final_assembly"))}
-                if world == 1:
+                if world == 1 and base is None:
                     base = dt
-                print(json.dumps({"world": world, "rank": rank, "split_streams": args.split if args.split >= 0 else "default", "ms_per_sequence": round(dt * 1e3, 3),
+                print(json.dumps({"world": world, "rank": rank, "transport": comm.kind if comm is not None else None,
+                                  "strip_graph": graph, "graph_launches": gst["launches"], "graph_broken": gst["broken"],
+                                  "host_us_per_gop_step_timed": round(host_timed, 1), "split_streams": args.split if args.split >= 0 else "default", "ms_per_sequence": round(dt * 1e3, 3),
                                   "speedup_vs_one_rank": round(base / dt, 2) if base else None,
-                                  "ideal": world, "host_us_per_gop_step": round(st["host_us_per_step"], 1),
+                                  "ideal": world, "host_us_per_gop_step_profiled_call_by_call": round(st["host_us_per_step"], 1),
                                   "of_which_inside_the_communicator": round(st["comm_us_per_step"], 1),
                                   "halo_ms": {"total": round(st["halo_total"], 3), "exposed": round(st["halo_exposed"], 3)},
                                   "sizes_gather_assembly_ms": round(st["gather"], 3), "kernel_ms": ks}))
