@@ -34,7 +34,7 @@ EXPORTS = [
     "m2v_strip_begin", "m2v_strip_info", "m2v_strip_step", "m2v_strip_step_edges", "m2v_strip_step_interior", "m2v_strip_halo_in", "m2v_strip_finish", "m2v_strip_assemble",
     "m2v_strip_finish_async", "m2v_strip_offsets", "m2v_strip_encode", "m2v_strip_stats",
     "m2v_comm_unique_id", "m2v_comm_init_rccl", "m2v_comm_init_local", "m2v_comm_init_solo", "m2v_comm_destroy", "m2v_comm_last_error", "m2v_comm_selftest",
-    "m2v_comm_init_solo_rccl", "m2v_comm_selftest_captured", "m2v_strip_graph_stats", "m2v_flow_state",
+    "m2v_comm_init_solo_rccl", "m2v_comm_selftest_captured", "m2v_strip_graph_stats",
 ]
 
 
@@ -111,7 +111,6 @@ def lib(debug=False):
             L.m2v_comm_selftest_captured.argtypes = [vp, ci, vp, vp, sz, vp, ci]
             ip = ctypes.POINTER(ci)
             L.m2v_strip_graph_stats.argtypes = [vp, ip, ip, ip]
-            L.m2v_flow_state.argtypes = [vp, ip]
         except AttributeError:
             # an OLDER build handed in through M2V_LIB for a same-box A/B (tools/ab.sh) may lack the newer entry points; the library of
             # this tree must have every one of them (tests/test_abi.py)
@@ -297,12 +296,6 @@ class Mpeg2Encoder:
         steps = self._chk(self._L.m2v_strip_stats(self._h, *[ctypes.byref(x) for x in v]), "m2v_strip_stats")
         return {"steps": steps, "halo_total": v[0].value, "halo_exposed": v[1].value, "gather": v[2].value, "host_us_per_step": v[3].value,
                 "comm_us_per_step": v[4].value, "host_us_per_step_outside_comm": v[3].value - v[4].value}
-
-    def flow_state(self):
-        """-> (did the last resident sequence run its P frames as ONE launch (option flow), times such a launch gave up on this handle)"""
-        t = ctypes.c_int(0)
-        r = self._chk(self._L.m2v_flow_state(self._h, ctypes.byref(t)), "m2v_flow_state")
-        return bool(r), t.value
 
     def strip_graph_stats(self):
         """-> dict: was the last strip_encode launched as a recorded hipGraph, how many recordings / launches so far, and whether

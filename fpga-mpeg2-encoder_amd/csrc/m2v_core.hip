@@ -88,7 +88,7 @@ void collect_timers(m2v_enc *e)
 //   finish_chunk scans, headers, stream assembly into `d_stream` (ctl carries base/total/cap)
 // Everything is enqueued on `s`; nothing is synchronised here.
 // ---------------------------------------------------------------------------------------------
-void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool last, uint32_t last_valid_beats, bool flow)
+void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool last, uint32_t last_valid_beats)
 {
     e->chain_ev = nullptr;                  // copies are enqueued below: the next timer records its own start event
     const Geom &g = e->g;
@@ -124,10 +124,7 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
             e->rec_pool.clear();
             e->rec_pool_bytes = e->rec_bytes;
         }
-        // FLOW: a reconstruction buffer of its own for every frame, as the debug option keep_recon has it - an address is then written
-        // once per launch, which is what lets the consumers of a FLOW launch read their reference with plain loads
-        const bool own_buffers = e->keep_recon || flow;
-        const size_t want = own_buffers ? nf + 1 : 2 * nseg + 1;
+        const size_t want = e->keep_recon ? nf + 1 : 2 * nseg + 1;
         while (e->rec_pool.size() < want) {
             uint8_t *p = nullptr;
             HIPCHK(hipMalloc((void **)&p, e->rec_pool_bytes));
@@ -150,7 +147,7 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
                 }
                 if (followed) {
                     int sl;
-                    if (own_buffers) sl = free_slots[fs++];
+                    if (e->keep_recon) sl = free_slots[fs++];
                     else {
                         const int which = (int)((k - a) & 1);
                         if (slots[which] < 0) slots[which] = free_slots[fs++];
@@ -208,38 +205,6 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
         e->plan_steps[j] = st;
     }
 
-    // ---- FLOW: the P-frame lists of all steps as one [rows][gmax] table of jobs; a frame whose reference is produced by the same
-    //      launch carries that frame's chunk index (rhidx), one whose reference is complete beforehand (an I frame of the chunk - its
-    //      launch precedes the FLOW launch on the stream -, the persisted last frame of the previous chunk) -1 ----
-    std::vector<FrameJob> flowjobs;
-    e->plan_flow = false;
-    e->plan_flow_rows = e->plan_flow_gmax = 0;
-    e->plan_flow_frames = 0;
-    if (flow && need_any_rec) {
-        int gmax = 0, rows = 0;
-        for (auto &st : e->plan_steps) { gmax = std::max(gmax, st.n_p); rows += st.n_p > 0; }
-        if (rows > 0) {
-            flowjobs.assign((size_t)rows * (size_t)gmax, FrameJob{});          // in == nullptr: no job
-            int row = 0;
-            for (auto &st : e->plan_steps) {
-                if (st.n_p == 0) continue;
-                for (int k = 0; k < st.n_p; ++k) {
-                    const int f = lists[(size_t)(st.off_p + k)];
-                    FrameJob fj = jobs[(size_t)f];
-                    fj.fidx = (uint32_t)f;
-                    const bool ref_in_launch = f > 0 && jobs[(size_t)f - 1].i_frame != 0 && jobs[(size_t)f].i_frame != 0 && fj.ref == jobs[(size_t)f - 1].rec;
-                    fj.rhidx = ref_in_launch ? f - 1 : -1;
-                    flowjobs[(size_t)row * (size_t)gmax + (size_t)k] = fj;
-                }
-                e->plan_flow_frames += (size_t)st.n_p;
-                ++row;
-            }
-            e->plan_flow = true;
-            e->plan_flow_rows = rows;
-            e->plan_flow_gmax = gmax;
-        }
-    }
-
     // ---- device buffers ----
     const size_t nmb = nf * (size_t)g.mbs;
     e->d_jobs.ensure(nf);
@@ -290,26 +255,6 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
         e->dev_jobs = jobs;
         e->dev_lists = lists;
         e->dev_jobs_p = e->d_jobs.p; e->dev_lists_p = e->d_lists.p; e->dev_joblist_p = e->d_joblist.p;
-    }
-    if (e->plan_flow) {
-        e->d_rowdone.ensure(nf * (size_t)g.mbh);
-        e->d_flowjobs.ensure(flowjobs.size());
-        m2v_enc::HostStage &h = e->st();
-        if (h.h_flowjobs_cap < flowjobs.size()) {
-            ++alloc_generation();
-            if (h.h_flowjobs) (void)hipHostFree(h.h_flowjobs);
-            h.h_flowjobs = nullptr; h.h_flowjobs_cap = 0;
-            HIPCHK(hipHostMalloc((void **)&h.h_flowjobs, flowjobs.size() * sizeof(FrameJob)));
-            h.h_flowjobs_cap = flowjobs.size();
-        }
-        const bool there = e->dev_flowjobs_p == e->d_flowjobs.p && e->dev_flowjobs.size() == flowjobs.size() &&
-                           !memcmp(e->dev_flowjobs.data(), flowjobs.data(), flowjobs.size() * sizeof(FrameJob));
-        if (!there) {
-            memcpy(h.h_flowjobs, flowjobs.data(), flowjobs.size() * sizeof(FrameJob));
-            HIPCHK(hipMemcpyAsync(e->d_flowjobs.p, h.h_flowjobs, flowjobs.size() * sizeof(FrameJob), hipMemcpyHostToDevice, s));
-            e->dev_flowjobs = flowjobs;
-            e->dev_flowjobs_p = e->d_flowjobs.p;
-        }
     }
     e->plan_nf = nf;
     e->dbg_frames = nf;
@@ -376,20 +321,9 @@ void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_s
 }
 
 void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool first, bool last,
-                  uint32_t last_valid_beats, uint8_t *d_stream, bool advance, bool flow)
+                  uint32_t last_valid_beats, uint8_t *d_stream, bool advance)
 {
-    plan_chunk(e, s, d_frames, nf, last, last_valid_beats, flow);
-    if (e->plan_flow) {
-        // the I frames of the chunk (all of them in step 0), then every P frame of every step in ONE launch: a macroblock starts when
-        // the rows of its reference around it are complete (k_mb<.., FLOW>), not when the previous step has drained
-        e->chain_ev = nullptr;
-        HIPCHK(hipMemsetAsync(e->d_rowdone.p, 0, nf * (size_t)e->g.mbh * sizeof(uint32_t), s));
-        for (size_t j = 0; j < e->plan_steps.size(); ++j) {
-            const m2v_enc::Step &st = e->plan_steps[j];
-            launch_mb<false>(e, s, e->d_lists.p + st.off_i, st.n_i, e->g);
-        }
-        launch_mb_flow(e, s, e->plan_flow_rows, e->plan_flow_gmax, e->g);
-    } else
+    plan_chunk(e, s, d_frames, nf, last, last_valid_beats);
     if (e->plan_groups > 1 && !e->profile && e->plan_steps.size() > 1) {
         // The GOP segments of the chunk as `plan_groups` independent groups, one stream each: a launch of 86 400
         // wavefronts ends with a partially filled GPU (10.55 rounds of 8 192 wave slots) and the next step of the
@@ -525,7 +459,6 @@ void m2v_destroy(m2v_enc *e)
     e->d_coef.release(); e->d_mbaux.release(); e->d_mbdep.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
     e->d_mboff.release(); e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
     e->d_jobs.release(); e->d_lists.release(); e->d_joblist.release(); e->d_ctl.release(); e->d_segs.release();
-    e->d_flowjobs.release(); e->d_rowdone.release();
     for (auto p : e->rec_pool) (void)hipFree(p);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto &h : e->hs) {
@@ -538,7 +471,6 @@ void m2v_destroy(m2v_enc *e)
         if (h.h_jobs) (void)hipHostFree(h.h_jobs);
         if (h.h_lists) (void)hipHostFree(h.h_lists);
         if (h.h_joblist) (void)hipHostFree(h.h_joblist);
-        if (h.h_flowjobs) (void)hipHostFree(h.h_flowjobs);
         if (h.ev_ctl) (void)hipEventDestroy(h.ev_ctl);
         if (h.ev_out) (void)hipEventDestroy(h.ev_out);
     }
@@ -575,7 +507,6 @@ int m2v_reset(m2v_enc *e)
     if (e->strip_stream && e->strip_stream != e->stream) (void)hipStreamSynchronize(e->strip_stream);
     for (auto &h : e->hs) { h.stage = 0; h.uploaded = 0; }
     e->dev_jobs.clear(); e->dev_lists.clear(); e->dev_jobs_p = nullptr;
-    e->dev_flowjobs.clear(); e->dev_flowjobs_p = nullptr;
     e->resident_inflight = false; e->resident_empty = false;
     e->pending.clear();
     e->state = m2v_enc::IDLE;
@@ -634,7 +565,6 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
     }
     if (!strcmp(name, "dct_mfma")) { e->dct_mfma = value != 0; return M2V_OK; }
     if (!strcmp(name, "strip_graph")) { e->strip_graph_opt = value != 0; return M2V_OK; }
-    if (!strcmp(name, "flow")) { e->flow_opt = value != 0; if (value == 2) e->flow_broken = false; return M2V_OK; }
     if (!strcmp(name, "direct_upload")) { e->direct_upload = value != 0; return M2V_OK; }
     if (!strcmp(name, "copy_threads")) { if (value < 1 || value > 64) return M2V_E_PARAM; e->copy_threads = (int)value; return M2V_OK; }
     if (kDebug) {       // libm2v_mi355x_dbg.so only (-DM2V_DEBUG): the shipped library does not know these names

@@ -96,8 +96,6 @@ struct m2v_enc {
         StreamCtl *h_ctl = nullptr;           // pinned: [0] read-back, [1] initial values
         FrameJob *h_jobs = nullptr;           // pinned staging of the per-frame jobs
         size_t h_jobs_cap = 0;
-        FrameJob *h_flowjobs = nullptr;       // pinned staging of the FLOW launch's [rows][gmax] job table
-        size_t h_flowjobs_cap = 0;
         FrameJob *h_joblist = nullptr;        // pinned staging of the jobs in launch-list order
         int *h_lists = nullptr;               // pinned staging of the launch lists
         size_t h_lists_cap = 0;
@@ -149,19 +147,6 @@ struct m2v_enc {
     DevBuf<int> d_lists;
     DevBuf<FrameJob> d_joblist;           // the jobs again, in launch-list order (k_mb reads its frame's job with ONE dependent scalar load)
     DevBuf<StreamCtl> d_ctl;
-    // FLOW (option "flow", the resident entry): every P-frame GOP step of a chunk in one launch, macroblock rows handed from frame to
-    // frame through completion counters (k_mb<.., FLOW>)
-    DevBuf<FrameJob> d_flowjobs;          // [plan_flow_rows][plan_flow_gmax]: the P-frame list of every GOP step that has one, padded with empty jobs
-    DevBuf<uint32_t> d_rowdone;           // [frames of the chunk][mbh]: macroblocks of that row whose reconstruction has reached memory
-    std::vector<FrameJob> dev_flowjobs;   // what d_flowjobs holds (see dev_jobs)
-    const void *dev_flowjobs_p = nullptr;
-    bool flow_opt = true;                 // option "flow"
-    bool flow_broken = false;             // a FLOW launch timed out once on this handle (blocks not started in id order?): step by step from then on
-    int flow_timeouts = 0;
-    bool plan_flow = false;               // the current plan is a FLOW plan
-    int plan_flow_rows = 0, plan_flow_gmax = 0;
-    size_t plan_flow_frames = 0;          // P frames in the FLOW launch
-    struct ResidentCall { uint32_t xs = 0, ys = 0, pf = 0; const uint8_t *d_in = nullptr; size_t n = 0; uint8_t *d_out = nullptr; size_t cap = 0; } resident_call;
     std::vector<uint8_t *> rec_pool;      // reconstruction buffers (4:2:0 planar), each ysz + 2*csz
     size_t rec_bytes = 0;
     size_t rec_pool_bytes = 0;            // allocation size of every buffer in rec_pool
@@ -240,13 +225,13 @@ namespace m2v {
 Geom make_geom(const m2v_enc *e, uint32_t xs, uint32_t ys);
 hipEvent_t pool_event(m2v_enc *e);
 void collect_timers(m2v_enc *e);
-void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool last, uint32_t last_valid_beats, bool flow = false);
+void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool last, uint32_t last_valid_beats);
 void run_step(m2v_enc *e, hipStream_t s, size_t j);
 void run_step_rows(m2v_enc *e, hipStream_t s, size_t j, int r0, int r1);
 void run_step_edges_fused(m2v_enc *e, hipStream_t s, size_t j, uint8_t *up, uint8_t *down, const uint8_t *nb_up, const uint8_t *nb_down);
 void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_stream, bool advance = false);
 void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool first, bool last, uint32_t last_valid_beats,
-                  uint8_t *d_stream, bool advance = false, bool flow = false);
+                  uint8_t *d_stream, bool advance = false);
 // pinned host memory of at least `bytes`, kept with the handle
 void ensure_pinned(uint8_t *&p, size_t &cap, size_t bytes);
 // every C-ABI entry runs its body through this: selects the handle's device, turns exceptions into M2V_E_* + the handle's error text
@@ -282,7 +267,6 @@ struct Timer {
 // handle there (config c4 creates 8 handles from 8 threads).
 void upload_tables(int device);
 template <bool P> void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g);
-void launch_mb_flow(m2v_enc *e, hipStream_t s, int rows, int gmax, const Geom &g);
 template <bool P> void launch_mb_edges(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g, uint8_t *up, uint8_t *down,
                                        const uint8_t *nb_up, const uint8_t *nb_down);
 extern template void launch_mb<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &);

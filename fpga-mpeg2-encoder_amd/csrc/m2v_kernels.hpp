@@ -91,7 +91,6 @@ constexpr int kS3Scratch = 1600 + 384 + 1536;            // the end of the trans
 // luma tiles (accumulator layout) were 4-way conflicted and the column pass of the IDCT 6-way; with 72 both are conflict-free (the row pass,
 // 16 bytes per lane, costs the same either way).  Same box, ms per step: 64 1.149 / 1.162, 68 1.145, 72 1.141 / 1.154, 76 1.153, 80 1.153.
 constexpr int kTileStride = 72;
-constexpr uint32_t kFlowSpinLimit = 20000;   // polls (~2.5 us each) before a FLOW block gives up on its reference rows: ~50 ms
 constexpr int kS3Flush = kS3Scratch;                     // running sums [t][group][k], 8 bytes each
 constexpr int kS3Rep = kS3Flush + 3 * 4 * 4 * 8;         // macroblock rows 13 14 15 13 14 15 ... (12 x 16 bytes) for the helpers
 static_assert((kS3Rep - kS3Cur) % 256 == 128, "a step reads one row of each in the same instruction: 32 banks apart");
@@ -686,30 +685,14 @@ __device__ u32x4_t d_lanetab[3][2][kQuadsPerBlock][64];
 // receive - in k_halo_pack's layout, so the step needs no pack kernel between the edge rows and the send; and the window rows
 // that lie in a neighbour's strip are read from `nb_up` / `nb_down`, the buffers the neighbours' rows of the reference frame
 // were received in, so there is no unpack kernel (and no launch gap) between the receive and the next step either.
-// FLOW = ALL the P-frame GOP steps of a chunk in ONE launch (the resident entry, option "flow"): blockIdx.y is the GOP step, and a
-// macroblock of frame f starts on its reference as soon as the three macroblock rows of recon(f - 1) around it are complete -
-// not when the whole previous step has drained.  Between launches a step ends with a partially filled GPU (10.55 rounds of wave
-// slots at 1920x1152 x 10 GOPs) and the next one ramps up again: 13 - 17 % of the vector ALU time of a sequence
-// (profiles/r03_experiments.txt item 8).  Hand-off per cdna_hip_programming.md 6 G16: the producer stores its reconstruction
-// write-through (sc1), drains (s_waitcnt vmcnt(0)) and adds 1 to its row's counter with an agent-scope atomic; the consumer polls
-// the (at most) three counters with relaxed agent-scope loads before it requests its window.  It needs no acquire and no sc1
-// loads: in FLOW mode every frame has a reconstruction buffer of its own, so an address is written once per launch and no CU reads
-// a line before the rows it holds are complete (a line of the window spans at most the rows the poll covered: W >= 64) - there is
-// no older copy of it in any L1 / L2 (both are invalidated when the launch starts).
-// Progress: the blocks of step j have smaller linear ids than those of step j + 1 and a macroblock's producers belong to the step
-// before it; as long as the hardware starts the blocks of an XCD in id order (observed; not a promise of HIP), every producer a
-// block can wait for is already resident or finished.  Should that ever not hold, a block gives up after ~50 ms of polling and
-// raises StreamCtl::flow_timeout; the host then encodes the sequence again step by step and stops using FLOW on the handle.
-template <int VL, bool P, bool CONF = false, bool MFMA = false, bool FILL = false, bool EDGE = false, bool FLOW = false>
+template <int VL, bool P, bool CONF = false, bool MFMA = false, bool FILL = false, bool EDGE = false>
 __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
                                            Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
                                            uint32_t *__restrict__ slots_small, uint32_t *__restrict__ slots,
                                            int16_t *__restrict__ coef_dbg, uint8_t *__restrict__ halo_up = nullptr,
                                            uint8_t *__restrict__ halo_down = nullptr, const uint8_t *__restrict__ nb_up = nullptr,
-                                           const uint8_t *__restrict__ nb_down = nullptr, uint32_t *__restrict__ flow_done = nullptr,
-                                           StreamCtl *__restrict__ flow_ctl = nullptr)
+                                           const uint8_t *__restrict__ nb_down = nullptr)
 {
-    static_assert(!FLOW || (P && !EDGE && !FILL), "FLOW is a P-frame launch of the whole frame");
     constexpr int UR = VL, YR = 2 * VL;
     constexpr int WROWS = 16 + 2 * YR;         // luma window rows -YR .. 16+YR-1 (RTL:1446)
     constexpr int CROWS = 8 + 2 * UR;          // chroma window rows -UR .. 8+UR-1 (RTL:1447)
@@ -845,12 +828,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     if constexpr (!P) M2V_REQUEST_BASIS();
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t li = udiv_magic(blk, g.strip_mbs, g.magic_strip);           // which frame of the launch list
-    // FLOW: the list of GOP step blockIdx.y is row blockIdx.y of a [steps][flow_gmax] table; gridDim.x is the longest step's block count
-    // rounded up to a multiple of 8 (so that block x of every step runs on XCD x % 8 and the remap above stays what it is): the surplus
-    // blocks and those of a shorter step find no job and leave
-    if constexpr (FLOW) { if (li >= (uint32_t)g.flow_gmax) return; }
-    const FrameJob job = jobs[FLOW ? blockIdx.y * (uint32_t)g.flow_gmax + li : li];   // `jobs` = the launch list as jobs: one dependent scalar load, not list -> job
-    if constexpr (FLOW) { if (job.in == nullptr) return; }
+    const FrameJob job = jobs[li];                 // `jobs` = the launch list as jobs: one dependent scalar load, not list -> job
     const int fidx = (int)job.fidx;
     int mb, by, bx;
     if constexpr (EDGE) {
@@ -904,32 +882,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         sl.even = s0.x; sl.odd = s0.y; sl.cur = s0.z; sl.cur12 = s0.w;
         sl.plus = s1.x; sl.minus = s1.y; sl.cb4 = s1.z; sl.dead_lo = s1.w; sl.dead_hi = s2;
     }
-    if constexpr (FLOW) {
-        // the reference is a frame of THIS launch (frame rhidx of the chunk; -1: complete before the launch started - an I frame, or the
-        // last frame of the previous chunk): wait until the macroblock rows by - 1 .. by + 1 of it are complete.  Lanes 0 .. 2 poll a
-        // row counter each, lane 3 the give-up flag; the current pixels and the lane tables requested above are in flight meanwhile.
-        if (job.rhidx >= 0 && !(kDebug && (g.ablate & 64))) {      // (ablate bit 6: timing experiment, no poll - results invalid)
-            typedef __attribute__((address_space(1))) uint32_t *gu32;
-            const int rlo = by - in_u, nrows = 1 + in_u + in_d;
-            gu32 const word = lane < nrows ? (gu32)(flow_done + (size_t)job.rhidx * (size_t)g.mbh + (size_t)(rlo + lane)) : (gu32)&flow_ctl->flow_timeout;
-            // (-DM2V_DEBUG, option ablate bit 5: a count no row ever reaches - the give-up path under test)
-            const uint32_t need = lane < nrows ? (uint32_t)g.mbw + (kDebug && (g.ablate & 32) ? 1u : 0u) : 0u;
-            for (uint32_t spins = 0;; ++spins) {
-                uint32_t c = need;
-                if (lane < 4) c = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long short_of = ballot(lane < nrows && c < need), gave_up = ballot(lane == 3 && c != 0u);
-                if (short_of == 0ull) break;
-                if (gave_up != 0ull) return;                // somebody timed out: the host encodes the sequence again without FLOW
-                if (spins > kFlowSpinLimit) {
-                    if (lane == 0) __hip_atomic_store((gu32)&flow_ctl->flow_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;
-                }
-                __builtin_amdgcn_s_sleep(32);
-            }
-        }
-    }
     if constexpr (P) {
-        const uint8_t *refY = job.ref, *refU = refY + g.ysz;
+        const uint8_t *refY = job.ref, *refU = refY + g.ysz;       // (V sits csz bytes behind U)
         if constexpr (EDGE) {
             // window rows above the strip's first / below its last macroblock row belong to a neighbour: they were received, for
             // this frame's reference, at position rhidx of nb_up / nb_down ([YR rows of W luma][UR rows of cw U][UR of V] per
@@ -1507,23 +1461,6 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         // scalar base + 32-bit lane offset (a generic pointer costs a 64-bit vector add per store); V sits csz bytes behind U
         typedef __attribute__((address_space(1))) uint32_t *gst32;
         uint8_t *recY = job.rec, *recU = recY + g.ysz;
-        if (FLOW && !(kDebug && (g.ablate & 128))) {              // (ablate bit 7: timing experiment, plain stores - results invalid)
-            // write-through (sc1) stores of 16 / 8 bytes per lane (a narrow sc1 store is a fabric write of its own: 4-byte ones cost ~6x
-            // per byte, MI355X_MICROARCH.md): lane l < 16 owns pixel row l of the macroblock - row l & 7 of the two tiles side by side -,
-            // lanes 16 .. 31 the 8-byte rows of U and V
-            if (lane < 16) {
-                const uint32_t src = lds_off(&s_pred[(lane >> 3) * 2][(lane & 7) * 8]);
-                const u32x2_t a = *(LdsU2)(uintptr_t)src, b = *(LdsU2)(uintptr_t)(src + 64u);
-                const u32x4_t v = {a.x, a.y, b.x, b.y};
-                const uint32_t off = __umul24((uint32_t)(16 * by + lane), (uint32_t)W) + (uint32_t)(16 * bx);
-                asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(off), "v"(v), "s"(recY) : "memory");
-            } else if (lane < 32) {
-                const uint32_t pl = (uint32_t)(lane >> 3) & 1u, row = (uint32_t)lane & 7u;
-                const u32x2_t v = *(LdsU2)(uintptr_t)lds_off(&s_pred[4 + pl][row * 8]);
-                const uint32_t off = __umul24(pl, (uint32_t)g.csz) + __umul24((uint32_t)(8 * by) + row, (uint32_t)g.cw) + (uint32_t)(8 * bx);
-                asm volatile("global_store_dwordx2 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(off), "v"(v), "s"(recU) : "memory");
-            }
-        } else {
         {
             const uint32_t v = *(LdsU32 *)(uintptr_t)kq0.z;                  // the lane's four pixels: s_pred[tile][ti] again
             *(gst32)(recY + pix_off) = v;
@@ -1535,7 +1472,6 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             const uint32_t c0 = __umul24(k4p, (uint32_t)g.csz) + (k4r + (uint32_t)sgpr((int)(__umul24((uint32_t)(8 * by), (uint32_t)g.cw) + (uint32_t)(8 * bx))));
             const uint32_t coff = __umul24(kq4.x, (uint32_t)g.cw) + c0;
             *(gst32)(recU + coff) = v;
-        }
         }
         if constexpr (EDGE) {
             // per frame of the step's halo list: [YR rows of W luma][UR rows of cw U][UR rows of cw V] (k_halo_pack's layout)
@@ -1669,16 +1605,6 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             aux.w2 = ((uint32_t)dcs[0] & 0xFFFFu) | (((uint32_t)dcs[3] & 0xFFFFu) << 16);
             aux.w3 = (uint32_t)dcs[4] & 0xFFFFu;
             mbaux[mbidx] = aux;
-        }
-    }
-    if constexpr (FLOW) {
-        // publish: the reconstruction left write-through before the entropy coder ran; once every store of this wavefront has
-        // been acknowledged the macroblock counts towards its row
-        if (job.rec != nullptr && !(kDebug && (g.ablate & 8))) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                __hip_atomic_fetch_add((__attribute__((address_space(1))) uint32_t *)(flow_done + (size_t)fidx * (size_t)g.mbh + (size_t)by), 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -209,30 +209,6 @@ void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Ge
     t.stop();
 }
 
-// every P-frame GOP step of the chunk in ONE launch (k_mb<.., FLOW>): blockIdx.y = row of the [rows][gmax] job table e->d_flowjobs,
-// the grid's x extent = the longest step's macroblocks, rounded up to a multiple of 8 (a step's block x then runs on XCD x % 8)
-void launch_mb_flow(m2v_enc *e, hipStream_t s, int rows, int gmax, const Geom &g0)
-{
-    if (rows <= 0 || gmax <= 0) return;
-    Geom g = g0;
-    g.flow_gmax = gmax;
-    const size_t per_step = ((size_t)gmax * (size_t)g.mbs + 7) & ~(size_t)7;
-    const dim3 grid((unsigned)per_step, (unsigned)rows), block(64);
-    Timer t(e, s, 0, (double)e->plan_flow_frames * g.ysz);
-#define M2V_LAUNCH_FLOW(VLV) \
-    hipLaunchKernelGGL((k_mb<VLV, true, false, true, false, false, true>), grid, block, 0, s, e->d_flowjobs.p, (const int *)nullptr, g, e->d_mbinfo.p, \
-                       e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, (int16_t *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr, (const uint8_t *)nullptr, \
-                       (const uint8_t *)nullptr, e->d_rowdone.p, e->d_ctl.p)
-    switch (e->VL) {
-        case 1: M2V_LAUNCH_FLOW(1); break;
-        case 2: M2V_LAUNCH_FLOW(2); break;
-        default: M2V_LAUNCH_FLOW(3); break;
-    }
-#undef M2V_LAUNCH_FLOW
-    HIPCHK(hipGetLastError());
-    t.stop();
-}
-
 template void launch_mb<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &);
 template void launch_mb<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &);
 template void launch_mb_edges<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *);
@@ -246,7 +222,7 @@ __global__ void k_ctl_chain(StreamCtl *ctl, unsigned long long cap, int first)
     ctl->cap_bytes = cap & ~3ull;
     ctl->prior_bytes = prior;
     ctl->overflow = 0;
-    ctl->flow_timeout = 0;
+    ctl->pad = 0;
 }
 
 void launch_ctl_chain(m2v_enc *e, hipStream_t s, unsigned long long cap, bool first)

@@ -8,8 +8,6 @@ struct ResidentArgs { uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; uint8_
 
 // The resident entry in two halves: everything enqueued (m2v_encode_resident_begin), then the one wait and the byte count
 // (m2v_encode_resident_end).  m2v_encode_resident is both, back to back.
-static int resident_impl(m2v_enc *e, void *argp);
-
 static int resident_end_impl(m2v_enc *e, void *argp)
 {
     auto *bytes = (size_t *)argp;
@@ -17,15 +15,6 @@ static int resident_end_impl(m2v_enc *e, void *argp)
     e->resident_inflight = false;
     HIPCHK(hipStreamSynchronize(e->resident_stream));
     collect_timers(e);
-    if (e->st().h_ctl->flow_timeout && !e->flow_broken) {
-        // a block of the FLOW launch gave up waiting for its reference rows (blocks not started in id order after all): the stream is
-        // invalid.  Once more, step by step - and step by step from now on.
-        e->flow_broken = true;
-        e->flow_timeouts++;
-        const m2v_enc::ResidentCall &c = e->resident_call;
-        ResidentArgs again{c.xs, c.ys, c.pf, c.d_in, c.n, c.d_out, c.cap, bytes, e->resident_stream == e->stream ? nullptr : e->resident_stream, false};
-        return resident_impl(e, &again);
-    }
     if (e->st().h_ctl->overflow) { e->set_err("output buffer too small"); return M2V_E_OVERFLOW; }
     if (bytes) *bytes = (size_t)e->st().h_ctl->total_bytes;
     return M2V_OK;
@@ -52,9 +41,6 @@ static int resident_impl(m2v_enc *e, void *argp)
     // the control word starts from a one-thread kernel, not from a host-to-device copy (a copy engine round trip in front of the first kernel)
     if (!e->st().h_ctl) HIPCHK(hipHostMalloc((void **)&e->st().h_ctl, 2 * sizeof(StreamCtl)));
     launch_ctl_chain(e, s, (unsigned long long)a->cap, true);
-    // FLOW (option "flow"): all P-frame steps of a chunk in one launch; not with the options whose kernels have no FLOW instantiation
-    const bool flow = e->flow_opt && !e->flow_broken && e->pframes > 0 && e->dct_mfma && !e->conformant && !e->keep_recon && (e->ablate & ~(32 | 64 | 128)) == 0;
-    e->resident_call = m2v_enc::ResidentCall{a->xs, a->ys, a->pf, a->d_in, a->n, a->d_out, a->cap};
     const size_t chunk = std::max<size_t>(1, e->batch_frames);
     // align chunks to GOP boundaries so every chunk starts with an I frame where possible
     const size_t gop = e->pframes + 1u;
@@ -62,7 +48,7 @@ static int resident_impl(m2v_enc *e, void *argp)
     for (size_t k = 0; k < a->n; k += step) {
         const size_t nf = std::min(step, a->n - k);
         const bool first = k == 0, last = k + nf == a->n;
-        encode_chunk(e, s, a->d_in + k * fb, nf, first, last, g.ysz / 4, a->d_out, /*advance=*/k > 0, flow);
+        encode_chunk(e, s, a->d_in + k * fb, nf, first, last, g.ysz / 4, a->d_out, /*advance=*/k > 0);
         if (!last) HIPCHK(hipStreamSynchronize(s));    // the per-chunk work buffers are reused
     }
     HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
@@ -88,13 +74,6 @@ int m2v_encode_resident_begin(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, ui
     ResidentArgs a{xsize16, ysize16, pframes_count, (const uint8_t *)d_frames444, nframes, (uint8_t *)d_out, cap, nullptr,
                    (hipStream_t)hip_stream, true};
     return guard(e, resident_impl, &a);
-}
-
-int m2v_flow_state(const m2v_enc *e, int *timeouts)
-{
-    if (!e) return M2V_E_PARAM;
-    if (timeouts) *timeouts = e->flow_timeouts;
-    return e->plan_flow ? 1 : 0;
 }
 
 int m2v_encode_resident_end(m2v_enc *e, size_t *out_bytes)

@@ -29,8 +29,7 @@ struct Geom {
     int row0, row1;  // macroblock rows this GPU encodes: [0, mbh) normally, a strip in multi-GPU strip mode
     int strip;       // 1 = strip mode: the stream buffer holds only this strip's slices, no headers
     int ablate;      // M2V_DEBUG builds only: profiling aid (option "ablate", default 0 = everything on; results are INVALID otherwise):
-                     // bit0 skip full-pel search, bit1 skip half-pel SADs, bit2 skip VLC, bit3 skip IDCT/recon, bit4 skip DCT/quant;
-                     // bit5 (valid results): the blocks of a FLOW launch never see their reference rows complete and give up (tests the fallback)
+                     // bit0 skip full-pel search, bit1 skip half-pel SADs, bit2 skip VLC, bit3 skip IDCT/recon, bit4 skip DCT/quant
     uint32_t strip_mbs;      // (row1 - row0) * mbw
     uint32_t magic_strip;    // floor(2^32 / strip_mbs), floor(2^32 / mbw): wave-uniform divisions on the scalar unit
     uint32_t magic_mbw;      // (geom_finish() fills the three after any change of the rows)
@@ -39,7 +38,6 @@ struct Geom {
                              // rows, the strip's first and its last (row0 and row0 + rstride)
     int edge_top, edge_bot;  // strip mode: the strip's first and last macroblock row (k_mb<.., EDGE> copies their outer rows of the
                              // reconstruction into the halo buffers)
-    int flow_gmax;           // FLOW launch: row length of the [GOP step][frame] job table (the longest step's list)
 };
 
 inline void geom_finish(Geom &g)
@@ -60,7 +58,6 @@ struct FrameJob {           // one per frame of the chunk (device memory)
     uint32_t       fidx;    // k_mb's copies in launch-list order: the frame's index in the chunk (0 in the per-frame array)
     int32_t        hidx;    // strip mode: the frame's position in its GOP step's halo list (frames whose reconstruction is referenced later), -1 = none
     int32_t        rhidx;   // ... and that of its reference frame in the previous step's list (where the neighbours' rows of it were received)
-                            // FLOW launch (never strip mode): the chunk index of the reference frame if THIS launch produces it, else -1
 };
 
 struct StreamCtl {          // device-resident stream bookkeeping, carried across chunks
@@ -69,7 +66,7 @@ struct StreamCtl {          // device-resident stream bookkeeping, carried acros
     unsigned long long cap_bytes;    // capacity of the output buffer
     unsigned long long prior_bytes;  // stream bytes of this sequence that left in earlier buffers (final padding rule)
     uint32_t overflow;               // 1 = the chunk did not fit, nothing was written
-    uint32_t flow_timeout;           // 1 = a block of a FLOW launch (k_mb<.., FLOW>) gave up waiting for its reference rows: the stream is invalid
+    uint32_t pad;
 };
 
 constexpr int kSlotWords = 304;       // per-macroblock bit slot: 3 bit-contiguous segments, <= 9300 bits

@@ -126,10 +126,6 @@ int m2v_encode_resident_begin(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, ui
                               const void *d_frames444, size_t nframes, void *d_out, size_t cap, void *hip_stream);
 int m2v_encode_resident_end(m2v_enc *e, size_t *out_bytes);
 
-/* 1 if the last sequence of the resident entry ran its P frames as ONE launch (option "flow"), 0 if step by step; *timeouts
- * (optional) = how often such a launch has given up on this handle and the sequence was encoded again step by step. */
-int m2v_flow_state(const m2v_enc *e, int *timeouts);
-
 /*
  * Strip mode (BASELINE config c5; no RTL counterpart — the RTL has one reference BRAM): several
  * handles, one per GPU, each encode the macroblock rows [row0,row1) of EVERY frame of one sequence.
@@ -253,11 +249,6 @@ int m2v_strip_graph_stats(const m2v_enc *e, int *last_call_was_graph, int *recor
  * "dct_mfma" (default 1: the four luma tiles' 2-D DCT runs on the matrix cores as two chained i8 GEMMs,
  * B16 . Z . B16^T with the 19-bit intermediate in three byte limbs; 0 = every tile on the integer v_dot4 / v_mad_i32_i24
  * path through LDS.  Bit-identical results either way; the default is the faster one under rocprofv3),
- * "flow" (default 1; the resident entry only: every P frame of a chunk - the j-th frame of every GOP, j = 1 .. - is encoded by ONE
- * launch in which a macroblock starts as soon as the three macroblock rows of its reference around it are complete, instead of one
- * launch per GOP step with the GPU draining in between; every frame then has a reconstruction buffer of its own.  Same bytes.
- * The launch relies on the hardware starting workgroups in index order to make progress; a workgroup that waits ~50 ms gives up, the
- * sequence is encoded again step by step and the handle stays step by step (m2v_flow_state; value 2 re-arms it).  0 = step by step),
  * "strip_graph" (default 1: m2v_strip_encode launches its sequence as a recorded hipGraph, see there; 0 = always call by call),
  * "conformant" (default 0 = the reference's arithmetic, byte-identical to the RTL.  1 = NOT the reference's
  * behaviour: the reconstruction loop follows ISO/IEC 13818-2 where the RTL deviates from it - four-sample average
