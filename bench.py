@@ -166,16 +166,21 @@ def rtl_sim_probe():
     runs wherever `iverilog` + `vvp` are installed and M2V_RTL points at mpeg2encoder.v (tools/run_rtl_oracle.py); this
     image and the GPU box have neither, so the line says so instead of pretending."""
     import shutil
-    iv, vvp, rtl = shutil.which("iverilog"), shutil.which("vvp"), os.environ.get("M2V_RTL")
-    if not (iv and vvp and rtl and os.path.exists(rtl)):
-        return {"available": False, "iverilog": iv, "vvp": vvp, "rtl": rtl,
+    iv, vvp, ver, rtl = shutil.which("iverilog"), shutil.which("vvp"), shutil.which("verilator"), os.environ.get("M2V_RTL")
+    if not (((iv and vvp) or ver) and rtl and os.path.exists(rtl)):
+        return {"available": False, "iverilog": iv, "vvp": vvp, "verilator": ver, "rtl": rtl,
                 "note": "RTL oracle unavailable: no Verilog simulator / RTL file on this host; parity is against oracle/m2v_oracle.c "
                         "(line-cited C restatement of the RTL, parity unpinned by the reference - DESIGN.md section 5)"}
     import subprocess
     t0 = time.perf_counter()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_rtl_oracle.py"), "--rtl", rtl], capture_output=True, text=True)
-    return {"available": True, "identical_to_oracle": r.returncode == 0, "seconds": round(time.perf_counter() - t0, 1),
-            "cores": 1, "log": r.stdout.strip().splitlines()[-8:]}
+    lines = r.stdout.strip().splitlines()
+    try:
+        verdict = json.loads(lines[-1])           # the tool's last line: RTL vs oracle vs product (m2v_tb), known answers, simulator
+    except (ValueError, IndexError):
+        verdict = {"available": True}
+    verdict.update({"identical_to_oracle": r.returncode == 0, "seconds": round(time.perf_counter() - t0, 1), "cores": 1, "log": lines[-10:-1]})
+    return verdict
 
 
 def end_to_end(M, clip_np, want_bytes):
