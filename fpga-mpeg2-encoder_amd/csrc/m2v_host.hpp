@@ -115,7 +115,7 @@ struct m2v_enc {
     HostStage &st() { return hs[cur]; }
     std::deque<int> pending;      // submitted stages, oldest first
     bool dct_mfma = true;         // option "dct_mfma": luma DCT through the matrix cores (k_mb<.., MFMA = true>); 0 = integer VALU / LDS
-                                  // path.  Same results; kept by the rocprofv3 number (profiles/r02_mfma_*: 138.3 vs 140.3 us per launch)
+                                  // path.  Same results; kept by the rocprofv3 number (profiles/archive/r02_mfma_*: 138.3 vs 140.3 us per launch)
     bool conformant = false;      // option "conformant": ISO reconstruction loop instead of the RTL's (NOT byte-identical to the reference)
     int copy_threads = 8;         // option "copy_threads": threads that copy m2v_push_frames input into pinned memory
     bool direct_upload = true;    // option "direct_upload": page-locked caller memory is uploaded without the staging copy

@@ -53,7 +53,7 @@ __constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for
 // c = lane & 15); register v of a 16x16 accumulator holds block row 4g + v, column c.  Filled by fill_mfma_tables().
 // Per-lane tables are stored QUAD-MAJOR on the device ([16-byte quad of the row][lane]): the 64 lanes of a dwordx4 load then read
 // 1 KB of consecutive bytes (8 cache lines).  Row-major, every lane of such a load touches its own cache line, and a dozen
-// of those per macroblock kept the vector memory pipe busier than the pixels do (profiles/r02_n_*).
+// of those per macroblock kept the vector memory pipe busier than the pixels do (profiles/archive/r02_n_*).
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));

@@ -72,7 +72,7 @@ struct StreamCtl {          // device-resident stream bookkeeping, carried acros
 constexpr int kSlotWords = 304;       // per-macroblock bit slot: 3 bit-contiguous segments, <= 9300 bits
 constexpr int kSmallSlotWords = 32;   // macroblocks of <= 1024 stored bits (nearly all) use a compact 128-byte slot instead (64-byte slots were
                                       // tried: k_assemble touches half the lines for P frames, but most macroblocks of an I frame then sit in
-                                      // the overflow slots, which it reads word by word - no net gain, profiles/r02_v_bench.json)
+                                      // the overflow slots, which it reads word by word - no net gain, profiles/archive/r02_v_bench.json)
 constexpr int kSlotChunks = kSmallSlotWords / 4;
 constexpr int kTinySlotWords = 16;    // ... and those of <= 512 bits (99 % of a P frame) a 64-byte slot in a second array behind the first:
                                       // k_assemble is bound by the cache lines it touches, two of these share one
