@@ -212,13 +212,12 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
     e->d_joblist.ensure(lists.size());
     if (e->keep_recon) e->d_coef.ensure(nmb * 384);
     e->d_mbaux.ensure(nmb);
-    e->d_mbdep.ensure(nmb);
     e->d_slots.ensure(nmb * (size_t)kSlotWords + 8);
-    e->d_slots_small.ensure(nmb * (size_t)(kSmallSlotWords + kTinySlotWords) + 8);      // the 128-byte class, then the 64-byte class
+    e->d_slots_small.ensure(nmb * (size_t)(kSmallSlotWords + kTinySlotWords + kMicroSlotWords) + 8);      // the 128-byte class, then the 64- and the 32-byte class
     e->g.s16_off = (uint32_t)(nmb * (size_t)kSmallSlotWords);
+    e->g.s8_off = (uint32_t)(nmb * (size_t)(kSmallSlotWords + kTinySlotWords));
     e->d_mbinfo.ensure(nmb);
     e->d_mblen.ensure(nmb);
-    e->d_mboff.ensure(nmb);
     e->d_slice_bytes.ensure(nf * g.mbh);
     e->d_slice_off.ensure(nf * g.mbh);
     e->d_frame_off.ensure(nf + 1);
@@ -456,8 +455,8 @@ void m2v_destroy(m2v_enc *e)
     if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
     if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
     for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
-    e->d_coef.release(); e->d_mbaux.release(); e->d_mbdep.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
-    e->d_mboff.release(); e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
+    e->d_coef.release(); e->d_mbaux.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
+    e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
     e->d_jobs.release(); e->d_lists.release(); e->d_joblist.release(); e->d_ctl.release(); e->d_segs.release();
     for (auto p : e->rec_pool) (void)hipFree(p);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);

@@ -138,10 +138,9 @@ struct m2v_enc {
     // device buffers
     DevBuf<int16_t> d_coef;               // debug only: quantised levels
     DevBuf<MbAux> d_mbaux;
-    DevBuf<MbDepRec> d_mbdep;             // neighbour-dependent codes of every macroblock (k_slice_scan -> k_assemble)
     DevBuf<uint32_t> d_slots;             // per-macroblock VLC bit segments (kSlotWords each), used on overflow only
     DevBuf<uint32_t> d_slots_small;       // compact 128-byte slots (kSmallSlotWords each): the common case
-    DevBuf<uint32_t> d_mbinfo, d_mblen, d_mboff, d_slice_bytes;
+    DevBuf<uint32_t> d_mbinfo, d_mblen, d_slice_bytes;
     DevBuf<unsigned long long> d_slice_off, d_frame_off;
     DevBuf<FrameJob> d_jobs;
     DevBuf<int> d_lists;

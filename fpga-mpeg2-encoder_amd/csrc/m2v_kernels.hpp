@@ -1587,8 +1587,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         else { lenA = offB; lenB = offC - offB; lenC = pos - offC; }   // intra: tiles 4 and 5 always carry at least the EOB
         M2V_WAVE_SYNC();
         const uint32_t nwords = (pos + 31u) >> 5;
-        if (nwords <= (uint32_t)kSmallSlotWords) {          // the common case: one 128-byte line
-            if (nwords <= (uint32_t)kTinySlotWords) {
+        if (nwords <= (uint32_t)kSmallSlotWords) {          // the common case: one 128-byte line, or a half / a quarter of one
+            if (nwords <= (uint32_t)kMicroSlotWords) {
+                if (lane < kMicroSlotWords) slots_small[g.s8_off + mbidx * kMicroSlotWords + lane] = s_bits[lane];
+            } else if (nwords <= (uint32_t)kTinySlotWords) {
                 if (lane < kTinySlotWords) slots_small[g.s16_off + mbidx * kTinySlotWords + lane] = s_bits[lane];
             } else if (lane < kSmallSlotWords) slots_small[mbidx * kSmallSlotWords + lane] = s_bits[lane];
         } else {
@@ -1610,15 +1612,21 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_slice_scan: one block per (frame, slice): total bit length of each macroblock (stored segments
-// + neighbour-dependent codes + 38-bit slice header on the first one), exclusive scan
+// k_slice_scan: one block per (frame, slice): total bit length of each macroblock (stored segments + neighbour-dependent codes
+// + 38-bit slice header on the first one) and, from their sum, the byte size of the slice - what k_frame_scan needs to place the
+// slices.  The codes themselves and the bit offsets inside the slice are formed again by k_assemble from the same 20 bytes per
+// macroblock (a round trip of 16 + 4 bytes per macroblock through memory cost more than the few dozen instructions).
 // ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mb_total_bits(const MbDep &d, const MbAux &aux, bool first_in_slice)
+{
+    return (first_in_slice ? 38u : 0u) + d.p1.len + d.p2.len + d.p3.len + (aux.w0 & 0xFFFFu) + (aux.w0 >> 16) + (aux.w1 & 0xFFFFu);
+}
+
 __global__ __launch_bounds__(128) void k_slice_scan(const FrameJob *__restrict__ jobs, Geom g,
                                                     const uint32_t *__restrict__ mbinfo, const MbAux *__restrict__ mbaux,
-                                                    uint32_t *__restrict__ mb_len, uint32_t *__restrict__ mb_bitoff,
-                                                    uint32_t *__restrict__ slice_bytes, MbDepRec *__restrict__ mbdep, int f0)
+                                                    uint32_t *__restrict__ mb_len, uint32_t *__restrict__ slice_bytes, int f0)
 {
-    __shared__ uint32_t s[128];
+    __shared__ uint32_t s_w[2];
     const int tid = threadIdx.x;
     const int rows = g.row1 - g.row0;
     const int f = f0 + (int)(blockIdx.x / rows), by = g.row0 + (int)(blockIdx.x % rows);      // blockIdx = (frame - f0) * rows + local row
@@ -1631,21 +1639,14 @@ __global__ __launch_bounds__(128) void k_slice_scan(const FrameJob *__restrict__
         const bool has_left = tid > 0;
         const uint32_t linfo = has_left ? mbinfo[idx - 1] : 0u;
         const MbAux laux = has_left ? mbaux[idx - 1] : MbAux{0, 0, 0, 0};
-        const MbDep d = mb_dependent(info, aux, has_left, linfo, laux, jobs[f].i_frame);
-        len = (tid == 0 ? 38u : 0u) + d.p1.len + d.p2.len + d.p3.len + (aux.w0 & 0xFFFFu) + (aux.w0 >> 16) + (aux.w1 & 0xFFFFu);
+        len = mb_total_bits(mb_dependent(info, aux, has_left, linfo, laux, jobs[f].i_frame), aux, tid == 0);
         mb_len[idx] = len;
-        mbdep[idx] = MbDepRec{d.p1.code, d.p2.code, d.p3.code, d.p1.len | (d.p2.len << 8) | (d.p3.len << 16)};
     }
-    s[tid] = len;
+    // the slice's bits: sums inside the two wavefronts by DPP, one word each through LDS
+    const uint32_t sum = (uint32_t)wave_scan_incl((int)len);
+    if ((tid & 63) == 63) s_w[tid >> 6] = sum;
     __syncthreads();
-    for (int o = 1; o < 128; o <<= 1) {
-        const uint32_t t = tid >= o ? s[tid - o] : 0u;
-        __syncthreads();
-        s[tid] += t;
-        __syncthreads();
-    }
-    if (tid < g.mbw) mb_bitoff[base + tid] = s[tid] - len;
-    if (tid == g.mbw - 1) slice_bytes[(size_t)f * g.mbh + by] = (s[tid] + 7u) >> 3;   // next header aligns (RTL:2940-2943)
+    if (tid == 0) slice_bytes[(size_t)f * g.mbh + by] = (s_w[0] + s_w[1] + 7u) >> 3;   // next header aligns (RTL:2940-2943)
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1725,6 +1726,14 @@ __device__ inline void write_sequence_headers(uint8_t *p, const Geom &g)
 // (Round 1-2 had one thread per OUTPUT word, which finds its macroblocks by binary search and looks at all six
 // pieces of each: 385 vector instructions per output word, 57 us per 90 frames; this form needs about a sixth.)
 // ----------------------------------------------------------------------------------------------
+// where the compact slot of macroblock `mb` lives, by the number of words it stores (k_mb's three compact classes)
+__device__ __forceinline__ const uint32_t *compact_slot(const uint32_t *slots_small, const Geom &g, size_t mb, uint32_t nwords)
+{
+    return nwords <= (uint32_t)kMicroSlotWords ? slots_small + g.s8_off + mb * kMicroSlotWords
+           : nwords <= (uint32_t)kTinySlotWords ? slots_small + g.s16_off + mb * kTinySlotWords
+                                                 : slots_small + mb * kSmallSlotWords;
+}
+
 constexpr int kAsmThreads = 128;          // >= macroblocks per row (W <= 2048)
 constexpr int kAsmImageWords = 1024;      // 4 KB image: a P-frame slice in one pass, an I-frame slice in a few (LDS bounds the occupancy
                                           // of this latency-bound kernel: 9 KB per workgroup = 16 workgroups, all 32 wavefronts, per CU)
@@ -1744,9 +1753,8 @@ __device__ __forceinline__ void asm_put(uint32_t *img, int nw, int pos, uint32_t
 }
 
 __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__restrict__ jobs, Geom g, int nframes,
-                                                 const MbAux *__restrict__ mbaux, const MbDepRec *__restrict__ mbdep,
+                                                 const uint32_t *__restrict__ mbinfo, const MbAux *__restrict__ mbaux,
                                                  const uint32_t *__restrict__ slots_small, const uint32_t *__restrict__ slots,
-                                                 const uint32_t *__restrict__ mb_len, const uint32_t *__restrict__ mb_bitoff,
                                                  const unsigned long long *__restrict__ slice_off,
                                                  uint32_t *__restrict__ out32, const StreamCtl *__restrict__ ctl,
                                                  int first, int last, const unsigned long long *__restrict__ frame_off,
@@ -1756,36 +1764,49 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
     __shared__ uint32_t s_slot[kAsmStageWords];
     __shared__ uint32_t s_nw[kAsmThreads];                 // stored words of every macroblock (compact slots only)
     __shared__ uint32_t s_so[kAsmThreads];                 // where its chunks start in s_slot (inclusive scan of the chunk words)
-    __shared__ uint32_t s_total, s_wave0;
-    static_assert(kAsmThreads == 128, "two wavefronts: the scan below");
+    __shared__ uint32_t s_wave0, s_bits[2];
+    static_assert(kAsmThreads == 128, "two wavefronts: the scans below");
+    static_assert(kAsmThreads * 5 <= kAsmImageWords, "the neighbour exchange borrows the image");
     const int tid = threadIdx.x;
     const int rows = g.row1 - g.row0;
     const int f = blockIdx.x / rows, by = g.row0 + (int)(blockIdx.x % rows);
     if (f >= nframes) return;
     const size_t base = ((size_t)f * g.mbh + by) * g.mbw;
     const bool have = tid < g.mbw;
-    uint32_t off = 0, lens = 0, c1 = 0, c2 = 0, c3 = 0;
-    int lenA = 0, lenB = 0, lenC = 0;
-    if (have) {
-        const MbAux aux = mbaux[base + tid];
-        const MbDepRec dep = mbdep[base + tid];
-        off = mb_bitoff[base + tid];
-        lenA = (int)(aux.w0 & 0xFFFFu); lenB = (int)(aux.w0 >> 16); lenC = (int)(aux.w1 & 0xFFFFu);
-        c1 = dep.c1; c2 = dep.c2; c3 = dep.c3; lens = dep.lens;
-        if (tid == g.mbw - 1) s_total = off + mb_len[base + tid];
-    }
+    uint32_t info = 0;
+    MbAux aux{0, 0, 0, 0};
+    if (have) { info = mbinfo[base + tid]; aux = mbaux[base + tid]; }
+    const int i_frame = jobs[f].i_frame;
+    const unsigned long long q = (ctl->base_bytes + slice_off[(size_t)f * g.mbh + by]) * 8ull;
+    const bool overflow = ctl->overflow != 0;
+    // the left neighbour's word and record, through LDS (the image is not in use yet): the neighbour-dependent codes - motion vector
+    // deltas, DC differentials (RTL:2736-2748, 2808-2821) - are formed here, as k_slice_scan formed them for their lengths
+    uint32_t *const s_x = s_img;
+    s_x[tid] = info; s_x[128 + tid] = aux.w0; s_x[256 + tid] = aux.w1; s_x[384 + tid] = aux.w2; s_x[512 + tid] = aux.w3;
+    const int lenA = (int)(aux.w0 & 0xFFFFu), lenB = (int)(aux.w0 >> 16), lenC = (int)(aux.w1 & 0xFFFFu);
     const uint32_t nwords = (uint32_t)(lenA + lenB + lenC + 31) >> 5;
     const bool small = nwords <= (uint32_t)kSmallSlotWords;
     s_nw[tid] = have && small ? nwords : 0u;
     // inclusive scan of the staged words: inside each wavefront by DPP, the first wavefront's total through LDS
     const uint32_t scan = (uint32_t)wave_scan_incl((int)(have && small ? (nwords + 3u) & ~3u : 0u));
     if (tid == 63) s_wave0 = scan;
-    const unsigned long long q = (ctl->base_bytes + slice_off[(size_t)f * g.mbh + by]) * 8ull;
-    const bool overflow = ctl->overflow != 0;
     __syncthreads();
     if (overflow) return;
+    const bool has_left = tid > 0;
+    const int tl = has_left ? tid - 1 : 0;
+    const uint32_t linfo = s_x[tl];
+    const MbAux laux{s_x[128 + tl], s_x[256 + tl], s_x[384 + tl], s_x[512 + tl]};
+    const MbDep dep = mb_dependent(info, aux, has_left, linfo, laux, i_frame);
+    const uint32_t c1 = dep.p1.code, c2 = dep.p2.code, c3 = dep.p3.code;
+    const int l1 = have ? (int)dep.p1.len : 0, l2 = have ? (int)dep.p2.len : 0, l3 = have ? (int)dep.p3.len : 0;
+    // bit offset of every macroblock inside the slice: the same scan over the macroblocks' total lengths
+    const uint32_t mylen = have ? mb_total_bits(dep, aux, tid == 0) : 0u;
+    const uint32_t bscan = (uint32_t)wave_scan_incl((int)mylen);
+    if ((tid & 63) == 63) s_bits[tid >> 6] = bscan;
     s_so[tid] = scan + (tid >= 64 ? s_wave0 : 0u);
     __syncthreads();
+    const uint32_t off = bscan - mylen + (tid >= 64 ? s_bits[0] : 0u);
+    const uint32_t total = s_bits[0] + s_bits[1];          // the slice's bits
     // stage the compact slots: up to kSlotChunks chunks of 16 bytes per macroblock, only the filled ones, packed.  All loads of a
     // thread are issued before the first LDS store (one memory round trip, not one per chunk).
     {
@@ -1798,8 +1819,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
             const uint32_t nwm = s_nw[m], end = s_so[m];   // end: one past the macroblock's last staged word
             const bool take = m < g.mbw && (uint32_t)(4 * c) < nwm && end <= (uint32_t)kAsmStageWords;
             dst[i] = take ? end - ((nwm + 3u) & ~3u) + 4u * (uint32_t)c : 0xFFFFFFFFu;
-            const uint32_t *const src = nwm <= (uint32_t)kTinySlotWords ? slots_small + g.s16_off + (base + m) * kTinySlotWords
-                                                                         : slots_small + (base + m) * kSmallSlotWords;
+            const uint32_t *const src = compact_slot(slots_small, g, base + m, nwm);
             v[i] = take ? *(const uint4 *)(src + 4 * c) : uint4{0, 0, 0, 0};
         }
 #pragma unroll
@@ -1811,15 +1831,11 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
     }
     const int sh = (int)(q & 31ull);
     const unsigned long long w0 = q >> 5;
-    const uint32_t total = s_total;
     const uint32_t nout = ((uint32_t)sh + total + 31u) / 32u;
     // this thread's segments: staged, or in memory (the overflow slot, or a compact slot that found no room in the staging)
     const bool staged = small && s_so[tid] <= (uint32_t)kAsmStageWords;
-    const uint32_t *const big = !small ? slots + (base + tid) * kSlotWords
-                                : nwords <= (uint32_t)kTinySlotWords ? slots_small + g.s16_off + (base + tid) * kTinySlotWords
-                                                                     : slots_small + (base + tid) * kSmallSlotWords;
+    const uint32_t *const big = !small ? slots + (base + tid) * kSlotWords : compact_slot(slots_small, g, base + tid, nwords);
     const uint32_t *const stg = &s_slot[staged ? s_so[tid] - ((nwords + 3u) & ~3u) : 0u];
-    const int l1 = (int)(lens & 255u), l2 = (int)((lens >> 8) & 255u), l3 = (int)((lens >> 16) & 255u);
 
     for (uint32_t c0 = 0; c0 < nout; c0 += kAsmImageWords) {
         const int nw = (int)(nout - c0 < (uint32_t)kAsmImageWords ? nout - c0 : (uint32_t)kAsmImageWords);

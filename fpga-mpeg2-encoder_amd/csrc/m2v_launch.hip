@@ -236,7 +236,7 @@ void launch_slice_scan(m2v_enc *e, hipStream_t s, const Geom &g, int f0, int f1)
     if (f1 <= f0) return;
     const size_t rows = (size_t)(g.row1 - g.row0);
     hipLaunchKernelGGL(k_slice_scan, dim3((unsigned)((size_t)(f1 - f0) * rows)), dim3(128), 0, s, e->d_jobs.p, g, e->d_mbinfo.p,
-                       e->d_mbaux.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_bytes.p, e->d_mbdep.p, f0);
+                       e->d_mbaux.p, e->d_mblen.p, e->d_slice_bytes.p, f0);
 }
 
 // offsets of every frame and slice, stream length, and the tail (end code + padding) cleared
@@ -251,7 +251,7 @@ void launch_assemble(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool f
 {
     const size_t rows = (size_t)(g.row1 - g.row0);
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)(nf * rows)), dim3(kAsmThreads), 0, s, e->d_jobs.p, g, (int)nf,
-                       e->d_mbaux.p, e->d_mbdep.p, e->d_slots_small.p, e->d_slots.p, e->d_mblen.p, e->d_mboff.p, e->d_slice_off.p,
+                       e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, e->d_slice_off.p,
                        (uint32_t *)d_stream, e->d_ctl.p, first ? 1 : 0, last ? 1 : 0, e->d_frame_off.p, e->d_slice_bytes.p);
 }
 

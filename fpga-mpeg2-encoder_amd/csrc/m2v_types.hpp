@@ -34,6 +34,7 @@ struct Geom {
     uint32_t magic_strip;    // floor(2^32 / strip_mbs), floor(2^32 / mbw): wave-uniform divisions on the scalar unit
     uint32_t magic_mbw;      // (geom_finish() fills the three after any change of the rows)
     uint32_t s16_off;        // word offset of the 64-byte slot class inside the compact-slot buffer (plan_chunk: macroblocks of the chunk * 32)
+    uint32_t s8_off;         // ... and of the 32-byte class behind it
     int rstride;             // macroblock rows between the launch's local rows: 1 normally; the EDGE launch of strip mode runs two local
                              // rows, the strip's first and its last (row0 and row0 + rstride)
     int edge_top, edge_bot;  // strip mode: the strip's first and last macroblock row (k_mb<.., EDGE> copies their outer rows of the
@@ -74,6 +75,7 @@ constexpr int kSmallSlotWords = 32;   // macroblocks of <= 1024 stored bits (nea
                                       // tried: k_assemble touches half the lines for P frames, but most macroblocks of an I frame then sit in
                                       // the overflow slots, which it reads word by word - no net gain, profiles/archive/r02_v_bench.json)
 constexpr int kSlotChunks = kSmallSlotWords / 4;
+constexpr int kMicroSlotWords = 8;    // ... and those of <= 256 bits (the median P macroblock is 134 bits) a 32-byte slot in a third array
 constexpr int kTinySlotWords = 16;    // ... and those of <= 512 bits (99 % of a P frame) a 64-byte slot in a second array behind the first:
                                       // k_assemble is bound by the cache lines it touches, two of these share one
 
@@ -83,8 +85,6 @@ struct MbAux {                        // 16 bytes per macroblock next to the uin
     uint32_t w2;                      // dcY00 | dcY11 << 16      (quantised DC levels, 16-bit two's complement)
     uint32_t w3;                      // dcU
 };
-
-struct MbDepRec { uint32_t c1, c2, c3, lens; };   // the three neighbour-dependent codes + l1 | l2 << 8 | l3 << 16, written by k_slice_scan
 
 // strip mode: final assembly on the output rank (k_strip_layout / k_strip_assemble)
 struct CopySeg { const uint8_t *src; unsigned long long dst_off; unsigned long long len; };

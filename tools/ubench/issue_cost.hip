@@ -34,6 +34,7 @@
         asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)");                                       \
         long long t1 = __builtin_readcyclecounter();                                         \
         if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = (uint32_t)(t1 - t0); }           \
+        if ((threadIdx.x & 63) == 0) { atomicMin((unsigned long long *)(out + 4), (unsigned long long)t0); atomicMax((unsigned long long *)(out + 6), (unsigned long long)t1); } \
         if (a == 0x12345678 && d0 + d1 + d2 + d3 + (uint32_t)e0 + (uint32_t)e1 == 77) out[1] = d0 + lds[5];  \
     }
 
@@ -96,6 +97,30 @@
 #define I_ADDLSHL(D)  "v_add_lshl_u32 " #D ", %4, %5, 2\n\t"
 #define I_SADHI(D)    "v_sad_hi_u8 " #D ", %4, %5, %6\n\t"
 #define I_BITOP3(D)   "v_bitop3_b32 " #D ", %4, %5, %6 bitop3:0xde\n\t"
+// round 4: which of the cheap-looking integer forms share the ~2-cycle rate of v_add_u32 / v_and_b32 / v_mov_b32 / v_bitop3_b32?
+#define I_SUBV(D)     "v_sub_u32 " #D ", %4, %5\n\t"
+#define I_SUBREVV(D)  "v_subrev_u32 " #D ", %4, %5\n\t"
+#define I_OR(D)       "v_or_b32 " #D ", %4, %5\n\t"
+#define I_XOR(D)      "v_xor_b32 " #D ", %4, %5\n\t"
+#define I_XNOR(D)     "v_xnor_b32 " #D ", %4, %5\n\t"
+#define I_NOT(D)      "v_not_b32 " #D ", %4\n\t"
+#define I_ADDK(D)     "v_add_u32 " #D ", 5, %4\n\t"
+#define I_ADDLIT(D)   "v_add_u32 " #D ", 0x808080, %4\n\t"
+#define I_ADDS(D)     "v_add_u32 " #D ", %7, %4\n\t"
+#define I_ANDLIT(D)   "v_and_b32 " #D ", 0xff00ff, %4\n\t"
+#define I_ASHR(D)     "v_ashrrev_i32 " #D ", 3, %4\n\t"
+#define I_LSHR(D)     "v_lshrrev_b32 " #D ", 3, %4\n\t"
+#define I_MINU(D)     "v_min_u32 " #D ", %4, %5\n\t"
+#define I_ADDCO(D)    "v_add_co_u32 " #D ", vcc, %4, %5\n\t"
+#define I_ADDE64(D)   "v_add_u32_e64 " #D ", %4, %5\n\t"
+#define I_ADDSDWA(D)  "v_add_u32_sdwa " #D ", %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+#define I_OR3(D)      "v_or3_b32 " #D ", %4, %5, %6\n\t"
+#define I_XOR3(D)     "v_bitop3_b32 " #D ", %4, %5, %6 bitop3:0x96\n\t"
+#define I_CVTF(D)     "v_cvt_f32_i32 " #D ", %4\n\t"
+#define I_ADDF(D)     "v_add_f32 " #D ", %4, %5\n\t"
+#define I_FMA(D)      "v_fma_f32 " #D ", %4, %5, %6\n\t"
+#define I_MULF(D)     "v_mul_f32 " #D ", %4, %5\n\t"
+#define I_PKADDF(D)   "v_pk_add_f32 " #D ", %8, %8\n\t"
 #define I_DSR32(D)    "ds_read_b32 " #D ", %9\n\t"
 #define I_DSW32(D)    "ds_write_b32 %9, %4\n\t"
 #define I_DSW16(D)    "ds_write_b16 %9, %4\n\t"
@@ -110,6 +135,9 @@ T(k_dot4, I_DOT4) T(k_dot4c, I_DOT4C) T(k_pkadd, I_PKADD) T(k_pksub, I_PKSUB) T(
 T(k_pkmul, I_PKMUL) T(k_pkashr, I_PKASHR) T(k_sdwa, I_SDWA) T(k_dppadd, I_DPPADD) T(k_dppmov, I_DPPMOV) T(k_dppbc, I_DPPBC)
 T(k_mbcnt, I_MBCNT) T(k_ffbh, I_FFBH) T(k_bcnt, I_BCNT) T(k_xad, I_XAD) T(k_addlshl, I_ADDLSHL)
 T(k_sadhi, I_SADHI) T(k_bitop3, I_BITOP3)
+T(k_subv, I_SUBV) T(k_subrevv, I_SUBREVV) T(k_or, I_OR) T(k_xor, I_XOR) T(k_xnor, I_XNOR) T(k_not, I_NOT) T(k_addk, I_ADDK) T(k_addlit, I_ADDLIT)
+T(k_adds, I_ADDS) T(k_andlit, I_ANDLIT) T(k_ashr, I_ASHR) T(k_lshr, I_LSHR) T(k_minu, I_MINU) T(k_addco, I_ADDCO) T(k_adde64, I_ADDE64)
+T(k_addsdwa, I_ADDSDWA) T(k_or3, I_OR3) T(k_xor3, I_XOR3) T(k_cvtf, I_CVTF) T(k_addf, I_ADDF) T(k_fma, I_FMA) T(k_mulf, I_MULF)
 T(k_dsr32, I_DSR32) T(k_dsw32, I_DSW32) T(k_dsw16, I_DSW16) T(k_dsor, I_DSOR)
 
 // 64-bit destinations
@@ -196,15 +224,19 @@ int main()
         E(k_sada, 32), E(k_cndv, 32), E(k_cnds, 32), E(k_cndv64, 32), E(k_cndvk, 32), E(k_cmpcnd, 64), E(k_cmpcnds, 64), E(k_cmpv, 32), E(k_cmps, 32), E(k_dot2, 32), E(k_dot2c, 32), E(k_dot4, 32),
         E(k_dot4c, 32), E(k_pkadd, 32), E(k_pksub, 32), E(k_pkmax, 32), E(k_pkmad, 32), E(k_pkmul, 32), E(k_pkashr, 32), E(k_sdwa, 32),
         E(k_dppadd, 32), E(k_dppmov, 32), E(k_dppbc, 32), E(k_mbcnt, 32), E(k_ffbh, 32), E(k_bcnt, 32), E(k_xad, 32), E(k_addlshl, 32),
-        E(k_sadhi, 32), E(k_bitop3, 32), E(k_swap32, 32), E(k_swap16, 32), E(k_qsad, 32), E(k_mqsad, 32), E(k_lshl64, 32), E(k_lshladd64, 32), E(k_madu64, 32),
+        E(k_sadhi, 32), E(k_bitop3, 32),
+        E(k_subv, 32), E(k_subrevv, 32), E(k_or, 32), E(k_xor, 32), E(k_xnor, 32), E(k_not, 32), E(k_addk, 32), E(k_addlit, 32), E(k_adds, 32), E(k_andlit, 32),
+        E(k_ashr, 32), E(k_lshr, 32), E(k_minu, 32), E(k_addco, 32), E(k_adde64, 32), E(k_addsdwa, 32), E(k_or3, 32), E(k_xor3, 32), E(k_cvtf, 32),
+        E(k_addf, 32), E(k_fma, 32), E(k_mulf, 32),
+        E(k_swap32, 32), E(k_swap16, 32), E(k_qsad, 32), E(k_mqsad, 32), E(k_lshl64, 32), E(k_lshladd64, 32), E(k_madu64, 32),
         E(k_readlane, 32), E(k_readfirst, 32), E(k_salu, 32), E(k_valu_salu, 64), E(k_valu_dsr, 64),
         E(k_dsr32, 32), E(k_dsr64, 32), E(k_dsw32, 32), E(k_dsw16, 32), E(k_dsor, 32),
         E(k_mfma16x16x32, 32), E(k_mfma_valu, 32),
     };
     printf("%d CUs; cost = shader cycles per wave-instruction per SIMD (wall time x measured clock / instructions), W waves per SIMD\n", cus);
-    printf("%-16s %8s %8s %8s   %s\n", "test", "W=1", "W=4", "W=8(wall@2.4GHz)", "(k_valu_salu / k_valu_dsr count 2 instructions per pair; k_mfma_valu counts 8 per group)");
+    printf("%-16s %8s %8s %8s %10s %8s  %s\n", "test", "W=1", "W=4", "W=8(wall@2.4GHz)", "W=8(ticks)", "MHz", "(W=8 ticks: first start to last end of all wavefronts in s_memtime ticks - clock independent; MHz = ticks / wall)");
     for (auto &t : tests) {
-        double cost[3];
+        double cost[3], cost_ticks = 0, mhz = 0;
         int wi = 0;
         for (int W : {1, 4, 8}) {
             hipEvent_t e0, e1;
@@ -217,14 +249,22 @@ int main()
             hipDeviceSynchronize();
             float best = 1e9f;
             uint32_t ticks = 0;
+            unsigned long long span = 0;
             for (int rep = 0; rep < 5; ++rep) {
+                const unsigned long long init[2] = {~0ull, 0ull};
+                hipMemcpy(out + 4, init, 16, hipMemcpyHostToDevice);
                 hipEventRecord(e0);
                 hipLaunchKernelGGL(t.fn, dim3(blocks), dim3(threads), 0, 0, out, 12345u);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms;
                 hipEventElapsedTime(&ms, e0, e1);
-                if (ms < best) { best = ms; hipMemcpy(&ticks, out, 4, hipMemcpyDeviceToHost); }
+                if (ms < best) {
+                    best = ms; hipMemcpy(&ticks, out, 4, hipMemcpyDeviceToHost);
+                    unsigned long long mm[2];
+                    hipMemcpy(mm, out + 4, 16, hipMemcpyDeviceToHost);
+                    span = mm[1] > mm[0] ? mm[1] - mm[0] : 0;
+                }
             }
             // cycles per instruction from the wave-local tick count of block 0 (tick = shader cycle): all W waves of a
             // SIMD run concurrently for `ticks`, issuing W * per_iter * ITERS instructions between them
@@ -232,9 +272,10 @@ int main()
             // W = 8 (two blocks per CU): the blocks may not overlap completely; the wall-clock figure is the honest one there
             const double wall_cycles = best * 1e-3 * 2.4e9;
             cost[wi++] = W == 8 ? wall_cycles / ((double)per * ITERS * W) : (double)ticks / ((double)per * ITERS * W);
+            if (W == 8) { cost_ticks = (double)span / ((double)per * ITERS * W); mhz = (double)span / (best * 1e-3) * 1e-6; }
             hipEventDestroy(e0); hipEventDestroy(e1);
         }
-        printf("%-16s %8.2f %8.2f %8.2f\n", t.name, cost[0], cost[1], cost[2]);
+        printf("%-16s %8.2f %8.2f %8.2f %10.2f %8.0f\n", t.name, cost[0], cost[1], cost[2], cost_ticks, mhz);
     }
     return 0;
 }
