@@ -1073,6 +1073,31 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         }
 
         M2V_STOP(2);        // ... up to the full-pel search
+        if (kDebug && ((g.ablate >> 16) & 15)) {
+            // -DM2V_DEBUG, option ablate bits 16-19: 64 extra INDEPENDENT vector instructions of one kind per macroblock - what does an
+            // instruction of that kind cost this kernel? (tools/valu_kind.sh; results unaffected: the values are discarded)
+            const int kind = sgpr((g.ablate >> 16) & 15);
+            uint32_t d0, d1, d2, d3;
+            const uint32_t a = (uint32_t)lane, b = cur4;
+#define M2V_PAD4(INS) INS(%0) INS(%1) INS(%2) INS(%3)
+#define M2V_PAD64(INS) asm volatile(M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) \
+                                    M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) M2V_PAD4(INS) \
+                                    : "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3) : "v"(a), "v"(b), "s"(kind))
+#define M2V_I_ADD(D)   "v_add_u32 " #D ", %4, %5\n\t"
+#define M2V_I_LSHL(D)  "v_lshlrev_b32 " #D ", 3, %4\n\t"
+#define M2V_I_MAD(D)   "v_mad_i32_i24 " #D ", %4, %5, %4\n\t"
+#define M2V_I_ADDS(D)  "v_add_u32 " #D ", %6, %4\n\t"
+#define M2V_I_ASHR(D)  "v_ashrrev_i32 " #D ", 3, %4\n\t"
+#define M2V_I_PERM(D)  "v_perm_b32 " #D ", %4, %5, %4\n\t"
+            if (kind == 1) M2V_PAD64(M2V_I_ADD);
+            else if (kind == 2) M2V_PAD64(M2V_I_LSHL);
+            else if (kind == 3) M2V_PAD64(M2V_I_MAD);
+            else if (kind == 4) M2V_PAD64(M2V_I_ADDS);
+            else if (kind == 5) M2V_PAD64(M2V_I_ASHR);
+            else M2V_PAD64(M2V_I_PERM);
+#undef M2V_PAD4
+#undef M2V_PAD64
+        }
         M2V_REQUEST_G3();                                       // requested here, used in stage G
         // ---- half-pel refinement + intra cost (RTL:1743-1816), four pixels per lane, packed bytes ----
         // T[y][x] = window[y+fy+YR][x+fx+8]; L/C/R = T[.][x-1 .. x+2], T[.][x .. x+3], T[.][x+1 .. x+4]
