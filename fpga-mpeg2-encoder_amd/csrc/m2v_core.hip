@@ -46,6 +46,7 @@ Geom make_geom(const m2v_enc *e, uint32_t xs, uint32_t ys)
     g.row1 = g.mbh;
     g.strip = 0;
     g.ablate = e->ablate;
+    g.cu_pack = e->cu_pack;
     geom_finish(g);
     return g;
 }
@@ -564,6 +565,7 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
     }
     if (!strcmp(name, "dct_mfma")) { e->dct_mfma = value != 0; return M2V_OK; }
     if (!strcmp(name, "strip_graph")) { e->strip_graph_opt = value != 0; return M2V_OK; }
+    if (!strcmp(name, "cu_pack")) { if (value < 0 || value > 8) return M2V_E_PARAM; e->cu_pack = (int)value; return M2V_OK; }
     if (!strcmp(name, "direct_upload")) { e->direct_upload = value != 0; return M2V_OK; }
     if (!strcmp(name, "copy_threads")) { if (value < 1 || value > 64) return M2V_E_PARAM; e->copy_threads = (int)value; return M2V_OK; }
     if (kDebug) {       // libm2v_mi355x_dbg.so only (-DM2V_DEBUG): the shipped library does not know these names

@@ -114,6 +114,7 @@ struct m2v_enc {
     int cur = 0;                  // stage being filled by m2v_push_*
     HostStage &st() { return hs[cur]; }
     std::deque<int> pending;      // submitted stages, oldest first
+    int cu_pack = 5;              // option "cu_pack": log2 of the CUs an XCD deals its workgroups to in turn (xcd_remap; 0 = plain XCD remap)
     bool dct_mfma = true;         // option "dct_mfma": luma DCT through the matrix cores (k_mb<.., MFMA = true>); 0 = integer VALU / LDS
                                   // path.  Same results; kept by the rocprofv3 number (profiles/archive/r02_mfma_*: 138.3 vs 140.3 us per launch)
     bool conformant = false;      // option "conformant": ISO reconstruction loop instead of the RTL's (NOT byte-identical to the reference)

@@ -289,11 +289,23 @@ __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b, uint32_t c, uin
 
 // XCD-aware block remap: consecutive logical blocks land on the same XCD (shared L2 for the
 // overlapping reference windows of neighbouring macroblocks).  Bijective for any grid size.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n, uint32_t cu_pack = 0)
 {
     const uint32_t xcd = b & 7u, q = n >> 3, r = n & 7u;
     const uint32_t start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-    return start + (b >> 3);
+    uint32_t i = b >> 3;                    // the XCD's i-th block
+    // cu_pack (option "cu_pack", default 5 = 32 CUs per XCD): the dispatcher deals an XCD's workgroups to its CUs in turn, so blocks i,
+    // i + 32, i + 64 ... of an XCD tend to land on ONE CU one after the other (observed, for speed only - the map is a bijection whatever
+    // the hardware does).  Those eight get horizontally neighbouring macroblocks: they read the same 128-byte lines of the frame and of
+    // the reference, and the CU's L1 serves some of the repeats instead of the L2 (-1.8 % per sequence, profiles/r04_experiments.txt item 7)
+    if (cu_pack) {
+        const uint32_t cus = 1u << cu_pack, span = cus << 3, qq = xcd < r ? q + 1u : q;
+        if (i < (qq / span) * span) {
+            const uint32_t c = i & (cus - 1u), j = i >> cu_pack;
+            i = (j >> 3) * span + (c << 3) + (j & 7u);
+        }
+    }
+    return start + i;
 }
 
 // n / d for a wave-uniform n with M = floor(2^32 / d) (0xFFFFFFFF for d = 1): the estimate mulhi(n, M) is the
@@ -826,7 +838,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         mj = uint2{mjv.x, mjv.y}; nj = uint2{njv.x, njv.y};                                                                             \
     } while (0)
     if constexpr (!P) M2V_REQUEST_BASIS();
-    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x, EDGE ? 0u : (uint32_t)g.cu_pack);
     const uint32_t li = udiv_magic(blk, g.strip_mbs, g.magic_strip);           // which frame of the launch list
     const FrameJob job = jobs[li];                 // `jobs` = the launch list as jobs: one dependent scalar load, not list -> job
     const int fidx = (int)job.fidx;

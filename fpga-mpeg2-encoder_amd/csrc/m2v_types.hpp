@@ -35,6 +35,7 @@ struct Geom {
     uint32_t magic_mbw;      // (geom_finish() fills the three after any change of the rows)
     uint32_t s16_off;        // word offset of the 64-byte slot class inside the compact-slot buffer (plan_chunk: macroblocks of the chunk * 32)
     uint32_t s8_off;         // ... and of the 32-byte class behind it
+    int cu_pack;             // experiment (xcd_remap): option "cu_pack"
     int rstride;             // macroblock rows between the launch's local rows: 1 normally; the EDGE launch of strip mode runs two local
                              // rows, the strip's first and its last (row0 and row0 + rstride)
     int edge_top, edge_bot;  // strip mode: the strip's first and last macroblock row (k_mb<.., EDGE> copies their outer rows of the
