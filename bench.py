@@ -696,16 +696,43 @@ def main():
         return [step() for _ in range(steps)][-1]
 
     # How the K sequences are submitted is settled in the warm-up: --inflight handles taking turns, or one blocking call after the
-    # other.  Taking turns wins by ~4 % when the handles' streams land on different hardware queues of the HIP runtime - which is
-    # the runtime's choice, and one box in ten serialises them (1.10 instead of 1.03 ms per step; the blocking form, two streams of
-    # ONE handle, was 1.07 there).  A short untimed probe of both forms picks the one the timed region uses.
+    # other.  Taking turns wins by ~8 % when the handles' streams sit on different hardware queues of the HIP runtime; whether they do
+    # is the runtime's choice, and one box in ten puts two streams of a process on ONE queue - the sequences then run one after the
+    # other (profiles/r04_queue_ab.txt reproduces it with GPU_MAX_HW_QUEUES=1).  So the placement is checked, untimed, and repaired:
+    # a handle whose sequences do not overlap with the other one's gets a NEW stream (the runtime deals its streams to the queues in
+    # turn: option stream_priority = 0 makes one), up to three times; if that does not help, a stream of another priority - those
+    # never share a queue with default-priority ones (overlap guaranteed, ~3 % behind the best placement).  Blocking calls are the
+    # last resort.  The line says what happened (`config.queue_placement`).
     submission = "in_flight" if nh > 1 else "blocking"
+    placement = None
     if nh > 1:
         for _ in range(max(3, args.warmup)):   # this handle has not run yet: its work buffers are allocated by its first call
             step()
         probe = max(2 * nh, min(10, args.steps))
-        p_fly = min(timed(probe)[0], timed(probe)[0])
+
+        def probe_fly():
+            run_steps(2 * nh)
+            return min(timed(probe)[0], timed(probe)[0])
         p_sync = min(timed(probe, sync_steps)[0], timed(probe, sync_steps)[0])
+        # the yardstick for "no overlap": the same sequences strictly one after the other on ONE stream
+        enc.set_option("split_streams", 1)
+        p_serial = min(timed(probe, sync_steps)[0], timed(probe, sync_steps)[0])
+        enc.set_option("split_streams", args.split if args.split >= 0 else 2)
+        p_fly = probe_fly()
+        placement = {"new_streams": 0, "priority": 0, "probe_ms_per_step": {"blocking": round(p_sync / probe * 1e3, 3), "one_stream": round(p_serial / probe * 1e3, 3),
+                                                                             "in_flight": [round(p_fly / probe * 1e3, 3)]}}
+        p_sync_ref = p_serial                  # in flight must beat the one-stream form by 4 % to count as overlapping
+        p_sync, p_sync_ref = p_sync, 0.96 * p_serial / 0.97
+        while p_fly > 0.97 * p_sync_ref and placement["new_streams"] < 3 and args.split < 0:
+            encs[-1].set_option("stream_priority", 0)            # a fresh stream: the next hardware queue in the runtime's rotation
+            placement["new_streams"] += 1
+            p_fly = probe_fly()
+            placement["probe_ms_per_step"]["in_flight"].append(round(p_fly / probe * 1e3, 3))
+        if p_fly > 0.97 * p_sync_ref and args.split < 0:
+            encs[-1].set_option("stream_priority", 1)
+            placement["priority"] = 1
+            p_fly = probe_fly()
+            placement["probe_ms_per_step"]["in_flight"].append(round(p_fly / probe * 1e3, 3))
         if p_sync < p_fly:
             submission = "blocking"
     # THE timed region: K steps of the encoder as shipped (no in-band timers)
@@ -776,7 +803,8 @@ def main():
                        "launched_by": os.environ.get("M2V_BENCH_LAUNCHED_BY", "caller"),
                        "dist_backend": backend if world > 1 else None,
                        "sequences_in_flight": nh if submission == "in_flight" else 1,
-                       "submission": submission + (" (chosen by an untimed probe of both forms in the warm-up)" if nh > 1 else "")},
+                       "submission": submission + (" (checked by an untimed probe of both forms in the warm-up)" if nh > 1 else ""),
+                       "queue_placement": placement},
             # `value`: K sequences, `sequences_in_flight` encoder handles taking turns (m2v_encode_resident_begin / _end): the stream
             # assembly of one sequence runs beside the first macroblock kernels of the next.  One handle, one blocking call per
             # sequence - what rounds 1 and 2 reported as `value` - is the entry below.

@@ -565,6 +565,20 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
     }
     if (!strcmp(name, "dct_mfma")) { e->dct_mfma = value != 0; return M2V_OK; }
     if (!strcmp(name, "strip_graph")) { e->strip_graph_opt = value != 0; return M2V_OK; }
+    if (!strcmp(name, "stream_priority")) {
+        // the handle's own stream again, at another priority (-1 low, 0 normal, 1 high).  HIP keeps the hardware queues of different
+        // priorities apart, so two handles with different priorities can never share one - which is what decides whether two
+        // sequences in flight really overlap (bench.py; on some boxes two default-priority streams of a process land on ONE queue).
+        if (value < -1 || value > 1 || e->state != m2v_enc::IDLE) return M2V_E_PARAM;
+        int lo = 0, hi = 0;
+        if (hipSetDevice(e->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return M2V_E_HIP;
+        hipStream_t ns = nullptr;
+        if (hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, value > 0 ? hi : value < 0 ? lo : (lo + hi) / 2) != hipSuccess) return M2V_E_HIP;
+        if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+        e->stream = ns;
+        ++alloc_generation();
+        return M2V_OK;
+    }
     if (!strcmp(name, "cu_pack")) { if (value < 0 || value > 8) return M2V_E_PARAM; e->cu_pack = (int)value; return M2V_OK; }
     if (!strcmp(name, "direct_upload")) { e->direct_upload = value != 0; return M2V_OK; }
     if (!strcmp(name, "copy_threads")) { if (value < 1 || value > 64) return M2V_E_PARAM; e->copy_threads = (int)value; return M2V_OK; }

@@ -249,6 +249,8 @@ int m2v_strip_graph_stats(const m2v_enc *e, int *last_call_was_graph, int *recor
  * "dct_mfma" (default 1: the four luma tiles' 2-D DCT runs on the matrix cores as two chained i8 GEMMs,
  * B16 . Z . B16^T with the 19-bit intermediate in three byte limbs; 0 = every tile on the integer v_dot4 / v_mad_i32_i24
  * path through LDS.  Bit-identical results either way; the default is the faster one under rocprofv3),
+ * "stream_priority" (-1 low, 0 normal, 1 high; only while idle: the handle's own stream is created again at that priority.  HIP keeps the hardware
+ * queues of different priorities apart, so two handles of different priorities never share one - see bench.py's queue placement check),
  * "cu_pack" (default 5; 0..8: which macroblocks tend to share a CU in time - see xcd_remap in csrc/m2v_kernels.hpp; 0 = none.  Same bytes),
  * "strip_graph" (default 1: m2v_strip_encode launches its sequence as a recorded hipGraph, see there; 0 = always call by call),
  * "conformant" (default 0 = the reference's arithmetic, byte-identical to the RTL.  1 = NOT the reference's
