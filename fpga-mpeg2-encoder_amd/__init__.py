@@ -373,13 +373,16 @@ class StripComm:
         return cls(h, "rccl", world)
 
     @classmethod
-    def local(cls, world):
-        L = lib()
+    def local(cls, world, debug=False):
+        """debug=True: made by the -DM2V_DEBUG library (for handles of that library: a communicator and its users come from ONE library)"""
+        L = lib(debug)
         err = ctypes.c_int(0)
         h = L.m2v_comm_init_local(world, ctypes.byref(err))
         if not h:
             raise M2VError("m2v_comm_init_local failed (%d): %s" % (err.value, L.m2v_comm_last_error().decode()))
-        return cls(h, "local", world)
+        c = cls(h, "local", world)
+        c._debug = debug
+        return c
 
     @classmethod
     def solo(cls, world, rccl=False):
@@ -405,5 +408,5 @@ class StripComm:
 
     def close(self):
         if getattr(self, "handle", None):
-            lib().m2v_comm_destroy(self.handle)
+            lib(getattr(self, "_debug", False)).m2v_comm_destroy(self.handle)
             self.handle = None

@@ -299,6 +299,7 @@ struct StripSeq {
     uint32_t gop;
     size_t nf;
     int steps;
+    int W;              // luma width of the sequence (the exchange sizes must not depend on whether this rank's plan succeeded)
 };
 
 // Enqueues the sequence on s (and the handle's side / comm streams, forked from and joined back into s by events): no allocation,
@@ -308,7 +309,6 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
                                    std::vector<hipEvent_t> *marks, double *us_in_comm)
 {
     using clk = std::chrono::steady_clock;
-    const Geom &g = e->g;
     auto local = [&](auto &&fn) {
         if (fail) return;
         if (recording) { fn(); return; }                    // a failure while recording abandons the recording, nothing has run yet
@@ -337,7 +337,7 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
     for (int j = 0; j < q.steps; ++j) {
         const int n_h = halo_frames_of_step(q.nf, q.gop, j);
         const bool xchg = q.world > 1 && n_h > 0 && (q.up || q.down);
-        const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)g.W;
+        const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)q.W;
         if (q.world > 1 && q.fused) {
             // EDGE(j) and interior(j) both need ALL of step j-1 on this strip; the neighbours' rows only EDGE(j) - and it follows
             // the receive in stream order.  Two launches, two event records, two waits and one exchange per step.
@@ -441,11 +441,12 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
             (void)hipGetLastError();
         }
     };
+    if (kDebug && (e->ablate & (1 << 21))) { fail = M2V_E_HIP; fail_text = "injected failure (ablate bit 21)"; }    // -DM2V_DEBUG: the failure protocol under test
     StripSeq q{};
     q.comm = a->comm; q.rank = rank; q.world = world; q.row0 = row0; q.row1 = row1;
     q.up = row0 > 0; q.down = row1 < full.mbh;
     q.fused = !e->conformant && e->dct_mfma && !e->keep_recon;
-    q.gop = gop; q.nf = nf;
+    q.gop = gop; q.nf = nf; q.W = full.W;
     q.steps = (int)std::min<size_t>(gop, nf);
     q.strip_cap = nf * ((size_t)(row1 - row0) * full.mbw * 1216 + (size_t)(row1 - row0) * 8 + 64) + 256;     // worst case
     const size_t halo_cap = (size_t)halo_frames_of_step(nf, gop, 0) * (size_t)(3 * e->VL) * (size_t)full.W;

@@ -264,3 +264,62 @@ def test_native_strip_loop_in_conformant_mode(world):
     got, _ = run_native_strips(M, d_clip, W, H, pf, VL, world, conformant=True)
     assert got == want
 
+
+
+def test_a_rank_whose_own_work_fails_keeps_the_call_order_and_everybody_returns_an_error():
+    """The failure protocol of m2v_strip_encode (the one RCCL peers depend on: nobody may be left waiting inside an exchange): rank 1 of
+    three fails locally right after its plan (injected, -DM2V_DEBUG library).  It still takes part in every halo exchange and in the
+    all-gather of the sizes, where it marks its row; every rank sees the mark after the same call, skips the gather and returns an
+    error - rank 1 its own, the others "rank 1 of the job failed".  The handles and a fresh communicator work afterwards."""
+    import ctypes
+    import threading
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    W, H, pf, n = 96, 96, 2, 6
+    clip = M.synth.clip(W, H, n, clip_index=92)
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
+    d_clip = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
+    out = torch.empty(M.parallel.strip_output_bound(n, W, H), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    encs = [M.Mpeg2Encoder(7, 7, 3, 2, debug=True) for _ in range(3)]
+    L = encs[0]._L
+
+    def run(comm, bad):
+        rc, msg = [None] * 3, [None] * 3
+
+        def work(r):
+            nb = ctypes.c_size_t(0)
+            rc[r] = L.m2v_strip_encode(encs[r]._h, comm.handle, r, 3, 0, W // 16, H // 16, pf, d_clip.data_ptr(), n,
+                                       out.data_ptr() if r == 0 else None, out.numel() if r == 0 else 0, ctypes.byref(nb), None)
+            msg[r] = L.m2v_last_error(encs[r]._h)
+            if r == 0:
+                rc.append(nb.value)
+        if bad is not None:
+            encs[bad].set_option("ablate", 1 << 21)
+        th = [threading.Thread(target=work, args=(r,)) for r in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=60)
+        assert not any(t.is_alive() for t in th), "a rank is still waiting"
+        if bad is not None:
+            encs[bad].set_option("ablate", 0)
+        return rc, msg
+    comm = M.StripComm.local(3, debug=True)
+    try:
+        rc, msg = run(comm, 1)
+        assert rc[1] < 0 and b"injected failure" in msg[1]
+        assert rc[0] < 0 and rc[2] < 0 and b"rank 1 of the job failed" in msg[0] and b"rank 1 of the job failed" in msg[2]
+    finally:
+        comm.close()
+    comm = M.StripComm.local(3, debug=True)
+    try:
+        rc, msg = run(comm, None)
+        assert rc[:3] == [0, 0, 0], msg
+        assert out[:rc[3]].cpu().numpy().tobytes() == want
+    finally:
+        comm.close()
+        for e in encs:
+            e.close()
