@@ -616,9 +616,21 @@ static int debug_impl(m2v_enc *e, void *argp)
             bytes = e->dbg_frames * rb;
             if (bytes > a->cap) return M2V_E_OVERFLOW;
             memset(a->dst, 0, bytes);
+            // the device keeps a reconstruction tiled (csrc/m2v_kernels.hpp, rec_luma_off): handed out as planar 4:2:0
+            std::vector<uint8_t> tiled(rb);
             for (size_t k = 0; k < e->dbg_frames; ++k)
-                if (k < e->dbg_rec_slot.size() && e->dbg_rec_slot[k] >= 0)
-                    HIPCHK(hipMemcpy((uint8_t *)a->dst + k * rb, e->rec_pool[e->dbg_rec_slot[k]], rb, hipMemcpyDeviceToHost));
+                if (k < e->dbg_rec_slot.size() && e->dbg_rec_slot[k] >= 0) {
+                    HIPCHK(hipMemcpy(tiled.data(), e->rec_pool[e->dbg_rec_slot[k]], rb, hipMemcpyDeviceToHost));
+                    uint8_t *Y = (uint8_t *)a->dst + k * rb, *U = Y + g.ysz, *V = U + g.csz;
+                    for (int mb = 0; mb < g.mbs; ++mb) {
+                        const int by = mb / g.mbw, bx = mb % g.mbw;
+                        for (int r = 0; r < 16; ++r) memcpy(Y + (size_t)(16 * by + r) * g.W + 16 * bx, tiled.data() + (size_t)mb * 256 + r * 16, 16);
+                        for (int r = 0; r < 8; ++r) {
+                            memcpy(U + (size_t)(8 * by + r) * g.cw + 8 * bx, tiled.data() + g.ysz + (size_t)mb * 128 + r * 8, 8);
+                            memcpy(V + (size_t)(8 * by + r) * g.cw + 8 * bx, tiled.data() + g.ysz + (size_t)mb * 128 + 64 + r * 8, 8);
+                        }
+                    }
+                }
             a->ret = (long long)bytes;
             return M2V_OK;
         }

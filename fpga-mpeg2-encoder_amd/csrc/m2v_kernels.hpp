@@ -287,6 +287,21 @@ __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b, uint32_t c, uin
     else return avg4x4(a, b, c, d);
 }
 
+// The reconstruction (= the next frame's reference) is stored TILED, one macroblock after the other: 256 bytes of luma (16 rows of 16)
+// at mb * 256, and behind all of those (ysz bytes) 128 bytes of chroma per macroblock - the 8x8 of U, then the 8x8 of V.  The kernel
+// that writes a frame and the kernel that reads it as a reference are the same one, so the layout is free: a macroblock's
+// reconstruction leaves as 3 full cache lines instead of 24 partial ones, and its +-YR window comes from 9 tiles - 18 + 9 lines
+// instead of 60 - 90 row pieces (profiles/r04_experiments.txt item 11).  Byte offset of luma sample (x, y) / of sample (x, y) of chroma
+// plane pl inside a reconstruction buffer:
+__device__ __forceinline__ uint32_t rec_luma_off(uint32_t x, uint32_t y, uint32_t mbw)
+{
+    return (__umul24(y >> 4, mbw) + (x >> 4)) * 256u + ((y & 15u) << 4) + (x & 15u);
+}
+__device__ __forceinline__ uint32_t rec_chroma_off(uint32_t pl, uint32_t x, uint32_t y, uint32_t mbw, uint32_t ysz)
+{
+    return ysz + (__umul24(y >> 3, mbw) + (x >> 3)) * 128u + (pl << 6) + ((y & 7u) << 3) + (x & 7u);
+}
+
 // XCD-aware block remap: consecutive logical blocks land on the same XCD (shared L2 for the
 // overlapping reference windows of neighbouring macroblocks).  Bijective for any grid size.
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n, uint32_t cu_pack = 0)
@@ -895,7 +910,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         sl.plus = s1.x; sl.minus = s1.y; sl.cb4 = s1.z; sl.dead_lo = s1.w; sl.dead_hi = s2;
     }
     if constexpr (P) {
-        const uint8_t *refY = job.ref, *refU = refY + g.ysz;       // (V sits csz bytes behind U)
+        const uint8_t *refY = job.ref;              // tiled (rec_luma_off / rec_chroma_off)
         if constexpr (EDGE) {
             // window rows above the strip's first / below its last macroblock row belong to a neighbour: they were received, for
             // this frame's reference, at position rhidx of nb_up / nb_down ([YR rows of W luma][UR rows of cw U][UR of V] per
@@ -910,34 +925,47 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 x0 = x0 < 0 ? 0 : x0 > W - 4 ? W - 4 : x0;
                 x1 = x1 < 0 ? 0 : x1 > W - 4 ? W - 4 : x1;
                 const uint8_t *src = refY;
-                uint32_t off = __umul24((uint32_t)yy, (uint32_t)W);
-                if (ext_u && row < YR) { src = nb_up; off = fb + (uint32_t)row * (uint32_t)W; }
-                if (ext_d && row >= YR + 16 && row < WROWS) { src = nb_down; off = fb + (uint32_t)(row - (YR + 16)) * (uint32_t)W; }
-                wwin[pass].x = *(const uint32_t *)(src + (off + (uint32_t)x0));
-                wwin[pass].y = *(const uint32_t *)(src + (off + (uint32_t)x1));
+                uint32_t o0 = rec_luma_off((uint32_t)x0, (uint32_t)yy, (uint32_t)g.mbw), o1 = rec_luma_off((uint32_t)x1, (uint32_t)yy, (uint32_t)g.mbw);
+                // (the halo buffers hold plain rows)
+                if (ext_u && row < YR) { src = nb_up; o0 = fb + (uint32_t)row * (uint32_t)W + (uint32_t)x0; o1 = o0 - (uint32_t)x0 + (uint32_t)x1; }
+                if (ext_d && row >= YR + 16 && row < WROWS) { src = nb_down; o0 = fb + (uint32_t)(row - (YR + 16)) * (uint32_t)W + (uint32_t)x0; o1 = o0 - (uint32_t)x0 + (uint32_t)x1; }
+                wwin[pass].x = *(const uint32_t *)(src + o0);
+                wwin[pass].y = *(const uint32_t *)(src + o1);
             }
             int yy = 8 * by - UR + crow, x0 = 8 * bx - 4 + 8 * chalf, x1 = x0 + 4;
             yy = yy < 0 ? 0 : yy > g.ch - 1 ? g.ch - 1 : yy;
             x0 = x0 < 0 ? 0 : x0 > g.cw - 4 ? g.cw - 4 : x0;
             x1 = x1 < 0 ? 0 : x1 > g.cw - 4 ? g.cw - 4 : x1;
-            const uint8_t *sc = refU;
-            uint32_t coff = __umul24((uint32_t)yy, (uint32_t)g.cw) + __umul24((uint32_t)cpl, g.csz);       // V sits csz bytes behind U
-            const uint32_t cbase = fb + (uint32_t)YR * (uint32_t)W + __umul24((uint32_t)cpl, (uint32_t)UR * (uint32_t)g.cw);   // and UR rows behind it in a halo chunk
-            if (ext_u && crow < UR) { sc = nb_up; coff = cbase + (uint32_t)crow * (uint32_t)g.cw; }
-            if (ext_d && crow >= UR + 8) { sc = nb_down; coff = cbase + (uint32_t)(crow - (UR + 8)) * (uint32_t)g.cw; }
-            wc.x = *(const uint32_t *)(sc + (coff + (uint32_t)x0));
-            wc.y = *(const uint32_t *)(sc + (coff + (uint32_t)x1));
+            const uint8_t *sc = refY;
+            uint32_t c0o = rec_chroma_off((uint32_t)cpl, (uint32_t)x0, (uint32_t)yy, (uint32_t)g.mbw, g.ysz), c1o = rec_chroma_off((uint32_t)cpl, (uint32_t)x1, (uint32_t)yy, (uint32_t)g.mbw, g.ysz);
+            const uint32_t cbase = fb + (uint32_t)YR * (uint32_t)W + __umul24((uint32_t)cpl, (uint32_t)UR * (uint32_t)g.cw);   // V sits UR rows behind U in a halo chunk
+            if (ext_u && crow < UR) { sc = nb_up; c0o = cbase + (uint32_t)crow * (uint32_t)g.cw + (uint32_t)x0; c1o = c0o - (uint32_t)x0 + (uint32_t)x1; }
+            if (ext_d && crow >= UR + 8) { sc = nb_down; c0o = cbase + (uint32_t)(crow - (UR + 8)) * (uint32_t)g.cw + (uint32_t)x0; c1o = c0o - (uint32_t)x0 + (uint32_t)x1; }
+            wc.x = *(const uint32_t *)(sc + c0o);
+            wc.y = *(const uint32_t *)(sc + c1o);
         } else
         if (sgpr(in_l & in_r & in_u & in_d)) {
             // interior macroblock (wave-uniform test): the whole window lies inside the frame, no clamping, and the
             // passes differ by a constant row offset
             // (the last pass reaches past the window - at most to row 16 by + 31 - YR -, still inside the frame: there is a macroblock row below)
-            const uint32_t w0 = __umul24((uint32_t)(16 * by - YR + wrow), (uint32_t)W) + (uint32_t)(16 * bx - 8 + 8 * wcp);
+            // the lane's 8 bytes of window row (pass * 16 + wrow), columns 8 wcp - 8 .. - 1: tile column bx - 1 (its right half), bx (both
+            // halves) or bx + 1 (its left half); tile row by - 1, by or by + 1
+            const uint32_t tcol = (uint32_t)(((wcp + 1) >> 1) - 1) * 256u + (uint32_t)(((wcp + 1) & 1) * 8) + (uint32_t)mb * 256u;
+            const uint32_t trow = (uint32_t)g.mbw * 256u;
 #pragma unroll
-            for (int pass = 0; pass < kWinPasses; ++pass)
-                wwin[pass] = *(gld64)(refY + (w0 + (uint32_t)(pass * 16) * (uint32_t)W));
-            const uint32_t coff = __umul24((uint32_t)(8 * by - UR + crow), (uint32_t)g.cw) + (uint32_t)(8 * bx - 4 + 8 * chalf) + __umul24((uint32_t)cpl, g.csz);
-            wc = *(gld64)(refU + coff);                     // (4-byte aligned: the chroma window starts at column 8 bx - 4)
+            for (int pass = 0; pass < kWinPasses; ++pass) {
+                const int yrel = pass * 16 + wrow - YR;                        // -YR .. 31 - YR
+                wwin[pass] = *(gld64)(refY + (tcol + (uint32_t)(yrel >> 4) * trow + (uint32_t)((yrel & 15) << 4)));
+            }
+            // chroma: 16 bytes of 14 rows of two planes = three pieces per row - 4 bytes of the tile to the left, 8 of the one in the middle,
+            // 4 of the one to the right.  wc.x / wc.y of lane (plane cpl, row crow, half chalf) = columns 8 chalf - 4 .. + 3: the half's outer
+            // dword from the neighbour tile, the inner one from the middle tile
+            const int cyr = crow - UR;
+            const uint32_t cmid = g.ysz + (uint32_t)mb * 128u + (uint32_t)(cyr >> 3) * ((uint32_t)g.mbw * 128u) + ((uint32_t)cpl << 6) + (uint32_t)((cyr & 7) << 3);
+            const uint32_t couter = chalf ? cmid + 128u : cmid - 128u + 4u;    // right neighbour's columns 0 .. 3 / left neighbour's 4 .. 7
+            const uint32_t cinner = chalf ? cmid + 4u : cmid;
+            const uint32_t a0 = *(gld32)(refY + (chalf ? cinner : couter)), a1 = *(gld32)(refY + (chalf ? couter : cinner));
+            wc.x = a0; wc.y = a1;
         } else {
 #pragma unroll
             for (int pass = 0; pass < kWinPasses; ++pass) {
@@ -945,17 +973,15 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 yy = yy < 0 ? 0 : yy > g.H - 1 ? g.H - 1 : yy;
                 x0 = x0 < 0 ? 0 : x0 > W - 4 ? W - 4 : x0;
                 x1 = x1 < 0 ? 0 : x1 > W - 4 ? W - 4 : x1;
-                const uint32_t off = __umul24((uint32_t)yy, (uint32_t)W);                          // 32-bit offsets from a uniform base
-                wwin[pass].x = *(gld32)(refY + (off + (uint32_t)x0));
-                wwin[pass].y = *(gld32)(refY + (off + (uint32_t)x1));
+                wwin[pass].x = *(gld32)(refY + rec_luma_off((uint32_t)x0, (uint32_t)yy, (uint32_t)g.mbw));      // 32-bit offsets from a uniform base
+                wwin[pass].y = *(gld32)(refY + rec_luma_off((uint32_t)x1, (uint32_t)yy, (uint32_t)g.mbw));
             }
             int yy = 8 * by - UR + crow, x0 = 8 * bx - 4 + 8 * chalf, x1 = x0 + 4;
             yy = yy < 0 ? 0 : yy > g.ch - 1 ? g.ch - 1 : yy;
             x0 = x0 < 0 ? 0 : x0 > g.cw - 4 ? g.cw - 4 : x0;
             x1 = x1 < 0 ? 0 : x1 > g.cw - 4 ? g.cw - 4 : x1;
-            const uint32_t coff = __umul24((uint32_t)yy, (uint32_t)g.cw) + __umul24((uint32_t)cpl, g.csz);
-            wc.x = *(gld32)(refU + (coff + (uint32_t)x0));
-            wc.y = *(gld32)(refU + (coff + (uint32_t)x1));
+            wc.x = *(gld32)(refY + rec_chroma_off((uint32_t)cpl, (uint32_t)x0, (uint32_t)yy, (uint32_t)g.mbw, g.ysz));
+            wc.y = *(gld32)(refY + rec_chroma_off((uint32_t)cpl, (uint32_t)x1, (uint32_t)yy, (uint32_t)g.mbw, g.ysz));
         }
     }
     if (sgpr((int)((job.valid_beats - (g.ysz >> 2)) >> 31))) {    // a frame cut short by i_sequence_stop: wave-uniform, almost never
@@ -1497,18 +1523,17 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         M2V_WAVE_SYNC();
         // scalar base + 32-bit lane offset (a generic pointer costs a 64-bit vector add per store); V sits csz bytes behind U
         typedef __attribute__((address_space(1))) uint32_t *gst32;
-        uint8_t *recY = job.rec, *recU = recY + g.ysz;
+        // tiled: the macroblock's 256 luma bytes are 64 consecutive dwords (row r, columns 4 c4 .. = dword lane), its 128 chroma bytes 32
+        // (plane, row, half = dword lane): two stores of consecutive addresses, three full cache lines
+        uint8_t *recY = job.rec;
         {
             const uint32_t v = *(LdsU32 *)(uintptr_t)kq0.z;                  // the lane's four pixels: s_pred[tile][ti] again
-            *(gst32)(recY + pix_off) = v;
+            *(gst32)(recY + ((uint32_t)mb * 256u + (uint32_t)lane * 4u)) = v;
         }
         if (lane < 32) {
-            // pl = lane >> 4, yc = (lane & 15) >> 1, half = lane & 1: s_pred[4 + pl][(yc << 3) | (half << 2)] goes to
-            // (8 by + yc) cw + 8 bx + 4 half + pl csz: two multiply-adds on the table's (yc, 4 half, pl)
+            // pl = lane >> 4, yc = (lane & 15) >> 1, half = lane & 1: s_pred[4 + pl][(yc << 3) | (half << 2)]
             const uint32_t v = *(LdsU32 *)(uintptr_t)kq3.w;
-            const uint32_t c0 = __umul24(k4p, (uint32_t)g.csz) + (k4r + (uint32_t)sgpr((int)(__umul24((uint32_t)(8 * by), (uint32_t)g.cw) + (uint32_t)(8 * bx))));
-            const uint32_t coff = __umul24(kq4.x, (uint32_t)g.cw) + c0;
-            *(gst32)(recU + coff) = v;
+            *(gst32)(recY + (g.ysz + (uint32_t)mb * 128u + (uint32_t)lane * 4u)) = v;
         }
         if constexpr (EDGE) {
             // per frame of the step's halo list: [YR rows of W luma][UR rows of cw U][UR rows of cw V] (k_halo_pack's layout)
@@ -2077,9 +2102,9 @@ __global__ void k_halo_pack(const FrameJob *__restrict__ jobs, const int *__rest
     const uint32_t nY = (uint32_t)YR * g.W, nC = (uint32_t)UR * g.cw;
     for (uint32_t i = threadIdx.x; i < chunk; i += blockDim.x) {
         uint8_t v;
-        if (i < nY) v = rec[(size_t)y0 * g.W + i];
-        else if (i < nY + nC) v = rec[g.ysz + (size_t)c0 * g.cw + (i - nY)];
-        else v = rec[g.ysz + g.csz + (size_t)c0 * g.cw + (i - nY - nC)];
+        if (i < nY) v = rec[rec_luma_off(i % (uint32_t)g.W, (uint32_t)y0 + i / (uint32_t)g.W, (uint32_t)g.mbw)];
+        else if (i < nY + nC) v = rec[rec_chroma_off(0u, (i - nY) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY) / (uint32_t)g.cw, (uint32_t)g.mbw, g.ysz)];
+        else v = rec[rec_chroma_off(1u, (i - nY - nC) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY - nC) / (uint32_t)g.cw, (uint32_t)g.mbw, g.ysz)];
         dst[i] = v;
     }
 }
@@ -2097,9 +2122,9 @@ __global__ void k_halo_unpack(const FrameJob *__restrict__ jobs, const int *__re
     const uint32_t nY = (uint32_t)YR * g.W, nC = (uint32_t)UR * g.cw;
     for (uint32_t i = threadIdx.x; i < chunk; i += blockDim.x) {
         const uint8_t v = src[i];
-        if (i < nY) rec[(size_t)y0 * g.W + i] = v;
-        else if (i < nY + nC) rec[g.ysz + (size_t)c0 * g.cw + (i - nY)] = v;
-        else rec[g.ysz + g.csz + (size_t)c0 * g.cw + (i - nY - nC)] = v;
+        if (i < nY) rec[rec_luma_off(i % (uint32_t)g.W, (uint32_t)y0 + i / (uint32_t)g.W, (uint32_t)g.mbw)] = v;
+        else if (i < nY + nC) rec[rec_chroma_off(0u, (i - nY) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY) / (uint32_t)g.cw, (uint32_t)g.mbw, g.ysz)] = v;
+        else rec[rec_chroma_off(1u, (i - nY - nC) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY - nC) / (uint32_t)g.cw, (uint32_t)g.mbw, g.ysz)] = v;
     }
 }
 
