@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 CFG=${1:-c3}
 for rep in 1 2; do
-for n in 1 2 3 4 5 6 4096; do
+for n in ${STOPS:-1 2 3 4 5 6 4096}; do
   python3 bench.py --config $CFG --ablate $((n * 256)) --inflight 1 --split 1 --steps 30 --warmup 5 --no-cpu-baseline --no-e2e 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); k=d['kernel_ms_per_step']; print('$CFG stop %4d  ms/step %.3f  P %.3f  I %.3f' % ($n, d['ms_per_step'], k['k_mb_P'], k['k_mb_I']))"
