@@ -303,8 +303,9 @@ __device__ __forceinline__ uint32_t rec_chroma_off(uint32_t pl, uint32_t x, uint
 }
 
 // XCD-aware block remap: consecutive logical blocks land on the same XCD (shared L2 for the
-// overlapping reference windows of neighbouring macroblocks).  Bijective for any grid size.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n, uint32_t cu_pack = 0)
+// overlapping reference windows of neighbouring macroblocks).  Bijective for any grid size and any cu_pack
+// (tests/test_abi.py walks it on the host through m2v_debug_table).
+__host__ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n, uint32_t cu_pack = 0)
 {
     const uint32_t xcd = b & 7u, q = n >> 3, r = n & 7u;
     const uint32_t start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
@@ -1035,6 +1036,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         // lane = (dy, group of 4 consecutive dx); v_qsad_pk_u16_u8 slides the 4 current pixels
         // over 8 reference bytes and accumulates the 4 SADs as packed u16.
         int fy = 0, fx = 0;
+        // the pixel sum of the intra cost (half-pel phase below) is formed here: its reduction chain then runs beside the search's
+        // LDS reads instead of at the head of the half-pel phase's dependency chain
+        const uint32_t S = (uint32_t)sgpr(wave_sum((int)__builtin_amdgcn_sad_u8(cur4, 0u, 0u)));
         {
             uint32_t key = 0xFFFFFFFFu;
             // dy = dyi - YR, dx = 4*gq - 8 + j
@@ -1171,8 +1175,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         int v10[10] = {4096, 4096, 4096, 4096, 0, 4096, 4096, 4096, 4096, 4095};
         if (!(kDebug && (g.ablate & 2))) {
             // "intra cost" accumulates the absolute deviation from the mean on top of the pixel sum, 16-bit wrap
-            // (RTL:1744, 1774-1777, 1791): the pixel sum S first, then the deviation rides along with the nine SADs
-            const uint32_t S = (uint32_t)wave_sum((int)__builtin_amdgcn_sad_u8(cur4, 0u, 0u));
+            // (RTL:1744, 1774-1777, 1791): the pixel sum S (formed in front of the search), then the deviation rides along with the nine SADs
             const uint32_t m = (S >> 8) & 255u;
             // ten sums as five packed pairs (each total <= 65280; v_sad_hi_u8 packs for free), four of them reduced
             // together by wave_sum4
@@ -1206,18 +1209,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         int hy = 0, hx = 0;
         if (inter) {
             hy = idx / 3 - 1; hx = idx % 3 - 1;
-            // the winner is wave-uniform: a scalar jump picks the register (one v_mov) instead of eight selects in every lane
-            switch (sgpr(idx)) {
-                case 0: pred4 = hp[0]; break;
-                case 1: pred4 = hp[1]; break;
-                case 2: pred4 = hp[2]; break;
-                case 3: pred4 = hp[3]; break;
-                case 4: pred4 = hp[4]; break;
-                case 5: pred4 = hp[5]; break;
-                case 6: pred4 = hp[6]; break;
-                case 7: pred4 = hp[7]; break;
-                default: pred4 = hp[8]; break;
-            }
+            // the winner is wave-uniform: the register is picked by VGPR index mode (s_set_gpr_idx_on, one v_mov), not by a jump tree
+            typedef uint32_t u32x9_t __attribute__((ext_vector_type(9)));
+            const u32x9_t hv = {hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8]};
+            pred4 = hv[sgpr(idx)];
         }
         mvy = 2 * fy + hy;                                      // RTL:1827-1828
         mvx = 2 * fx + hx;

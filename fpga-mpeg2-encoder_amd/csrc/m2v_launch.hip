@@ -289,7 +289,10 @@ int debug_table(int which, int i, int j)
         case 4: return i >= 0 && i < 64 ? kCbpCode[i] : -1;
         case 5: return i >= 0 && i < 2 && j >= 0 && j < 12 ? (kDcSizeLen[i][j] << 16) | kDcSizeCode[i][j] : -1;
         case 6: return i >= 0 && i < 32 && j >= 1 && j <= 40 ? kAcCode[i * 40 + j - 1] : 0;
-        default: return -1;
+        default:
+            // 16 + cu_pack: where k_mb sends block i of a launch of j blocks (the XCD / CU permutation of xcd_remap)
+            if (which >= 16 && which <= 16 + 8 && i >= 0 && j > 0 && i < j) return (int)xcd_remap((uint32_t)i, (uint32_t)j, (uint32_t)(which - 16));
+            return -1;
     }
 }
 

@@ -286,7 +286,9 @@ const char *m2v_last_error(const m2v_enc *e);
  * The product's constant tables, readable without a GPU (tests/test_abi.py compares them with the oracle's and
  * with the RTL's assign lines): which 0 = DCT basis [i][j] (RTL:2020-2027), 1 = intra quantiser matrix (RTL:2080-2087),
  * 2 = zig-zag position (RTL:2439-2446), 3 = motion code i (len << 8 | code, RTL:2500-2519), 4 = coded block pattern i,
- * 5 = DC size code (len << 16 | code) of component i, size j, 6 = run/level code of run i, level j (0 = escape).
+ * 5 = DC size code (len << 16 | code) of component i, size j, 6 = run/level code of run i, level j (0 = escape);
+ * 16 + p (p = 0 .. 8) = the macroblock position that block i of a launch of j blocks works on with option "cu_pack" = p
+ * (a permutation of 0 .. j-1 for every j and p).
  */
 int m2v_debug_table(int which, int i, int j);
 

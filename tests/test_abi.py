@@ -80,6 +80,23 @@ def test_product_tables_match_oracle_tables(L):
             assert L.m2v_debug_table(6, run, lvl) == ((n << 8) | c if n else 0)
 
 
+def test_block_permutation_is_a_bijection_for_every_grid_and_cu_pack(L):
+    """k_mb finds its macroblock through xcd_remap(blockIdx, gridDim, option "cu_pack"): whatever the launch size and the option, every
+    position 0 .. n-1 must be taken exactly once (a position left out would be a macroblock nobody encodes).  Walked on the host."""
+    sizes = list(range(1, 260)) + [511, 512, 513, 1200, 2047, 2048, 2049, 2055, 4095, 4104, 8640, 16383, 16392, 20480]
+    for p in range(9):
+        for n in sizes:
+            got = sorted(L.m2v_debug_table(16 + p, b, n) for b in range(n))
+            assert got == list(range(n)), (p, n)
+    for p in (0, 5, 8):                                    # one launch of the benchmark's P step
+        n = 86400
+        seen = bytearray(n)
+        for b in range(n):
+            seen[L.m2v_debug_table(16 + p, b, n)] += 1
+        assert seen == bytearray([1]) * n, p
+    assert L.m2v_debug_table(16 + 9, 0, 8) == -1 and L.m2v_debug_table(16, 8, 8) == -1
+
+
 def test_communicator_constructors_validate_without_a_gpu(L):
     """m2v_comm_*: the in-process communicators are plain host objects (creating one needs no GPU); bad arguments give NULL, a code and
     a text; the RCCL one refuses a bad rank before it touches the device."""

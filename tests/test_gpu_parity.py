@@ -87,6 +87,25 @@ def test_split_streams_option(G, streams):
             enc.close()
 
 
+@pytest.mark.parametrize("cu_pack", [0, 1, 2, 3, 4, 6, 7, 8])
+def test_cu_pack_option(G, cu_pack):
+    """Option "cu_pack" only permutes which block of a launch takes which macroblock (default 5, what every other test runs
+    with): the bytes must not depend on it - launches smaller than one span of the permutation, just beyond one, and a few
+    thousand blocks with a ragged tail; an out-of-range value is refused."""
+    from oracle import m2v_oracle_ctypes as orc
+    for (W, H, n, pf) in ((64, 64, 5, 2), (272, 160, 7, 3), (1008, 528, 4, 1)):
+        f = G.M.synth.clip(W, H, n, clip_index=17)
+        want = orc.encode(f, W // 16, H // 16, pf, XL=6, YL=6)
+        enc = G.M.Mpeg2Encoder(6, 6, 3, 2, device=0)
+        try:
+            enc.set_option("cu_pack", cu_pack)
+            assert G.resident_encode(f, W // 16, H // 16, pf, XL=6, YL=6, enc=enc) == want, (W, H)
+            with pytest.raises(Exception):
+                enc.set_option("cu_pack", 9)
+        finally:
+            enc.close()
+
+
 @pytest.mark.parametrize("mfma", [0, 1])
 @pytest.mark.parametrize("kind", ["synth", "noise", "checker", "flat255vs0"])
 def test_dct_variants_are_bit_identical(G, mfma, kind):
