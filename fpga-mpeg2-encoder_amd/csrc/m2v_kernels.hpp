@@ -695,7 +695,7 @@ constexpr int kQuadSearch0 = kQuadsLaneK, kQuadMfma0 = kQuadSearch0 + kQuadsSear
 // behind the lane quads, the small constant tables k_mb reads (copies: the originals stay where the other kernels and the FILL
 // pass read them) - reached from the same pinned bases instead of one s_getpc_b64 / s_add_u32 / s_addc_u32 triple per access
 constexpr int kQuadConst0 = kQuadMfma0 + kQuadsMfma;                 // 1 KB: c_dct32 | c_dct | c_dct_neg | d_cbp_code
-constexpr int kConstDct32 = 0, kConstDct = 256, kConstDctNeg = 320, kConstCbp = 384;
+constexpr int kConstDct32 = 0, kConstDct = 256, kConstCbp = 384;     // kConstDct: 8 rows of [8 basis bytes | their 8 negatives]
 constexpr int kConstDcLuma = 512;            // 12 dwords: dct_dc_size_luminance code | length << 16 (read by the SCALAR unit, dc_code_uniform)
 constexpr int kQuadAc0 = kQuadConst0 + 1;                            // d_ac_code2
 constexpr int kQuadsPerBlock = kQuadAc0 + (2 * 2 * 33 * 41 + 1023) / 1024;
@@ -825,13 +825,13 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     long mf_b1 = 0, mf_a2lo = 0, mf_a2hi = 0;   // matrix-core operands of the lane (c_mfma), requested with group 3
     u32x4_t mf_zoff = {0, 0, 0, 0};
     u32x4_t kq2, kq3;                           // the lane table's last three quads (not before the search: registers)
-    u32x3_t kq4;
+    u32x3_t kq4 = {0, 0, 0};
 #define M2V_REQUEST_G3()                                                                                             \
     do {                                                                                                             \
         kq2 = M2V_LANEK4(xc4); kq3 = M2V_LANEK4(zz2);                                                                \
         /* only the words that are used: a dead register of a wide load is reused at once, and the write-after-write   \
            wait then stalls the wavefront for the whole round trip */                                                  \
-        kq4 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_LANEK4(crec_r);                               \
+        if constexpr (EDGE) kq4 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_LANEK4(crec_r);   /* halo rows only */ \
         if constexpr (MFMA && !CONF) {                                                                               \
             const u32x2_t m0 = *(const __attribute__((address_space(1))) u32x2_t *)&M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]); \
             const u32x4_t m1 = M2V_QUAD(kQuadMfma0, MfmaLane, a2[0]);                                                 \
@@ -849,9 +849,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     do {                                                                                                                                \
         _Pragma("unroll") for (int k = 0; k < 8; ++k)                                                                                   \
             bi[k] = *(const __attribute__((address_space(1))) int32_t *)(ltab2 - 1024 + kConstDct32 + (uint32_t)(di * 32) + 4 * k);    \
-        typedef const __attribute__((address_space(1))) u32x2_t *gld64;                                                                 \
-        const u32x2_t mjv = *(gld64)(ltab2 - 1024 + kConstDct + (uint32_t)(dj * 8)), njv = *(gld64)(ltab2 - 1024 + kConstDctNeg + (uint32_t)(dj * 8)); \
-        mj = uint2{mjv.x, mjv.y}; nj = uint2{njv.x, njv.y};                                                                             \
+        const u32x4_t mnv = *(gld128)(ltab2 - 1024 + kConstDct + (uint32_t)(dj * 16));     /* row j | minus row j */                    \
+        mj = uint2{mnv.x, mnv.y}; nj = uint2{mnv.z, mnv.w};                                                                             \
     } while (0)
     if constexpr (!P) M2V_REQUEST_BASIS();
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x, EDGE ? 0u : (uint32_t)g.cu_pack);
@@ -1131,6 +1130,28 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 #define M2V_I_ADDS(D)  "v_add_u32 " #D ", %6, %4\n\t"
 #define M2V_I_ASHR(D)  "v_ashrrev_i32 " #D ", 3, %4\n\t"
 #define M2V_I_PERM(D)  "v_perm_b32 " #D ", %4, %5, %4\n\t"
+            if (kind == 7) {
+                // 16 LDS reads of 8 bytes per lane (64 LDS data cycles: + 5 % of the macroblock's), the lane's own window words
+                unsigned long long t0, t1, t2, t3;
+                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:48\n\tds_read_b64 %2, %4 offset:96\n\tds_read_b64 %3, %4 offset:144\n\t"
+                             "ds_read_b64 %0, %4 offset:192\n\tds_read_b64 %1, %4 offset:240\n\tds_read_b64 %2, %4 offset:288\n\tds_read_b64 %3, %4 offset:336\n\t"
+                             "ds_read_b64 %0, %4 offset:8\n\tds_read_b64 %1, %4 offset:56\n\tds_read_b64 %2, %4 offset:104\n\tds_read_b64 %3, %4 offset:152\n\t"
+                             "ds_read_b64 %0, %4 offset:200\n\tds_read_b64 %1, %4 offset:248\n\tds_read_b64 %2, %4 offset:296\n\tds_read_b64 %3, %4 offset:344\n\t"
+                             "s_waitcnt lgkmcnt(0)" : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(kq0.x) : "memory");
+            } else if (kind == 8) {
+                // 8 vector loads of one dword per lane from the lane table (L1 / L2 hits): + 24 % vector memory instructions
+                asm volatile("global_load_dword %0, %4, %5 offset:-4096\n\tglobal_load_dword %1, %4, %5 offset:-3072\n\t"
+                             "global_load_dword %2, %4, %5 offset:-2048\n\tglobal_load_dword %3, %4, %5 offset:-1024\n\t"
+                             "global_load_dword %0, %4, %5 offset:-4092\n\tglobal_load_dword %1, %4, %5 offset:-3068\n\t"
+                             "global_load_dword %2, %4, %5 offset:-2044\n\tglobal_load_dword %3, %4, %5 offset:-1020\n\t"
+                             "s_waitcnt vmcnt(0)" : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(lane16), "s"(ltab) : "memory");
+            } else if (kind == 9) {
+                // ONE vector load and the wait for it: what an exposed memory round trip costs
+                asm volatile("global_load_dword %0, %1, %2 offset:-4096\n\ts_waitcnt vmcnt(0)" : "=&v"(d0) : "v"(lane16), "s"(ltab) : "memory");
+            } else if (kind == 10) {
+                // ONE LDS read and the wait for it
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(d0) : "v"(kq0.x) : "memory");
+            } else
             if (kind == 1) M2V_PAD64(M2V_I_ADD);
             else if (kind == 2) M2V_PAD64(M2V_I_LSHL);
             else if (kind == 3) M2V_PAD64(M2V_I_MAD);
@@ -1488,9 +1509,81 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     M2V_WAVE_SYNC();
 
     M2V_STOP(5);            // ... up to the quantiser / inverse quantiser
+    // ---- stage T, coefficient part: run/level VLC of the six tiles (RTL:2777-2847) -----------------
+    // Pass 1 (per tile, lane = zig-zag index): ballot the non-zero levels, rank them, and append
+    // {run, level} / raw-code symbols to one compact list.  Pass 2 (once per macroblock): table lookup,
+    // wave prefix sum of the code lengths, codes ORed MSB-first into the LDS bit buffer.
+    // Pass 1 and the table look-up of the first 64 symbols run BEFORE the inverse transform, the rest of pass 2 behind it: the look-up is a
+    // memory round trip with nothing of its own to hide behind (an exposed one costs 3 % of the kernel, profiles/r04_experiments.txt item 14);
+    // the symbol list lives in R1, which the reconstruction does not touch, the bit buffer (in s_t) is first written behind it.
+    // Bits that need the left neighbour (motion vector deltas, DC of Y00 / U / V) are NOT produced here;
+    // the rest forms three bit-contiguous segments: A = [cbp][all tiles] (inter) or
+    // [AC of Y00][Y01][Y10][Y11] (intra), B = AC of U, C = AC of V.
+    uint32_t nsym = 0, idxB = 0, idxC = 0;
+    int dcs[6] = {0, 0, 0, 0, 0, 0};
+    const uint32_t lane_pos = (uint32_t)lane << 20;
+    if (!(kDebug && (g.ablate & 4))) {
+        if (inter) {
+            const uint32_t e = *(const __attribute__((address_space(1))) uint16_t *)(ltab2 - 1024 + kConstCbp + (uint32_t)(2 * cbp));    // d_cbp_code[cbp]
+            uint32_t nsym4 = ((uint32_t)-cbp >> 31) << 2;   // pattern 0 (motion vector only) has no code, and a raw symbol needs a length
+            const uint32_t eob = (uint32_t)vgpr_const((int)sym_raw(2u, 2u, true));
+            const uint32_t sym_base = lds_off(s_sym);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if ((cbp >> (5 - t)) & 1) nsym4 = vlc_tile_symbols_inter(s_zig[t], sym_base, lane, lane_pos, nsym4, eob);
+            // stored last: its table load has the tile passes to arrive (the empty asm keeps the loaded value in its vector
+            // register until here: a wave-uniform value is otherwise moved to a scalar register - and waited for - at once)
+            uint32_t ev = e;
+            asm volatile("" : "+v"(ev));
+            if (lane == 0) s_sym[0] = sym_raw(ev >> 8, ev & 255u, true);
+            nsym = nsym4 >> 2;
+        } else {
+            if (lane == 0) s_sym[-1] = sym_raw(1u, 0u, false);  // the symbol "before" the first one: a block start
+            uint32_t nsym4 = 0;
+            const uint32_t eob = (uint32_t)vgpr_const((int)sym_raw(2u, 2u, false));
+            const uint32_t sym_base = lds_off(s_sym);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                if (t == 4) idxB = nsym4 >> 2;
+                if (t == 5) idxC = nsym4 >> 2;
+                nsym4 = vlc_tile_symbols_intra(s_zig[t], sym_base, lane, lane_pos, nsym4, eob, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3,
+                                               ltab2 - 1024 + kConstDcLuma);
+            }
+            nsym = nsym4 >> 2;
+        }
+    }
+    M2V_WAVE_SYNC();
+    // front half of pass 2 for symbol i: the symbol and, for a {run, level} one, its table entry (left in the load's register: anything
+    // computed from it here would be waited for here)
+    // run = zig-zag positions skipped since the symbol in front: the previous level of the block, or a raw code
+    // (pattern code, DC code, the previous block's end code) that carries the position a block starts from
+    auto vlc_run = [&](uint32_t sym, uint32_t before) { return (int)((sym >> 20) & 63u) - ((int)(before << 5) >> 25) - 1; };
+    auto vlc_front = [&](uint32_t i, uint32_t &sym, uint32_t &e) {
+        sym = s_sym[i];
+        e = 0u;
+        if (!(sym >> 27)) {
+            const int v = (int16_t)(sym & 0xFFFFu);
+            const uint32_t before = s_sym[(int)i - 1];
+            const int run = vlc_run(sym, before);
+            const uint32_t a = (uint32_t)iabs(v);
+            // no range test, no select: clamped indices land on the table's zero row / column, the '1s' rule is bank 1
+            typedef const __attribute__((address_space(1))) uint16_t *gld16;
+            const uint32_t idx = __umul24(umin32((uint32_t)run, (uint32_t)kAcRuns - 1u), (uint32_t)kAcLevels) + umin32(a, (uint32_t)kAcLevels) - 1u +
+                                 __umul24((before >> 26) & 1u, (uint32_t)(kAcRuns * kAcLevels));
+            e = *(gld16)(ltab2 + 2u * idx);          // d_ac_code2[idx]
+        }
+    };
+    uint32_t sym0 = 0u, e0 = 0u;
+    // Every older vector load has been used by now on every path; saying so (s_waitcnt vmcnt(0), free here) keeps the compiler's
+    // bookkeeping from putting that wait in front of the first register it is unsure about - in the middle of the inverse transform,
+    // where it would wait for the look-up issued below
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if ((uint32_t)lane < nsym) vlc_front((uint32_t)lane, sym0, e0);
+
     // ---- stages H..R: Chen-Wang IDCT, reconstruction, store as next reference ------------------
     if (need_rec) {
-        keep_alive(kq3); keep_alive(kq4);
+        keep_alive(kq3);
+        if constexpr (EDGE) keep_alive(kq4);
         if (lane < 48) {                                // rows: lane = tile*8 + row (RTL:2159-2189), in place
             const int t = lane >> 3, row = lane & 7;
             int a[8], o[8];
@@ -1516,81 +1609,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             }
         }
         M2V_WAVE_SYNC();
-        // scalar base + 32-bit lane offset (a generic pointer costs a 64-bit vector add per store); V sits csz bytes behind U
-        typedef __attribute__((address_space(1))) uint32_t *gst32;
-        // tiled: the macroblock's 256 luma bytes are 64 consecutive dwords (row r, columns 4 c4 .. = dword lane), its 128 chroma bytes 32
-        // (plane, row, half = dword lane): two stores of consecutive addresses, three full cache lines
-        uint8_t *recY = job.rec;
-        {
-            const uint32_t v = *(LdsU32 *)(uintptr_t)kq0.z;                  // the lane's four pixels: s_pred[tile][ti] again
-            *(gst32)(recY + ((uint32_t)mb * 256u + (uint32_t)lane * 4u)) = v;
-        }
-        if (lane < 32) {
-            // pl = lane >> 4, yc = (lane & 15) >> 1, half = lane & 1: s_pred[4 + pl][(yc << 3) | (half << 2)]
-            const uint32_t v = *(LdsU32 *)(uintptr_t)kq3.w;
-            *(gst32)(recY + (g.ysz + (uint32_t)mb * 128u + (uint32_t)lane * 4u)) = v;
-        }
-        if constexpr (EDGE) {
-            // per frame of the step's halo list: [YR rows of W luma][UR rows of cw U][UR rows of cw V] (k_halo_pack's layout)
-            constexpr uint32_t YR2 = 2 * VL, UR2 = VL;
-            const uint32_t chunk = (YR2 + UR2) * (uint32_t)W, cw = (uint32_t)g.cw;
-            const uint32_t fbase = (uint32_t)job.hidx * chunk;
-            const uint32_t vy = *(LdsU32 *)(uintptr_t)kq0.z;                // the lane's four luma pixels of row r
-            const uint32_t vc = *(LdsU32 *)(uintptr_t)kq3.w;                // lanes < 32: four chroma pixels of row kq4.x, plane k4p
-            const uint32_t xl = (uint32_t)(16 * bx + 4 * c4), xc = (uint32_t)(8 * bx) + k4r;
-            if (halo_up != nullptr && by == g.edge_top) {                   // wave-uniform
-                if ((uint32_t)r < YR2) *(gst32)(halo_up + (fbase + (uint32_t)r * (uint32_t)W + xl)) = vy;
-                if (lane < 32 && kq4.x < UR2) *(gst32)(halo_up + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + kq4.x) * cw + xc)) = vc;
-            }
-            if (halo_down != nullptr && by == g.edge_bot) {
-                if ((uint32_t)r >= 16u - YR2) *(gst32)(halo_down + (fbase + ((uint32_t)r - (16u - YR2)) * (uint32_t)W + xl)) = vy;
-                if (lane < 32 && kq4.x >= 8u - UR2) *(gst32)(halo_down + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + (kq4.x - (8u - UR2))) * cw + xc)) = vc;
-            }
-        }
     }
 
-    M2V_STOP(6);            // everything but the entropy coder
-    // ---- stage T, coefficient part: run/level VLC of the six tiles (RTL:2777-2847) -----------------
-    // Pass 1 (per tile, lane = zig-zag index): ballot the non-zero levels, rank them, and append
-    // {run, level} / raw-code symbols to one compact list.  Pass 2 (once per macroblock): table lookup,
-    // wave prefix sum of the code lengths, codes ORed MSB-first into the LDS bit buffer.
-    // Bits that need the left neighbour (motion vector deltas, DC of Y00 / U / V) are NOT produced here;
-    // the rest forms three bit-contiguous segments: A = [cbp][all tiles] (inter) or
-    // [AC of Y00][Y01][Y10][Y11] (intra), B = AC of U, C = AC of V.
+    M2V_STOP(6);            // everything but the second half of the entropy coder
     {
-        uint32_t nsym = 0, idxB = 0, idxC = 0;
-        int dcs[6] = {0, 0, 0, 0, 0, 0};
-        const uint32_t lane_pos = (uint32_t)lane << 20;
-        if (!(kDebug && (g.ablate & 4))) {
-            if (inter) {
-                const uint32_t e = *(const __attribute__((address_space(1))) uint16_t *)(ltab2 - 1024 + kConstCbp + (uint32_t)(2 * cbp));    // d_cbp_code[cbp]
-                uint32_t nsym4 = ((uint32_t)-cbp >> 31) << 2;   // pattern 0 (motion vector only) has no code, and a raw symbol needs a length
-                const uint32_t eob = (uint32_t)vgpr_const((int)sym_raw(2u, 2u, true));
-                const uint32_t sym_base = lds_off(s_sym);
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-                    if ((cbp >> (5 - t)) & 1) nsym4 = vlc_tile_symbols_inter(s_zig[t], sym_base, lane, lane_pos, nsym4, eob);
-                // stored last: its table load has the tile passes to arrive (the empty asm keeps the loaded value in its vector
-                // register until here: a wave-uniform value is otherwise moved to a scalar register - and waited for - at once)
-                uint32_t ev = e;
-                asm volatile("" : "+v"(ev));
-                if (lane == 0) s_sym[0] = sym_raw(ev >> 8, ev & 255u, true);
-                nsym = nsym4 >> 2;
-            } else {
-                if (lane == 0) s_sym[-1] = sym_raw(1u, 0u, false);  // the symbol "before" the first one: a block start
-                uint32_t nsym4 = 0;
-                const uint32_t eob = (uint32_t)vgpr_const((int)sym_raw(2u, 2u, false));
-                const uint32_t sym_base = lds_off(s_sym);
-#pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    if (t == 4) idxB = nsym4 >> 2;
-                    if (t == 5) idxC = nsym4 >> 2;
-                    nsym4 = vlc_tile_symbols_intra(s_zig[t], sym_base, lane, lane_pos, nsym4, eob, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3,
-                                                   ltab2 - 1024 + kConstDcLuma);
-                }
-                nsym = nsym4 >> 2;
-            }
-        }
         // clear what pass 2 can reach: a symbol is at most 26 bits (typically 25 symbols: ONE store of 64 words instead of five
         // predicated ones over the whole 304-word buffer); the first 64 words always, they are what a compact slot copies out
         s_bits[lane] = 0u;
@@ -1604,28 +1626,20 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             const uint32_t i = base + (uint32_t)lane;
             uint32_t code = 0, len = 0;
             if (i < nsym) {
-                const uint32_t sym = s_sym[i];
+                uint32_t sym = sym0, e = e0;
+                if (base) vlc_front(i, sym, e);             // (wave-uniform: more than 64 symbols is an I-frame matter)
                 const uint32_t rawlen = sym >> 27;
                 if (rawlen) {
                     code = sym & 0xFFFFFu;
                     len = rawlen;
                 } else {
                     const int v = (int16_t)(sym & 0xFFFFu);
-                    // run = zig-zag positions skipped since the symbol in front: the previous level of the block, or a raw code
-                    // (pattern code, DC code, the previous block's end code) that carries the position a block starts from
-                    const uint32_t before = s_sym[(int)i - 1];
-                    const int run = (int)((sym >> 20) & 63u) - ((int)(before << 5) >> 25) - 1;
-                    const uint32_t a = (uint32_t)iabs(v);
-                    // no range test, no select: clamped indices land on the table's zero row / column, the '1s' rule is bank 1
-                    typedef const __attribute__((address_space(1))) uint16_t *gld16;
-                    const uint32_t idx = __umul24(umin32((uint32_t)run, (uint32_t)kAcRuns - 1u), (uint32_t)kAcLevels) + umin32(a, (uint32_t)kAcLevels) - 1u +
-                                         __umul24((before >> 26) & 1u, (uint32_t)(kAcRuns * kAcLevels));
-                    const uint32_t e = *(gld16)(ltab2 + 2u * idx);          // d_ac_code2[idx]
+                    e &= 0xFFFFu;
                     if (e) {                                 // run/level VLC + sign (RTL:2535-2540)
                         code = ((e & 255u) << 1) | (v < 0 ? 1u : 0u);
                         len = (e >> 8) + 1u;
-                    } else {                                 // escape (RTL:2542-2543)
-                        code = (1u << 18) | ((uint32_t)run << 12) | ((uint32_t)v & 0xFFFu);
+                    } else {                                 // escape (RTL:2542-2543); rare: the run is formed again from the list
+                        code = (1u << 18) | ((uint32_t)vlc_run(sym, s_sym[(int)i - 1]) << 12) | ((uint32_t)v & 0xFFFu);
                         len = 24;
                     }
                 }
@@ -1638,6 +1652,41 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 if (idxC >= base && idxC < base + 64) offC = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)(idxC - base));
             }
             pos += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+        }
+        // the reconstruction goes out here, behind pass 2: in front of it the stores would be waited for together with the look-up
+        // (the counter that tells when a load has arrived counts stores as well)
+        if (need_rec) {
+            // scalar base + 32-bit lane offset (a generic pointer costs a 64-bit vector add per store); V sits csz bytes behind U
+            typedef __attribute__((address_space(1))) uint32_t *gst32;
+            // tiled: the macroblock's 256 luma bytes are 64 consecutive dwords (row r, columns 4 c4 .. = dword lane), its 128 chroma bytes 32
+            // (plane, row, half = dword lane): two stores of consecutive addresses, three full cache lines
+            uint8_t *recY = job.rec;
+            {
+                const uint32_t v = *(LdsU32 *)(uintptr_t)kq0.z;                  // the lane's four pixels: s_pred[tile][ti] again
+                *(gst32)(recY + ((uint32_t)mb * 256u + (uint32_t)lane * 4u)) = v;
+            }
+            if (lane < 32) {
+                // pl = lane >> 4, yc = (lane & 15) >> 1, half = lane & 1: s_pred[4 + pl][(yc << 3) | (half << 2)]
+                const uint32_t v = *(LdsU32 *)(uintptr_t)kq3.w;
+                *(gst32)(recY + (g.ysz + (uint32_t)mb * 128u + (uint32_t)lane * 4u)) = v;
+            }
+            if constexpr (EDGE) {
+                // per frame of the step's halo list: [YR rows of W luma][UR rows of cw U][UR rows of cw V] (k_halo_pack's layout)
+                constexpr uint32_t YR2 = 2 * VL, UR2 = VL;
+                const uint32_t chunk = (YR2 + UR2) * (uint32_t)W, cw = (uint32_t)g.cw;
+                const uint32_t fbase = (uint32_t)job.hidx * chunk;
+                const uint32_t vy = *(LdsU32 *)(uintptr_t)kq0.z;                // the lane's four luma pixels of row r
+                const uint32_t vc = *(LdsU32 *)(uintptr_t)kq3.w;                // lanes < 32: four chroma pixels of row kq4.x, plane k4p
+                const uint32_t xl = (uint32_t)(16 * bx + 4 * c4), xc = (uint32_t)(8 * bx) + k4r;
+                if (halo_up != nullptr && by == g.edge_top) {                   // wave-uniform
+                    if ((uint32_t)r < YR2) *(gst32)(halo_up + (fbase + (uint32_t)r * (uint32_t)W + xl)) = vy;
+                    if (lane < 32 && kq4.x < UR2) *(gst32)(halo_up + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + kq4.x) * cw + xc)) = vc;
+                }
+                if (halo_down != nullptr && by == g.edge_bot) {
+                    if ((uint32_t)r >= 16u - YR2) *(gst32)(halo_down + (fbase + ((uint32_t)r - (16u - YR2)) * (uint32_t)W + xl)) = vy;
+                    if (lane < 32 && kq4.x >= 8u - UR2) *(gst32)(halo_down + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + (kq4.x - (8u - UR2))) * cw + xc)) = vc;
+                }
+            }
         }
         uint32_t lenA, lenB = 0, lenC = 0;
         if (inter) lenA = pos;

@@ -114,8 +114,11 @@ void upload_tables_now()
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), mlq, mlq_bytes, blk + (size_t)kQuadMfma0 * 64 * 16));
             const size_t cst = blk + (size_t)kQuadConst0 * 64 * 16;
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dct32, sizeof dct32, cst + kConstDct32));
-            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), kDctBasis, sizeof kDctBasis, cst + kConstDct));
-            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dct_neg, sizeof dct_neg, cst + kConstDctNeg));
+            // basis row j as signed bytes and its negative, 16 bytes per row: ONE vector load per lane (a vector memory instruction costs
+            // this kernel as much as ten arithmetic ones, profiles/r04_experiments.txt item 14)
+            int8_t dct_pn[8][16];
+            for (int j = 0; j < 8; ++j) { memcpy(dct_pn[j], &kDctBasis[j * 8], 8); memcpy(dct_pn[j] + 8, &dct_neg[j * 8], 8); }
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dct_pn, sizeof dct_pn, cst + kConstDct));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), kCbpCode, sizeof kCbpCode, cst + kConstCbp));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dcl, sizeof dcl, cst + kConstDcLuma));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), ac2, ac2_bytes, blk + (size_t)kQuadAc0 * 64 * 16));
