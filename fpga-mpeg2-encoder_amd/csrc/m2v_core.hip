@@ -42,6 +42,7 @@ Geom make_geom(const m2v_enc *e, uint32_t xs, uint32_t ys)
     g.mbs = g.mbw * g.mbh;
     g.ysz = (uint32_t)g.W * g.H;
     g.csz = (uint32_t)g.cw * g.ch;
+    g.rysz = (uint32_t)(g.mbw + 1) * (uint32_t)g.mbh * 256u;
     g.row0 = 0;
     g.row1 = g.mbh;
     g.strip = 0;
@@ -114,7 +115,7 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
         if (k == 0 || jobs[k].i_frame == 0) seg_start.push_back((int)k);
     }
     const size_t nseg = seg_start.size();
-    e->rec_bytes = (size_t)g.ysz + 2 * (size_t)g.csz;
+    e->rec_bytes = (size_t)g.rysz * 3 / 2;           // tiled, with one extra tile column (rec_luma_off)
     const bool need_any_rec = e->pframes > 0;
     std::vector<int> rec_slot(nf, -1);
     if (need_any_rec) {
@@ -612,24 +613,31 @@ static int debug_impl(m2v_enc *e, void *argp)
         case 1: if (!e->keep_recon) return M2V_E_STATE; src = e->d_coef.p; bytes = nmb * 768; break;
         case 2: src = e->d_mblen.p; bytes = nmb * 4; break;
         case 3: {
-            const size_t rb = e->rec_bytes;
-            bytes = e->dbg_frames * rb;
+            const size_t rb = e->rec_bytes, pb = (size_t)g.ysz + 2 * (size_t)g.csz;
+            bytes = e->dbg_frames * pb;
             if (bytes > a->cap) return M2V_E_OVERFLOW;
             memset(a->dst, 0, bytes);
-            // the device keeps a reconstruction tiled (csrc/m2v_kernels.hpp, rec_luma_off): handed out as planar 4:2:0
+            // the device keeps a reconstruction in shifted tiles (csrc/m2v_kernels.hpp, rec_luma_off): handed out as planar 4:2:0.
+            // Luma tile tx of a tile row holds columns 16 tx - 8 .. 16 tx + 7, chroma tile tx columns 8 tx - 4 .. 8 tx + 3.
             std::vector<uint8_t> tiled(rb);
+            const int tw = g.mbw + 1;
             for (size_t k = 0; k < e->dbg_frames; ++k)
                 if (k < e->dbg_rec_slot.size() && e->dbg_rec_slot[k] >= 0) {
                     HIPCHK(hipMemcpy(tiled.data(), e->rec_pool[e->dbg_rec_slot[k]], rb, hipMemcpyDeviceToHost));
-                    uint8_t *Y = (uint8_t *)a->dst + k * rb, *U = Y + g.ysz, *V = U + g.csz;
-                    for (int mb = 0; mb < g.mbs; ++mb) {
-                        const int by = mb / g.mbw, bx = mb % g.mbw;
-                        for (int r = 0; r < 16; ++r) memcpy(Y + (size_t)(16 * by + r) * g.W + 16 * bx, tiled.data() + (size_t)mb * 256 + r * 16, 16);
-                        for (int r = 0; r < 8; ++r) {
-                            memcpy(U + (size_t)(8 * by + r) * g.cw + 8 * bx, tiled.data() + g.ysz + (size_t)mb * 128 + r * 8, 8);
-                            memcpy(V + (size_t)(8 * by + r) * g.cw + 8 * bx, tiled.data() + g.ysz + (size_t)mb * 128 + 64 + r * 8, 8);
+                    uint8_t *Y = (uint8_t *)a->dst + k * pb, *U = Y + g.ysz, *V = U + g.csz;
+                    for (int ty = 0; ty < g.mbh; ++ty)
+                        for (int tx = 0; tx < tw; ++tx) {
+                            const uint8_t *lt = tiled.data() + ((size_t)ty * tw + tx) * 256, *ct = tiled.data() + g.rysz + ((size_t)ty * tw + tx) * 128;
+                            const int x0 = 16 * tx - 8, c0 = 8 * tx - 4;
+                            for (int r = 0; r < 16; ++r) {
+                                if (tx > 0) memcpy(Y + (size_t)(16 * ty + r) * g.W + x0, lt + r * 16, 8);
+                                if (tx < g.mbw) memcpy(Y + (size_t)(16 * ty + r) * g.W + x0 + 8, lt + r * 16 + 8, 8);
+                            }
+                            for (int r = 0; r < 8; ++r) {
+                                if (tx > 0) { memcpy(U + (size_t)(8 * ty + r) * g.cw + c0, ct + r * 8, 4); memcpy(V + (size_t)(8 * ty + r) * g.cw + c0, ct + 64 + r * 8, 4); }
+                                if (tx < g.mbw) { memcpy(U + (size_t)(8 * ty + r) * g.cw + c0 + 4, ct + r * 8 + 4, 4); memcpy(V + (size_t)(8 * ty + r) * g.cw + c0 + 4, ct + 64 + r * 8 + 4, 4); }
+                            }
                         }
-                    }
                 }
             a->ret = (long long)bytes;
             return M2V_OK;

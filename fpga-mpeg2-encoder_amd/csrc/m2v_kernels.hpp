@@ -57,12 +57,13 @@ __constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
-struct MfmaLane {        // three quads: b1 | a2 | zoff
+struct MfmaLane {        // two quads in use: b1, a | zoff (the third keeps the constant tables behind it where the second table base expects them)
     uint32_t b1[2];      // pass 1 B operand: +-basis row (c & 7) for the k group that matches c's tile column, else 0
-    uint32_t pad0[2];
-    uint32_t a2[4];      // pass 2 A operand {a, 0, 0, a}: a = basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1,
-                         // else 0; the pair {a, 0} multiplies the low dword of a B operand, the pair {0, a} the high dword
+    uint32_t a2;         // pass 2 A operand: a = basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1, else 0; the
+                         // kernel forms the pair {a, 0} (multiplies the low dword of a B operand) and the pair {0, a} (the high dword)
+    uint32_t pad0;
     uint32_t zoff[4];    // byte offset of coefficient v inside s_zig: tile * 128 + zigzag position * 2
+    uint32_t pad1[4];
 };
 // luma window in LDS (k_mb): row stride in dwords, and the distance in dwords from copy A to copy B (see the LDS map in k_mb)
 constexpr int kWinStride = 12;
@@ -287,19 +288,21 @@ __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b, uint32_t c, uin
     else return avg4x4(a, b, c, d);
 }
 
-// The reconstruction (= the next frame's reference) is stored TILED, one macroblock after the other: 256 bytes of luma (16 rows of 16)
-// at mb * 256, and behind all of those (ysz bytes) 128 bytes of chroma per macroblock - the 8x8 of U, then the 8x8 of V.  The kernel
-// that writes a frame and the kernel that reads it as a reference are the same one, so the layout is free: a macroblock's
-// reconstruction leaves as 3 full cache lines instead of 24 partial ones, and its +-YR window comes from 9 tiles - 18 + 9 lines
-// instead of 60 - 90 row pieces (profiles/r04_experiments.txt item 11).  Byte offset of luma sample (x, y) / of sample (x, y) of chroma
-// plane pl inside a reconstruction buffer:
-__device__ __forceinline__ uint32_t rec_luma_off(uint32_t x, uint32_t y, uint32_t mbw)
+// The reconstruction (= the next frame's reference) is stored TILED: 256-byte luma tiles (16 rows of 16 bytes), and behind all of
+// those (g.rysz bytes) 128-byte chroma tiles - 8 rows of 8 of U, then of V.  The kernel that writes a frame and the kernel that reads
+// it as a reference are the same one, so the layout is free (profiles/r04_experiments.txt items 11 and 14).  The tiles are SHIFTED by half
+// a macroblock: luma tile (ty, tx), tx = 0 .. mbw, holds frame columns 16 tx - 8 .. 16 tx + 7, chroma tile tx columns 8 tx - 4 .. 8 tx + 3
+// (mbw + 1 tiles per tile row, the outer halves of the first and last unused).  The +-YR window of macroblock bx - columns
+// 16 bx - 8 .. 16 bx + 23 - is then exactly the tile columns bx and bx + 1: every window row is two full 16-byte tile rows, the whole
+// window ONE 16-byte load per lane (one 8-byte load for the chroma windows); a macroblock's reconstruction leaves as the right half
+// of tile bx and the left half of tile bx + 1.  Byte offset of luma sample (x, y) / of sample (x, y) of chroma plane pl:
+__device__ __forceinline__ uint32_t rec_luma_off(uint32_t x, uint32_t y, const Geom &g)
 {
-    return (__umul24(y >> 4, mbw) + (x >> 4)) * 256u + ((y & 15u) << 4) + (x & 15u);
+    return (__umul24(y >> 4, (uint32_t)g.mbw + 1u) + ((x + 8u) >> 4)) * 256u + ((y & 15u) << 4) + ((x + 8u) & 15u);
 }
-__device__ __forceinline__ uint32_t rec_chroma_off(uint32_t pl, uint32_t x, uint32_t y, uint32_t mbw, uint32_t ysz)
+__device__ __forceinline__ uint32_t rec_chroma_off(uint32_t pl, uint32_t x, uint32_t y, const Geom &g)
 {
-    return ysz + (__umul24(y >> 3, mbw) + (x >> 3)) * 128u + (pl << 6) + ((y & 7u) << 3) + (x & 7u);
+    return g.rysz + (__umul24(y >> 3, (uint32_t)g.mbw + 1u) + ((x + 4u) >> 3)) * 128u + (pl << 6) + ((y & 7u) << 3) + ((x + 4u) & 7u);
 }
 
 // XCD-aware block remap: consecutive logical blocks land on the same XCD (shared L2 for the
@@ -670,7 +673,7 @@ __device__ __forceinline__ void search_rows13(uint32_t cur, uint32_t cur12, uint
 // its only source), so the values cannot drift from the LDS map they describe.
 struct LaneK {
     // quads 0, 1: requested with the pixels; quad 2 onwards: before the half-pel phase (registers)
-    uint32_t win_st;                // LDS address of s_win[(lane >> 2) kWS + 2 (lane & 3)]: the lane's 8 bytes of a 16-row window pass
+    uint32_t win_st;                // LDS address of s_win[(lane >> 1) kWS + 4 (lane & 1)]: the lane's 16 bytes of the window (lanes < 2 WROWS)
     uint32_t hp;                    // LDS address of s_win[r kWS + c4]: the lane part of the half-pel neighbourhood
     uint32_t pred_st, cp_st;        // &s_pred[tile][ti], &s_cp[tile][r & 7][(c4 & 1) << 2]
     uint32_t cpc_st;                // &s_cp[4][r >> 1][2 c4]
@@ -769,7 +772,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     auto lane_consts = [&]() {
         LaneK k{};
         const int r = lane >> 2, c4 = lane & 3;
-        k.win_st = lds_off(&s_win[(lane >> 2) * kWS + 2 * (lane & 3)]);
+        k.win_st = lds_off(&s_win[((lane >> 1) < WROWS ? lane >> 1 : WROWS - 1) * kWS + 4 * (lane & 1)]);
         k.hp = lds_off(&s_win[r * kWS + c4]);
         const int tile = ((r >> 3) << 1) | (c4 >> 1), ti = ((r & 7) << 3) | ((c4 & 1) << 2);
         k.pred_st = lds_off(&s_pred[tile][ti]);
@@ -833,10 +836,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
            wait then stalls the wavefront for the whole round trip */                                                  \
         if constexpr (EDGE) kq4 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_LANEK4(crec_r);   /* halo rows only */ \
         if constexpr (MFMA && !CONF) {                                                                               \
-            const u32x2_t m0 = *(const __attribute__((address_space(1))) u32x2_t *)&M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]); \
-            const u32x4_t m1 = M2V_QUAD(kQuadMfma0, MfmaLane, a2[0]);                                                 \
+            /* ONE load for the three words (a vector memory instruction costs what ten arithmetic ones do) */           \
+            const u32x3_t m0 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]); \
             mf_b1 = (long)(((unsigned long long)m0.y << 32) | m0.x);                                                 \
-            mf_a2lo = (long)(((unsigned long long)m1.y << 32) | m1.x); mf_a2hi = (long)(((unsigned long long)m1.w << 32) | m1.z); \
+            mf_a2lo = (long)(unsigned long long)m0.z; mf_a2hi = (long)((unsigned long long)m0.z << 32);              \
         }                                                                                                            \
     } while (0)
     if constexpr (!P) M2V_REQUEST_G3();
@@ -871,6 +874,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         bx = mb - by * g.mbw;
     }
     const int W = g.W;
+    const uint32_t tile = (uint32_t)mb + (uint32_t)by;           // by * (mbw + 1) + bx: the reconstruction tile (luma and chroma) whose right half this macroblock fills
     const int r = lane >> 2, c4 = lane & 3;
     // 1 = the macroblock has a neighbour on that side (left, right, up, down).  Sign-bit arithmetic, not compares: these
     // wave-uniform flags feed range limits and candidate masks that must stay on the scalar unit, and a compare that is
@@ -884,20 +888,23 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // back to back through explicit global-address-space pointers and waited for once: the wavefront pays ONE
     // memory round trip.  Window samples outside the frame can never be selected (RTL:1642-1645), so their
     // addresses are clamped into the frame instead of being branched around.
-    // The windows arrive 8 bytes per lane: a luma pass is 16 rows x 32 bytes (lane = row, 8-byte column), both chroma windows are
-    // one pass (lane = plane, row, half of the 16 bytes).  An interior macroblock - 95 % of a frame - needs one dwordx2 load per pass: three
-    // vector loads instead of six (vector memory instructions are the second thing this kernel is sensitive to:
-    // profiles/r03_experiments.txt item 8); at the frame border, where the two dwords are clamped separately, it is two loads per pass.
+    // The windows arrive in ONE load each for an interior macroblock - 95 % of a frame -: 16 bytes per lane for the luma window (lane =
+    // row, tile column), 8 bytes per lane for both chroma windows (lane = plane, row, tile column); the shifted tiles of the reconstruction
+    // (rec_luma_off) make every window row two full tile rows.  Vector memory instructions are the second thing this kernel is sensitive
+    // to - one costs what ten arithmetic instructions do (profiles/r04_experiments.txt item 14).  At the frame border, where every dword
+    // is clamped separately, it is four loads + two.
     typedef const __attribute__((address_space(1))) uint32_t *gld32;
     const uint8_t *inY = job.in, *inU = inY + g.ysz, *inV = inU + g.ysz;
     const uint32_t pix_off = __umul24((uint32_t)(16 * by + r), (uint32_t)W) + (uint32_t)(16 * bx + 4 * c4);   // rows, W < 2^12
     uint32_t cur4 = *(gld32)(inY + pix_off);
     uint32_t u4 = *(gld32)(inU + pix_off);
     uint32_t v4 = *(gld32)(inV + pix_off);
-    constexpr int kWinPasses = (WROWS + 15) / 16;
     typedef const __attribute__((address_space(1))) u32x2_t *gld64;
-    u32x2_t wwin[P ? kWinPasses : 1], wc = {0, 0};
-    const int wrow = lane >> 2, wcp = lane & 3;                                  // luma window pass: row, 8-byte column
+    // the windows: lane = (window row, half) takes the 16 bytes of one luma tile row (2 WROWS lanes), lane = (plane, row, half) the 8 bytes
+    // of one chroma tile row
+    u32x4_t wwin = {0, 0, 0, 0};
+    u32x2_t wc = {0, 0};
+    const int wrow = (lane >> 1) < WROWS ? lane >> 1 : WROWS - 1, whalf = lane & 1;
     const int cpl = lane >> 5, crow0 = (lane & 31) >> 1, chalf = lane & 1;       // chroma windows: plane, row, half
     const int crow = crow0 < CROWS ? crow0 : CROWS - 1;
     SearchLane sl{};                             // the lane's search addresses: loaded with the pixels, one memory round trip
@@ -911,33 +918,35 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     }
     if constexpr (P) {
         const uint8_t *refY = job.ref;              // tiled (rec_luma_off / rec_chroma_off)
+        const uint32_t trow = (uint32_t)g.mbw + 1u;              // tiles per tile row
         if constexpr (EDGE) {
             // window rows above the strip's first / below its last macroblock row belong to a neighbour: they were received, for
             // this frame's reference, at position rhidx of nb_up / nb_down ([YR rows of W luma][UR rows of cw U][UR of V] per
             // frame, rows top to bottom); everything else as the clamped form below
             const bool ext_u = nb_up != nullptr && by == g.edge_top, ext_d = nb_down != nullptr && by == g.edge_bot;     // wave-uniform
             const uint32_t chunk = (uint32_t)(YR + UR) * (uint32_t)W, fb = (uint32_t)job.rhidx * chunk;
-#pragma unroll
-            for (int pass = 0; pass < kWinPasses; ++pass) {
-                const int row = pass * 16 + wrow;
-                int yy = 16 * by - YR + row, x0 = 16 * bx - 8 + 8 * wcp, x1 = x0 + 4;
+            {
+                int yy = 16 * by - YR + wrow;
                 yy = yy < 0 ? 0 : yy > g.H - 1 ? g.H - 1 : yy;
-                x0 = x0 < 0 ? 0 : x0 > W - 4 ? W - 4 : x0;
-                x1 = x1 < 0 ? 0 : x1 > W - 4 ? W - 4 : x1;
-                const uint8_t *src = refY;
-                uint32_t o0 = rec_luma_off((uint32_t)x0, (uint32_t)yy, (uint32_t)g.mbw), o1 = rec_luma_off((uint32_t)x1, (uint32_t)yy, (uint32_t)g.mbw);
-                // (the halo buffers hold plain rows)
-                if (ext_u && row < YR) { src = nb_up; o0 = fb + (uint32_t)row * (uint32_t)W + (uint32_t)x0; o1 = o0 - (uint32_t)x0 + (uint32_t)x1; }
-                if (ext_d && row >= YR + 16 && row < WROWS) { src = nb_down; o0 = fb + (uint32_t)(row - (YR + 16)) * (uint32_t)W + (uint32_t)x0; o1 = o0 - (uint32_t)x0 + (uint32_t)x1; }
-                wwin[pass].x = *(const uint32_t *)(src + o0);
-                wwin[pass].y = *(const uint32_t *)(src + o1);
+                const bool up = ext_u && wrow < YR, dn = ext_d && wrow >= YR + 16;
+                const uint8_t *src = up ? nb_up : dn ? nb_down : refY;
+                const uint32_t rowbase = fb + (uint32_t)(up ? wrow : wrow - (YR + 16)) * (uint32_t)W;      // (the halo buffers hold plain rows)
+                uint32_t w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int xk = 16 * bx - 8 + 16 * whalf + 4 * k;
+                    xk = xk < 0 ? 0 : xk > W - 4 ? W - 4 : xk;
+                    const uint32_t o = (up || dn) ? rowbase + (uint32_t)xk : rec_luma_off((uint32_t)xk, (uint32_t)yy, g);
+                    w4[k] = *(const uint32_t *)(src + o);
+                }
+                wwin = u32x4_t{w4[0], w4[1], w4[2], w4[3]};
             }
             int yy = 8 * by - UR + crow, x0 = 8 * bx - 4 + 8 * chalf, x1 = x0 + 4;
             yy = yy < 0 ? 0 : yy > g.ch - 1 ? g.ch - 1 : yy;
             x0 = x0 < 0 ? 0 : x0 > g.cw - 4 ? g.cw - 4 : x0;
             x1 = x1 < 0 ? 0 : x1 > g.cw - 4 ? g.cw - 4 : x1;
             const uint8_t *sc = refY;
-            uint32_t c0o = rec_chroma_off((uint32_t)cpl, (uint32_t)x0, (uint32_t)yy, (uint32_t)g.mbw, g.ysz), c1o = rec_chroma_off((uint32_t)cpl, (uint32_t)x1, (uint32_t)yy, (uint32_t)g.mbw, g.ysz);
+            uint32_t c0o = rec_chroma_off((uint32_t)cpl, (uint32_t)x0, (uint32_t)yy, g), c1o = rec_chroma_off((uint32_t)cpl, (uint32_t)x1, (uint32_t)yy, g);
             const uint32_t cbase = fb + (uint32_t)YR * (uint32_t)W + __umul24((uint32_t)cpl, (uint32_t)UR * (uint32_t)g.cw);   // V sits UR rows behind U in a halo chunk
             if (ext_u && crow < UR) { sc = nb_up; c0o = cbase + (uint32_t)crow * (uint32_t)g.cw + (uint32_t)x0; c1o = c0o - (uint32_t)x0 + (uint32_t)x1; }
             if (ext_d && crow >= UR + 8) { sc = nb_down; c0o = cbase + (uint32_t)(crow - (UR + 8)) * (uint32_t)g.cw + (uint32_t)x0; c1o = c0o - (uint32_t)x0 + (uint32_t)x1; }
@@ -945,43 +954,33 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             wc.y = *(const uint32_t *)(sc + c1o);
         } else
         if (sgpr(in_l & in_r & in_u & in_d)) {
-            // interior macroblock (wave-uniform test): the whole window lies inside the frame, no clamping, and the
-            // passes differ by a constant row offset
-            // (the last pass reaches past the window - at most to row 16 by + 31 - YR -, still inside the frame: there is a macroblock row below)
-            // the lane's 8 bytes of window row (pass * 16 + wrow), columns 8 wcp - 8 .. - 1: tile column bx - 1 (its right half), bx (both
-            // halves) or bx + 1 (its left half); tile row by - 1, by or by + 1
-            const uint32_t tcol = (uint32_t)(((wcp + 1) >> 1) - 1) * 256u + (uint32_t)(((wcp + 1) & 1) * 8) + (uint32_t)mb * 256u;
-            const uint32_t trow = (uint32_t)g.mbw * 256u;
-#pragma unroll
-            for (int pass = 0; pass < kWinPasses; ++pass) {
-                const int yrel = pass * 16 + wrow - YR;                        // -YR .. 31 - YR
-                wwin[pass] = *(gld64)(refY + (tcol + (uint32_t)(yrel >> 4) * trow + (uint32_t)((yrel & 15) << 4)));
-            }
-            // chroma: 16 bytes of 14 rows of two planes = three pieces per row - 4 bytes of the tile to the left, 8 of the one in the middle,
-            // 4 of the one to the right.  wc.x / wc.y of lane (plane cpl, row crow, half chalf) = columns 8 chalf - 4 .. + 3: the half's outer
-            // dword from the neighbour tile, the inner one from the middle tile
-            const int cyr = crow - UR;
-            const uint32_t cmid = g.ysz + (uint32_t)mb * 128u + (uint32_t)(cyr >> 3) * ((uint32_t)g.mbw * 128u) + ((uint32_t)cpl << 6) + (uint32_t)((cyr & 7) << 3);
-            const uint32_t couter = chalf ? cmid + 128u : cmid - 128u + 4u;    // right neighbour's columns 0 .. 3 / left neighbour's 4 .. 7
-            const uint32_t cinner = chalf ? cmid + 4u : cmid;
-            const uint32_t a0 = *(gld32)(refY + (chalf ? cinner : couter)), a1 = *(gld32)(refY + (chalf ? couter : cinner));
-            wc.x = a0; wc.y = a1;
+            // interior macroblock (wave-uniform test): the whole window lies inside the frame, no clamping: window row yrel = -YR .. 15 + YR
+            // is row yrel & 15 of tile row by + (yrel >> 4), tile columns bx (window columns -8 .. 7) and bx + 1 (8 .. 23); ONE load each for
+            // the luma window and for both chroma windows
+            const int yrel = wrow - YR, cyr = crow - UR;
+            typedef const __attribute__((address_space(1))) u32x4_t *gld128w;
+            if (lane < 2 * WROWS)
+                wwin = *(gld128w)(refY + ((tile + (uint32_t)whalf) * 256u + (uint32_t)(yrel >> 4) * (trow * 256u) + (uint32_t)((yrel & 15) << 4)));
+            wc = *(gld64)(refY + (g.rysz + (tile + (uint32_t)chalf) * 128u + (uint32_t)(cyr >> 3) * (trow * 128u) + ((uint32_t)cpl << 6) + (uint32_t)((cyr & 7) << 3)));
         } else {
-#pragma unroll
-            for (int pass = 0; pass < kWinPasses; ++pass) {
-                int yy = 16 * by - YR + pass * 16 + wrow, x0 = 16 * bx - 8 + 8 * wcp, x1 = x0 + 4;
+            {
+                int yy = 16 * by - YR + wrow;
                 yy = yy < 0 ? 0 : yy > g.H - 1 ? g.H - 1 : yy;
-                x0 = x0 < 0 ? 0 : x0 > W - 4 ? W - 4 : x0;
-                x1 = x1 < 0 ? 0 : x1 > W - 4 ? W - 4 : x1;
-                wwin[pass].x = *(gld32)(refY + rec_luma_off((uint32_t)x0, (uint32_t)yy, (uint32_t)g.mbw));      // 32-bit offsets from a uniform base
-                wwin[pass].y = *(gld32)(refY + rec_luma_off((uint32_t)x1, (uint32_t)yy, (uint32_t)g.mbw));
+                uint32_t w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int xk = 16 * bx - 8 + 16 * whalf + 4 * k;
+                    xk = xk < 0 ? 0 : xk > W - 4 ? W - 4 : xk;
+                    w4[k] = *(gld32)(refY + rec_luma_off((uint32_t)xk, (uint32_t)yy, g));      // 32-bit offsets from a uniform base
+                }
+                wwin = u32x4_t{w4[0], w4[1], w4[2], w4[3]};
             }
             int yy = 8 * by - UR + crow, x0 = 8 * bx - 4 + 8 * chalf, x1 = x0 + 4;
             yy = yy < 0 ? 0 : yy > g.ch - 1 ? g.ch - 1 : yy;
             x0 = x0 < 0 ? 0 : x0 > g.cw - 4 ? g.cw - 4 : x0;
             x1 = x1 < 0 ? 0 : x1 > g.cw - 4 ? g.cw - 4 : x1;
-            wc.x = *(gld32)(refY + rec_chroma_off((uint32_t)cpl, (uint32_t)x0, (uint32_t)yy, (uint32_t)g.mbw, g.ysz));
-            wc.y = *(gld32)(refY + rec_chroma_off((uint32_t)cpl, (uint32_t)x1, (uint32_t)yy, (uint32_t)g.mbw, g.ysz));
+            wc.x = *(gld32)(refY + rec_chroma_off((uint32_t)cpl, (uint32_t)x0, (uint32_t)yy, g));
+            wc.y = *(gld32)(refY + rec_chroma_off((uint32_t)cpl, (uint32_t)x1, (uint32_t)yy, g));
         }
     }
     if (sgpr((int)((job.valid_beats - (g.ysz >> 2)) >> 31))) {    // a frame cut short by i_sequence_stop: wave-uniform, almost never
@@ -1016,16 +1015,16 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     if constexpr (P) {
         // ---- stages X..Z: reference window of recon(f-1) into LDS (RTL:1350-1425, 1612-1629) --
         typedef __attribute__((address_space(3))) u32x2_t *LdsW64;
-#pragma unroll
-        for (int pass = 0; pass < kWinPasses; ++pass)
-            if ((pass + 1) * 16 <= WROWS || lane < (WROWS - pass * 16) * 4) {
-                // s_win[(pass * 16 + (lane >> 2)) * kWS + 2 (lane & 3)] (8-byte aligned: one ds_write_b64) and the same two elements of copy
-                // B, one dword to the left (column 0 lands in padding): the lane's address from the table, everything else an immediate
-                typedef __attribute__((address_space(3))) uint32_t *LdsW;
-                *(LdsW64)(uintptr_t)(kq0.x + (uint32_t)(pass * 16 * kWS * 4)) = wwin[pass];
-                *(LdsW)(uintptr_t)(kq0.x + (uint32_t)(pass * 16 * kWS * 4 + kWinBGap * 4 - 4)) = wwin[pass].x;
-                *(LdsW)(uintptr_t)(kq0.x + (uint32_t)(pass * 16 * kWS * 4 + kWinBGap * 4)) = wwin[pass].y;
-            }
+        if (lane < 2 * WROWS) {
+            // s_win[row * kWS + 4 half .. + 3] (16-byte aligned: one ds_write_b128) and the same four elements of copy B, one dword to the
+            // left (column 0 lands in padding): the lane's address from the table, everything else an immediate
+            typedef __attribute__((address_space(3))) uint32_t *LdsW;
+            typedef __attribute__((address_space(3))) u32x4_t *LdsW128;
+            *(LdsW128)(uintptr_t)kq0.x = wwin;
+            *(LdsW)(uintptr_t)(kq0.x + (uint32_t)(kWinBGap * 4 - 4)) = wwin.x;
+            *(LdsW64)(uintptr_t)(kq0.x + (uint32_t)(kWinBGap * 4)) = u32x2_t{wwin.y, wwin.z};
+            *(LdsW)(uintptr_t)(kq0.x + (uint32_t)(kWinBGap * 4 + 8)) = wwin.w;
+        }
         if (crow0 < CROWS)                      // s_cwin[plane][row * 4 + 2 * half]: (lane & 31) * 8 bytes into the plane's window
             *(LdsW64)(uintptr_t)(lds_off(&s_cwin[0][0]) + (uint32_t)cpl * (uint32_t)kCwinBytes + (uint32_t)(lane & 31) * 8u) = wc;
         M2V_WAVE_SYNC();
@@ -1658,17 +1657,18 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         if (need_rec) {
             // scalar base + 32-bit lane offset (a generic pointer costs a 64-bit vector add per store); V sits csz bytes behind U
             typedef __attribute__((address_space(1))) uint32_t *gst32;
-            // tiled: the macroblock's 256 luma bytes are 64 consecutive dwords (row r, columns 4 c4 .. = dword lane), its 128 chroma bytes 32
-            // (plane, row, half = dword lane): two stores of consecutive addresses, three full cache lines
+            // tiled (rec_luma_off): the lane's four pixels (row r, columns 4 c4 ..) go to the right half of tile bx - byte 16 r + 8 + 4 c4 - or, from
+            // column 8 on, to the left half of tile bx + 1 - byte 256 + 16 r + 4 (c4 - 2): 4 lane + 8 + 240 (c4 >> 1); chroma (lanes < 32:
+            // plane, row, half) likewise 4 lane + 4 + 120 half
             uint8_t *recY = job.rec;
             {
                 const uint32_t v = *(LdsU32 *)(uintptr_t)kq0.z;                  // the lane's four pixels: s_pred[tile][ti] again
-                *(gst32)(recY + ((uint32_t)mb * 256u + (uint32_t)lane * 4u)) = v;
+                *(gst32)(recY + (tile * 256u + 8u + __umul24((uint32_t)lane & 2u, 120u) + (uint32_t)lane * 4u)) = v;
             }
             if (lane < 32) {
                 // pl = lane >> 4, yc = (lane & 15) >> 1, half = lane & 1: s_pred[4 + pl][(yc << 3) | (half << 2)]
                 const uint32_t v = *(LdsU32 *)(uintptr_t)kq3.w;
-                *(gst32)(recY + (g.ysz + (uint32_t)mb * 128u + (uint32_t)lane * 4u)) = v;
+                *(gst32)(recY + (g.rysz + tile * 128u + 4u + __umul24((uint32_t)lane & 1u, 120u) + (uint32_t)lane * 4u)) = v;
             }
             if constexpr (EDGE) {
                 // per frame of the step's halo list: [YR rows of W luma][UR rows of cw U][UR rows of cw V] (k_halo_pack's layout)
@@ -2146,9 +2146,9 @@ __global__ void k_halo_pack(const FrameJob *__restrict__ jobs, const int *__rest
     const uint32_t nY = (uint32_t)YR * g.W, nC = (uint32_t)UR * g.cw;
     for (uint32_t i = threadIdx.x; i < chunk; i += blockDim.x) {
         uint8_t v;
-        if (i < nY) v = rec[rec_luma_off(i % (uint32_t)g.W, (uint32_t)y0 + i / (uint32_t)g.W, (uint32_t)g.mbw)];
-        else if (i < nY + nC) v = rec[rec_chroma_off(0u, (i - nY) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY) / (uint32_t)g.cw, (uint32_t)g.mbw, g.ysz)];
-        else v = rec[rec_chroma_off(1u, (i - nY - nC) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY - nC) / (uint32_t)g.cw, (uint32_t)g.mbw, g.ysz)];
+        if (i < nY) v = rec[rec_luma_off(i % (uint32_t)g.W, (uint32_t)y0 + i / (uint32_t)g.W, g)];
+        else if (i < nY + nC) v = rec[rec_chroma_off(0u, (i - nY) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY) / (uint32_t)g.cw, g)];
+        else v = rec[rec_chroma_off(1u, (i - nY - nC) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY - nC) / (uint32_t)g.cw, g)];
         dst[i] = v;
     }
 }
@@ -2166,9 +2166,9 @@ __global__ void k_halo_unpack(const FrameJob *__restrict__ jobs, const int *__re
     const uint32_t nY = (uint32_t)YR * g.W, nC = (uint32_t)UR * g.cw;
     for (uint32_t i = threadIdx.x; i < chunk; i += blockDim.x) {
         const uint8_t v = src[i];
-        if (i < nY) rec[rec_luma_off(i % (uint32_t)g.W, (uint32_t)y0 + i / (uint32_t)g.W, (uint32_t)g.mbw)] = v;
-        else if (i < nY + nC) rec[rec_chroma_off(0u, (i - nY) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY) / (uint32_t)g.cw, (uint32_t)g.mbw, g.ysz)] = v;
-        else rec[rec_chroma_off(1u, (i - nY - nC) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY - nC) / (uint32_t)g.cw, (uint32_t)g.mbw, g.ysz)] = v;
+        if (i < nY) rec[rec_luma_off(i % (uint32_t)g.W, (uint32_t)y0 + i / (uint32_t)g.W, g)] = v;
+        else if (i < nY + nC) rec[rec_chroma_off(0u, (i - nY) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY) / (uint32_t)g.cw, g)] = v;
+        else rec[rec_chroma_off(1u, (i - nY - nC) % (uint32_t)g.cw, (uint32_t)c0 + (i - nY - nC) / (uint32_t)g.cw, g)] = v;
     }
 }
 

@@ -61,8 +61,7 @@ void upload_tables_now()
                 m.b1[b >> 2] |= (uint32_t)(uint8_t)w << (8 * (b & 3));
             }
         if ((c >> 3) == (g >> 1))
-            for (int b = 0; b < 4; ++b) m.a2[0] |= (uint32_t)(uint8_t)kDctBasis[(c & 7) * 8 + 4 * (g & 1) + b] << (8 * b);
-        m.a2[3] = m.a2[0];
+            for (int b = 0; b < 4; ++b) m.a2 |= (uint32_t)(uint8_t)kDctBasis[(c & 7) * 8 + 4 * (g & 1) + b] << (8 * b);
         const int tile = ((g >> 1) << 1) | (c >> 3);
         for (int v = 0; v < 4; ++v) {
             const int raster = (4 * (g & 1) + v) * 8 + (c & 7);

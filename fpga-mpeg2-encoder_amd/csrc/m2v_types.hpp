@@ -26,6 +26,7 @@ struct Geom {
     int mbs;         // mbw * mbh
     uint32_t ysz;    // W*H
     uint32_t csz;    // cw*ch
+    uint32_t rysz;   // bytes of the luma tiles of a reconstruction: (mbw + 1) * mbh * 256 (the chroma tiles follow; m2v_kernels.hpp, rec_luma_off)
     int row0, row1;  // macroblock rows this GPU encodes: [0, mbh) normally, a strip in multi-GPU strip mode
     int strip;       // 1 = strip mode: the stream buffer holds only this strip's slices, no headers
     int ablate;      // M2V_DEBUG builds only: profiling aid (option "ablate", default 0 = everything on; results are INVALID otherwise):
