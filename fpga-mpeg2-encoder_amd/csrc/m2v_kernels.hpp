@@ -36,7 +36,6 @@ namespace m2v {
 __constant__ int8_t   c_dct[64];
 __constant__ int8_t   c_dct_neg[64];      // -c_dct: the prediction's half of the residual dot product (k_mb, stage G)
 __constant__ int32_t  c_dct32[64];        // c_dct widened: a lane loads its basis row as two 16-byte reads, no unpacking
-__constant__ uint8_t  c_intra_w[64];
 __constant__ uint8_t  c_zigzag[64];
 __device__ uint16_t   d_motion_code[17];
 __device__ uint16_t   d_cbp_code[64];
@@ -48,7 +47,6 @@ __device__ uint16_t   d_ac_code[32 * 40];
 // block is '1s' instead of '11s' (RTL:2798-2802)
 constexpr int kAcRuns = 33, kAcLevels = 41;
 __device__ uint16_t   d_ac_code2[2 * kAcRuns * kAcLevels];
-__constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for n < 25575 (tests/test_host_logic.py)
 // DCT-as-GEMM variant of stage G (k_mb<.., MFMA = true>): per-lane operands of the matrix-core formulation, lane = (g = lane >> 4,
 // c = lane & 15); register v of a 16x16 accumulator holds block row 4g + v, column c.  Filled by fill_mfma_tables().
 // Per-lane tables are stored QUAD-MAJOR on the device ([16-byte quad of the row][lane]): the 64 lanes of a dwordx4 load then read
@@ -57,13 +55,14 @@ __constant__ uint32_t c_intra_recip[64];      // ceil(2^21 / W): exact n / W for
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
-struct MfmaLane {        // two quads in use: b1, a | zoff (the third keeps the constant tables behind it where the second table base expects them)
+struct MfmaLane {        // three quads: b1, a | zoff | the intra quantiser's reciprocals
     uint32_t b1[2];      // pass 1 B operand: +-basis row (c & 7) for the k group that matches c's tile column, else 0
     uint32_t a2;         // pass 2 A operand: a = basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1, else 0; the
                          // kernel forms the pair {a, 0} (multiplies the low dword of a B operand) and the pair {0, a} (the high dword)
     uint32_t pad0;
     uint32_t zoff[4];    // byte offset of coefficient v inside s_zig: tile * 128 + zigzag position * 2
-    uint32_t pad1[4];
+    uint32_t irecip[4];  // intra macroblocks only: ceil(2^21 / W) of the lane's four coefficients (the intra words share two otherwise
+                         // unused quads - this one and SearchLane's last - so that an I frame gets all seven in two loads)
 };
 // luma window in LDS (k_mb): row stride in dwords, and the distance in dwords from copy A to copy B (see the LDS map in k_mb)
 constexpr int kWinStride = 12;
@@ -104,17 +103,12 @@ struct SearchLane {      // absolute LDS byte offsets of one lane
     // position byte of the lane's four candidates, 255 - (dy' << 4 | dx + 8), and the SAD bits that mark the dx slots outside +-6
     // (and everything in a helper lane) as dead
     uint32_t cb4, dead_lo, dead_hi;
-    uint32_t pad[3];
+    // intra macroblocks only (nothing to do with the search: the quad has room): quantiser weights of the lane's four matrix-core
+    // coefficients as bytes; weight and ceil(2^21 / W) of the lane's raster position (chroma tiles)
+    uint32_t iwq4, iw, iwrecip;
 };
 
-struct MfmaLaneIntra {   // the part only intra macroblocks read
-    uint32_t wq;         // quantiser weights of this lane's four coefficients (bytes)
-    uint32_t recip[4];   // ceil(2^21 / W) of the four coefficients
-    uint32_t pad[3];
-};
-static_assert(sizeof(MfmaLaneIntra) == 32, "indexed by a shift");
 
-__constant__ MfmaLaneIntra c_mfma_intra[64];
 
 
 // ----------------------------------------------------------------------------------------------
@@ -843,6 +837,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         }                                                                                                            \
     } while (0)
     if constexpr (!P) M2V_REQUEST_G3();
+    // the intra quantiser's lane constants (weights, reciprocals): two loads; an I frame asks up front, a P frame inside its (rare) intra branch
+    u32x4_t iq_recip = {0, 0, 0, 0}, iq_w = {0, 0, 0, 0};
+#define M2V_REQUEST_INTRA() do { iq_recip = M2V_QUAD(kQuadMfma0, MfmaLane, irecip[0]); iq_w = M2V_QUAD(kQuadSearch0, SearchLane, dead_hi); } while (0)
+    if constexpr (!P) M2V_REQUEST_INTRA();
     // the transform's basis rows: basis row i = lane >> 3 widened to int32, basis row j = lane & 7 and its negative as int8 x 8
     const int dj = lane & 7;
     const int di = lane >> 3;
@@ -1359,7 +1357,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // the intra quantiser's lane constants: an I frame loads them up front, a P frame only inside its (rare) intra branch
     int wq = 0;
     uint32_t wrecip = 0;
-    if constexpr (!P) { wq = c_intra_w[lane]; wrecip = c_intra_recip[lane]; }
+    if constexpr (!P) { wq = (int)iq_w.z; wrecip = iq_w.w; }
     const int zz = (int)(kq3.x >> 1);                 // zig-zag position of the lane (the table holds the byte offset in a tile)
     const int Q = g.Q;
     // group 4 (column pass and chroma store of the reconstruction), requested two phases ahead
@@ -1432,21 +1430,21 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             }
         }
     } else {
-        if constexpr (P) { wq = c_intra_w[lane]; wrecip = c_intra_recip[lane]; }
+        if constexpr (P) { M2V_REQUEST_INTRA(); wq = (int)iq_w.z; wrecip = iq_w.w; }
         const uint32_t qoff = __umul24((uint32_t)wq, (3u << Q) + 2u) >> 3;
         if constexpr (kMfmaLuma) {
             const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
-            const MfmaLaneIntra ml = c_mfma_intra[lane];
+            const uint32_t ml_wq = iq_w.y, ml_recip[4] = {iq_recip.x, iq_recip.y, iq_recip.z, iq_recip.w};
             int32_t *const xrow = (int32_t *)(__attribute__((address_space(3))) int32_t *)(uintptr_t)kq2.w;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int wv = (int)((ml.wq >> (8 * v)) & 255u);
+                const int wv = (int)((ml_wq >> (8 * v)) & 255u);
                 const uint32_t qo = __umul24((uint32_t)wv, (3u << Q) + 2u) >> 3;
                 const bool is_dc = v == 0 && (lane & 0x17) == 0;           // row 0 of a tile (g even, v = 0), column 0 of a tile
                 const int C = (yacc[v] >> 12) - (kRound >> 12);        // yacc carries kRound
                 const int sg = C >> 31;
                 uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
-                if (!is_dc) a = __umul24((a + qo) >> Q, ml.recip[v]) >> 21;
+                if (!is_dc) a = __umul24((a + qo) >> Q, ml_recip[v]) >> 21;
                 else        a = (a + 8u) >> 4;
                 // RTL:2075 clamps to 2047 here and RTL:2139-2144 keeps the inverse quantiser's product in 17 bits and clamps it to +-2047:
                 // an intra block is pixel - 128, so |C| <= 8192, the level is at most 512 (DC) / 272 (AC) and |level * W| < 2^14 - none
@@ -1505,6 +1503,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         }
         cbp = 63;                                       // intra: every tile is coded (RTL:2461)
     }
+    // the pattern's code (d_cbp_code[cbp], wave-uniform): a SCALAR load, issued here so that the wait below covers it
+    const uint32_t cbp_word = *(const __attribute__((address_space(4))) uint32_t *)(ltab2 - 1024 + kConstCbp + 4u * ((uint32_t)sgpr(cbp) >> 1));
     M2V_WAVE_SYNC();
 
     M2V_STOP(5);            // ... up to the quantiser / inverse quantiser
@@ -1523,18 +1523,14 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     const uint32_t lane_pos = (uint32_t)lane << 20;
     if (!(kDebug && (g.ablate & 4))) {
         if (inter) {
-            const uint32_t e = *(const __attribute__((address_space(1))) uint16_t *)(ltab2 - 1024 + kConstCbp + (uint32_t)(2 * cbp));    // d_cbp_code[cbp]
+            const uint32_t e = (cbp_word >> (16 * (cbp & 1))) & 0xFFFFu;                    // d_cbp_code[cbp]
             uint32_t nsym4 = ((uint32_t)-cbp >> 31) << 2;   // pattern 0 (motion vector only) has no code, and a raw symbol needs a length
             const uint32_t eob = (uint32_t)vgpr_const((int)sym_raw(2u, 2u, true));
             const uint32_t sym_base = lds_off(s_sym);
 #pragma unroll
             for (int t = 0; t < 6; ++t)
                 if ((cbp >> (5 - t)) & 1) nsym4 = vlc_tile_symbols_inter(s_zig[t], sym_base, lane, lane_pos, nsym4, eob);
-            // stored last: its table load has the tile passes to arrive (the empty asm keeps the loaded value in its vector
-            // register until here: a wave-uniform value is otherwise moved to a scalar register - and waited for - at once)
-            uint32_t ev = e;
-            asm volatile("" : "+v"(ev));
-            if (lane == 0) s_sym[0] = sym_raw(ev >> 8, ev & 255u, true);
+            if (lane == 0) s_sym[0] = sym_raw(e >> 8, e & 255u, true);
             nsym = nsym4 >> 2;
         } else {
             if (lane == 0) s_sym[-1] = sym_raw(1u, 0u, false);  // the symbol "before" the first one: a block start

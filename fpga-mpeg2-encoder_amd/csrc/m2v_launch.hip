@@ -25,7 +25,6 @@ void upload_tables_now()
     int32_t dct32[64];
     for (int i = 0; i < 64; ++i) dct32[i] = kDctBasis[i];
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dct32), dct32, sizeof dct32));
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_intra_w), kIntraW, sizeof kIntraW));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_zigzag), kZigzagPos, sizeof kZigzagPos));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_motion_code), kMotionCode, sizeof kMotionCode));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_cbp_code), kCbpCode, sizeof kCbpCode));
@@ -44,17 +43,13 @@ void upload_tables_now()
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_ac_code2), ac2, ac2_bytes));
     uint32_t recip[64];
     for (int i = 0; i < 64; ++i) recip[i] = ((1u << 21) + kIntraW[i] - 1u) / kIntraW[i];      // ceil(2^21 / W)
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_intra_recip), recip, sizeof recip));
     // per-lane operands of the DCT-as-GEMM variant (k_mb<.., MFMA = true>, see MfmaLane)
     MfmaLane ml[64];
-    MfmaLaneIntra mi[64];
     SearchLane sl[64];
     for (int lane = 0; lane < 64; ++lane) {
         const int g = lane >> 4, c = lane & 15;
         MfmaLane &m = ml[lane];
-        MfmaLaneIntra &n = mi[lane];
         memset(&m, 0, sizeof m);
-        memset(&n, 0, sizeof n);
         if ((c >> 3) == (g & 1))
             for (int b = 0; b < 8; ++b) {
                 const int8_t w = (int8_t)(g < 2 ? kDctBasis[(c & 7) * 8 + b] : -kDctBasis[(c & 7) * 8 + b]);
@@ -63,11 +58,12 @@ void upload_tables_now()
         if ((c >> 3) == (g >> 1))
             for (int b = 0; b < 4; ++b) m.a2 |= (uint32_t)(uint8_t)kDctBasis[(c & 7) * 8 + 4 * (g & 1) + b] << (8 * b);
         const int tile = ((g >> 1) << 1) | (c >> 3);
+        uint32_t wq4 = 0;
         for (int v = 0; v < 4; ++v) {
             const int raster = (4 * (g & 1) + v) * 8 + (c & 7);
             m.zoff[v] = (uint32_t)(tile * 128 + kZigzagPos[raster] * 2);
-            n.wq |= (uint32_t)kIntraW[raster] << (8 * v);
-            n.recip[v] = recip[raster];
+            wq4 |= (uint32_t)kIntraW[raster] << (8 * v);
+            m.irecip[v] = recip[raster];
         }
         // the reference pairs (w0,w1) (w2,w3) start at dword gq of window row dy', the pairs (w1,w2) (w3,w4) at gq + 1: one of the
         // two starts is even in copy A, the other in copy B (which holds dword j + 1 at index j); VECTOR_LEVEL 3 geometry
@@ -77,6 +73,7 @@ void upload_tables_now()
         // candidate j of the lane has dx = 4 gq - 8 + j
         const uint32_t cbase = 255u - (uint32_t)((dyi << 4) | (4 * gq));
         q.cb4 = cbase | ((cbase - 1u) << 8) | ((cbase - 2u) << 16) | ((cbase - 3u) << 24);
+        q.iwq4 = wq4; q.iw = kIntraW[lane]; q.iwrecip = recip[lane];            // (the intra quantiser's words that share this quad)
         q.dead_lo = dyi > 12 || gq == 0 ? 0xFFFFFFFFu : 0u;                    // dx = -8, -7; the helper lanes own no candidates
         q.dead_hi = dyi > 12 ? 0xFFFFFFFFu : gq == 3 ? 0xFFFF0000u : 0u;       // dx = +7
         q.even = (uint32_t)kS3Win + 4u * (uint32_t)((gq & 1) ? gap + dyi * kWinStride + gq - 1 : dyi * kWinStride + gq);
@@ -122,7 +119,6 @@ void upload_tables_now()
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dcl, sizeof dcl, cst + kConstDcLuma));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), ac2, ac2_bytes, blk + (size_t)kQuadAc0 * 64 * 16));
         }
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mfma_intra), mi, sizeof mi));
     HIPCHK(hipDeviceSynchronize());         // the copies read stack arrays: complete before they go out of scope
     // the lane tables d_lanek[VL - 1][P]: every instantiation of the macroblock kernel writes its own (LaneK, FILL = true); they
     // read the constant tables uploaded above
