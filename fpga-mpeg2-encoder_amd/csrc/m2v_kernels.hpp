@@ -1574,6 +1574,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // where it would wait for the look-up issued below
     __builtin_amdgcn_s_waitcnt(0x0F70);
     if ((uint32_t)lane < nsym) vlc_front((uint32_t)lane, sym0, e0);
+    // (the second 64 symbols of an I frame's macroblock are looked up inside pass 2: issued here as well, config c2 loses 3 %,
+    // profiles/r04_experiments.txt item 14)
 
     // ---- stages H..R: Chen-Wang IDCT, reconstruction, store as next reference ------------------
     if (need_rec) {
