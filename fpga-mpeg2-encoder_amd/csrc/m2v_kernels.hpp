@@ -55,12 +55,19 @@ __device__ uint16_t   d_ac_code2[2 * kAcRuns * kAcLevels];
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+// The six 8x8 tiles of a macroblock (Y00 Y01 Y10 Y11 U V = tiles 0 .. 5) sit in the coefficient buffers of k_mb (s_t, s_zig) in SLOTS:
+// tile 0 in slot 0, U in slot 1, tile 1 in slot 2, tile 3 in slot 3, V in slot 4, tile 2 in slot 5.  The matrix-core transform leaves the
+// coefficients of luma tile 2 (g >> 1) + (c >> 3) in lane (g, c); run on the chroma block [U 0; 0 V] it leaves U where tile 0's are and V
+// where tile 3's are - with this order the chroma pass stores through the luma pass's lane addresses plus ONE constant (one slot).
+__host__ __device__ constexpr int slot_of_tile(int t) { return t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 5 : t == 3 ? 3 : t == 4 ? 1 : 4; }
+__host__ __device__ constexpr int tile_of_slot(int s) { return s == 0 ? 0 : s == 1 ? 4 : s == 2 ? 1 : s == 3 ? 3 : s == 4 ? 5 : 2; }
+static_assert(slot_of_tile(4) == slot_of_tile(0) + 1 && slot_of_tile(5) == slot_of_tile(3) + 1 && tile_of_slot(slot_of_tile(2)) == 2 && tile_of_slot(slot_of_tile(1)) == 1, "chroma one slot behind luma tiles 0 and 3");
 struct MfmaLane {        // three quads: b1, a | zoff | the intra quantiser's reciprocals
     uint32_t b1[2];      // pass 1 B operand: +-basis row (c & 7) for the k group that matches c's tile column, else 0
     uint32_t a2;         // pass 2 A operand: a = basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1, else 0; the
                          // kernel forms the pair {a, 0} (multiplies the low dword of a B operand) and the pair {0, a} (the high dword)
     uint32_t pad0;
-    uint32_t zoff[4];    // byte offset of coefficient v inside s_zig: tile * 128 + zigzag position * 2
+    uint32_t zoff[4];    // byte offset of coefficient v inside s_zig: slot * 128 + zigzag position * 2
     uint32_t irecip[4];  // intra macroblocks only: ceil(2^21 / W) of the lane's four coefficients (the intra words share two otherwise
                          // unused quads - this one and SearchLane's last - so that an I frame gets all seven in two loads)
 };
@@ -678,7 +685,7 @@ struct LaneK {
     uint32_t a1;                    // pass-1 A operand of the matrix-core transform
     uint32_t xrow;                  // &s_t[..] of the lane's first accumulator register (dequantised coefficients, raster order)
     uint32_t zz2;                   // 2 * zig-zag position of the lane
-    uint32_t col_rd, col_pred;      // &s_t[t][col], &s_pred[t][col] of the column pass
+    uint32_t col_rd, col_pred;      // &s_t[slot][col], &s_pred[tile of that slot][col] of the column pass
     uint32_t crec_rd;               // &s_pred[4 + pl][yc << 3 | half << 2] of the chroma store
     uint32_t crec_r, crec_c, crec_p;// yc, 4 half, pl
     uint32_t pad;
@@ -781,11 +788,11 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         k.cp_rd = lds_off(&s_cp[0][di][0]);
         const int mg = lane >> 4, mc = lane & 15;
         k.a1 = lds_off(&s_cp[((mc >> 3) << 1) | (mg & 1)][mc & 7][8 * (mg >> 1)]);
-        k.xrow = lds_off(&s_t[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)]);
+        k.xrow = lds_off(&s_t[slot_of_tile(((mg >> 1) << 1) | (mc >> 3))][((mg & 1) << 5) | (mc & 7)]);
         k.zz2 = 2u * c_zigzag[lane];
-        const int ct = lane < 48 ? lane >> 3 : 5;               // column pass: 48 lanes
+        const int ct = lane < 48 ? lane >> 3 : 5;               // column pass: 48 lanes, lane group = SLOT of the coefficient buffer
         k.col_rd = lds_off(&s_t[ct][lane & 7]);
-        k.col_pred = lds_off(&s_pred[ct][lane & 7]);
+        k.col_pred = lds_off(&s_pred[tile_of_slot(ct)][lane & 7]);
         const int pl2 = (lane >> 4) & 1, l16 = lane & 15, yc2 = l16 >> 1, half = l16 & 1;     // chroma store: 32 lanes
         k.crec_rd = lds_off(&s_pred[4 + pl2][(yc2 << 3) | (half << 2)]);
         k.crec_r = (uint32_t)yc2; k.crec_c = (uint32_t)(4 * half); k.crec_p = (uint32_t)pl2;
@@ -1302,7 +1309,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         acc = __builtin_amdgcn_sdot4((int)xr.y, (int)mj.y, acc, false);
         acc = __builtin_amdgcn_sdot4((int)xr.z, (int)nj.x, acc, false);
         acc = __builtin_amdgcn_sdot4((int)xr.w, (int)nj.y, acc, false);
-        s_t[t][lane] = acc;
+        s_t[slot_of_tile(t)][lane] = acc;
     }
     // The 16x16 luma block Z = current - prediction holds the 2x2 tiles; with B16 = blockdiag(DCTM, DCTM) the four 8x8
     // transforms are B16 . Z . B16^T in place (tools/ubench/mfma_dct_check.hip checks this formulation on its own).
@@ -1382,7 +1389,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 // see the chroma loop below for the arithmetic; yacc already holds acc + (2 << 12)
                 const int q = mad24_ms(yacc[v] >> 31, qneg, yacc[v]) >> (16 + Q);
                 *(int16_t *)((uint8_t *)&s_zig[0][0] + zo[v]) = (int16_t)q;
-                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + (zo[v] >> 1)] = (int16_t)q;
+                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + tile_of_slot((int)(zo[v] >> 7)) * 64 + ((zo[v] & 127u) >> 1)] = (int16_t)q;
                 nzor |= q;
                 qv[v] = q;
             }
@@ -1401,9 +1408,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         }
 #pragma unroll
         for (int t = kT0; t < 6; ++t) {
-            int acc = mad24_s(bi[0], s_t[t][dj], kRound);   // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12, and + (2 << 12)
+            int acc = mad24_s(bi[0], s_t[slot_of_tile(t)][dj], kRound);   // C[i][j] = (sum_k DCTM[i][k] * R1[k][j] + 2048) >> 12, and + (2 << 12)
 #pragma unroll
-            for (int k = 1; k < 8; ++k) acc = mad24(bi[k], s_t[t][k * 8 + dj], acc);   // |R1| < 2^18
+            for (int k = 1; k < 8; ++k) acc = mad24(bi[k], s_t[slot_of_tile(t)][k * 8 + dj], acc);   // |R1| < 2^18
             // RTL:2070: sign(C) * min((|C| + 2) >> s, 2047) with C = acc >> 12 and s = 4 + Q, computed on the signed value:
             // for C < 0 it is ceil((C - 2) / 2^s) = (C + 2^s - 3) >> s (identity checked over the 17-bit range in
             // tests/test_host_logic.py).  Two floor shifts with an integer added in between are one:
@@ -1413,7 +1420,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             // The "+ 2" rides in the accumulator, so the sign taken is that of C + 2, not of C: they differ for C = -2, -1,
             // where both formulas give 0 (s >= 4).  sign mask * (-bias) + acc is one v_mad_i32_i24.
             const int q = mad24_ms(acc >> 31, qneg, acc) >> (16 + Q);
-            *(LdsW16)(uintptr_t)(lds_off(&s_zig[t][0]) + kq3.x) = (uint16_t)q;      // s_zig[t][zz]
+            *(LdsW16)(uintptr_t)(lds_off(&s_zig[slot_of_tile(t)][0]) + kq3.x) = (uint16_t)q;      // s_zig[t][zz]
             if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
             cbp = (cbp << 1) | (int)any_lane(q != 0);
             if (need_rec) {                             // RTL:2134-2137: (2q + sign(q)) << Q, clamped to +-2047
@@ -1426,7 +1433,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     const bool even = (__popcll(ballot(x & 1)) & 1) == 0;
                     if (coded && even && lane == 63) x ^= 1;
                 }                                       // (the reference's +-2047 clamp cannot bind: see the luma tiles above)
-                s_t[t][lane] = x;                       // behind this tile's phase-2 reads of s_t[t] (one wavefront: LDS operations execute in order)
+                s_t[slot_of_tile(t)][lane] = x;         // behind this tile's phase-2 reads of it (one wavefront: LDS operations execute in order)
             }
         }
     } else {
@@ -1452,7 +1459,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 // build keeps its own saturation.
                 const int q = (int)(a ^ (uint32_t)sg) - sg;
                 *(int16_t *)((uint8_t *)&s_zig[0][0] + zo[v]) = (int16_t)q;
-                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + (zo[v] >> 1)] = (int16_t)q;
+                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + tile_of_slot((int)(zo[v] >> 7)) * 64 + ((zo[v] & 127u) >> 1)] = (int16_t)q;
                 if (need_rec) {
                     int x;
                     if (!is_dc) {
@@ -1467,9 +1474,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         }
 #pragma unroll
         for (int t = kT0; t < 6; ++t) {
-            int acc = mad24_s(bi[0], s_t[t][dj], 2048);
+            int acc = mad24_s(bi[0], s_t[slot_of_tile(t)][dj], 2048);
 #pragma unroll
-            for (int k = 1; k < 8; ++k) acc = mad24(bi[k], s_t[t][k * 8 + dj], acc);
+            for (int k = 1; k < 8; ++k) acc = mad24(bi[k], s_t[slot_of_tile(t)][k * 8 + dj], acc);
             const int C = acc >> 12;
             const int sg = C >> 31;
             uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
@@ -1477,7 +1484,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             else           a = (a + 8u) >> 4;                                       // (a >> 4) + bit 3, RTL:2074
             if constexpr (CONF) { if (a > 2047u) a = 2047u; }                       // RTL:2075; cannot bind (see the luma tiles)
             const int q = (int)(a ^ (uint32_t)sg) - sg;
-            *(LdsW16)(uintptr_t)(lds_off(&s_zig[t][0]) + kq3.x) = (uint16_t)q;      // s_zig[t][zz]
+            *(LdsW16)(uintptr_t)(lds_off(&s_zig[slot_of_tile(t)][0]) + kq3.x) = (uint16_t)q;      // s_zig[t][zz]
             if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + t * 64 + zz] = (int16_t)q;
             if (need_rec) {
                 int x;
@@ -1498,7 +1505,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 } else {
                     x = 2 * q;
                 }
-                s_t[t][lane] = x;                       // behind this tile's phase-2 reads of s_t[t] (one wavefront: LDS operations execute in order)
+                s_t[slot_of_tile(t)][lane] = x;         // behind this tile's phase-2 reads of it (one wavefront: LDS operations execute in order)
             }
         }
         cbp = 63;                                       // intra: every tile is coded (RTL:2461)
@@ -1529,7 +1536,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             const uint32_t sym_base = lds_off(s_sym);
 #pragma unroll
             for (int t = 0; t < 6; ++t)
-                if ((cbp >> (5 - t)) & 1) nsym4 = vlc_tile_symbols_inter(s_zig[t], sym_base, lane, lane_pos, nsym4, eob);
+                if ((cbp >> (5 - t)) & 1) nsym4 = vlc_tile_symbols_inter(s_zig[slot_of_tile(t)], sym_base, lane, lane_pos, nsym4, eob);
             if (lane == 0) s_sym[0] = sym_raw(e >> 8, e & 255u, true);
             nsym = nsym4 >> 2;
         } else {
@@ -1541,7 +1548,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             for (int t = 0; t < 6; ++t) {
                 if (t == 4) idxB = nsym4 >> 2;
                 if (t == 5) idxC = nsym4 >> 2;
-                nsym4 = vlc_tile_symbols_intra(s_zig[t], sym_base, lane, lane_pos, nsym4, eob, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3,
+                nsym4 = vlc_tile_symbols_intra(s_zig[slot_of_tile(t)], sym_base, lane, lane_pos, nsym4, eob, dcs[t], t ? dcs[t - 1] : 0, t >= 1 && t <= 3,
                                                ltab2 - 1024 + kConstDcLuma);
             }
             nsym = nsym4 >> 2;
@@ -1581,7 +1588,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     if (need_rec) {
         keep_alive(kq3);
         if constexpr (EDGE) keep_alive(kq4);
-        if (lane < 48) {                                // rows: lane = tile*8 + row (RTL:2159-2189), in place
+        if (lane < 48) {                                // rows: lane = slot*8 + row (RTL:2159-2189), in place
             const int t = lane >> 3, row = lane & 7;
             int a[8], o[8];
 #pragma unroll

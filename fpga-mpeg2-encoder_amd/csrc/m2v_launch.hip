@@ -61,7 +61,7 @@ void upload_tables_now()
         uint32_t wq4 = 0;
         for (int v = 0; v < 4; ++v) {
             const int raster = (4 * (g & 1) + v) * 8 + (c & 7);
-            m.zoff[v] = (uint32_t)(tile * 128 + kZigzagPos[raster] * 2);
+            m.zoff[v] = (uint32_t)(slot_of_tile(tile) * 128 + kZigzagPos[raster] * 2);
             wq4 |= (uint32_t)kIntraW[raster] << (8 * v);
             m.irecip[v] = recip[raster];
         }
