@@ -62,11 +62,12 @@ typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 __host__ __device__ constexpr int slot_of_tile(int t) { return t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 5 : t == 3 ? 3 : t == 4 ? 1 : 4; }
 __host__ __device__ constexpr int tile_of_slot(int s) { return s == 0 ? 0 : s == 1 ? 4 : s == 2 ? 1 : s == 3 ? 3 : s == 4 ? 5 : 2; }
 static_assert(slot_of_tile(4) == slot_of_tile(0) + 1 && slot_of_tile(5) == slot_of_tile(3) + 1 && tile_of_slot(slot_of_tile(2)) == 2 && tile_of_slot(slot_of_tile(1)) == 1, "chroma one slot behind luma tiles 0 and 3");
-struct MfmaLane {        // three quads: b1, a | zoff | the intra quantiser's reciprocals
+constexpr int kMfmaCpOff = 704;      // k_mb's kOffCp (static_assert there): the host fills MfmaLane::a1c with absolute LDS addresses
+struct MfmaLane {        // three quads: b1, a, a1c | zoff | the intra quantiser's reciprocals
     uint32_t b1[2];      // pass 1 B operand: +-basis row (c & 7) for the k group that matches c's tile column, else 0
     uint32_t a2;         // pass 2 A operand: a = basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1, else 0; the
                          // kernel forms the pair {a, 0} (multiplies the low dword of a B operand) and the pair {0, a} (the high dword)
-    uint32_t pad0;
+    uint32_t a1c;        // pass 1 A operand of the CHROMA block [U 0; 0 V]: LDS address of s_cp[4 + (c >> 3)][c & 7][8 (g >> 1)] (kMfmaCpOff = k_mb's kOffCp)
     uint32_t zoff[4];    // byte offset of coefficient v inside s_zig: slot * 128 + zigzag position * 2
     uint32_t irecip[4];  // intra macroblocks only: ceil(2^21 / W) of the lane's four coefficients (the intra words share two otherwise
                          // unused quads - this one and SearchLane's last - so that an I frame gets all seven in two loads)
@@ -751,6 +752,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // byte 704 - and are dead before the symbol list is written.  4 288 bytes per wavefront (5 056 before round 3); eight wavefronts per SIMD -
     // the hardware's limit - with the 64 VGPRs of the P-frame kernel.
     constexpr int kOffCp = 704;
+    static_assert(kOffCp == kMfmaCpOff, "MfmaLane::a1c is filled by the host");
     static_assert(2 * kCwinBytes + 256 <= kOffCp && kOffCp + 768 <= kR1, "s_cp behind the chroma windows and the current rows, inside R1");
     constexpr int kOffPred = kR1, kOffT = kOffPred + 384, kOffZig = kOffT + 6 * kTileStride * 4;
     static_assert(!P || (kOffWin % 8 == 0 && kOffWinB + kWinBytes <= kS3Scratch && kS3Scratch <= kOffZig), "window copies may run over s_pred and s_t only, and end in front of the search's scratch");
@@ -826,7 +828,13 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         kq0.z = t.x; kq0.w = t.y;
     }
     const u32x4_t kq1 = M2V_LANEK4(cpc_st);
+    constexpr bool kMfmaLuma = MFMA && !CONF;   // the transform of the four luma tiles on the matrix cores ...
+    // ... and of the two chroma tiles as well, in I frames only: same box, P kernel 0.904 -> 0.924 ms per sequence with it (twelve vector
+    // instructions more on the unit that is 89 % busy there outweigh three loads and eighteen LDS instructions less), I kernel of config c2
+    // 0.2135 -> 0.2059 ms (profiles/r04_experiments.txt item 15)
+    constexpr bool kMfmaChroma = kMfmaLuma && !P;
     long mf_b1 = 0, mf_a2lo = 0, mf_a2hi = 0;   // matrix-core operands of the lane (c_mfma), requested with group 3
+    uint32_t mf_a1c = 0;
     u32x4_t mf_zoff = {0, 0, 0, 0};
     u32x4_t kq2, kq3;                           // the lane table's last three quads (not before the search: registers)
     u32x3_t kq4 = {0, 0, 0};
@@ -838,9 +846,13 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         if constexpr (EDGE) kq4 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_LANEK4(crec_r);   /* halo rows only */ \
         if constexpr (MFMA && !CONF) {                                                                               \
             /* ONE load for the three words (a vector memory instruction costs what ten arithmetic ones do) */           \
-            const u32x3_t m0 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]); \
+            /* ONE load for the three / four words (only the words that are used, see above) */                         \
+            u32x4_t m0 = {0, 0, 0, 0};                                                                                \
+            if constexpr (kMfmaChroma) m0 = M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]);                                    \
+            else { const u32x3_t m3 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_QUAD(kQuadMfma0, MfmaLane, b1[0]); m0.x = m3.x; m0.y = m3.y; m0.z = m3.z; } \
             mf_b1 = (long)(((unsigned long long)m0.y << 32) | m0.x);                                                 \
             mf_a2lo = (long)(unsigned long long)m0.z; mf_a2hi = (long)((unsigned long long)m0.z << 32);              \
+            mf_a1c = m0.w;                                                                                           \
         }                                                                                                            \
     } while (0)
     if constexpr (!P) M2V_REQUEST_G3();
@@ -851,8 +863,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // the transform's basis rows: basis row i = lane >> 3 widened to int32, basis row j = lane & 7 and its negative as int8 x 8
     const int dj = lane & 7;
     const int di = lane >> 3;
-    int bi[8];
-    uint2 mj, nj;
+    int bi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint2 mj = {0, 0}, nj = {0, 0};
 #define M2V_REQUEST_BASIS()                                                                                                             \
     do {                                                                                                                                \
         _Pragma("unroll") for (int k = 0; k < 8; ++k)                                                                                   \
@@ -860,7 +872,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         const u32x4_t mnv = *(gld128)(ltab2 - 1024 + kConstDct + (uint32_t)(dj * 16));     /* row j | minus row j */                    \
         mj = uint2{mnv.x, mnv.y}; nj = uint2{mnv.z, mnv.w};                                                                             \
     } while (0)
-    if constexpr (!P) M2V_REQUEST_BASIS();
+    if constexpr (!P && !kMfmaChroma) M2V_REQUEST_BASIS();     // (the matrix-core transform needs none of them)
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x, EDGE ? 0u : (uint32_t)g.cu_pack);
     const uint32_t li = udiv_magic(blk, g.strip_mbs, g.magic_strip);           // which frame of the launch list
     const FrameJob job = jobs[li];                 // `jobs` = the launch list as jobs: one dependent scalar load, not list -> job
@@ -1299,8 +1311,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // ---- stage G: 2-D forward DCT (RTL:2029-2062); lane = (i = lane>>3, j = lane&7) ------------
     keep_alive(kq2);
     // DCT-as-GEMM trial (north star): the four luma tiles through the matrix cores, the two chroma tiles as before
-    constexpr bool kMfmaLuma = MFMA && !CONF;
-    constexpr int kT0 = kMfmaLuma ? 4 : 0;             // first tile on the VALU path
+    constexpr int kT0 = kMfmaChroma ? 6 : kMfmaLuma ? 4 : 0;         // first tile on the VALU path
 #pragma unroll
     for (int t = kT0; t < 6; ++t) {
         // R1[r][j] = sum_k (c[r][k] - p[r][k]) * DCTM[j][k]: 16 bytes of LDS, 4 v_dot4
@@ -1318,44 +1329,54 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     //   pass 2  Y = B16 . T: T is 19 bit, i8 operands: three signed byte limbs (T + 0x808080) ^ 0x808080, the accumulator
     //           layout of pass 1 (rows 4g .. 4g+3 of column c) IS the B layout of a K = 4g .. 4g+3 slice, a 4x4 byte transpose
     //           (7 v_perm) sorts the limbs, one MFMA per limb, recombined by two shift-adds per coefficient.
+    // The two chroma tiles go through the same four instructions as the block [U x; x V]: A row c < 8 = row c of U in both halves of
+    // K, row c >= 8 = row c - 8 of V; B16 being block diagonal, the quadrants beside the diagonal (x: U, V again) only reach output
+    // quadrants that are never stored.  No basis rows in registers, no second pass through LDS (round 3 costed this at 49 against 44
+    // vector instructions and left it; what it removes is three vector loads, eighteen LDS instructions and twelve registers).
     // transform sum of block row 4g + v, column c, PLUS kRound = 2048 + (2 << 12): the DCT's rounding constant and the inter
     // quantiser's "+ 2" (below), both added for free as the accumulator input 40 of the middle limb (40 << 8)
     constexpr int kRound = P ? 2048 + (2 << 12) : 2048;        // an I frame has no non-intra macroblock: just the transform's rounding
-    int yacc[4] = {0, 0, 0, 0};
+    int yacc[4] = {0, 0, 0, 0}, yacc_c[4] = {0, 0, 0, 0};
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     // (matrix-core lane = (g = lane >> 4, c = lane & 15); its LDS slots come from the lane table)
     if constexpr (kMfmaLuma) {
-        // s_cp[((mc >> 3) << 1) | (mg & 1)][mc & 7][8 * (mg >> 1)]
-        const long a1 = *(const __attribute__((address_space(3))) long *)(uintptr_t)kq2.z;
         const long b1 = mf_b1, a2lo = mf_a2lo, a2hi = mf_a2hi;
         mf_zoff = M2V_QUAD(kQuadMfma0, MfmaLane, zoff[0]);     // for the quantiser
-        const v4i_t zero4 = {0, 0, 0, 0};
-        const v4i_t tt = __builtin_amdgcn_mfma_i32_16x16x32_i8(a1, b1, zero4, 0, 0, 0);
-        uint32_t e[4];
+        auto mfma_dct = [&](const long a1, int (&ya)[4]) {
+            const v4i_t zero4 = {0, 0, 0, 0};
+            const v4i_t tt = __builtin_amdgcn_mfma_i32_16x16x32_i8(a1, b1, zero4, 0, 0, 0);
+            uint32_t e[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) e[v] = (uint32_t)tt[v] + 0x808080u;       // bias here, the sign flip on the three sorted registers
-        const uint32_t p01 = __builtin_amdgcn_perm(e[1], e[0], 0x05010400u), p23 = __builtin_amdgcn_perm(e[3], e[2], 0x05010400u);
-        const uint32_t w0 = __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u, w1 = __builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u;
-        const uint32_t q01 = __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), q23 = __builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u);
-        const uint32_t w2 = __builtin_amdgcn_perm(q23, q01, 0x05040100u) ^ 0x80808080u;
-        // K = 32 per instruction, a limb fills 16: limbs 0 and 1 share one B operand (A = {a, 0} picks the low dword, {0, a} the
-        // high one); limb 2 rides with a dword that A multiplies by zero - any register will do, none is written for it
-        uint32_t junk;
-        asm volatile("" : "=v"(junk));
-        const long b01 = (long)(((unsigned long long)w1 << 32) | w0), b2 = (long)(((unsigned long long)junk << 32) | w2);
-        const v4i_t y0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2lo, b01, zero4, 0, 0, 0);
-        const v4i_t round4 = {kRound >> 8, kRound >> 8, kRound >> 8, kRound >> 8};
-        const v4i_t y1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2hi, b01, round4, 0, 0, 0);
-        const v4i_t y2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2lo, b2, zero4, 0, 0, 0);
+            for (int v = 0; v < 4; ++v) e[v] = (uint32_t)tt[v] + 0x808080u;       // bias here, the sign flip on the three sorted registers
+            const uint32_t p01 = __builtin_amdgcn_perm(e[1], e[0], 0x05010400u), p23 = __builtin_amdgcn_perm(e[3], e[2], 0x05010400u);
+            const uint32_t w0 = __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u, w1 = __builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u;
+            const uint32_t q01 = __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0602u), q23 = __builtin_amdgcn_perm(e[3], e[2], 0x0c0c0602u);
+            const uint32_t w2 = __builtin_amdgcn_perm(q23, q01, 0x05040100u) ^ 0x80808080u;
+            // K = 32 per instruction, a limb fills 16: limbs 0 and 1 share one B operand (A = {a, 0} picks the low dword, {0, a} the
+            // high one); limb 2 rides with a dword that A multiplies by zero - any register will do, none is written for it
+            uint32_t junk;
+            asm volatile("" : "=v"(junk));
+            const long b01 = (long)(((unsigned long long)w1 << 32) | w0), b2 = (long)(((unsigned long long)junk << 32) | w2);
+            const v4i_t y0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2lo, b01, zero4, 0, 0, 0);
+            const v4i_t round4 = {kRound >> 8, kRound >> 8, kRound >> 8, kRound >> 8};
+            const v4i_t y1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2hi, b01, round4, 0, 0, 0);
+            const v4i_t y2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2lo, b2, zero4, 0, 0, 0);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            // two v_lshl_add_u32.  Both are left to the compiler: an instruction that reads a matrix-core result needs wait
-            // states behind the MFMA which the compiler inserts for its own instructions only, never for inline asm.  The
-            // empty asm in between merely keeps it from re-associating the chain into two shifts and a three-operand add.
-            int t = (y2[v] << 8) + y1[v];
-            asm("" : "+v"(t));
-            yacc[v] = (t << 8) + y0[v];
-        }
+            for (int v = 0; v < 4; ++v) {
+                // two v_lshl_add_u32.  Both are left to the compiler: an instruction that reads a matrix-core result needs wait
+                // states behind the MFMA which the compiler inserts for its own instructions only, never for inline asm.  The
+                // empty asm in between merely keeps it from re-associating the chain into two shifts and a three-operand add.
+                int t = (y2[v] << 8) + y1[v];
+                asm("" : "+v"(t));
+                ya[v] = (t << 8) + y0[v];
+            }
+        };
+        // s_cp[((mc >> 3) << 1) | (mg & 1)][mc & 7][8 * (mg >> 1)] / s_cp[4 + (mc >> 3)][mc & 7][8 * (mg >> 1)]
+        const long a1 = *(const __attribute__((address_space(3))) long *)(uintptr_t)kq2.z;
+        long a1c = 0;
+        if constexpr (kMfmaChroma) a1c = *(const __attribute__((address_space(3))) long *)(uintptr_t)mf_a1c;
+        mfma_dct(a1, yacc);
+        if constexpr (kMfmaChroma) mfma_dct(a1c, yacc_c);
     }
     M2V_WAVE_SYNC();
 
@@ -1372,6 +1393,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     const size_t mbidx = (size_t)fidx * g.mbs + mb;
     const bool need_rec = job.rec != nullptr && !(kDebug && (g.ablate & 8));
     int cbp = 0;
+    const bool chroma_lane = ((((uint32_t)lane >> 5) ^ ((uint32_t)lane >> 3)) & 1u) == 0u;     // matrix-core layout: g >> 1 == c >> 3
     if (kDebug && (g.ablate & 16)) {
         for (int t = 0; t < 6; ++t) s_zig[t][lane] = 0;
         cbp = inter ? 0 : 63;
@@ -1382,29 +1404,41 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             // i.e. four coefficients of tile 2 (g >> 1) + (c >> 3); their s_zig slots come from the lane table, their
             // raster slots in s_t are 32 bytes apart
             const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
-            int32_t *const xrow = (int32_t *)(__attribute__((address_space(3))) int32_t *)(uintptr_t)kq2.w;   // &s_t[((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)]
-            int nzor = 0, qv[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                // see the chroma loop below for the arithmetic; yacc already holds acc + (2 << 12)
-                const int q = mad24_ms(yacc[v] >> 31, qneg, yacc[v]) >> (16 + Q);
-                *(int16_t *)((uint8_t *)&s_zig[0][0] + zo[v]) = (int16_t)q;
-                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + tile_of_slot((int)(zo[v] >> 7)) * 64 + ((zo[v] & 127u) >> 1)] = (int16_t)q;
-                nzor |= q;
-                qv[v] = q;
-            }
-            if (need_rec) {                     // one test for the four coefficients
+            int32_t *const xrow = (int32_t *)(__attribute__((address_space(3))) int32_t *)(uintptr_t)kq2.w;   // &s_t[slot of tile ((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)]
+            // four coefficients of one pass of the transform: levels to s_zig (+ zadd bytes), dequantised values to s_t (+ xadd dwords)
+            auto quant4 = [&](const int (&ya)[4], const uint32_t zadd, const int xadd) {
+                int nzor = 0, qv[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    // RTL:2134-2137 clamps to +-2047; the clamp cannot bind here: |q| <= 16322 >> (4 + Q), so (2 |q| + 1) << Q <= 2044
-                    // for every Q_LEVEL (tests/test_host_logic.py::test_inverse_quantisers_never_reach_their_clamps)
-                    xrow[v * 8] = (2 * qv[v] + sign_of(qv[v])) << Q;
+                    // see the VALU-path loop below for the arithmetic; ya already holds acc + (2 << 12)
+                    const int q = mad24_ms(ya[v] >> 31, qneg, ya[v]) >> (16 + Q);
+                    *(int16_t *)((uint8_t *)&s_zig[0][0] + zo[v] + zadd) = (int16_t)q;
+                    if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + tile_of_slot((int)((zo[v] + zadd) >> 7)) * 64 + ((zo[v] & 127u) >> 1)] = (int16_t)q;
+                    nzor |= q;
+                    qv[v] = q;
                 }
-            }
-            // coded flags of the four tiles: tile 2 ty + tx lives in lanes 32 ty + 16 h + 8 tx + (0 .. 7), h = 0, 1
-            const unsigned long long nzm = ballot(nzor != 0);
+                if (need_rec) {                     // one test for the four coefficients
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        // RTL:2134-2137 clamps to +-2047; the clamp cannot bind here: |q| <= 16322 >> (4 + Q), so (2 |q| + 1) << Q <= 2044
+                        // for every Q_LEVEL (tests/test_host_logic.py::test_inverse_quantisers_never_reach_their_clamps)
+                        xrow[v * 8 + xadd] = (2 * qv[v] + sign_of(qv[v])) << Q;
+                    }
+                }
+                return nzor;
+            };
+            // coded flags of the four luma tiles: tile 2 ty + tx lives in lanes 32 ty + 16 h + 8 tx + (0 .. 7), h = 0, 1
+            const unsigned long long nzm = ballot(quant4(yacc, 0u, 0) != 0);
             const uint32_t lo = (uint32_t)sgpr((int)(uint32_t)nzm), hi = (uint32_t)sgpr((int)(uint32_t)(nzm >> 32));
             cbp = ((lo & 0x00FF00FFu) ? 8 : 0) | ((lo & 0xFF00FF00u) ? 4 : 0) | ((hi & 0x00FF00FFu) ? 2 : 0) | (int)(((hi & 0xFF00FF00u) | (0u - (hi & 0xFF00FF00u))) >> 31);
+            // the chroma block: U where luma tile 0 is (g < 2, c < 8: lanes 0-7, 16-23), V where tile 3 is (lanes 40-47, 56-63), one slot
+            // further in both buffers; the other lanes hold the quadrants nobody wants
+            if constexpr (kMfmaChroma) {
+                int nzor_c = 0;
+                if (chroma_lane) nzor_c = quant4(yacc_c, 128u, kTileStride);
+                const unsigned long long nzc = ballot(nzor_c != 0);
+                cbp = (cbp << 2) | ((uint32_t)sgpr((int)(uint32_t)nzc) ? 2 : 0) | ((uint32_t)sgpr((int)(uint32_t)(nzc >> 32)) ? 1 : 0);
+            }
         }
 #pragma unroll
         for (int t = kT0; t < 6; ++t) {
@@ -1443,34 +1477,39 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
             const uint32_t ml_wq = iq_w.y, ml_recip[4] = {iq_recip.x, iq_recip.y, iq_recip.z, iq_recip.w};
             int32_t *const xrow = (int32_t *)(__attribute__((address_space(3))) int32_t *)(uintptr_t)kq2.w;
+            // (the chroma block's coefficients sit at the raster positions of the lane's luma coefficients: same weights, same DC lane)
+            auto quant4 = [&](const int (&ya)[4], const uint32_t zadd, const int xadd) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int wv = (int)((ml_wq >> (8 * v)) & 255u);
-                const uint32_t qo = __umul24((uint32_t)wv, (3u << Q) + 2u) >> 3;
-                const bool is_dc = v == 0 && (lane & 0x17) == 0;           // row 0 of a tile (g even, v = 0), column 0 of a tile
-                const int C = (yacc[v] >> 12) - (kRound >> 12);        // yacc carries kRound
-                const int sg = C >> 31;
-                uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
-                if (!is_dc) a = __umul24((a + qo) >> Q, ml_recip[v]) >> 21;
-                else        a = (a + 8u) >> 4;
-                // RTL:2075 clamps to 2047 here and RTL:2139-2144 keeps the inverse quantiser's product in 17 bits and clamps it to +-2047:
-                // an intra block is pixel - 128, so |C| <= 8192, the level is at most 512 (DC) / 272 (AC) and |level * W| < 2^14 - none
-                // of the three can bind (tests/test_host_logic.py::test_inverse_quantisers_never_reach_their_clamps).  The conformant
-                // build keeps its own saturation.
-                const int q = (int)(a ^ (uint32_t)sg) - sg;
-                *(int16_t *)((uint8_t *)&s_zig[0][0] + zo[v]) = (int16_t)q;
-                if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + tile_of_slot((int)(zo[v] >> 7)) * 64 + ((zo[v] & 127u) >> 1)] = (int16_t)q;
-                if (need_rec) {
-                    int x;
-                    if (!is_dc) {
-                        x = __mul24(q, wv);
-                        x = Q >= 3 ? x << (Q - 3) : x >> (3 - Q);
-                    } else {
-                        x = 2 * q;
+                for (int v = 0; v < 4; ++v) {
+                    const int wv = (int)((ml_wq >> (8 * v)) & 255u);
+                    const uint32_t qo = __umul24((uint32_t)wv, (3u << Q) + 2u) >> 3;
+                    const bool is_dc = v == 0 && (lane & 0x17) == 0;           // row 0 of a tile (g even, v = 0), column 0 of a tile
+                    const int C = (ya[v] >> 12) - (kRound >> 12);          // ya carries kRound
+                    const int sg = C >> 31;
+                    uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
+                    if (!is_dc) a = __umul24((a + qo) >> Q, ml_recip[v]) >> 21;
+                    else        a = (a + 8u) >> 4;
+                    // RTL:2075 clamps to 2047 here and RTL:2139-2144 keeps the inverse quantiser's product in 17 bits and clamps it to +-2047:
+                    // an intra block is pixel - 128, so |C| <= 8192, the level is at most 512 (DC) / 272 (AC) and |level * W| < 2^14 - none
+                    // of the three can bind (tests/test_host_logic.py::test_inverse_quantisers_never_reach_their_clamps).  The conformant
+                    // build keeps its own saturation.
+                    const int q = (int)(a ^ (uint32_t)sg) - sg;
+                    *(int16_t *)((uint8_t *)&s_zig[0][0] + zo[v] + zadd) = (int16_t)q;
+                    if (kDebug && coef_dbg) coef_dbg[mbidx * 384 + tile_of_slot((int)((zo[v] + zadd) >> 7)) * 64 + ((zo[v] & 127u) >> 1)] = (int16_t)q;
+                    if (need_rec) {
+                        int x;
+                        if (!is_dc) {
+                            x = __mul24(q, wv);
+                            x = Q >= 3 ? x << (Q - 3) : x >> (3 - Q);
+                        } else {
+                            x = 2 * q;
+                        }
+                        xrow[v * 8 + xadd] = x;
                     }
-                    xrow[v * 8] = x;
                 }
-            }
+            };
+            quant4(yacc, 0u, 0);
+            if constexpr (kMfmaChroma) { if (chroma_lane) quant4(yacc_c, 128u, kTileStride); }
         }
 #pragma unroll
         for (int t = kT0; t < 6; ++t) {
