@@ -178,7 +178,9 @@ __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_
 __device__ __forceinline__ uint32_t any_lane(bool p)
 {
     const int n = sgpr(__builtin_popcountll(ballot(p)));
-    return (uint32_t)-n >> 31;                  // n > 0 as 0 / 1 without a boolean (see find_min_in_10_values)
+    // n > 0 as 0 / 1 without a boolean (see find_min_in_10_values); pinned to a scalar register: (x << 1) | (-n >> 31) is otherwise
+    // matched as a funnel shift, which only the vector ALU has (v_mov + v_alignbit + v_readfirstlane per use)
+    return (uint32_t)sgpr((int)((uint32_t)-n >> 31));
 }
 
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -320,7 +322,7 @@ __host__ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n, u
     // the hardware does).  Those eight get horizontally neighbouring macroblocks: they read the same 128-byte lines of the frame and of
     // the reference, and the CU's L1 serves some of the repeats instead of the L2 (-1.8 % per sequence, profiles/r04_experiments.txt item 7)
     if (cu_pack) {
-        const uint32_t cus = 1u << cu_pack, span = cus << 3, qq = xcd < r ? q + 1u : q;
+        const uint32_t cus = 1u << cu_pack, span = cus << 3, qq = q + ((xcd - r) >> 31);      // q + 1 for xcd < r, by the sign bit (a 0 / 1 from a compare goes through the vector ALU)
         if (i < (qq / span) * span) {
             const uint32_t c = i & (cus - 1u), j = i >> cu_pack;
             i = (j >> 3) * span + (c << 3) + (j & 7u);
@@ -974,11 +976,12 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             // interior macroblock (wave-uniform test): the whole window lies inside the frame, no clamping: window row yrel = -YR .. 15 + YR
             // is row yrel & 15 of tile row by + (yrel >> 4), tile columns bx (window columns -8 .. 7) and bx + 1 (8 .. 23); ONE load each for
             // the luma window and for both chroma windows
-            const int yrel = wrow - YR, cyr = crow - UR;
+            // (row + 16 and row + 8 keep the tile-row factor non-negative: a 24-bit multiply, not the quarter-rate 32-bit one; every lane
+            // loads - lanes >= 2 WROWS fetch the last row again, nobody stores it)
+            const uint32_t yr16 = (uint32_t)(wrow - YR + 16), cr8 = (uint32_t)(crow - UR + 8);
             typedef const __attribute__((address_space(1))) u32x4_t *gld128w;
-            if (lane < 2 * WROWS)
-                wwin = *(gld128w)(refY + ((tile + (uint32_t)whalf) * 256u + (uint32_t)(yrel >> 4) * (trow * 256u) + (uint32_t)((yrel & 15) << 4)));
-            wc = *(gld64)(refY + (g.rysz + (tile + (uint32_t)chalf) * 128u + (uint32_t)(cyr >> 3) * (trow * 128u) + ((uint32_t)cpl << 6) + (uint32_t)((cyr & 7) << 3)));
+            wwin = *(gld128w)(refY + (__umul24(yr16 >> 4, trow * 256u) + ((yr16 & 15u) << 4) + ((tile + (uint32_t)whalf - trow) * 256u)));
+            wc = *(gld64)(refY + (__umul24(cr8 >> 3, trow * 128u) + ((cr8 & 7u) << 3) + ((uint32_t)cpl << 6) + (g.rysz + (tile + (uint32_t)chalf - trow) * 128u)));
         } else {
             {
                 int yy = 16 * by - YR + wrow;

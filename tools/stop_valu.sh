@@ -15,7 +15,7 @@ python3 - "$OUT" <<'PY'
 import json, sys
 out = sys.argv[1]
 names = {1: "loads, 4:2:0, window staging", 2: "full-pel search", 3: "half-pel, decision, prediction", 4: "forward transform", 5: "quantiser + inverse quantiser",
-         6: "IDCT, reconstruction", 0: "run/level VLC, slot store"}
+         6: "VLC pass 1 + look-up, IDCT", 0: "VLC pass 2, reconstruction and slot stores"}
 prev = dict(valu=0, salu=0, lds=0, act=0, ldsc=0, conf=0)
 rows = []
 for n in (1, 2, 3, 4, 5, 6, 0):
