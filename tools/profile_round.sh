@@ -8,25 +8,36 @@ export TMPDIR=/tmp
 TAG=${1:-prof}
 HEAD=${2:--}
 OUT=gpurun_out/$TAG
-mkdir -p $OUT
+RAW=/tmp/profile_round_$TAG          # raw rocprofv3 output: large, stays out of gpurun_out (64 MiB come back from a visit)
+rm -rf $RAW; mkdir -p $OUT $RAW
+step() { echo "$(date +%T) $*" >> $OUT/progress.log; }
 python3 -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw_stats -o s -- python3 bench.py --inflight 1 --split 1 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+step raw_stats
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/raw_stats -o s -- python3 bench.py --inflight 1 --split 1 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
 grep -h '^{' $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
-python3 tools/summarize_rocprof.py $OUT/raw_stats/s_kernel_stats.csv $OUT/kernel_stats.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/raw_f -o f -- python3 bench.py --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/raw_w -o w -- python3 bench.py --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
-python3 tools/summarize_pmc.py $OUT/raw_f $OUT/raw_w > $OUT/pmc_hbm.json
+python3 tools/summarize_rocprof.py $RAW/raw_stats/s_kernel_stats.csv $OUT/kernel_stats.csv
+step raw_f
+timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/raw_f -o f -- python3 bench.py --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
+step raw_w
+timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/raw_w -o w -- python3 bench.py --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
+python3 tools/summarize_pmc.py $RAW/raw_f $RAW/raw_w > $OUT/pmc_hbm.json
 # config c2 (640x480, I frames only): kernel stats and HBM counters of the I-frame kernel
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw_c2 -o s -- python3 bench.py --config c2 --inflight 1 --split 1 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/c2_bench_under_rocprof.log 2>&1
-python3 tools/summarize_rocprof.py $OUT/raw_c2/s_kernel_stats.csv $OUT/c2_kernel_stats.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/raw_c2f -o f -- python3 bench.py --config c2 --gops 128 --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/raw_c2w -o w -- python3 bench.py --config c2 --gops 128 --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
-python3 tools/summarize_pmc.py $OUT/raw_c2f $OUT/raw_c2w > $OUT/c2_pmc_hbm.json
+step raw_c2
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/raw_c2 -o s -- python3 bench.py --config c2 --inflight 1 --split 1 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/c2_bench_under_rocprof.log 2>&1
+python3 tools/summarize_rocprof.py $RAW/raw_c2/s_kernel_stats.csv $OUT/c2_kernel_stats.csv
+step raw_c2f
+timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/raw_c2f -o f -- python3 bench.py --config c2 --gops 128 --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
+step raw_c2w
+timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/raw_c2w -o w -- python3 bench.py --config c2 --gops 128 --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
+python3 tools/summarize_pmc.py $RAW/raw_c2f $RAW/raw_c2w > $OUT/c2_pmc_hbm.json
 python3 tools/make_pmc_traffic.py $OUT/pmc_hbm.json $OUT/c2_pmc_hbm.json $HEAD > $OUT/pmc_traffic.json
-sh tools/pmc_sq.sh $OUT/sq > /dev/null 2>&1
+step sq
+timeout 600 sh tools/pmc_sq.sh $OUT/sq > /dev/null 2>&1
 cp $OUT/sq/summary.json $OUT/pmc_sq.json
-rm -rf $OUT/raw_stats $OUT/raw_f $OUT/raw_w $OUT/raw_c2 $OUT/raw_c2f $OUT/raw_c2w $OUT/sq
+rm -rf $RAW $OUT/sq
 cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
-python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-python3 bench.py --config c2 > $OUT/c2_bench.json 2> $OUT/c2_bench.err
+step bench
+timeout 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+step bench_c2
+timeout 600 python3 bench.py --config c2 > $OUT/c2_bench.json 2> $OUT/c2_bench.err
 ls -la $OUT
