@@ -1180,7 +1180,6 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
 #undef M2V_PAD4
 #undef M2V_PAD64
         }
-        M2V_REQUEST_G3();                                       // requested here, used in stage G
         // ---- half-pel refinement + intra cost (RTL:1743-1816), four pixels per lane, packed bytes ----
         // T[y][x] = window[y+fy+YR][x+fx+8]; L/C/R = T[.][x-1 .. x+2], T[.][x .. x+3], T[.][x+1 .. x+4]
         uint32_t L0, C0, R0, L1, C1, R1, L2, C2, R2;
@@ -1258,7 +1257,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         mvx = 2 * fx + hx;
     }
 
-    if constexpr (P) M2V_REQUEST_BASIS();       // one phase ahead of stage G (an I frame asked at the start)
+    // group 3 of the lane table and the basis rows: one phase ahead of stage G (an I frame asked at the start).  In front of the half-pel
+    // phase, where group 3 used to be asked for, its eleven registers cost more than the longer head start gained (- 0.5 % per step here)
+    if constexpr (P) { M2V_REQUEST_G3(); M2V_REQUEST_BASIS(); }
     // ---- prediction into tile layout; current and predicted samples as SIGNED bytes for the transform (RTL:1891-1917,
     // 1980-2014).  The 9-bit residual c - p is never formed: stage G needs only sum_k M[j][k] (c_k - p_k), which is
     // sum_k M[j][k] (c_k - 128) + sum_k (-M[j][k]) (p_k - 128), two v_dot4_i32_i8 chains on the bytes XOR 0x80.
@@ -1292,7 +1293,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 // Row row + 1 is only used with a vertical half sample, and then cyi <= UR - 1: it stays inside the window
                 // (without one the fetch below may reach one row past it - inside this kernel's LDS, value unused).
                 // row = yc + cyi + UR, col = xc + cxi + 4: the lane parts (plane, yc + UR; xc + 4) from the table
-                const uint32_t col = kq2.x + (uint32_t)cxi;
+                const uint32_t col = 2u * (uint32_t)c4 + 4u + (uint32_t)cxi;      // (xc + 4 by arithmetic: the table's copy, kq2.x, was asked for a moment ago)
                 const uint32_t sft = col & 3u;
                 const uint32_t *const cw = (const uint32_t *)(LdsU32 *)(uintptr_t)(kq1.w + (uint32_t)sgpr(cyi * 16) + (col & ~3u));
                 const uint32_t a = __builtin_amdgcn_alignbyte(cw[1], cw[0], sft);      // T[row][col..col+3]
