@@ -1167,6 +1167,13 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             } else if (kind == 9) {
                 // ONE vector load and the wait for it: what an exposed memory round trip costs
                 asm volatile("global_load_dword %0, %1, %2 offset:-4096\n\ts_waitcnt vmcnt(0)" : "=&v"(d0) : "v"(lane16), "s"(ltab) : "memory");
+            } else if (kind == 11) {
+                // 64 scalar ALU instructions (four independent chains)
+                int a0 = sgpr(kind), a1 = a0, a2 = a0, a3 = a0;
+#define M2V_S4 "s_add_u32 %0, %0, 1\n\ts_add_u32 %1, %1, 1\n\ts_add_u32 %2, %2, 1\n\ts_add_u32 %3, %3, 1\n\t"
+                asm volatile(M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4 M2V_S4
+                             : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3) : : "scc");
+#undef M2V_S4
             } else if (kind == 10) {
                 // ONE LDS read and the wait for it
                 asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(d0) : "v"(kq0.x) : "memory");

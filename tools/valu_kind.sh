@@ -2,7 +2,7 @@
 # What does one more vector instruction of a given kind cost k_mb<3,true>?  The -DM2V_DEBUG library adds 64 independent instructions of
 # one kind per macroblock behind the full-pel search (option ablate bits 16-19); the P-kernel time of bench.py's profiled pass against kind 0.
 #   kinds: 1 v_add_u32 (VOP2, registers)  2 v_lshlrev_b32  3 v_mad_i32_i24 (VOP3)  4 v_add_u32 with an SGPR operand  5 v_ashrrev_i32  6 v_perm_b32
-#          7 = 16 ds_read_b64 (not vector ALU: + 64 LDS data cycles)  8 = 8 global_load_dword from the lane table (+ 24 % vector memory instructions)
+#          11 = 64 s_add_u32 (scalar ALU)   7 = 16 ds_read_b64 (not vector ALU: + 64 LDS data cycles)  8 = 8 global_load_dword from the lane table (+ 24 % vector memory instructions)
 #   usage: sh tools/valu_kind.sh ["kinds"]     default "1 2 3 4 5 6"
 export TMPDIR=/tmp
 for rep in 1 2 3; do
