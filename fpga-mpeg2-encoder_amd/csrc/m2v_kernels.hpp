@@ -875,20 +875,20 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         mj = uint2{mnv.x, mnv.y}; nj = uint2{mnv.z, mnv.w};                                                                             \
     } while (0)
     if constexpr (!P && !kMfmaChroma) M2V_REQUEST_BASIS();     // (the matrix-core transform needs none of them)
-    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x, EDGE ? 0u : (uint32_t)g.cu_pack);
-    const uint32_t li = udiv_magic(blk, g.strip_mbs, g.magic_strip);           // which frame of the launch list
+    // grid = (macroblocks of one frame's share, frames of the launch list): the frame comes from blockIdx.y, no division for it
+    const uint32_t li = blockIdx.y;                                            // which frame of the launch list
+    const uint32_t local = xcd_remap(blockIdx.x, gridDim.x, EDGE ? 0u : (uint32_t)g.cu_pack);
     const FrameJob job = jobs[li];                 // `jobs` = the launch list as jobs: one dependent scalar load, not list -> job
     const int fidx = (int)job.fidx;
     int mb, by, bx;
     if constexpr (EDGE) {
         // two local rows: the strip's first macroblock row and, rstride rows below, its last
-        const uint32_t local = blk - li * g.strip_mbs;
         const uint32_t lrow = udiv_magic(local, (uint32_t)g.mbw, g.magic_mbw);
         bx = (int)(local - lrow * (uint32_t)g.mbw);
         by = g.row0 + (int)lrow * g.rstride;
         mb = by * g.mbw + bx;
     } else {
-        mb = g.row0 * g.mbw + (int)(blk - li * g.strip_mbs);
+        mb = g.row0 * g.mbw + (int)local;
         by = (int)udiv_magic((uint32_t)mb, (uint32_t)g.mbw, g.magic_mbw);
         bx = mb - by * g.mbw;
     }

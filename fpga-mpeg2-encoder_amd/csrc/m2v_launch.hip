@@ -151,7 +151,7 @@ void launch_mb_edges(m2v_enc *e, hipStream_t s, const int *d_list, int count, co
                      const uint8_t *nb_up, const uint8_t *nb_down)
 {
     if (count <= 0) return;
-    const dim3 grid((unsigned)((size_t)count * (size_t)(g.row1 - g.row0) * g.mbw)), block(64);
+    const dim3 grid((unsigned)((g.row1 - g.row0) * g.mbw), (unsigned)count), block(64);
     Timer t(e, s, P ? 0 : 1, (double)count * (g.row1 - g.row0) * g.mbw * 256.0);
     int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
     const FrameJob *const jl = e->d_joblist.p + (d_list - e->d_lists.p);
@@ -172,7 +172,7 @@ template <bool P>
 void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g)
 {
     if (count <= 0) return;
-    const dim3 grid((unsigned)((size_t)count * (size_t)(g.row1 - g.row0) * g.mbw)), block(64);      // one wavefront per macroblock
+    const dim3 grid((unsigned)((g.row1 - g.row0) * g.mbw), (unsigned)count), block(64);      // one wavefront per macroblock; y = frame of the launch list
     Timer t(e, s, P ? 0 : 1, (double)count * g.ysz);
     int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
     const FrameJob *const jl = e->d_joblist.p + (d_list - e->d_lists.p);      // the same launch list, as jobs

@@ -21,6 +21,8 @@ cap = n * W * H * 3 // 2
 d_out = torch.empty(cap, dtype=torch.uint8, device="cuda:0")
 enc = M.Mpeg2Encoder(7, 7, 3, 2, device=0)
 enc.set_option("batch_frames", n)
+if "cupack0" in variant:          # (tools/variant_run.sh passes the library's name as part of the variant)
+    enc.set_option("cu_pack", 0)
 stream = torch.cuda.current_stream().cuda_stream
 
 
