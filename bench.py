@@ -32,6 +32,7 @@ XL = YL = 7
 VL, Q = 3, 2
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 FPGA_MPIXELS = 268.0           # README.md:22, Kintex-7
+LIB_DEFAULT_SPLIT_STREAMS = 2  # option split_streams as m2v_create leaves it (csrc/m2v_host.hpp)
 
 
 GOP_CODE, END_CODE = b"\x00\x00\x01\xb8", b"\x00\x00\x01\xb7"
@@ -179,7 +180,9 @@ def rtl_sim_probe():
         verdict = json.loads(lines[-1])           # the tool's last line: RTL vs oracle vs product (m2v_tb), known answers, simulator
     except (ValueError, IndexError):
         verdict = {"available": True}
-    verdict.update({"identical_to_oracle": r.returncode == 0, "seconds": round(time.perf_counter() - t0, 1), "cores": 1, "log": lines[-10:-1]})
+    # the RTL against the ORACLE is what pins parity; the tool's exit code also covers RTL against the product and the known answers
+    verdict.update({"identical_to_oracle": bool(verdict.get("rtl_equals_oracle")) if "rtl_equals_oracle" in verdict else None,
+                    "tool_exit_code": r.returncode, "seconds": round(time.perf_counter() - t0, 1), "cores": 1, "log": lines[-10:-1]})
     return verdict
 
 
@@ -276,6 +279,63 @@ def end_to_end(M, clip_np, want_bytes):
             "h2d_copy_measured_GBps": round(h2d * 1e-9, 1), "fraction_of_measured_h2d": round(px * 3 / t_pin / h2d, 3)}
 
 
+def gpu_sensors(index=0):
+    """Clocks / power / temperature of GPU `index` as amdgpu's sysfs files give them (no subprocess, no SMI library: readable by an
+    ordinary user where the files exist at all); None for what cannot be read.  Cards are taken in the order of their PCI addresses,
+    which is the order HIP enumerates them in when no *_VISIBLE_DEVICES variable reorders it."""
+    import glob
+    cards = []
+    for d in glob.glob("/sys/class/drm/card[0-9]*/device"):
+        if os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+            cards.append((os.path.realpath(d), d))
+    cards.sort()
+    if index >= len(cards):
+        return None
+    d = cards[index][1]
+
+    def current(name):                       # "1: 2400Mhz *" marks the level in use
+        try:
+            for ln in open(os.path.join(d, name)):
+                if ln.rstrip().endswith("*"):
+                    return int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    def hwmon(name, scale):
+        for f in glob.glob(os.path.join(d, "hwmon", "hwmon*", name)):
+            try:
+                return round(int(open(f).read().strip()) * scale, 1)
+            except (OSError, ValueError):
+                pass
+        return None
+    out = {"sclk_mhz": current("pp_dpm_sclk"), "mclk_mhz": current("pp_dpm_mclk"),
+           "power_w": hwmon("power1_average", 1e-6) or hwmon("power1_input", 1e-6), "temp_c": hwmon("temp1_input", 1e-3)}
+    return out if any(v is not None for v in out.values()) else None
+
+
+def visible_gpus():
+    """How many GPUs a rank of this job would see, WITHOUT touching the HIP runtime (the launcher must not initialise the GPU
+    before it starts its children): the *_VISIBLE_DEVICES list if one is set, else the KFD topology's nodes that have SIMDs.
+    None when neither can be read (then the ranks themselves check, as before)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    import glob
+    n, seen = 0, False
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for ln in open(f):
+                k, _, val = ln.partition(" ")
+                if k == "simd_count":
+                    seen = True
+                    n += int(val) > 0
+        except (OSError, ValueError):
+            pass
+    return n if seen else None
+
+
 def hbm_copy_rate(torch, dev):
     """Achievable HBM bandwidth of this device with a plain device-to-device copy (read + write bytes), GB/s."""
     n = 1 << 30
@@ -338,8 +398,28 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
 
         def step(timings=None):
             return M.parallel.encode_strips(eng, rank, world, dist, timings=timings)
+    def describe():
+        """what this rank was running, for the failure path of ANY rank (stderr: rank 0's stdout carries the JSON line only)"""
+        d = {"rank": rank, "ranks_seen": dist.get_world_size() if dist is not None else 1, "strip_loop": loop, "strip_loop_why": why,
+             "transport": comm.kind if comm is not None else None, "dist_backend": backend, "device": dev}
+        if loop == "native":
+            try:
+                d["strip_graph"] = enc.strip_graph_stats()
+                d["last_error"] = enc._L.m2v_last_error(enc._h).decode()
+            except Exception as ex:  # noqa: BLE001
+                d["strip_graph"] = "unreadable: %s" % ex
+        return d
+
+    def guarded(fn, *a):
+        try:
+            return fn(*a)
+        except BaseException as ex:
+            sys.stderr.write("bench.py --mode strips: rank %d failed: %s\n  state: %s\n" % (rank, ex, json.dumps(describe())))
+            sys.stderr.flush()
+            raise
+
     for _ in range((20 if args.prewarm > 0 else 0) + args.warmup):     # fixed count: every rank takes part in the halo exchange
-        out = step()
+        out = guarded(step)
 
     def barrier():
         torch.cuda.synchronize()
@@ -350,7 +430,7 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out = guarded(step)
     barrier()
     dt = time.perf_counter() - t0
     graph_stats = enc.strip_graph_stats() if loop == "native" else None      # the timed steps: one recorded hipGraph launch each?
@@ -358,8 +438,8 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
     # one more pass with per-launch HIP events (option profile) and the exchange bracketed by events on the engine's stream
     enc.set_option("profile", 1)
     timings = {}
-    step(timings)
-    step(timings)
+    guarded(step, timings)
+    guarded(step, timings)
     if loop == "native":
         timings = enc.strip_stats()
     launches, ms_p, px_p = enc.kernel_stats(0)
@@ -392,6 +472,7 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
                        "stream_bytes": int(out.numel()) if out is not None else None,
                        "baseline": "FPGA Kintex-7 268 MPixels/s (README.md:22)",
                        "strip_loop": loop, "strip_loop_why": why, "dist_backend": backend,
+                       "transport": comm.kind if comm is not None else None,
                        "strip_graph": graph_stats,
                        "launched_by": os.environ.get("M2V_BENCH_LAUNCHED_BY", "caller")},
             "roofline": {"bound": "hbm", "kernel": "k_mb<3,true> on rank 0's strip (%d macroblock rows), P-frame launches of one step" % (rows[1] - rows[0]),
@@ -561,6 +642,9 @@ def main():
     ap.add_argument("--prewarm", type=float, default=1.5,
                     help="seconds of untimed encoder steps BEFORE the W warmup steps: a step is ~2 ms, far shorter than the "
                          "GPU's clock ramp out of its idle state (sclk 312 MHz), so a cold start would time the ramp")
+    ap.add_argument("--sustain", type=float, default=5.0,
+                    help="seconds of the SAME in-flight loop run once more after the K timed steps, in 0.5 s windows (the line's `sustained` "
+                         "object: clocks, power cap, thermal state over thousands of sequences instead of K); 0 = skip")
     ap.add_argument("--split", type=int, default=-1,
                     help="option split_streams of the encoder (GOP groups on that many HIP streams); -1 = the library's default (2)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host end_to_end leg")
@@ -576,6 +660,9 @@ def main():
 
     # ---- N ranks: started by the caller (WORLD_SIZE set) or, failing that, by this process before it touches the GPU ----
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        have = visible_gpus()
+        if not args.dry_launch and os.environ.get("M2V_BENCH_SHARE_GPU") != "1" and have is not None and have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but %d GPU(s) visible on this node (one rank per GPU): nothing was started" % (args.gpus, have))
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -717,18 +804,21 @@ def main():
         # the yardstick for "no overlap": the same sequences strictly one after the other on ONE stream
         enc.set_option("split_streams", 1)
         p_serial = min(timed(probe, sync_steps)[0], timed(probe, sync_steps)[0])
-        enc.set_option("split_streams", args.split if args.split >= 0 else 2)
+        enc.set_option("split_streams", args.split if args.split >= 0 else LIB_DEFAULT_SPLIT_STREAMS)
         p_fly = probe_fly()
         placement = {"new_streams": 0, "priority": 0, "probe_ms_per_step": {"blocking": round(p_sync / probe * 1e3, 3), "one_stream": round(p_serial / probe * 1e3, 3),
                                                                              "in_flight": [round(p_fly / probe * 1e3, 3)]}}
-        p_sync_ref = p_serial                  # in flight must beat the one-stream form by 4 % to count as overlapping
-        p_sync, p_sync_ref = p_sync, 0.96 * p_serial / 0.97
-        while p_fly > 0.97 * p_sync_ref and placement["new_streams"] < 3 and args.split < 0:
+
+        def overlapping(t_fly):                # in flight must beat the one-stream form by 4 % to count as overlapping
+            return t_fly <= 0.96 * p_serial
+        # The repair re-streams ONE handle, the last one: with the default two handles that is the pair; with --inflight > 2 the others
+        # keep the streams they were created with (more than two in flight buys nothing, DESIGN.md section 2, and is not repaired).
+        while not overlapping(p_fly) and placement["new_streams"] < 3 and args.split < 0:
             encs[-1].set_option("stream_priority", 0)            # a fresh stream: the next hardware queue in the runtime's rotation
             placement["new_streams"] += 1
             p_fly = probe_fly()
             placement["probe_ms_per_step"]["in_flight"].append(round(p_fly / probe * 1e3, 3))
-        if p_fly > 0.97 * p_sync_ref and args.split < 0:
+        if not overlapping(p_fly) and args.split < 0:
             encs[-1].set_option("stream_priority", 1)
             placement["priority"] = 1
             p_fly = probe_fly()
@@ -741,6 +831,31 @@ def main():
     dt_other, nbytes_other = timed(args.steps, sync_steps if submission == "in_flight" else run_steps) if nh > 1 else (dt, nbytes)
     assert nbytes_other == nbytes
     dt_sync, dt_fly = (dt_other, dt) if submission == "in_flight" else (dt, dt_other)
+    # The K steps above are ~0.1 s of GPU time.  The same loop again for --sustain seconds of wall clock, in windows of ~0.5 s (a
+    # window ends by collecting every handle, a bubble of one sequence in ~500): what the GPU holds once clocks, power and
+    # temperature have settled.  Reported beside `value`, never as `value`.
+    sustained = None
+    if args.sustain > 0:
+        fn = run_steps if submission == "in_flight" else sync_steps
+        per = max(2 * nh, int(0.5 / max(dt / args.steps, 1e-6)))
+        s0 = gpu_sensors(local_rank)
+        barrier()
+        wins, t_begin = [], time.perf_counter()
+        while time.perf_counter() - t_begin < args.sustain:
+            t0 = time.perf_counter()
+            nb = fn(per)
+            torch.cuda.synchronize()
+            wins.append(time.perf_counter() - t0)
+            assert nb == nbytes
+        t_all = time.perf_counter() - t_begin
+        s1 = gpu_sensors(local_rank)
+        rate = [per * nframes * W * H / w * 1e-6 for w in wins]
+        sustained = {"seconds": round(t_all, 2), "sequences": per * len(wins), "sequences_per_window": per, "windows": len(wins),
+                     "value": round(per * len(wins) * nframes * W * H / sum(wins) * 1e-6, 2), "unit": "MPixels/s (this rank)",
+                     "window_min": round(min(rate), 2), "window_max": round(max(rate), 2),
+                     "first_window": round(rate[0], 2), "last_window": round(rate[-1], 2),
+                     "submission": submission, "sensors_start": s0, "sensors_end": s1,
+                     "sensors_source": "amdgpu sysfs (pp_dpm_sclk / pp_dpm_mclk / hwmon)" if (s0 or s1) else "not readable on this host"}
     # second pass, same K steps, for the per-kernel numbers: option "profile" brackets every launch with HIP events on the
     # launch stream and keeps the whole chunk on ONE stream, so that a launch's duration is the kernel alone on the GPU
     enc.set_option("profile", 1)
@@ -829,6 +944,9 @@ def main():
             "streams": {"per_sequence_in_the_timed_loop": args.split if args.split >= 0 else (1 if submission == "in_flight" else 2),
                         "per_sequence_in_a_synchronous_call": args.split if args.split >= 0 else 2},
         }
+        if sustained is not None:
+            sustained["vs_value"] = round(sustained["value"] * world / value, 4) if value > 0 else None
+            out["sustained"] = sustained
         if dom == "P":
             # secondary "operation roofline" of SURVEY.md 8(d): the search alone is (2*6+1)^2 + 9 = 178 byte absolute
             # differences per luma pixel of a P frame; v_qsad / v_sad retire one per lane per clock
@@ -836,8 +954,10 @@ def main():
                                   "achieved": round(178.0 * px / (ms * 1e-3) * 1e-12, 2) if ms > 0 else 0.0,
                                   "peak": round(256 * 4 * 64 * 2.4e9 * 1e-12, 1),
                                   "frac": round(178.0 * px / (ms * 1e-3) / (256 * 4 * 64 * 2.4e9), 4) if ms > 0 else 0.0,
-                                  "note": "256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz; the macroblock kernel is VALU-issue bound "
-                                          "(VALUBusy 100 %), the SADs are ~21 % of its VALU cycles at 66 % lane efficiency"}
+                                  "note": "256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz; every unit the macroblock kernel touches is 65-90 % busy "
+                                          "(vector ALU 85-89 %, SQ_ACTIVE_INST_VALU; LDS ~70 %, scalar unit ~69 %): the full-pel search is ~30 % of its "
+                                          "vector cycles (52 v_qsad_pk_u16_u8 = 832 of ~2 800) at 81 % of the instruction's candidate slots "
+                                          "(169 of 208 live) - DESIGN.md section 4, profiles/r04_final_pmc_sq.json"}
         out["roofline"]["timed_in"] = "profiled_pass (one stream, HIP events around every launch on the launch stream)"
         if rank_parity is not None:
             out["parity_check"] = rank_parity

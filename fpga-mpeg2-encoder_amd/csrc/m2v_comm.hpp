@@ -44,6 +44,9 @@ struct m2v_comm {
     // true when every call above only ENQUEUES on the stream it is given, so that a whole strip sequence can be recorded into a
     // hipGraph (m2v_strip_encode) - false for the in-process communicator, whose calls block on the other threads
     virtual bool capturable() const { return false; }
+    // ... and whether m2v_strip_encode does so without being asked (option strip_graph = -1, the default): the single-GPU timing
+    // communicators yes; a real multi-rank RCCL communicator only when the caller opts in (strip_graph = 1)
+    virtual bool graph_by_default() const { return false; }
     virtual const char *kind() const = 0;
 };
 
@@ -120,6 +123,7 @@ struct RcclComm final : m2v_comm {
     ~RcclComm() override { if (comm) (void)api.CommDestroy(comm); }
     const char *kind() const override { return "rccl"; }
     bool capturable() const override { return true; }
+    bool graph_by_default() const override { return world == 1; }
     void chk(ncclResult_t r, const char *what) const
     {
         if (r != ncclSuccess) throw CommError(std::string(what) + ": " + api.GetErrorString(r));
@@ -341,6 +345,7 @@ struct SoloComm final : m2v_comm {
     ~SoloComm() override { delete self; }
     const char *kind() const override { return self ? "solo-rccl" : "solo"; }
     bool capturable() const override { return true; }
+    bool graph_by_default() const override { return true; }
     void halo(int r, const void *send_up, void *recv_up, const void *send_down, void *recv_down, size_t n, hipStream_t s) override
     {
         if (!n) return;

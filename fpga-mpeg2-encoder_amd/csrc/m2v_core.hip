@@ -418,6 +418,7 @@ m2v_enc *m2v_create(int XL, int YL, int VECTOR_LEVEL, int Q_LEVEL, int device, i
     m2v_enc *e = new (std::nothrow) m2v_enc();
     if (!e) return fail(M2V_E_NOMEM, "m2v_create: host allocation failed");
     e->XL = XL; e->YL = YL; e->VL = VECTOR_LEVEL; e->Q = Q_LEVEL; e->device = device;
+    e->d_gather.recorded = false;
     try {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -457,6 +458,7 @@ void m2v_destroy(m2v_enc *e)
     if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
     if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
     for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
+    (void)hipGetLastError();            // (a caller's stream that no longer exists: tolerated above, and not left behind as HIP's last error)
     e->d_coef.release(); e->d_mbaux.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
     e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
     e->d_jobs.release(); e->d_lists.release(); e->d_joblist.release(); e->d_ctl.release(); e->d_segs.release();
@@ -506,6 +508,7 @@ int m2v_reset(m2v_enc *e)
     if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
     for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
     if (e->strip_stream && e->strip_stream != e->stream) (void)hipStreamSynchronize(e->strip_stream);
+    (void)hipGetLastError();            // (a caller's stream that no longer exists: the next launch must not trip over this)
     for (auto &h : e->hs) { h.stage = 0; h.uploaded = 0; }
     e->dev_jobs.clear(); e->dev_lists.clear(); e->dev_jobs_p = nullptr;
     e->resident_inflight = false; e->resident_empty = false;
@@ -565,7 +568,7 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
         return M2V_OK;
     }
     if (!strcmp(name, "dct_mfma")) { e->dct_mfma = value != 0; return M2V_OK; }
-    if (!strcmp(name, "strip_graph")) { e->strip_graph_opt = value != 0; return M2V_OK; }
+    if (!strcmp(name, "strip_graph")) { e->strip_graph_opt = value < 0 ? -1 : value != 0; return M2V_OK; }
     if (!strcmp(name, "stream_priority")) {
         // the handle's own stream again, at another priority (-1 low, 0 normal, 1 high).  HIP keeps the hardware queues of different
         // priorities apart, so two handles with different priorities can never share one - which is what decides whether two
@@ -576,6 +579,9 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
         hipStream_t ns = nullptr;
         if (hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, value > 0 ? hi : value < 0 ? lo : (lo + hi) / 2) != hipSuccess) return M2V_E_HIP;
         if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+        // nothing may keep pointing at the stream that is gone (m2v_reset / m2v_destroy synchronise these two)
+        if (e->strip_stream == e->stream) e->strip_stream = nullptr;
+        if (e->resident_stream == e->stream) e->resident_stream = nullptr;
         e->stream = ns;
         ++alloc_generation();
         return M2V_OK;

@@ -46,16 +46,17 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool recorded = true;       // false: no recorded graph ever references this buffer (its reallocation invalidates none)
     void ensure(size_t count)
     {
         if (count <= n) return;
-        ++alloc_generation();
+        if (recorded) ++alloc_generation();
         if (p) (void)hipFree(p);
         p = nullptr; n = 0;
         HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
         n = count;
     }
-    void release() { if (p) { ++alloc_generation(); (void)hipFree(p); } p = nullptr; n = 0; }
+    void release() { if (p) { if (recorded) ++alloc_generation(); (void)hipFree(p); } p = nullptr; n = 0; }
 };
 
 struct KStat { int launches = 0; double ms = 0, units = 0; };
@@ -182,7 +183,7 @@ struct m2v_enc {
     size_t strip_nf = 0;
     hipEvent_t ev_strip = nullptr;
     // m2v_strip_encode: the whole strip sequence in one call
-    DevBuf<uint8_t> d_halo, d_strip_own, d_gather;
+    DevBuf<uint8_t> d_halo, d_strip_own, d_gather;      // (d_gather: sized from the other ranks' strips AFTER the host wait; no recording references it)
     hipStream_t comm_stream = nullptr;    // send / recv with the neighbours, beside the interior rows on the main stream
     hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_interior = nullptr, ev_done = nullptr;
     // m2v_strip_encode as a recorded hipGraph (option "strip_graph"): everything one call enqueues before its one host wait
@@ -193,7 +194,9 @@ struct m2v_enc {
         bool broken = false;                       // recording failed once on this handle: not tried again
         int launches = 0, captures = 0;
     } strip_graph;
-    bool strip_graph_opt = true;
+    // -1 = automatic: recorded with world == 1 and with the single-GPU timing communicators; call by call between the ranks of a real
+    // RCCL job (a recording with cross-rank ncclSend / ncclRecv inside has never run on hardware: opt in with 1); 0 = never
+    int strip_graph_opt = -1;
     struct StripStats { double halo_total_ms = 0, halo_exposed_ms = 0, gather_ms = 0, host_us_per_step = 0, comm_us_per_step = 0; int steps = 0; int graph = 0; } strip_stats;
 
     // debug bookkeeping of the last resident encode

@@ -165,6 +165,7 @@ static int strip_offsets_impl(m2v_enc *e, void *argp)
     auto *a = (StripFinishArgs *)argp;
     if (!e->ev_strip || e->strip_nf == 0) { e->set_err("m2v_strip_offsets: no finished strip"); return M2V_E_STATE; }
     HIPCHK(hipEventSynchronize(e->ev_strip));           // the one wait of a strip sequence: its sizes are needed on the host
+    e->strip_stream = nullptr;                          // nothing of the sequence is left on the (possibly caller-owned) stream
     collect_timers(e);
     memcpy(a->frame_off, e->h_strip, (e->strip_nf + 1) * sizeof(unsigned long long));
     const StreamCtl *c = (const StreamCtl *)(e->h_strip + (e->strip_nf + 1) * sizeof(unsigned long long));
@@ -270,9 +271,11 @@ int m2v_strip_assemble(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t 
 //      side stream:  interior(j), beside both
 // then the strip's slices and one all-gather of the per-frame sizes.  All of that is the SEQUENCE: it depends on nothing the
 // host has to look at, so it is enqueued in one go - or, from the second call of the same shape on, launched as ONE recorded
-// hipGraph (option "strip_graph"): a strip of an 8-GPU job is ~24 us of GPU work per GOP step, less than the ~31 us the host
-// needs to issue a step's launches, event records and waits one by one (profiles/r03_strip_solo.jsonl).  Then the one host
-// wait (the sizes decide the receive counts), the strips to the output rank, the final assembly there.
+// hipGraph (option "strip_graph").  The recording does NOT shorten the sequence: hipGraphLaunch takes the host as long as the
+// individual calls did on this runtime, and the step is bound by the GPU-side chain edge rows -> exchange -> next edge rows, not
+// by the host (profiles/r04_experiments.txt item 1: output rank -4 %, inner rank +9 %).  It is kept for world == 1 and as an
+// opt-in; the peer transport (below) is what takes the exchange out of the chain.  Then the one host wait (the sizes decide the
+// receive counts), the strips to the output rank, the final assembly there.
 //
 // Failures: a rank whose local work fails (a launch or a copy refused) keeps the collective call order - it goes on exchanging,
 // with whatever is in its buffers - and marks its row of the all-gathered sizes; every rank then sees the mark after the same
@@ -419,8 +422,6 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         e->set_err("m2v_strip_encode: bad rank / world / communicator");
         return M2V_E_PARAM;
     }
-    if (rank == a->dst && !a->d_out) { e->set_err("m2v_strip_encode: the output rank needs d_out"); return M2V_E_PARAM; }     // before anything collective
-    if (rank == a->dst && ((uintptr_t)a->d_out & 15u) != 0) { e->set_err("m2v_strip_encode: d_out must be 16-byte aligned"); return M2V_E_PARAM; }
     if (e->state != m2v_enc::IDLE || e->strip_active || e->resident_inflight) { e->set_err("m2v_strip_encode: encoder busy"); return M2V_E_STATE; }
     // contiguous strips, sizes differing by at most one row, the first mbh % world ranks get the extra row (parallel.partition_rows)
     const int base = full.mbh / world, rem = full.mbh % world;
@@ -442,6 +443,13 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         }
     };
     if (kDebug && (e->ablate & (1 << 21))) { fail = M2V_E_HIP; fail_text = "injected failure (ablate bit 21)"; }    // -DM2V_DEBUG: the failure protocol under test
+    // a bad output buffer is the output rank's alone to know: a local failure like any other (the other ranks are told through the
+    // size table, nobody is left waiting in an exchange); with one rank it is simply the answer
+    if (rank == a->dst && (!a->d_out || ((uintptr_t)a->d_out & 15u) != 0)) {
+        const char *why = !a->d_out ? "the output rank needs d_out" : "d_out must be 16-byte aligned";
+        if (world == 1) { e->set_err("m2v_strip_encode: %s", why); return M2V_E_PARAM; }
+        fail = M2V_E_PARAM; fail_text = why;
+    }
     StripSeq q{};
     q.comm = a->comm; q.rank = rank; q.world = world; q.row0 = row0; q.row1 = row1;
     q.up = row0 > 0; q.down = row1 < full.mbh;
@@ -497,8 +505,18 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     int graph_used = 0;
     // (the general form - options conformant / dct_mfma = 0 - is enqueued call by call: it issues the exchange on a stream of its own,
     // and RCCL 2.26 crashes when its send / recv group is recorded on a stream that joined the recording through an event)
-    const bool graph_ok = e->strip_graph_opt && !sg.broken && !fail && !e->profile && (world == 1 || q.fused) && (!a->comm || a->comm->capturable());
+    // Automatic (the default): world == 1 and the single-GPU timing communicators.  Between the ranks of a real RCCL job the sequence
+    // is enqueued call by call unless the caller opts in with option strip_graph = 1: a recording with cross-rank ncclSend / ncclRecv
+    // inside has never run on hardware, the ranks of a job do not necessarily record on the same call, and on one GPU the recorded
+    // form is no faster for an inner rank (profiles/r04_experiments.txt item 1).
+    const bool graph_wanted = e->strip_graph_opt > 0 || (e->strip_graph_opt < 0 && (!a->comm || a->comm->graph_by_default()));
+    const bool graph_ok = graph_wanted && !sg.broken && !fail && !e->profile && (world == 1 || q.fused) && (!a->comm || a->comm->capturable());
     if (graph_ok) {
+        // everything a recording references exists before the key (which holds the allocation generation) is taken: the output rank's
+        // assembly tables are allocated here, not after the host wait - a rank must not find its own recording stale on the next call
+        if (rank == a->dst) local([&] { e->d_segs.ensure(nf * (size_t)world * sizeof(CopySeg) + 16); e->d_frame_pos.ensure(nf + 1); });
+    }
+    if (graph_ok && !fail) {
         const std::vector<unsigned long long> key = {alloc_generation().load(), (unsigned long long)full.W, (unsigned long long)full.H, (unsigned long long)full.Q,
             (unsigned long long)row0, (unsigned long long)row1, (unsigned long long)nf, (unsigned long long)gop, (unsigned long long)rank,
             (unsigned long long)world, (unsigned long long)(uintptr_t)a->comm, (unsigned long long)q.fused, (unsigned long long)e->VL,
@@ -632,6 +650,7 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         e->strip_stats.halo_exposed_ms = exp;
     }
     collect_timers(e);
+    e->strip_stream = nullptr;                               // synchronised above: nothing of the sequence is left on the caller's stream
     if (a->bytes) *a->bytes = out_bytes;
     return M2V_OK;
 }

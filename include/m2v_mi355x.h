@@ -215,9 +215,13 @@ int       m2v_comm_selftest_captured(m2v_comm *c, int rank, const void *d_send, 
  * of the communicator must make the call with the same sequence parameters.
  * Everything a call enqueues before its one host wait - the GOP steps with their exchanges, the strip's slices, the all-gather of
  * the sizes - is recorded into a hipGraph when the same shape comes a second time, and launched as one graph from then on
- * (option "strip_graph", default 1; RCCL and solo communicators; not with option "profile" or an in-process communicator).
- * A rank whose own work fails keeps the collective call order and marks its sizes; every rank then returns an error from the
- * same call instead of waiting for it inside an exchange.
+ * (option "strip_graph": by default with world == 1 and the single-GPU timing communicators; between the ranks of an RCCL job
+ * only when asked for with 1; never with option "profile" or an in-process communicator).
+ * A rank whose own work fails - a launch or an allocation refused, the output rank's d_out missing or not 16-byte aligned - keeps
+ * the collective call order and marks its sizes; every rank then returns an error from the same call instead of waiting for it
+ * inside an exchange.  What is rank-local and NOT covered: M2V_E_PARAM for rank / world / communicator arguments (the same on
+ * every rank by construction) and M2V_E_STATE for a handle that is busy with another sequence - the caller's bug on that rank;
+ * the other ranks of an RCCL job then wait for it, and the job has to be taken down (bench.py's launcher does).
  */
 int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_rank, uint32_t xsize16, uint32_t ysize16,
                      uint32_t pframes_count, const void *d_frames444, size_t nframes, void *d_out, size_t cap, size_t *out_bytes,
@@ -252,7 +256,9 @@ int m2v_strip_graph_stats(const m2v_enc *e, int *last_call_was_graph, int *recor
  * "stream_priority" (-1 low, 0 normal, 1 high; only while idle: the handle's own stream is created again at that priority.  HIP keeps the hardware
  * queues of different priorities apart, so two handles of different priorities never share one - see bench.py's queue placement check),
  * "cu_pack" (default 5; 0..8: which macroblocks tend to share a CU in time - see xcd_remap in csrc/m2v_kernels.hpp; 0 = none.  Same bytes),
- * "strip_graph" (default 1: m2v_strip_encode launches its sequence as a recorded hipGraph, see there; 0 = always call by call),
+ * "strip_graph" (default -1 = automatic: m2v_strip_encode launches its sequence as a recorded hipGraph with world == 1 and with the
+ * single-GPU timing communicators, call by call between the ranks of an RCCL job; 1 = recorded wherever the communicator can be
+ * recorded - cross-rank RCCL included, which no hardware run has covered yet -; 0 = always call by call),
  * "conformant" (default 0 = the reference's arithmetic, byte-identical to the RTL.  1 = NOT the reference's
  * behaviour: the reconstruction loop follows ISO/IEC 13818-2 where the RTL deviates from it - four-sample average
  * rounded with +2, 4:2:0 chroma vector = mv / 2 toward zero, inverse quantiser truncating toward zero with

@@ -112,14 +112,33 @@ def product_bytes(clip_path, W, H, pf, XL, YL, VL, Q, nframes, work, tag):
     """the product's testbench counterpart (m2v_tb: file -> C-ABI beats -> file) on the same clip; None without a GPU or without the
     built binary.  m2v_tb pushes the complete frames of the file (TB:220), so it serves the cases that stop on a frame boundary."""
     tb = os.path.join(ROOT, "fpga-mpeg2-encoder_amd", "m2v_tb")
-    if not os.path.exists(tb):
-        return None
+    if not os.path.exists(tb) or not product_possible():
+        return None                                   # "not run": no binary, or no GPU on this host
     out = os.path.join(work, tag + ".product.m2v")
     r = subprocess.run([tb, "-XL", str(XL), "-YL", str(YL), "-VL", str(VL), "-Q", str(Q), "-p", str(pf), clip_path, str(W), str(H), out],
                        capture_output=True, text=True)
     if r.returncode != 0 or not os.path.exists(out):
-        return None
+        # the product RAN and failed: that is a mismatch, not an absence
+        sys.stderr.write("m2v_tb failed on %s (exit code %d):\n%s\n" % (tag, r.returncode, (r.stderr or r.stdout)[-2000:]))
+        return PRODUCT_FAILED
     return open(out, "rb").read()
+
+
+PRODUCT_FAILED = b"\xffm2v_tb failed"             # never equal to a stream (a stream starts with 00 00 01 B3)
+
+
+def product_possible():
+    """is there a GPU for m2v_tb to run on?  (KFD topology: a node with SIMDs; no HIP call from this process)"""
+    import glob
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for ln in open(f):
+                k, _, val = ln.partition(" ")
+                if k == "simd_count" and int(val) > 0:
+                    return True
+        except (OSError, ValueError):
+            pass
+    return False
 
 
 def main():
@@ -177,7 +196,7 @@ def main():
         secs += dt
         print("case %d %dx%d x%d pf=%d VL=%d Q=%d: RTL %d bytes, oracle %d bytes -> %s; product (m2v_tb) %s   (%.1f s, %s clocks, %.4f MPixels/s)"
               % (ci, W, H, nf, pf, VL, Q, len(got), len(want), "IDENTICAL" if ok else "DIFFERENT",
-                 "not run" if prod is None else "IDENTICAL to the RTL" if prod == got else "DIFFERENT from the RTL", dt,
+                 "not run" if prod is None else "FAILED" if prod == PRODUCT_FAILED else "IDENTICAL to the RTL" if prod == got else "DIFFERENT from the RTL", dt,
                  clocks if clocks is not None else "?", nbeats * 4 / dt * 1e-6))
     verdict = {"available": True, "simulator": simname, "known_answers_identical": kat_ok, "cases": len(CASES),
                "rtl_equals_oracle": bad_oracle == 0 and kat_ok, "product_cases": product_cases,
@@ -189,7 +208,8 @@ def main():
     print(json.dumps(verdict))
     if not args.keep:
         shutil.rmtree(tmp, ignore_errors=True)
-    return 1 if (bad_oracle or bad_product or not kat_ok) else 0
+    # exit code: bit 0 = the RTL and the ORACLE differ (or a known answer does), bit 1 = the RTL and the PRODUCT differ (or m2v_tb failed)
+    return (1 if (bad_oracle or not kat_ok) else 0) | (2 if bad_product else 0)
 
 
 if __name__ == "__main__":
