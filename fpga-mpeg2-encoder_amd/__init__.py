@@ -35,7 +35,21 @@ EXPORTS = [
     "m2v_strip_finish_async", "m2v_strip_offsets", "m2v_strip_encode", "m2v_strip_stats",
     "m2v_comm_unique_id", "m2v_comm_init_rccl", "m2v_comm_init_local", "m2v_comm_init_solo", "m2v_comm_destroy", "m2v_comm_last_error", "m2v_comm_selftest",
     "m2v_comm_init_solo_rccl", "m2v_comm_selftest_captured", "m2v_strip_graph_stats",
+    "m2v_comm_init_callbacks", "m2v_comm_init_peer", "m2v_comm_peer_export", "m2v_comm_peer_connect", "m2v_comm_peer_connect_all",
+    "m2v_comm_peer_stats", "m2v_comm_kind", "m2v_strip_last_form",
 ]
+
+PEER_DESC_BYTES = 128          # M2V_PEER_DESC_BYTES
+
+
+class CommCallbacks(ctypes.Structure):
+    """m2v_comm_callbacks (include/m2v_mi355x.h): the exchange supplied by the caller"""
+    HALO = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                            ctypes.c_size_t, ctypes.c_void_p)
+    ALLGATHER = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+    GATHER = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t),
+                              ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p)
+    _fields_ = [("halo", HALO), ("allgather_u64", ALLGATHER), ("gather", GATHER), ("user", ctypes.c_void_p)]
 
 
 class M2VError(RuntimeError):
@@ -111,6 +125,18 @@ def lib(debug=False):
             L.m2v_comm_selftest_captured.argtypes = [vp, ci, vp, vp, sz, vp, ci]
             ip = ctypes.POINTER(ci)
             L.m2v_strip_graph_stats.argtypes = [vp, ip, ip, ip]
+            L.m2v_comm_init_callbacks.restype = vp
+            L.m2v_comm_init_callbacks.argtypes = [ci, ctypes.POINTER(CommCallbacks), ip]
+            L.m2v_comm_init_peer.restype = vp
+            L.m2v_comm_init_peer.argtypes = [vp, ci, ci, sz, ip]
+            L.m2v_comm_peer_export.argtypes = [vp, vp, sz]
+            L.m2v_comm_peer_connect.argtypes = [vp, vp, vp]
+            L.m2v_comm_peer_connect_all.argtypes = [vp]
+            ullp = ctypes.POINTER(ctypes.c_ulonglong)
+            L.m2v_comm_peer_stats.argtypes = [vp, ullp, ullp]
+            L.m2v_comm_kind.restype = ctypes.c_char_p
+            L.m2v_comm_kind.argtypes = [vp]
+            L.m2v_strip_last_form.argtypes = [vp]
         except AttributeError:
             # an OLDER build handed in through M2V_LIB for a same-box A/B (tools/ab.sh) may lack the newer entry points; the library of
             # this tree must have every one of them (tests/test_abi.py)
@@ -297,6 +323,10 @@ class Mpeg2Encoder:
         return {"steps": steps, "halo_total": v[0].value, "halo_exposed": v[1].value, "gather": v[2].value, "host_us_per_step": v[3].value,
                 "comm_us_per_step": v[4].value, "host_us_per_step_outside_comm": v[3].value - v[4].value}
 
+    def strip_last_form(self):
+        """how the last strip_encode ran its GOP steps: "calls", "graph" or "peer" (m2v_strip_last_form)"""
+        return ("calls", "graph", "peer")[self._chk(self._L.m2v_strip_last_form(self._h), "m2v_strip_last_form")]
+
     def strip_graph_stats(self):
         """-> dict: was the last strip_encode launched as a recorded hipGraph, how many recordings / launches so far, and whether
         recording has failed on this handle (the sequence is then enqueued call by call)"""
@@ -394,6 +424,70 @@ class StripComm:
         if not h:
             raise M2VError("m2v_comm_init_solo%s failed (%d): %s" % ("_rccl" if rccl else "", err.value, L.m2v_comm_last_error().decode()))
         return cls(h, "solo-rccl" if rccl else "solo", world)
+
+    @classmethod
+    def callbacks(cls, world, halo, allgather_u64, gather, debug=False):
+        """The exchange supplied by the caller (m2v_comm_init_callbacks).  The three Python callables get the C arguments of
+        m2v_comm_callbacks without `user` - device addresses as ints, the HIP stream as an int - and return 0 for success; an exception
+        is reported as failure.  The callback objects live as long as the communicator."""
+        L = lib(debug)
+
+        def guard(fn):
+            def run(user, *a):
+                try:
+                    return int(fn(*a) or 0)
+                except BaseException as ex:  # noqa: BLE001  (nothing may unwind into C)
+                    sys.stderr.write("m2v: communicator callback failed: %r\n" % (ex,))
+                    return 1
+            return run
+        cb = CommCallbacks(CommCallbacks.HALO(guard(halo)), CommCallbacks.ALLGATHER(guard(allgather_u64)), CommCallbacks.GATHER(guard(gather)), None)
+        err = ctypes.c_int(0)
+        h = L.m2v_comm_init_callbacks(world, ctypes.byref(cb), ctypes.byref(err))
+        if not h:
+            raise M2VError("m2v_comm_init_callbacks failed (%d): %s" % (err.value, L.m2v_comm_last_error().decode()))
+        c = cls(h, "callbacks", world)
+        c._keep, c._debug = cb, debug
+        return c
+
+    @classmethod
+    def peer(cls, base, rank, device=0, halo_bytes=0, connect=True):
+        """The peer transport on top of `base` (m2v_comm_init_peer): rows stored straight into the neighbours' landing blocks by the
+        macroblock kernel.  connect=True: m2v_comm_peer_connect_all - collective over `base` (every rank of it makes this call).
+        `base` stays alive as long as the result (close this one first)."""
+        L = lib(getattr(base, "_debug", False))
+        err = ctypes.c_int(0)
+        h = L.m2v_comm_init_peer(base.handle, rank, device, halo_bytes, ctypes.byref(err))
+        if not h:
+            raise M2VError("m2v_comm_init_peer failed (%d): %s" % (err.value, L.m2v_comm_last_error().decode()))
+        c = cls(h, L.m2v_comm_kind(h).decode(), base.world)
+        c._base, c._debug = base, getattr(base, "_debug", False)
+        if connect:
+            r = L.m2v_comm_peer_connect_all(h)
+            if r < 0:
+                msg = L.m2v_comm_last_error().decode()
+                c.close()
+                raise M2VError("m2v_comm_peer_connect_all failed (%d): %s" % (r, msg))
+        return c
+
+    def peer_export(self):
+        buf = ctypes.create_string_buffer(PEER_DESC_BYTES)
+        r = lib(getattr(self, "_debug", False)).m2v_comm_peer_export(self.handle, buf, PEER_DESC_BYTES)
+        if r < 0:
+            raise M2VError("m2v_comm_peer_export failed (%d): %s" % (r, lib().m2v_comm_last_error().decode()))
+        return buf.raw
+
+    def peer_connect(self, desc_up, desc_down):
+        r = lib(getattr(self, "_debug", False)).m2v_comm_peer_connect(self.handle, desc_up, desc_down)
+        if r < 0:
+            raise M2VError("m2v_comm_peer_connect failed (%d): %s" % (r, lib().m2v_comm_last_error().decode()))
+
+    def peer_stats(self):
+        """-> dict: sequences that ran in the peer form, waits that gave up, and whether the communicator has fallen back to its base for good"""
+        a, b = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+        r = lib(getattr(self, "_debug", False)).m2v_comm_peer_stats(self.handle, ctypes.byref(a), ctypes.byref(b))
+        if r < 0:
+            raise M2VError("m2v_comm_peer_stats: not a peer communicator")
+        return {"peer_sequences": a.value, "giveups": b.value, "fell_back": bool(r)}
 
     def selftest(self, rank, d_send_ptr, d_recv_ptr, nbytes, stream=0):
         r = lib().m2v_comm_selftest(self.handle, rank, d_send_ptr, d_recv_ptr, nbytes, stream)

@@ -21,15 +21,26 @@
 
 #include <dlfcn.h>
 
+#include <unistd.h>
+
+#include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
+#include "../../include/m2v_mi355x.h"
+
+namespace m2v { struct PeerState; }
+
 struct m2v_comm {
     int world = 1;
     virtual ~m2v_comm() {}
+    // the peer transport's state when this communicator offers it (PeerComm), else null
+    virtual m2v::PeerState *peer() { return nullptr; }
     // halo rows of one GOP step: nbytes to / from the rank above (rank - 1) and the rank below (rank + 1); a null pair = no neighbour
     virtual void halo(int rank, const void *send_up, void *recv_up, const void *send_down, void *recv_down, size_t nbytes, hipStream_t s) = 0;
     // every rank's `count` values into all[world][count] on every rank (device memory on both sides)
@@ -389,6 +400,201 @@ struct SoloComm final : m2v_comm {
     {
         if (self) { self->loopback(0, d_send, d_recv, n, s); return; }
         M2V_COMM_HIP(hipMemcpyAsync(d_recv, d_send, n, hipMemcpyDeviceToDevice, s));
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// The exchange supplied by the CALLER (m2v_comm_init_callbacks): three functions of the host program - its MPI, its torch.distributed
+// process group, a test's pipes - behind the same interface.  Each gets device pointers and the stream the data is ordered on and
+// must leave its effect ordered on that stream (enqueue there, or synchronise it, move the bytes, and return).  0 = success.
+// ---------------------------------------------------------------------------------------------
+struct CallbackComm final : m2v_comm {
+    m2v_comm_callbacks cb;
+    explicit CallbackComm(int w, const m2v_comm_callbacks &c) : cb(c) { world = w; }
+    const char *kind() const override { return "callbacks"; }
+    static void chk(int r, const char *what) { if (r != 0) throw CommError(std::string(what) + ": the caller's function returned " + std::to_string(r)); }
+    void halo(int r, const void *send_up, void *recv_up, const void *send_down, void *recv_down, size_t n, hipStream_t s) override
+    {
+        if (!n) return;
+        const bool up = r > 0 && send_up && recv_up, down = r < world - 1 && send_down && recv_down;
+        chk(cb.halo(cb.user, r, up ? send_up : nullptr, up ? recv_up : nullptr, down ? send_down : nullptr, down ? recv_down : nullptr, n, (void *)s), "halo");
+    }
+    void allgather_u64(int r, const unsigned long long *d_src, unsigned long long *d_all, size_t count, hipStream_t s) override
+    {
+        chk(cb.allgather_u64(cb.user, r, d_src, d_all, count, (void *)s), "allgather_u64");
+    }
+    void gather(int r, int dst, const void *d_strip, const size_t *sizes, void *const *bufs, hipStream_t s) override
+    {
+        chk(cb.gather(cb.user, r, dst, d_strip, sizes, bufs, (void *)s), "gather");
+    }
+    void loopback(int, const void *d_send, void *d_recv, size_t n, hipStream_t s) override
+    {
+        M2V_COMM_HIP(hipMemcpyAsync(d_recv, d_send, n, hipMemcpyDeviceToDevice, s));
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// The PEER transport: no exchange step at all.  Every rank owns a LANDING BLOCK in fine-grained device memory - four buffers (rows
+// from the rank above / below, two GOP-step parities) and a few counters -, its two neighbours map it (the same process: the pointer,
+// plus hipDeviceEnablePeerAccess across GPUs; another process: hipIpcOpenMemHandle), and the macroblock kernel of the strip's edge
+// rows stores their outer rows straight into the neighbour's block and counts its arrival there (k_mb<.., EDGE, PEER>, PeerStep).
+// "or peer-to-peer stores over xGMI".  Sizes and strips still travel through the BASE communicator this one wraps
+// (RCCL, local, callbacks), which is also what the halo falls back to - for good - when a wait runs out of budget.
+//
+//   landing block:  [1 KB control][buf(parity 0, from above)][buf(0, from below)][buf(1, from above)][buf(1, from below)]   cap bytes each
+//   control:        arrival counters cnt[set][side] on 128-byte lines (set = sequence parity: a sequence clears the set of the NEXT one,
+//                   which nobody touches meanwhile - every rank is past the previous sequence's all-gather -, so no rank ever clears a
+//                   counter a neighbour may be adding to), then the give-up word
+// ---------------------------------------------------------------------------------------------
+struct PeerDesc {                    // what a rank tells its neighbours (m2v_comm_peer_export): plain bytes, M2V_PEER_DESC_BYTES
+    uint32_t magic, version;
+    int32_t pid, device;
+    unsigned long long ptr, bytes, cap;
+    hipIpcMemHandle_t ipc;
+    uint8_t pad[M2V_PEER_DESC_BYTES - 40 - sizeof(hipIpcMemHandle_t)];
+};
+static_assert(sizeof(PeerDesc) == M2V_PEER_DESC_BYTES, "the descriptor is M2V_PEER_DESC_BYTES of plain data");
+
+struct PeerState {
+    static constexpr uint32_t kMagic = 0x4D325650u;       // "M2VP"
+    static constexpr size_t kCtl = 1024;
+    int rank = 0, world = 1, device = 0;
+    uint8_t *block = nullptr;         // own landing block
+    size_t bytes = 0, cap = 0;        // its size; capacity of one landing buffer
+    bool fine = false;                // allocated fine-grained (the cross-GPU requirement); false only with M2V_PEER_COARSE=1 (one GPU)
+    uint8_t *nb[2] = {nullptr, nullptr};   // the neighbours' blocks as mapped into this process: [0] the rank above, [1] the rank below
+    bool nb_ipc[2] = {false, false};
+    bool mirror = false;              // solo timing: both "neighbours" are this rank itself, rows come back on the side they left from
+    bool connected = false;
+    bool degraded = false;            // a wait once ran out of budget: this communicator exchanges through its base from then on
+    unsigned long long seq = 0;       // peer sequences so far (selects the counter set)
+    unsigned int budget = 20000000u;  // bound of one wait in 10 ns ticks: 200 ms (M2V_PEER_BUDGET_US overrides)
+    unsigned long long sequences = 0, giveups = 0;
+
+    static size_t off_cnt(unsigned set, int side) { return (size_t)(set * 2u + (unsigned)side) * 128u; }
+    static size_t off_gaveup() { return 512; }
+    size_t off_buf(unsigned parity, int side) const { return kCtl + (size_t)(parity * 2u + (unsigned)side) * cap; }
+    // own side: rows that arrived from the rank above (side 0) / below (side 1)
+    const uint8_t *got(int side, unsigned parity) const { return block + off_buf(parity, side); }
+    const unsigned int *seen(int side, unsigned set) const { return (const unsigned int *)(block + off_cnt(set, side)); }
+    unsigned int *gaveup() const { return (unsigned int *)(block + off_gaveup()); }
+    // neighbour n (0 above, 1 below): where this rank's rows land there - in ITS buffer "from below" / "from above"
+    uint8_t *put(int n, unsigned parity) const { return nb[n] + off_buf(parity, mirror ? n : 1 - n); }
+    unsigned int *cnt(int n, unsigned set) const { return (unsigned int *)(nb[n] + off_cnt(set, mirror ? n : 1 - n)); }
+};
+
+struct PeerComm final : m2v_comm {
+    m2v_comm *base;                   // not owned: sizes, strips, and the halo when the peer form cannot run
+    PeerState st;
+    std::string kind_text;
+    PeerComm(m2v_comm *b, int rank, int device, size_t halo_bytes) : base(b)
+    {
+        world = b->world;
+        st.rank = rank; st.world = b->world; st.device = device;
+        kind_text = std::string("peer+") + b->kind();
+        M2V_COMM_HIP(hipSetDevice(device));
+        st.cap = (halo_bytes + 255) & ~(size_t)255;
+        st.bytes = PeerState::kCtl + 4 * st.cap;
+        const char *coarse = getenv("M2V_PEER_COARSE");
+        st.fine = !(coarse && coarse[0] == '1');
+        if (st.fine) M2V_COMM_HIP(hipExtMallocWithFlags((void **)&st.block, st.bytes, hipDeviceMallocFinegrained));
+        else M2V_COMM_HIP(hipMalloc((void **)&st.block, st.bytes));
+        M2V_COMM_HIP(hipMemset(st.block, 0, st.bytes));
+        M2V_COMM_HIP(hipDeviceSynchronize());
+        if (const char *b_us = getenv("M2V_PEER_BUDGET_US")) {
+            const long long us = atoll(b_us);
+            st.budget = (unsigned int)std::min<long long>(std::max<long long>(us, 0) * 100, 0x7FFFFFFFll);
+        }
+    }
+    ~PeerComm() override
+    {
+        (void)hipSetDevice(st.device);
+        (void)hipDeviceSynchronize();
+        for (int n = 0; n < 2; ++n)
+            if (st.nb[n] && st.nb_ipc[n]) (void)hipIpcCloseMemHandle(st.nb[n]);
+        if (st.block) (void)hipFree(st.block);
+    }
+    PeerState *peer() override { return &st; }
+    const char *kind() const override { return kind_text.c_str(); }
+    void abort() override { base->abort(); }
+    void halo(int r, const void *su, void *ru, const void *sd, void *rd, size_t n, hipStream_t s) override { base->halo(r, su, ru, sd, rd, n, s); }
+    void allgather_u64(int r, const unsigned long long *a, unsigned long long *b, size_t c, hipStream_t s) override { base->allgather_u64(r, a, b, c, s); }
+    void gather(int r, int dst, const void *p, const size_t *sizes, void *const *bufs, hipStream_t s) override { base->gather(r, dst, p, sizes, bufs, s); }
+    void loopback(int r, const void *a, void *b, size_t n, hipStream_t s) override { base->loopback(r, a, b, n, s); }
+
+    void export_desc(PeerDesc &d) const
+    {
+        memset(&d, 0, sizeof d);
+        d.magic = PeerState::kMagic; d.version = 1;
+        d.pid = (int32_t)getpid(); d.device = st.device;
+        d.ptr = (unsigned long long)(uintptr_t)st.block; d.bytes = st.bytes; d.cap = st.cap;
+        M2V_COMM_HIP(hipSetDevice(st.device));
+        M2V_COMM_HIP(hipIpcGetMemHandle(&d.ipc, st.block));
+    }
+    uint8_t *map(const PeerDesc &d, bool &ipc)
+    {
+        if (d.magic != PeerState::kMagic || d.version != 1) throw CommError("peer transport: not a landing-block descriptor");
+        if (d.cap != st.cap || d.bytes != st.bytes) throw CommError("peer transport: the ranks were created with different halo capacities");
+        M2V_COMM_HIP(hipSetDevice(st.device));
+        if (d.pid == (int32_t)getpid()) {                   // the same process: its pointer is good here
+            ipc = false;
+            if (d.device != st.device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, st.device, d.device) != hipSuccess || !can) throw CommError("peer transport: no peer access between the two GPUs");
+                const hipError_t pe = hipDeviceEnablePeerAccess(d.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) throw CommError(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
+            return (uint8_t *)(uintptr_t)d.ptr;
+        }
+        void *p = nullptr;
+        M2V_COMM_HIP(hipIpcOpenMemHandle(&p, d.ipc, hipIpcMemLazyEnablePeerAccess));
+        ipc = true;
+        return (uint8_t *)p;
+    }
+    // the neighbours' descriptors (null where there is none); both null on a rank that has neighbours = solo timing: itself, mirrored
+    void connect(const PeerDesc *up, const PeerDesc *down, bool mirror_self)
+    {
+        if (st.connected) throw CommError("peer transport: already connected");
+        if (mirror_self) {
+            st.nb[0] = st.nb[1] = st.block;
+            st.mirror = true;
+        } else {
+            if ((st.rank > 0) != (up != nullptr) || (st.rank < world - 1) != (down != nullptr))
+                throw CommError("peer transport: a descriptor for every neighbour, and only for neighbours");
+            if (up) st.nb[0] = map(*up, st.nb_ipc[0]);
+            if (down) st.nb[1] = map(*down, st.nb_ipc[1]);
+        }
+        st.connected = true;
+    }
+    // export + all-gather through the base communicator + connect: collective over the base
+    void connect_all()
+    {
+        const std::string bk = base->kind();
+        if (bk.rfind("solo", 0) == 0) { connect(nullptr, nullptr, true); return; }
+        constexpr size_t kWords = sizeof(PeerDesc) / 8;
+        PeerDesc mine;
+        export_desc(mine);
+        hipStream_t s = nullptr;
+        unsigned long long *d_src = nullptr, *d_all = nullptr;
+        std::vector<PeerDesc> all((size_t)world);
+        M2V_COMM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        try {
+            M2V_COMM_HIP(hipMalloc((void **)&d_src, sizeof mine));
+            M2V_COMM_HIP(hipMalloc((void **)&d_all, sizeof mine * (size_t)world));
+            M2V_COMM_HIP(hipMemcpyAsync(d_src, &mine, sizeof mine, hipMemcpyHostToDevice, s));
+            M2V_COMM_HIP(hipStreamSynchronize(s));
+            base->allgather_u64(st.rank, d_src, d_all, kWords, s);
+            M2V_COMM_HIP(hipStreamSynchronize(s));
+            M2V_COMM_HIP(hipMemcpy(all.data(), d_all, sizeof mine * (size_t)world, hipMemcpyDeviceToHost));
+        } catch (...) {
+            if (d_src) (void)hipFree(d_src);
+            if (d_all) (void)hipFree(d_all);
+            (void)hipStreamDestroy(s);
+            throw;
+        }
+        (void)hipFree(d_src); (void)hipFree(d_all); (void)hipStreamDestroy(s);
+        connect(st.rank > 0 ? &all[(size_t)st.rank - 1] : nullptr, st.rank < world - 1 ? &all[(size_t)st.rank + 1] : nullptr, false);
     }
 };
 

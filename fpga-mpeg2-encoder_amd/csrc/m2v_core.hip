@@ -300,6 +300,22 @@ void run_step_edges_fused(m2v_enc *e, hipStream_t s, size_t j, uint8_t *up, uint
     launch_mb_edges<true>(e, s, e->d_lists.p + st.off_p, st.n_p, gg, up, down, nb_up, nb_down);
 }
 
+// strip mode, peer transport: GOP step j of the WHOLE strip as one launch each for the I and the P frames of the step (edge rows first
+// in dispatch order; k_mb<.., EDGE, PEER>).  ps: the counters and the budget; n_edge is filled in here.
+void run_step_peer(m2v_enc *e, hipStream_t s, size_t j, uint8_t *put_up, uint8_t *put_down, const uint8_t *got_up, const uint8_t *got_down, PeerStep ps)
+{
+    const m2v_enc::Step &st = e->plan_steps[j];
+    Geom gg = e->g;
+    const int r0 = e->g.row0, r1 = e->g.row1, nrows = r1 - r0 >= 2 ? 2 : 1;
+    gg.rstride = nrows == 2 ? r1 - 1 - r0 : 1;
+    gg.edge_top = r0;
+    gg.edge_bot = r1 - 1;
+    geom_finish(gg);
+    ps.n_edge = (unsigned int)(nrows * gg.mbw);
+    launch_mb_peer<false>(e, s, e->d_lists.p + st.off_i, st.n_i, gg, put_up, put_down, nullptr, nullptr, ps);      // an I frame has no reference
+    launch_mb_peer<true>(e, s, e->d_lists.p + st.off_p, st.n_p, gg, put_up, put_down, got_up, got_down, ps);
+}
+
 void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_stream, bool advance)
 {
     const Geom &g = e->g;

@@ -197,7 +197,7 @@ struct m2v_enc {
     // -1 = automatic: recorded with world == 1 and with the single-GPU timing communicators; call by call between the ranks of a real
     // RCCL job (a recording with cross-rank ncclSend / ncclRecv inside has never run on hardware: opt in with 1); 0 = never
     int strip_graph_opt = -1;
-    struct StripStats { double halo_total_ms = 0, halo_exposed_ms = 0, gather_ms = 0, host_us_per_step = 0, comm_us_per_step = 0; int steps = 0; int graph = 0; } strip_stats;
+    struct StripStats { double halo_total_ms = 0, halo_exposed_ms = 0, gather_ms = 0, host_us_per_step = 0, comm_us_per_step = 0; int steps = 0; int graph = 0; int peer = 0; } strip_stats;
 
     // debug bookkeeping of the last resident encode
     size_t dbg_frames = 0;
@@ -232,6 +232,7 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
 void run_step(m2v_enc *e, hipStream_t s, size_t j);
 void run_step_rows(m2v_enc *e, hipStream_t s, size_t j, int r0, int r1);
 void run_step_edges_fused(m2v_enc *e, hipStream_t s, size_t j, uint8_t *up, uint8_t *down, const uint8_t *nb_up, const uint8_t *nb_down);
+void run_step_peer(m2v_enc *e, hipStream_t s, size_t j, uint8_t *put_up, uint8_t *put_down, const uint8_t *got_up, const uint8_t *got_down, PeerStep ps);
 void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_stream, bool advance = false);
 void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool first, bool last, uint32_t last_valid_beats,
                   uint8_t *d_stream, bool advance = false);
@@ -272,6 +273,11 @@ void upload_tables(int device);
 template <bool P> void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g);
 template <bool P> void launch_mb_edges(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g, uint8_t *up, uint8_t *down,
                                        const uint8_t *nb_up, const uint8_t *nb_down);
+template <bool P> void launch_mb_peer(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g, uint8_t *put_up, uint8_t *put_down,
+                                      const uint8_t *got_up, const uint8_t *got_down, const PeerStep &ps);
+extern template void launch_mb_peer<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *, const PeerStep &);
+extern template void launch_mb_peer<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *, const PeerStep &);
+void launch_peer_verdict(m2v_enc *e, hipStream_t s, const unsigned int *gaveup, int nf, unsigned long long mark);
 extern template void launch_mb<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &);
 extern template void launch_mb<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &);
 extern template void launch_mb_edges<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *);

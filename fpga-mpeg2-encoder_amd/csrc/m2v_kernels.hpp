@@ -720,14 +720,38 @@ __device__ u32x4_t d_lanetab[3][2][kQuadsPerBlock][64];
 // receive - in k_halo_pack's layout, so the step needs no pack kernel between the edge rows and the send; and the window rows
 // that lie in a neighbour's strip are read from `nb_up` / `nb_down`, the buffers the neighbours' rows of the reference frame
 // were received in, so there is no unpack kernel (and no launch gap) between the receive and the next step either.
-template <int VL, bool P, bool CONF = false, bool MFMA = false, bool FILL = false, bool EDGE = false>
+// PEER (with EDGE) = the peer transport's form of the same: ALL rows of the strip in one launch, edge rows first in dispatch order; the
+// halo buffers are the neighbours' memory, written through and published by an arrival counter; see PeerStep (m2v_types.hpp).
+// Wait (bounded) until `*seen` has reached `need`: the neighbour's edge blocks of the previous GOP steps have all delivered.  Every lane
+// loads the same word (one request); system scope: the counter is written by another GPU (or another process on this one).
+__device__ __forceinline__ void peer_wait(const unsigned int *seen, unsigned int need, unsigned int *gaveup, unsigned int budget, int lane)
+{
+    typedef __attribute__((address_space(1))) unsigned int *gu32p;
+    unsigned int v = __hip_atomic_load((gu32p)seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= need) return;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(8);
+        v = __hip_atomic_load((gu32p)seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned int)__builtin_amdgcn_readfirstlane((int)v) >= need) return;
+        // somebody of this launch has given up already (the sequence is lost anyway: nobody waits a second time), or this wait's time is up
+        const unsigned int gu = __hip_atomic_load((gu32p)gaveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_readfirstlane((int)gu) != 0 || wall_clock64() - t0 > (long long)budget) {
+            if (lane == 0) __hip_atomic_store((gu32p)gaveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+}
+
+template <int VL, bool P, bool CONF = false, bool MFMA = false, bool FILL = false, bool EDGE = false, bool PEER = false>
 __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
                                            Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
                                            uint32_t *__restrict__ slots_small, uint32_t *__restrict__ slots,
                                            int16_t *__restrict__ coef_dbg, uint8_t *__restrict__ halo_up = nullptr,
                                            uint8_t *__restrict__ halo_down = nullptr, const uint8_t *__restrict__ nb_up = nullptr,
-                                           const uint8_t *__restrict__ nb_down = nullptr)
+                                           const uint8_t *__restrict__ nb_down = nullptr, PeerStep ps = PeerStep{})
 {
+    static_assert(!PEER || EDGE, "the peer form is a form of the edge-row kernel");
     constexpr int UR = VL, YR = 2 * VL;
     constexpr int WROWS = 16 + 2 * YR;         // luma window rows -YR .. 16+YR-1 (RTL:1446)
     constexpr int CROWS = 8 + 2 * UR;          // chroma window rows -UR .. 8+UR-1 (RTL:1447)
@@ -810,6 +834,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // quad-major tables: ONE scalar base (pinned: the compiler would re-derive the symbol's address with s_getpc at every use),
     // 1 KB per quad as the load's immediate, 16 * lane in a register
     const uint32_t lane16 = (uint32_t)lane * 16u;
+    // is this block one of the strip's edge rows?  (EDGE alone: every block of the launch is; PEER: the first n_edge; wave-uniform)
+    bool edge_blk = EDGE;
+    if constexpr (PEER) edge_blk = sgpr((int)((blockIdx.x - ps.n_edge) >> 31)) != 0;
     typedef const __attribute__((address_space(1))) u32x4_t *gld128;
     const uint8_t *ltab = (const uint8_t *)&d_lanetab[VL - 1][P ? 1 : 0][4][0];
     asm volatile("" : "+s"(ltab));
@@ -845,7 +872,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         kq2 = M2V_LANEK4(xc4); kq3 = M2V_LANEK4(zz2);                                                                \
         /* only the words that are used: a dead register of a wide load is reused at once, and the write-after-write   \
            wait then stalls the wavefront for the whole round trip */                                                  \
-        if constexpr (EDGE) kq4 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_LANEK4(crec_r);   /* halo rows only */ \
+        if constexpr (EDGE) { if (edge_blk) kq4 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_LANEK4(crec_r); }   /* halo rows only */ \
         if constexpr (MFMA && !CONF) {                                                                               \
             /* ONE load for the three words (a vector memory instruction costs what ten arithmetic ones do) */           \
             /* ONE load for the three / four words (only the words that are used, see above) */                         \
@@ -877,18 +904,25 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     if constexpr (!P && !kMfmaChroma) M2V_REQUEST_BASIS();     // (the matrix-core transform needs none of them)
     // grid = (macroblocks of one frame's share, frames of the launch list): the frame comes from blockIdx.y, no division for it
     const uint32_t li = blockIdx.y;                                            // which frame of the launch list
-    const uint32_t local = xcd_remap(blockIdx.x, gridDim.x, EDGE ? 0u : (uint32_t)g.cu_pack);
+    uint32_t local;
+    if constexpr (PEER) {
+        // the edge rows take the launch's first n_edge blocks - they go first in dispatch order, so their rows are on their way to the
+        // neighbours while the rows in between are encoded -, each part with its own XCD-aware permutation
+        local = edge_blk ? xcd_remap(blockIdx.x, ps.n_edge, 0u) : xcd_remap(blockIdx.x - ps.n_edge, gridDim.x - ps.n_edge, (uint32_t)g.cu_pack);
+    } else {
+        local = xcd_remap(blockIdx.x, gridDim.x, EDGE ? 0u : (uint32_t)g.cu_pack);
+    }
     const FrameJob job = jobs[li];                 // `jobs` = the launch list as jobs: one dependent scalar load, not list -> job
     const int fidx = (int)job.fidx;
     int mb, by, bx;
-    if constexpr (EDGE) {
+    if (EDGE && edge_blk) {
         // two local rows: the strip's first macroblock row and, rstride rows below, its last
         const uint32_t lrow = udiv_magic(local, (uint32_t)g.mbw, g.magic_mbw);
         bx = (int)(local - lrow * (uint32_t)g.mbw);
         by = g.row0 + (int)lrow * g.rstride;
         mb = by * g.mbw + bx;
     } else {
-        mb = g.row0 * g.mbw + (int)local;
+        mb = (g.row0 + (PEER ? 1 : 0)) * g.mbw + (int)local;      // (the peer form's other blocks: the rows behind the strip's first)
         by = (int)udiv_magic((uint32_t)mb, (uint32_t)g.mbw, g.magic_mbw);
         bx = mb - by * g.mbw;
     }
@@ -938,11 +972,27 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     if constexpr (P) {
         const uint8_t *refY = job.ref;              // tiled (rec_luma_off / rec_chroma_off)
         const uint32_t trow = (uint32_t)g.mbw + 1u;              // tiles per tile row
-        if constexpr (EDGE) {
+        if (EDGE && edge_blk) {
             // window rows above the strip's first / below its last macroblock row belong to a neighbour: they were received, for
             // this frame's reference, at position rhidx of nb_up / nb_down ([YR rows of W luma][UR rows of cw U][UR of V] per
             // frame, rows top to bottom); everything else as the clamped form below
             const bool ext_u = nb_up != nullptr && by == g.edge_top, ext_d = nb_down != nullptr && by == g.edge_bot;     // wave-uniform
+            // peer transport: the neighbour's rows were written into this rank's memory by ANOTHER GPU's kernel (or another process's on
+            // this one) - wait for its arrival counter, then read with loads that no cache of this GPU can answer from an older copy
+            // (system-scope relaxed atomic loads = global_load .. sc0 sc1; the whole window of such a block, six loads per lane)
+            bool far = false;
+            if constexpr (PEER) {
+                if (ps.need != 0u) {
+                    if (ext_u) peer_wait(ps.seen_up, ps.need, ps.gaveup, ps.budget, lane);
+                    if (ext_d) peer_wait(ps.seen_down, ps.need, ps.gaveup, ps.budget, lane);
+                }
+                far = ext_u || ext_d;
+            }
+            auto ld = [&](const uint8_t *base, uint32_t off) -> uint32_t {
+                typedef __attribute__((address_space(1))) unsigned int *gu32p;
+                if (PEER && far) return __hip_atomic_load((gu32p)(base + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return *(const uint32_t *)(base + off);
+            };
             const uint32_t chunk = (uint32_t)(YR + UR) * (uint32_t)W, fb = (uint32_t)job.rhidx * chunk;
             {
                 int yy = 16 * by - YR + wrow;
@@ -956,7 +1006,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     int xk = 16 * bx - 8 + 16 * whalf + 4 * k;
                     xk = xk < 0 ? 0 : xk > W - 4 ? W - 4 : xk;
                     const uint32_t o = (up || dn) ? rowbase + (uint32_t)xk : rec_luma_off((uint32_t)xk, (uint32_t)yy, g);
-                    w4[k] = *(const uint32_t *)(src + o);
+                    w4[k] = ld(src, o);
                 }
                 wwin = u32x4_t{w4[0], w4[1], w4[2], w4[3]};
             }
@@ -969,8 +1019,8 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             const uint32_t cbase = fb + (uint32_t)YR * (uint32_t)W + __umul24((uint32_t)cpl, (uint32_t)UR * (uint32_t)g.cw);   // V sits UR rows behind U in a halo chunk
             if (ext_u && crow < UR) { sc = nb_up; c0o = cbase + (uint32_t)crow * (uint32_t)g.cw + (uint32_t)x0; c1o = c0o - (uint32_t)x0 + (uint32_t)x1; }
             if (ext_d && crow >= UR + 8) { sc = nb_down; c0o = cbase + (uint32_t)(crow - (UR + 8)) * (uint32_t)g.cw + (uint32_t)x0; c1o = c0o - (uint32_t)x0 + (uint32_t)x1; }
-            wc.x = *(const uint32_t *)(sc + c0o);
-            wc.y = *(const uint32_t *)(sc + c1o);
+            wc.x = ld(sc, c0o);
+            wc.y = ld(sc, c1o);
         } else
         if (sgpr(in_l & in_r & in_u & in_d)) {
             // interior macroblock (wave-uniform test): the whole window lies inside the frame, no clamping: window row yrel = -YR .. 15 + YR
@@ -1725,7 +1775,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 const uint32_t v = *(LdsU32 *)(uintptr_t)kq3.w;
                 *(gst32)(recY + (g.rysz + tile * 128u + 4u + __umul24((uint32_t)lane & 1u, 120u) + (uint32_t)lane * 4u)) = v;
             }
-            if constexpr (EDGE) {
+            if (EDGE && edge_blk) {
                 // per frame of the step's halo list: [YR rows of W luma][UR rows of cw U][UR rows of cw V] (k_halo_pack's layout)
                 constexpr uint32_t YR2 = 2 * VL, UR2 = VL;
                 const uint32_t chunk = (YR2 + UR2) * (uint32_t)W, cw = (uint32_t)g.cw;
@@ -1733,13 +1783,34 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 const uint32_t vy = *(LdsU32 *)(uintptr_t)kq0.z;                // the lane's four luma pixels of row r
                 const uint32_t vc = *(LdsU32 *)(uintptr_t)kq3.w;                // lanes < 32: four chroma pixels of row kq4.x, plane k4p
                 const uint32_t xl = (uint32_t)(16 * bx + 4 * c4), xc = (uint32_t)(8 * bx) + k4r;
-                if (halo_up != nullptr && by == g.edge_top) {                   // wave-uniform
-                    if ((uint32_t)r < YR2) *(gst32)(halo_up + (fbase + (uint32_t)r * (uint32_t)W + xl)) = vy;
-                    if (lane < 32 && kq4.x < UR2) *(gst32)(halo_up + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + kq4.x) * cw + xc)) = vc;
+                // peer transport: the buffers are the NEIGHBOURS' memory.  Write-through stores (system-scope relaxed atomic stores =
+                // global_store .. sc0 sc1: the bytes leave this GPU's caches at once), then - below - the wavefront drains its stores and ONE
+                // lane adds 1 to the neighbour's arrival counter: the hand-off of MI355X_MICROARCH.md "visibility" (write-through payload,
+                // drain, flag), at system scope.  Measured for ALL rows of a frame at agent scope (profiles/r04_experiments.txt item 2) the
+                // write-through costs 16 %; here it is 9 of a strip's 24 rows' worth of one macroblock row in sixteen.
+                auto st = [&](uint8_t *base, uint32_t off, uint32_t v) {
+                    typedef __attribute__((address_space(1))) unsigned int *gu32p;
+                    if constexpr (PEER) __hip_atomic_store((gu32p)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    else *(gst32)(base + off) = v;
+                };
+                const bool put_u = halo_up != nullptr && by == g.edge_top, put_d = halo_down != nullptr && by == g.edge_bot;     // wave-uniform
+                if (put_u) {
+                    if ((uint32_t)r < YR2) st(halo_up, fbase + (uint32_t)r * (uint32_t)W + xl, vy);
+                    if (lane < 32 && kq4.x < UR2) st(halo_up, fbase + YR2 * (uint32_t)W + (k4p * UR2 + kq4.x) * cw + xc, vc);
                 }
-                if (halo_down != nullptr && by == g.edge_bot) {
-                    if ((uint32_t)r >= 16u - YR2) *(gst32)(halo_down + (fbase + ((uint32_t)r - (16u - YR2)) * (uint32_t)W + xl)) = vy;
-                    if (lane < 32 && kq4.x >= 8u - UR2) *(gst32)(halo_down + (fbase + YR2 * (uint32_t)W + (k4p * UR2 + (kq4.x - (8u - UR2))) * cw + xc)) = vc;
+                if (put_d) {
+                    if ((uint32_t)r >= 16u - YR2) st(halo_down, fbase + ((uint32_t)r - (16u - YR2)) * (uint32_t)W + xl, vy);
+                    if (lane < 32 && kq4.x >= 8u - UR2) st(halo_down, fbase + YR2 * (uint32_t)W + (k4p * UR2 + (kq4.x - (8u - UR2))) * cw + xc, vc);
+                }
+                if constexpr (PEER) {
+                    if (put_u || put_d) {
+                        typedef __attribute__((address_space(1))) unsigned int *gu32p;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every store of this wavefront has left (one wavefront per block)
+                        if (lane == 0) {
+                            if (put_u) __hip_atomic_fetch_add((gu32p)ps.cnt_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (put_d) __hip_atomic_fetch_add((gu32p)ps.cnt_down, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
                 }
             }
         }

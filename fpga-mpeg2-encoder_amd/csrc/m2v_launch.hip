@@ -168,6 +168,31 @@ void launch_mb_edges(m2v_enc *e, hipStream_t s, const int *d_list, int count, co
     t.stop();
 }
 
+// strip mode, peer transport: ALL rows of the strip in one launch of the EDGE + PEER instantiation - the first ps.n_edge blocks are the
+// strip's first and last macroblock row, which store their outer rows into the neighbours' landing buffers (put_up / put_down) and
+// read the neighbours' rows of the previous step from this rank's own (got_up / got_down); see PeerStep.  gg: row0 / row1 = the strip,
+// rstride = distance from its first to its last row.
+template <bool P>
+void launch_mb_peer(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g, uint8_t *put_up, uint8_t *put_down,
+                    const uint8_t *got_up, const uint8_t *got_down, const PeerStep &ps)
+{
+    if (count <= 0) return;
+    const dim3 grid((unsigned)((g.row1 - g.row0) * g.mbw), (unsigned)count), block(64);
+    Timer t(e, s, P ? 0 : 1, (double)count * (g.row1 - g.row0) * g.mbw * 256.0);
+    const FrameJob *const jl = e->d_joblist.p + (d_list - e->d_lists.p);
+#define M2V_LAUNCH_PEER(VLV) \
+    hipLaunchKernelGGL((k_mb<VLV, P, false, true, false, true, true>), grid, block, 0, s, jl, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
+                       e->d_slots_small.p, e->d_slots.p, (int16_t *)nullptr, put_up, put_down, got_up, got_down, ps)
+    switch (e->VL) {
+        case 1: M2V_LAUNCH_PEER(1); break;
+        case 2: M2V_LAUNCH_PEER(2); break;
+        default: M2V_LAUNCH_PEER(3); break;
+    }
+#undef M2V_LAUNCH_PEER
+    HIPCHK(hipGetLastError());
+    t.stop();
+}
+
 template <bool P>
 void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Geom &g)
 {
@@ -212,6 +237,20 @@ template void launch_mb<false>(m2v_enc *, hipStream_t, const int *, int, const G
 template void launch_mb<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &);
 template void launch_mb_edges<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *);
 template void launch_mb_edges<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *);
+template void launch_mb_peer<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *, const PeerStep &);
+template void launch_mb_peer<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *, const PeerStep &);
+
+// peer transport: a sequence in which some wait ran out of budget is marked in the strip's size table ("encode it again, the ordinary
+// way"), where every rank sees it after the all-gather - on the device, because the host does not look before that
+__global__ void k_peer_verdict(const unsigned int *gaveup, unsigned long long *frame_off, int nf, unsigned long long mark)
+{
+    if (*gaveup) frame_off[nf] = mark;
+}
+
+void launch_peer_verdict(m2v_enc *e, hipStream_t s, const unsigned int *gaveup, int nf, unsigned long long mark)
+{
+    hipLaunchKernelGGL(k_peer_verdict, dim3(1), dim3(1), 0, s, gaveup, e->d_frame_off.p, nf, mark);
+}
 
 __global__ void k_ctl_chain(StreamCtl *ctl, unsigned long long cap, int first)
 {

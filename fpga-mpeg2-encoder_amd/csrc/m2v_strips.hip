@@ -2,6 +2,7 @@
 // frame; slices are independent (RTL:2704-2715) and strips meet only in the +-2 VECTOR_LEVEL luma / +-VECTOR_LEVEL chroma rows of the
 // previous reconstruction (window geometry RTL:1446-1448), which the communicators of m2v_comm.hpp move between the GPUs.
 #include <chrono>
+#include <functional>
 #include <new>
 
 #include "m2v_host.hpp"
@@ -294,6 +295,7 @@ static int halo_frames_of_step(size_t nf, uint32_t gop, int j)
 }
 
 constexpr unsigned long long kStripPoison = ~0ull;         // a failed rank's "size" in the all-gathered table
+constexpr unsigned long long kStripRetry = ~0ull - 1ull;   // peer transport: a wait on this rank ran out of budget - the sequence has to be encoded again
 
 struct StripSeq {
     m2v_comm *comm; int rank, world, row0, row1; bool up, down, fused;
@@ -303,6 +305,8 @@ struct StripSeq {
     size_t nf;
     int steps;
     int W;              // luma width of the sequence (the exchange sizes must not depend on whether this rank's plan succeeded)
+    int mbw;
+    PeerState *peer;    // non-null: the peer form of the step (one launch, rows stored into the neighbours' landing blocks)
 };
 
 // Enqueues the sequence on s (and the handle's side / comm streams, forked from and joined back into s by events): no allocation,
@@ -337,10 +341,43 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
     };
     hipStream_t side = q.world > 1 ? e->side[0] : nullptr;
     if (q.world > 1) local([&] { HIPCHK(hipEventRecord(e->ev_done, s)); });          // the plan's uploads
+    if (q.peer) {
+        // this sequence's counters were cleared by the previous peer sequence (or by the allocation); clear the NEXT one's - nobody
+        // adds to those before this rank has contributed to this sequence's all-gather, which is behind this memset on the stream -
+        // and this rank's own give-up word
+        PeerState &ps = *q.peer;
+        local([&] {
+            HIPCHK(hipMemsetAsync(ps.block + PeerState::off_cnt((unsigned)((ps.seq + 1) & 1), 0), 0, 256, s));
+            HIPCHK(hipMemsetAsync(ps.gaveup(), 0, sizeof(unsigned int), s));
+        });
+    }
+    unsigned int peer_need = 0;                             // edge blocks of a neighbour that have delivered once its steps < j are complete
     for (int j = 0; j < q.steps; ++j) {
         const int n_h = halo_frames_of_step(q.nf, q.gop, j);
         const bool xchg = q.world > 1 && n_h > 0 && (q.up || q.down);
         const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)q.W;
+        if (q.peer) {
+            // ONE launch per frame type for the whole strip; the rows of step j land in the neighbours' buffers of parity j & 1, the
+            // neighbours' rows of step j - 1 are read from this rank's buffers of the other parity once `peer_need` blocks have
+            // delivered.  Why two parities are enough: a block stores into a neighbour's buffer only after it has seen that
+            // neighbour's count for step j - 1 complete, i.e. after every read the neighbour made of that buffer in step j - 1.
+            PeerState &ps = *q.peer;
+            const unsigned set = (unsigned)(ps.seq & 1), par = (unsigned)(j & 1);
+            PeerStep k{};
+            k.cnt_up = q.up ? ps.cnt(0, set) : nullptr;
+            k.cnt_down = q.down ? ps.cnt(1, set) : nullptr;
+            k.seen_up = ps.seen(0, set);
+            k.seen_down = ps.seen(1, set);
+            k.gaveup = ps.gaveup();
+            k.need = peer_need;
+            k.budget = ps.budget;
+            local([&] {
+                run_step_peer(e, s, (size_t)j, xchg && q.up ? ps.put(0, par) : nullptr, xchg && q.down ? ps.put(1, par) : nullptr,
+                              q.up ? ps.got(0, par ^ 1u) : nullptr, q.down ? ps.got(1, par ^ 1u) : nullptr, k);
+            });
+            peer_need += (unsigned int)(n_h * q.mbw);
+            continue;
+        }
         if (q.world > 1 && q.fused) {
             // EDGE(j) and interior(j) both need ALL of step j-1 on this strip; the neighbours' rows only EDGE(j) - and it follows
             // the receive in stream order.  Two launches, two event records, two waits and one exchange per step.
@@ -403,6 +440,7 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
         HIPCHK(hipMemcpyAsync(e->h_strip, e->d_frame_off.p, (q.nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(e->h_strip + (q.nf + 1) * sizeof(unsigned long long), e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
     });
+    if (q.peer) local([&] { launch_peer_verdict(e, s, q.peer->gaveup(), (int)q.nf, kStripRetry); HIPCHK(hipGetLastError()); });
     if (q.world > 1) {
         if (fail) (void)hipMemsetAsync(e->d_frame_off.p, 0xFF, (q.nf + 1) * sizeof(unsigned long long), s);        // the mark
         q.comm->allgather_u64(q.rank, e->d_frame_off.p, e->d_alloff.p, q.nf + 1, s);
@@ -466,13 +504,29 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         ensure_pinned(e->h_asm, e->h_asm_cap, (size_t)world * (nf + 1) * sizeof(unsigned long long));
     }
     q.send_up = e->d_halo.p; q.send_down = q.send_up + halo_cap; q.recv_up = q.send_down + halo_cap; q.recv_down = q.recv_up + halo_cap;
+    // peer transport (m2v_comm.hpp, PeerComm): the usual form of the step, a connected communicator that has not fallen back, and a
+    // step's rows fitting its landing buffers - all of it the same on every rank
+    PeerState *const pst = a->comm ? a->comm->peer() : nullptr;
+    bool use_peer = pst && pst->connected && !pst->degraded && world > 1 && q.fused && halo_cap <= pst->cap && pst->world == world && pst->rank == rank;
+    q.mbw = full.mbw;
+    hipStream_t s = nullptr;
+    std::vector<hipEvent_t> marks;
+    int graph_used = 0;
+    hipEvent_t g0 = nullptr, g1 = nullptr;
+    const void *strips[kMaxStripRanks] = {};
+    const unsigned long long *d_all = nullptr;
+    int failed_rank = -1;
+    // Twice at most: a peer sequence in which some rank's wait ran out of budget (every rank reads that in the all-gathered sizes) is
+    // encoded again, exchanged through the base communicator, and the communicator stays there.
+    for (int attempt = 0;; ++attempt) {
+    q.peer = use_peer ? pst : nullptr;
     int r = M2V_OK;
     local([&] {
         StripBeginArgs b{a->xs, a->ys, a->pf, a->d_in, a->n, row0, row1, a->s};
         r = strip_begin_impl(e, &b);
     });
     if (r < 0) return r;                                    // (parameters: the same answer on every rank)
-    hipStream_t s = e->strip_active ? e->strip_stream : (a->s ? a->s : e->stream);
+    s = e->strip_active ? e->strip_stream : (a->s ? a->s : e->stream);
     local([&] {
         if ((int)e->plan_steps.size() != q.steps) throw HipError{hipErrorInvalidValue, "strip plan and step count disagree"};
         for (int j = 0; j < q.steps; ++j)
@@ -480,7 +534,7 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         e->d_strip_own.ensure(q.strip_cap);
         ensure_pinned(e->h_strip, e->h_strip_cap, (nf + 1) * sizeof(unsigned long long) + sizeof(StreamCtl));
         e->d_ctl.ensure(1);
-        if (world > 1) {
+        if (world > 1 && !q.peer) {
             // (the general form's exchange stream only when that form runs: every stream a process creates moves the others around the
             // handful of hardware queues)
             if (!q.fused && !e->comm_stream) HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
@@ -498,19 +552,20 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     // ---- the sequence: recorded graph, or call by call ----
     // profile: GPU events around the exchange of every step: halo_total = edge rows (and their halo) written .. neighbour rows and
     // interior rows both there; halo_exposed = how much of that came after the interior rows were done
-    std::vector<hipEvent_t> marks;
+    marks.clear();
     double us_in_comm = 0;                 // host time inside the communicator (a local communicator blocks there until the neighbour thread has posted)
     const auto t_loop = clk::now();
     m2v_enc::StripGraph &sg = e->strip_graph;
-    int graph_used = 0;
+    graph_used = 0;
     // (the general form - options conformant / dct_mfma = 0 - is enqueued call by call: it issues the exchange on a stream of its own,
     // and RCCL 2.26 crashes when its send / recv group is recorded on a stream that joined the recording through an event)
     // Automatic (the default): world == 1 and the single-GPU timing communicators.  Between the ranks of a real RCCL job the sequence
     // is enqueued call by call unless the caller opts in with option strip_graph = 1: a recording with cross-rank ncclSend / ncclRecv
     // inside has never run on hardware, the ranks of a job do not necessarily record on the same call, and on one GPU the recorded
-    // form is no faster for an inner rank (profiles/r04_experiments.txt item 1).
+    // form is no faster for an inner rank (profiles/r04_experiments.txt item 1).  The peer form is never recorded: its counter set
+    // and its launch arguments change from sequence to sequence, and it is five launches per step shorter to begin with.
     const bool graph_wanted = e->strip_graph_opt > 0 || (e->strip_graph_opt < 0 && (!a->comm || a->comm->graph_by_default()));
-    const bool graph_ok = graph_wanted && !sg.broken && !fail && !e->profile && (world == 1 || q.fused) && (!a->comm || a->comm->capturable());
+    const bool graph_ok = graph_wanted && !q.peer && !sg.broken && !fail && !e->profile && (world == 1 || q.fused) && (!a->comm || a->comm->capturable());
     if (graph_ok) {
         // everything a recording references exists before the key (which holds the allocation generation) is taken: the output rank's
         // assembly tables are allocated here, not after the host wait - a rank must not find its own recording stale on the next call
@@ -563,7 +618,7 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         HIPCHK(hipGraphLaunch(sg.exec, s));
         sg.launches++;
     } else {
-        strip_enqueue_sequence(e, s, q, false, fail, fail_text, e->profile ? &marks : nullptr, &us_in_comm);
+        strip_enqueue_sequence(e, s, q, false, fail, fail_text, e->profile && !q.peer ? &marks : nullptr, &us_in_comm);
     }
     // host state the sequence leaves behind, recorded or not
     if (e->strip_active) {
@@ -571,23 +626,38 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         e->strip_nf = nf;
         strip_close(e);
     }
+    if (q.peer) { pst->seq++; pst->sequences++; }           // (the same on every rank, whatever became of this rank's local work)
     e->strip_stats.steps = q.steps;
     e->strip_stats.graph = graph_used;
+    e->strip_stats.peer = q.peer ? 1 : 0;
     e->strip_stats.host_us_per_step = std::chrono::duration<double, std::micro>(clk::now() - t_loop).count() / std::max(1, q.steps);
     e->strip_stats.comm_us_per_step = us_in_comm / std::max(1, q.steps);
-    hipEvent_t g0 = nullptr, g1 = nullptr;
+    g0 = g1 = nullptr;
     if (e->profile && !fail) { g0 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g0, s)); }     // from here: gather, final assembly
 
     // ---- the one host wait; strips to the output rank; final assembly ----
-    const void *strips[kMaxStripRanks] = {};
-    const unsigned long long *d_all = e->d_frame_off.p;
-    int failed_rank = fail ? rank : -1;
+    for (auto &sp : strips) sp = nullptr;
+    d_all = e->d_frame_off.p;
+    failed_rank = fail ? rank : -1;
     if (world > 1) {
         const hipError_t se = hipStreamSynchronize(s);      // the sizes decide the receive counts
         if (se != hipSuccess && !fail) throw HipError{se, "hipStreamSynchronize(strip sequence)"};
         const unsigned long long *all = (const unsigned long long *)e->h_asm;
-        for (int k = 0; k < world && failed_rank < 0; ++k)
-            if (all[(size_t)k * (nf + 1) + nf] == kStripPoison) failed_rank = k;
+        int retry_rank = -1;
+        for (int k = 0; k < world; ++k) {
+            const unsigned long long mark = all[(size_t)k * (nf + 1) + nf];
+            if (mark == kStripPoison && failed_rank < 0) failed_rank = k;
+            if (mark == kStripRetry && retry_rank < 0) retry_rank = k;
+        }
+        if (failed_rank < 0 && retry_rank >= 0) {
+            if (!q.peer || attempt > 0) throw HipError{hipErrorUnknown, "a retry mark in the size table of a sequence that was not in the peer form"};
+            // no error: the sequence again, the rows exchanged through the base communicator - on every rank, they all read the same table
+            pst->degraded = true;
+            pst->giveups++;
+            use_peer = false;
+            collect_timers(e);
+            continue;
+        }
         if (failed_rank < 0) {
             // (an overflow of this strip's buffer - impossible with the worst-case size above - is reported at the end: the other ranks
             // are waiting in the gather, and a rank that left now would leave them there)
@@ -614,6 +684,8 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     } else {
         strips[0] = e->d_strip_own.p;
     }
+    break;
+    }   // attempt
     if (failed_rank >= 0) {
         (void)hipStreamSynchronize(s);
         collect_timers(e);
@@ -689,6 +761,12 @@ int m2v_strip_graph_stats(const m2v_enc *e, int *last_call_was_graph, int *recor
     return e->strip_graph.broken ? 1 : 0;
 }
 
+int m2v_strip_last_form(const m2v_enc *e)
+{
+    if (!e) return M2V_E_PARAM;
+    return e->strip_stats.peer ? 2 : e->strip_stats.graph ? 1 : 0;
+}
+
 // ---- communicators (m2v_comm.hpp) ----
 
 int m2v_comm_unique_id(void *id, size_t cap)
@@ -746,6 +824,91 @@ m2v_comm *m2v_comm_init_local(int world, int *err)
     if (err) *err = c ? M2V_OK : M2V_E_NOMEM;
     return c;
 }
+
+m2v_comm *m2v_comm_init_callbacks(int world, const m2v_comm_callbacks *cb, int *err)
+{
+    if (world < 1 || world > kMaxStripRanks || !cb || !cb->halo || !cb->allgather_u64 || !cb->gather) {
+        t_comm_err = "m2v_comm_init_callbacks: 1..16 ranks and all three functions";
+        if (err) *err = M2V_E_PARAM;
+        return nullptr;
+    }
+    m2v_comm *c = new (std::nothrow) CallbackComm(world, *cb);
+    if (err) *err = c ? M2V_OK : M2V_E_NOMEM;
+    return c;
+}
+
+// ---- the peer transport (m2v_comm.hpp, PeerComm) ----
+static int comm_call(const char *what, const std::function<void()> &fn)
+{
+    try {
+        fn();
+        return M2V_OK;
+    } catch (const std::bad_alloc &) {
+        t_comm_err = std::string(what) + ": host allocation failed";
+        return M2V_E_NOMEM;
+    } catch (const std::exception &ex) {
+        t_comm_err = std::string(what) + ": " + ex.what();
+        (void)hipGetLastError();
+        return M2V_E_HIP;
+    }
+}
+
+m2v_comm *m2v_comm_init_peer(m2v_comm *base, int rank, int device, size_t halo_bytes, int *err)
+{
+    auto fail = [&](int code, const std::string &why) -> m2v_comm * { t_comm_err = why; if (err) *err = code; return nullptr; };
+    if (!base || rank < 0 || rank >= base->world) return fail(M2V_E_PARAM, "m2v_comm_init_peer: a base communicator and a rank inside it");
+    if (base->peer()) return fail(M2V_E_PARAM, "m2v_comm_init_peer: the base communicator is a peer communicator itself");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(M2V_E_NODEVICE, "m2v_comm_init_peer: device ordinal out of range");
+    m2v_comm *c = nullptr;
+    const int r = comm_call("m2v_comm_init_peer", [&] { c = new PeerComm(base, rank, device, halo_bytes ? halo_bytes : (size_t)4 << 20); });
+    if (err) *err = r;
+    return c;
+}
+
+static PeerComm *as_peer(m2v_comm *c)
+{
+    if (!c || !c->peer()) { t_comm_err = "not a peer communicator (m2v_comm_init_peer)"; return nullptr; }
+    return static_cast<PeerComm *>(c);           // peer() is non-null for PeerComm only
+}
+
+int m2v_comm_peer_export(m2v_comm *c, void *desc, size_t cap)
+{
+    PeerComm *p = as_peer(c);
+    if (!p || !desc || cap < sizeof(PeerDesc)) return M2V_E_PARAM;
+    const int r = comm_call("m2v_comm_peer_export", [&] { PeerDesc d; p->export_desc(d); memcpy(desc, &d, sizeof d); });
+    return r < 0 ? r : (int)sizeof(PeerDesc);
+}
+
+int m2v_comm_peer_connect(m2v_comm *c, const void *desc_up, const void *desc_down)
+{
+    PeerComm *p = as_peer(c);
+    if (!p) return M2V_E_PARAM;
+    return comm_call("m2v_comm_peer_connect", [&] {
+        PeerDesc u, d;
+        if (desc_up) memcpy(&u, desc_up, sizeof u);
+        if (desc_down) memcpy(&d, desc_down, sizeof d);
+        p->connect(desc_up ? &u : nullptr, desc_down ? &d : nullptr, false);
+    });
+}
+
+int m2v_comm_peer_connect_all(m2v_comm *c)
+{
+    PeerComm *p = as_peer(c);
+    if (!p) return M2V_E_PARAM;
+    return comm_call("m2v_comm_peer_connect_all", [&] { p->connect_all(); });
+}
+
+int m2v_comm_peer_stats(m2v_comm *c, unsigned long long *peer_sequences, unsigned long long *giveups)
+{
+    if (!c || !c->peer()) return M2V_E_PARAM;
+    const PeerState &st = *c->peer();
+    if (peer_sequences) *peer_sequences = st.sequences;
+    if (giveups) *giveups = st.giveups;
+    return st.degraded ? 1 : 0;
+}
+
+const char *m2v_comm_kind(const m2v_comm *c) { return c ? c->kind() : ""; }
 
 void m2v_comm_destroy(m2v_comm *c) { delete c; }
 

@@ -88,6 +88,20 @@ struct MbAux {                        // 16 bytes per macroblock next to the uin
     uint32_t w3;                      // dcU
 };
 
+// strip mode, peer transport (k_mb<.., EDGE, PEER>; m2v_comm.hpp PeerState): the strip's whole GOP step is ONE launch whose first
+// n_edge blocks are the strip's first and last macroblock row.  They store their outer rows of the reconstruction straight into
+// the NEIGHBOURS' landing buffers (the launch's halo_up / halo_down: peer or IPC-mapped memory) with write-through stores, then add
+// one to the neighbour's arrival counter; before they read the rows the neighbours delivered in the previous step (nb_up / nb_down:
+// this rank's own landing buffers) they wait - bounded - until this rank's own counters have reached `need`.
+struct PeerStep {
+    unsigned int *cnt_up, *cnt_down;            // the neighbours' arrival counters (the one this rank's top row / bottom row adds to)
+    const unsigned int *seen_up, *seen_down;    // own arrival counters: edge blocks of the rank above / below that have delivered
+    unsigned int *gaveup;                       // own word: set when a wait ran out of budget (the sequence is then encoded again, exchanged the ordinary way)
+    unsigned int need;                          // what the own counters must have reached: every edge block of the neighbour's previous steps
+    unsigned int budget;                        // bound of one wait, in 10 ns ticks of the 100 MHz wall clock
+    unsigned int n_edge;                        // blocks [0, n_edge) of the launch are the edge rows, the others the rows in between
+};
+
 // strip mode: final assembly on the output rank (k_strip_layout / k_strip_assemble)
 struct CopySeg { const uint8_t *src; unsigned long long dst_off; unsigned long long len; };
 struct StripSrc { const uint8_t *strip[16]; };            // by value: the strips' device pointers (<= kMaxStripRanks)

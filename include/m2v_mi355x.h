@@ -206,6 +206,55 @@ int       m2v_comm_selftest(m2v_comm *c, int rank, const void *d_send, void *d_r
 int       m2v_comm_selftest_captured(m2v_comm *c, int rank, const void *d_send, void *d_recv, size_t nbytes, void *hip_stream, int launches);
 
 /*
+ * The exchange supplied by the CALLER: three functions of the host program (its MPI, its torch.distributed process group, a test's
+ * pipes) behind the communicator interface.  Every pointer is DEVICE memory; `hip_stream` is the stream the data is ordered on, and
+ * the function must leave its effect ordered on that stream (enqueue there - or synchronise it, move the bytes, and return).
+ * Return 0 for success; anything else fails the m2v_strip_encode call with M2V_E_HIP.
+ *   halo           nbytes to / from the rank above (rank - 1) and the rank below (rank + 1); a null pair = no neighbour on that side
+ *   allgather_u64  every rank's `count` values into d_all[world][count] on every rank
+ *   gather         rank != dst sends sizes[rank] bytes of d_strip to dst, which receives sizes[r] bytes of rank r in bufs[r]
+ */
+typedef struct m2v_comm_callbacks {
+    int (*halo)(void *user, int rank, const void *d_send_up, void *d_recv_up, const void *d_send_down, void *d_recv_down, size_t nbytes, void *hip_stream);
+    int (*allgather_u64)(void *user, int rank, const unsigned long long *d_src, unsigned long long *d_all, size_t count, void *hip_stream);
+    int (*gather)(void *user, int rank, int dst, const void *d_strip, const size_t *sizes, void *const *bufs, void *hip_stream);
+    void *user;
+} m2v_comm_callbacks;
+m2v_comm *m2v_comm_init_callbacks(int world, const m2v_comm_callbacks *cb, int *err);
+
+/*
+ * The PEER transport ("or peer-to-peer stores over xGMI"): a communicator on top of another one (`base`: RCCL, local,
+ * callbacks, solo - not owned, destroy this one first) that takes the halo exchange OUT of the GOP step.  Every rank owns a landing
+ * block in fine-grained device memory; its neighbours map it (the same process: the pointer + hipDeviceEnablePeerAccess across GPUs;
+ * another process: hipIpcOpenMemHandle); the macroblock kernel of the strip's edge rows stores their outer 2 VECTOR_LEVEL luma /
+ * VECTOR_LEVEL chroma rows of the reconstruction (RTL:1446-1448) straight into the neighbour's block with write-through stores and
+ * counts its arrival there; the next step's edge blocks wait - bounded - for the neighbours' count before they load their window.
+ * A GOP step is then ONE launch (edge rows first in dispatch order), no exchange kernel, no second stream.  Sizes and strips still go
+ * through `base`.  A wait that runs out of budget (M2V_PEER_BUDGET_US, default 200 000) is not an error: every rank sees it in the
+ * all-gathered sizes, the sequence is encoded again exchanging through `base`, and the communicator stays with `base` from then on
+ * (m2v_comm_peer_stats says so) - which is what happens when several ranks share ONE GPU and the waiting blocks of one keep the
+ * blocks of another from being scheduled.  m2v_strip_encode uses the peer form for the usual form of the step (not with options
+ * conformant / dct_mfma = 0) when a step's rows fit `halo_bytes` per direction ((frames of the step) x 9 VECTOR_LEVEL/3 x width).
+ *   m2v_comm_init_peer     allocates the block (halo_bytes = 0: 4 MiB per buffer)
+ *   m2v_comm_peer_export   this rank's descriptor (M2V_PEER_DESC_BYTES of plain bytes: process, device, address, IPC handle)
+ *   m2v_comm_peer_connect  the neighbours' descriptors (NULL where the rank has no neighbour)
+ *   m2v_comm_peer_connect_all = export + all-gather through `base` + connect: collective over `base` (solo bases: the rank connects
+ *                          to itself, the timing aid's "its own rows come back")
+ * Status: byte-identical on one GPU (ranks = threads, and ranks = processes through IPC handles); never run between two GPUs - RCCL
+ * stays what bench.py uses by default for N > 1.
+ */
+#define M2V_PEER_DESC_BYTES 128
+m2v_comm *m2v_comm_init_peer(m2v_comm *base, int rank, int device, size_t halo_bytes, int *err);
+int       m2v_comm_peer_export(m2v_comm *c, void *desc, size_t cap);
+int       m2v_comm_peer_connect(m2v_comm *c, const void *desc_up, const void *desc_down);
+int       m2v_comm_peer_connect_all(m2v_comm *c);
+/* sequences that ran in the peer form, waits that gave up; returns 1 if the communicator has fallen back to its base for good, 0 if not,
+ * M2V_E_PARAM for a communicator without the peer transport */
+int       m2v_comm_peer_stats(m2v_comm *c, unsigned long long *peer_sequences, unsigned long long *giveups);
+/* what kind of communicator this is: "rccl", "local", "solo", "solo-rccl", "callbacks", "peer+<base>" */
+const char *m2v_comm_kind(const m2v_comm *c);
+
+/*
  * One strip of one sequence, start to finish, in ONE call: the loop that parallel.encode_strips() spells out in Python (begin,
  * per GOP step edge rows -> exchange beside the interior rows -> neighbour rows in, finish, sizes, strips to `dst_rank`, final
  * assembly there), natively and without an interpreter between the steps.  Rank r of `world` encodes macroblock rows
@@ -233,6 +282,10 @@ int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_ra
  * to the output rank + final assembly).  Returns the step count. */
 int m2v_strip_stats(const m2v_enc *e, double *halo_total_ms, double *halo_exposed_ms, double *gather_ms, double *host_us_per_step,
                     double *comm_us_per_step);
+
+/* How the last m2v_strip_encode on this handle ran its GOP steps: 0 = enqueued call by call, 1 = one recorded hipGraph, 2 = the peer
+ * form (one launch per step, rows stored into the neighbours' landing blocks); after a fallback inside the call: what the second attempt was. */
+int m2v_strip_last_form(const m2v_enc *e);
 
 /* The recorded-graph side of m2v_strip_encode on this handle: whether the last call was launched as a graph, recordings and graph
  * launches so far.  Returns 1 if recording has failed on this handle (the sequence is then enqueued call by call), else 0. */

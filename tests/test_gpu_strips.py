@@ -239,7 +239,9 @@ def test_a_failing_rank_does_not_leave_the_others_waiting():
             t.join(timeout=60)
         assert not any(t.is_alive() for t in th), "a rank is still waiting for the one that failed"
         assert rc[1] == -1 and b"d_out" in msg[1]
-        assert rc[0] < 0 and rc[2] < 0 and b"another rank" in msg[0] + msg[2]
+        # (rank 1 keeps the call order and marks its sizes - "rank 1 of the job failed" -, then aborts the communicator on its way out:
+        # a rank still inside the size exchange at that moment reads "another rank ... has failed" instead)
+        assert rc[0] < 0 and rc[2] < 0 and (b"another rank" in msg[0] + msg[2] or b"rank 1 of the job failed" in msg[0] + msg[2])
         for e in encs:                                 # the handles are usable afterwards
             assert not e.busy and e.encode(d_clip[:2].cpu().numpy(), W // 16, H // 16, pf)
     finally:

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--gops", type=int, default=10)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--rccl", type=int, default=0, help="1: the rows go through a 1-rank RCCL communicator (ncclSend / ncclRecv to itself) instead of device copies")
+    ap.add_argument("--peer", type=int, default=0, help="1: the peer transport on top (the edge blocks store their rows into the rank's own landing block and "
+                                                     "count their arrival there: one launch per GOP step, no exchange step)")
     ap.add_argument("--graph", type=int, nargs="+", default=[0, 1], help="option strip_graph: 0 = the sequence call by call, 1 = one recorded hipGraph launch")
     ap.add_argument("--split", type=int, default=-1, help="option split_streams of the handle (GOP groups on a stream each; default: the library's)")
     args = ap.parse_args()
@@ -42,7 +44,8 @@ def main():
             enc.set_option("strip_graph", graph)
             if args.split >= 0:
                 enc.set_option("split_streams", args.split)
-            comm = M.StripComm.solo(world, rccl=bool(args.rccl)) if world > 1 else None
+            cbase = M.StripComm.solo(world, rccl=bool(args.rccl)) if world > 1 else None
+            comm = M.StripComm.peer(cbase, rank, 0) if (cbase is not None and args.peer) else cbase
             try:
                 run = lambda: M.parallel.encode_strips_native(enc, comm, rank, world, clip, 128, 128, pf, out if rank == 0 else None)   # noqa: E731
                 t0 = time.perf_counter()
@@ -63,6 +66,7 @@ def main():
                 if world == 1 and base is None:
                     base = dt
                 print(json.dumps({"world": world, "rank": rank, "transport": comm.kind if comm is not None else None,
+                                  "form": enc.strip_last_form(), "peer": comm.peer_stats() if (comm is not None and args.peer) else None,
                                   "strip_graph": graph, "graph_launches": gst["launches"], "graph_broken": gst["broken"],
                                   "host_us_per_gop_step_timed": round(host_timed, 1), "split_streams": args.split if args.split >= 0 else "default", "ms_per_sequence": round(dt * 1e3, 3),
                                   "speedup_vs_one_rank": round(base / dt, 2) if base else None,
@@ -73,8 +77,10 @@ def main():
                 sys.stdout.flush()
             finally:
                 enc.close()
-                if comm is not None:
+                if comm is not None and comm is not cbase:
                     comm.close()
+                if cbase is not None:
+                    cbase.close()
 
 
 if __name__ == "__main__":
