@@ -415,15 +415,17 @@ class StripComm:
         return c
 
     @classmethod
-    def solo(cls, world, rccl=False):
+    def solo(cls, world, rccl=False, debug=False):
         """timing aid (tools/strip_solo.py): one rank of `world` alone on its GPU; the output is NOT a valid stream.
         rccl=True: the rows travel through a 1-rank RCCL communicator (ncclSend / ncclRecv to itself) instead of device copies"""
-        L = lib()
+        L = lib(debug)
         err = ctypes.c_int(0)
         h = (L.m2v_comm_init_solo_rccl if rccl else L.m2v_comm_init_solo)(world, ctypes.byref(err))
         if not h:
             raise M2VError("m2v_comm_init_solo%s failed (%d): %s" % ("_rccl" if rccl else "", err.value, L.m2v_comm_last_error().decode()))
-        return cls(h, "solo-rccl" if rccl else "solo", world)
+        c = cls(h, "solo-rccl" if rccl else "solo", world)
+        c._debug = debug
+        return c
 
     @classmethod
     def callbacks(cls, world, halo, allgather_u64, gather, debug=False):

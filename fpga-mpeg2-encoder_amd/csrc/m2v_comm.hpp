@@ -441,10 +441,10 @@ struct CallbackComm final : m2v_comm {
 // "or peer-to-peer stores over xGMI".  Sizes and strips still travel through the BASE communicator this one wraps
 // (RCCL, local, callbacks), which is also what the halo falls back to - for good - when a wait runs out of budget.
 //
-//   landing block:  [1 KB control][buf(parity 0, from above)][buf(0, from below)][buf(1, from above)][buf(1, from below)]   cap bytes each
-//   control:        arrival counters cnt[set][side] on 128-byte lines (set = sequence parity: a sequence clears the set of the NEXT one,
-//                   which nobody touches meanwhile - every rank is past the previous sequence's all-gather -, so no rank ever clears a
-//                   counter a neighbour may be adding to), then the give-up word
+//   landing block:  [control][buf(parity 0, from above)][buf(0, from below)][buf(1, from above)][buf(1, from below)]   cap bytes each
+//   control:        arrival counters cnt[set][GOP of the sequence][side] on 128-byte lines (set = sequence parity: a sequence clears
+//                   the set of the NEXT one, which nobody touches meanwhile - every rank is past the previous sequence's all-gather -,
+//                   so no rank ever clears a counter a neighbour may be adding to), then the give-up word
 // ---------------------------------------------------------------------------------------------
 struct PeerDesc {                    // what a rank tells its neighbours (m2v_comm_peer_export): plain bytes, M2V_PEER_DESC_BYTES
     uint32_t magic, version;
@@ -457,7 +457,8 @@ static_assert(sizeof(PeerDesc) == M2V_PEER_DESC_BYTES, "the descriptor is M2V_PE
 
 struct PeerState {
     static constexpr uint32_t kMagic = 0x4D325650u;       // "M2VP"
-    static constexpr size_t kCtl = 1024;
+    static constexpr size_t kCntBytes = (size_t)kPeerCntStride * 4 / 2;                                   // one counter's line: 128 bytes
+    static constexpr size_t kCtl = 2 * (size_t)kPeerSlots * 2 * kCntBytes + 1024;                          // the counters, then the give-up word's KB
     int rank = 0, world = 1, device = 0;
     uint8_t *block = nullptr;         // own landing block
     size_t bytes = 0, cap = 0;        // its size; capacity of one landing buffer
@@ -471,8 +472,8 @@ struct PeerState {
     unsigned int budget = 20000000u;  // bound of one wait in 10 ns ticks: 200 ms (M2V_PEER_BUDGET_US overrides)
     unsigned long long sequences = 0, giveups = 0;
 
-    static size_t off_cnt(unsigned set, int side) { return (size_t)(set * 2u + (unsigned)side) * 128u; }
-    static size_t off_gaveup() { return 512; }
+    static size_t off_cnt(unsigned set, int side) { return ((size_t)set * kPeerSlots * 2 + (size_t)side) * kCntBytes; }     // GOP 0's; GOP g: + g * 2 * kCntBytes
+    static size_t off_gaveup() { return kCtl - 1024; }
     size_t off_buf(unsigned parity, int side) const { return kCtl + (size_t)(parity * 2u + (unsigned)side) * cap; }
     // own side: rows that arrived from the rank above (side 0) / below (side 1)
     const uint8_t *got(int side, unsigned parity) const { return block + off_buf(parity, side); }

@@ -982,11 +982,15 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             // (system-scope relaxed atomic loads = global_load .. sc0 sc1; the whole window of such a block, six loads per lane)
             bool far = false;
             if constexpr (PEER) {
-                if (ps.need != 0u) {
-                    if (ext_u) peer_wait(ps.seen_up, ps.need, ps.gaveup, ps.budget, lane);
-                    if (ext_d) peer_wait(ps.seen_down, ps.need, ps.gaveup, ps.budget, lane);
+                // (-DM2V_DEBUG, option ablate bits 22-25: the hand-off's parts switched off one by one, to see what each costs - results invalid)
+                if (!(kDebug && (g.ablate & (1 << 24)))) {
+                    // every block of the neighbour's edge row, for every earlier frame of this GOP (they all are referenced: each has delivered)
+                    const unsigned int need = (unsigned int)job.i_frame * (unsigned int)g.mbw;
+                    const uint32_t slot = (uint32_t)job.rhidx * (uint32_t)kPeerCntStride;
+                    if (ext_u) peer_wait(ps.seen_up + slot, need, ps.gaveup, ps.budget, lane);
+                    if (ext_d) peer_wait(ps.seen_down + slot, need, ps.gaveup, ps.budget, lane);
                 }
-                far = ext_u || ext_d;
+                far = (ext_u || ext_d) && !(kDebug && (g.ablate & (1 << 25)));
             }
             auto ld = [&](const uint8_t *base, uint32_t off) -> uint32_t {
                 typedef __attribute__((address_space(1))) unsigned int *gu32p;
@@ -1790,7 +1794,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 // write-through costs 16 %; here it is 9 of a strip's 24 rows' worth of one macroblock row in sixteen.
                 auto st = [&](uint8_t *base, uint32_t off, uint32_t v) {
                     typedef __attribute__((address_space(1))) unsigned int *gu32p;
-                    if constexpr (PEER) __hip_atomic_store((gu32p)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (PEER && !(kDebug && (g.ablate & (1 << 22)))) __hip_atomic_store((gu32p)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     else *(gst32)(base + off) = v;
                 };
                 const bool put_u = halo_up != nullptr && by == g.edge_top, put_d = halo_down != nullptr && by == g.edge_bot;     // wave-uniform
@@ -1806,9 +1810,10 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     if (put_u || put_d) {
                         typedef __attribute__((address_space(1))) unsigned int *gu32p;
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every store of this wavefront has left (one wavefront per block)
-                        if (lane == 0) {
-                            if (put_u) __hip_atomic_fetch_add((gu32p)ps.cnt_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            if (put_d) __hip_atomic_fetch_add((gu32p)ps.cnt_down, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (lane == 0 && !(kDebug && (g.ablate & (1 << 23)))) {
+                            const uint32_t slot = (uint32_t)job.hidx * (uint32_t)kPeerCntStride;
+                            if (put_u) __hip_atomic_fetch_add((gu32p)(ps.cnt_up + slot), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (put_d) __hip_atomic_fetch_add((gu32p)(ps.cnt_down + slot), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         }
                     }
                 }

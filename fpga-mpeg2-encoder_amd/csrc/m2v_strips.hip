@@ -340,27 +340,28 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
         if (us_in_comm) *us_in_comm += std::chrono::duration<double, std::micro>(clk::now() - t_c).count();
     };
     hipStream_t side = q.world > 1 ? e->side[0] : nullptr;
-    if (q.world > 1) local([&] { HIPCHK(hipEventRecord(e->ev_done, s)); });          // the plan's uploads
+    if (q.world > 1 && !q.peer) local([&] { HIPCHK(hipEventRecord(e->ev_done, s)); });          // the plan's uploads
     if (q.peer) {
         // this sequence's counters were cleared by the previous peer sequence (or by the allocation); clear the NEXT one's - nobody
         // adds to those before this rank has contributed to this sequence's all-gather, which is behind this memset on the stream -
         // and this rank's own give-up word
         PeerState &ps = *q.peer;
         local([&] {
-            HIPCHK(hipMemsetAsync(ps.block + PeerState::off_cnt((unsigned)((ps.seq + 1) & 1), 0), 0, 256, s));
+            HIPCHK(hipMemsetAsync(ps.block + PeerState::off_cnt((unsigned)((ps.seq + 1) & 1), 0), 0,
+                                  (size_t)std::max(1, halo_frames_of_step(q.nf, q.gop, 0)) * 2 * PeerState::kCntBytes, s));
             HIPCHK(hipMemsetAsync(ps.gaveup(), 0, sizeof(unsigned int), s));
         });
     }
-    unsigned int peer_need = 0;                             // edge blocks of a neighbour that have delivered once its steps < j are complete
     for (int j = 0; j < q.steps; ++j) {
         const int n_h = halo_frames_of_step(q.nf, q.gop, j);
         const bool xchg = q.world > 1 && n_h > 0 && (q.up || q.down);
         const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)q.W;
         if (q.peer) {
             // ONE launch per frame type for the whole strip; the rows of step j land in the neighbours' buffers of parity j & 1, the
-            // neighbours' rows of step j - 1 are read from this rank's buffers of the other parity once `peer_need` blocks have
-            // delivered.  Why two parities are enough: a block stores into a neighbour's buffer only after it has seen that
-            // neighbour's count for step j - 1 complete, i.e. after every read the neighbour made of that buffer in step j - 1.
+            // neighbours' rows of step j - 1 are read from this rank's buffers of the other parity once the GOP's counter says that
+            // every block of the neighbour's row has delivered.  Why two parities are enough: a block stores into a neighbour's
+            // buffer (at its GOP's place) only after it has seen that neighbour's count for the GOP's frame of step j - 1 complete,
+            // i.e. after every read the neighbour made of that place in step j - 1.
             PeerState &ps = *q.peer;
             const unsigned set = (unsigned)(ps.seq & 1), par = (unsigned)(j & 1);
             PeerStep k{};
@@ -369,13 +370,11 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
             k.seen_up = ps.seen(0, set);
             k.seen_down = ps.seen(1, set);
             k.gaveup = ps.gaveup();
-            k.need = peer_need;
             k.budget = ps.budget;
             local([&] {
                 run_step_peer(e, s, (size_t)j, xchg && q.up ? ps.put(0, par) : nullptr, xchg && q.down ? ps.put(1, par) : nullptr,
                               q.up ? ps.got(0, par ^ 1u) : nullptr, q.down ? ps.got(1, par ^ 1u) : nullptr, k);
             });
-            peer_need += (unsigned int)(n_h * q.mbw);
             continue;
         }
         if (q.world > 1 && q.fused) {
@@ -507,7 +506,8 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     // peer transport (m2v_comm.hpp, PeerComm): the usual form of the step, a connected communicator that has not fallen back, and a
     // step's rows fitting its landing buffers - all of it the same on every rank
     PeerState *const pst = a->comm ? a->comm->peer() : nullptr;
-    bool use_peer = pst && pst->connected && !pst->degraded && world > 1 && q.fused && halo_cap <= pst->cap && pst->world == world && pst->rank == rank;
+    bool use_peer = pst && pst->connected && !pst->degraded && world > 1 && q.fused && halo_cap <= pst->cap && pst->world == world && pst->rank == rank &&
+                    halo_frames_of_step(nf, gop, 0) <= kPeerSlots;
     q.mbw = full.mbw;
     hipStream_t s = nullptr;
     std::vector<hipEvent_t> marks;

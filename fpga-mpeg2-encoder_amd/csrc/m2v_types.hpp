@@ -91,13 +91,17 @@ struct MbAux {                        // 16 bytes per macroblock next to the uin
 // strip mode, peer transport (k_mb<.., EDGE, PEER>; m2v_comm.hpp PeerState): the strip's whole GOP step is ONE launch whose first
 // n_edge blocks are the strip's first and last macroblock row.  They store their outer rows of the reconstruction straight into
 // the NEIGHBOURS' landing buffers (the launch's halo_up / halo_down: peer or IPC-mapped memory) with write-through stores, then add
-// one to the neighbour's arrival counter; before they read the rows the neighbours delivered in the previous step (nb_up / nb_down:
-// this rank's own landing buffers) they wait - bounded - until this rank's own counters have reached `need`.
+// one to the neighbour's arrival counter of their GOP; before they read the rows the neighbours delivered in the previous step (nb_up /
+// nb_down: this rank's own landing buffers) they wait - bounded - until this rank's own counter of the GOP has reached
+// (frame's index in the GOP) x (macroblocks per row): every block of the neighbour's edge row, of every earlier frame of this GOP.
+// One counter per GOP of the sequence (= position in the step's halo list) and side, kPeerCntStride words apart: a thousand
+// wavefronts asking for ONE word at the start of a launch are served one after the other (~12 ns each, measured: 36 us per step).
+constexpr int kPeerSlots = 256;            // GOPs of one sequence the peer form can count (more: the ordinary exchange)
+constexpr int kPeerCntStride = 64;         // uint32 words between the counters of consecutive GOPs: [slot][side], 128 bytes each
 struct PeerStep {
-    unsigned int *cnt_up, *cnt_down;            // the neighbours' arrival counters (the one this rank's top row / bottom row adds to)
-    const unsigned int *seen_up, *seen_down;    // own arrival counters: edge blocks of the rank above / below that have delivered
+    unsigned int *cnt_up, *cnt_down;            // the neighbours' arrival counters of GOP 0 (the one this rank's top row / bottom row adds to)
+    const unsigned int *seen_up, *seen_down;    // own arrival counters of GOP 0: edge blocks of the rank above / below that have delivered
     unsigned int *gaveup;                       // own word: set when a wait ran out of budget (the sequence is then encoded again, exchanged the ordinary way)
-    unsigned int need;                          // what the own counters must have reached: every edge block of the neighbour's previous steps
     unsigned int budget;                        // bound of one wait, in 10 ns ticks of the 100 MHz wall clock
     unsigned int n_edge;                        // blocks [0, n_edge) of the launch are the edge rows, the others the rows in between
 };

@@ -59,11 +59,12 @@ def run_peer_threads(M, d_clip, W, H, pf, VL, world, calls=1, halo_bytes=0, debu
         base.close()
 
 
-@pytest.mark.parametrize("world,W,H,pf,VL", [(2, 128, 96, 4, 3), (3, 96, 160, 2, 2), (4, 160, 128, 3, 1), (2, 64, 32, 3, 3), (4, 64, 128, 1, 3)])
+@pytest.mark.parametrize("world,W,H,pf,VL", [(2, 128, 96, 4, 3), (3, 96, 160, 2, 2), (4, 160, 128, 3, 1), (4, 64, 64, 3, 3), (4, 64, 128, 1, 3)])
 def test_peer_transport_threads_equal_oracle(world, W, H, pf, VL):
-    """strips of 1 .. 4 rows (one row: the same block is the strip's first AND last row, stores both ways, waits both ways); three
-    sequences in a row on the same communicator (the counter sets alternate).  Whether a wait ever ran out of budget depends on how
-    the GPU schedules the ranks' launches - the bytes must not."""
+    """strips of 1 .. 4 rows (one row: the same block is the strip's first AND last row, stores both ways, waits both ways; the
+    smallest frame the module accepts is 4 x 4 macroblocks, RTL:985-991); three sequences in a row on the same communicator (the
+    counter sets alternate).  Whether a wait ever ran out of budget depends on how the GPU schedules the ranks' launches (four ranks'
+    streams share the process's four hardware queues with torch's) - the bytes must not."""
     import torch
     import m2v_load
     from oracle import m2v_oracle_ctypes as orc
@@ -77,6 +78,45 @@ def test_peer_transport_threads_equal_oracle(world, W, H, pf, VL):
     assert all(s["peer_sequences"] >= 1 for s in stats), stats
     assert len({(s["peer_sequences"], s["giveups"], s["fell_back"]) for s in stats}) == 1, "the ranks disagree about what happened: %r" % (stats,)
     print("peer transport, %d ranks as threads: %r, last form %r" % (world, stats[0], forms[0]))
+
+
+PEER_THREADS_CHILD = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import torch
+import m2v_load
+from oracle import m2v_oracle_ctypes as orc
+from test_gpu_strip_peer import run_peer_threads
+M = m2v_load.load()
+out = []
+for world, W, H, pf, VL in json.loads(sys.argv[2]):
+    n = 2 * (pf + 1) + 1
+    clip = M.synth.clip(W, H, n, clip_index=330 + world, scene_len=4)
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, VL, 2)
+    d_clip = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
+    got, stats, forms = run_peer_threads(M, d_clip, W, H, pf, VL, world, calls=3)
+    out.append({"case": [world, W, H, pf, VL], "identical": all(g == want for g in got), "stats": stats[0], "agree": all(s == stats[0] for s in stats), "forms": forms})
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_peer_transport_many_ranks_with_a_hardware_queue_each(tmp_path):
+    """Four and eight ranks as threads in a process of its own that asks the HIP runtime for sixteen hardware queues
+    (GPU_MAX_HW_QUEUES, read when the runtime starts): with a queue per rank no launch waits behind another rank's waiting blocks, and
+    strips of ONE macroblock row with neighbours on both sides run in the peer form for real.  The bytes are the oracle's whatever
+    the scheduling; how many sequences ran in the peer form is printed."""
+    import json
+    script = tmp_path / "child.py"
+    script.write_text(PEER_THREADS_CHILD)
+    cases = [(4, 64, 64, 3, 3), (8, 64, 128, 2, 3), (8, 256, 256, 4, 3)]
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    r = subprocess.run([sys.executable, str(script), ROOT, json.dumps(cases)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    for c in res:
+        print("peer transport, sixteen hardware queues:", c)
+        assert c["identical"] and c["agree"], c
 
 
 def test_peer_transport_two_ranks_really_run_the_peer_form():

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--rccl", type=int, default=0, help="1: the rows go through a 1-rank RCCL communicator (ncclSend / ncclRecv to itself) instead of device copies")
     ap.add_argument("--peer", type=int, default=0, help="1: the peer transport on top (the edge blocks store their rows into the rank's own landing block and "
                                                      "count their arrival there: one launch per GOP step, no exchange step)")
+    ap.add_argument("--ablate", type=int, default=0, help="-DM2V_DEBUG library, option ablate (results invalid): bit 22 plain halo stores, 23 no arrival count, 24 no wait, 25 plain window loads")
     ap.add_argument("--graph", type=int, nargs="+", default=[0, 1], help="option strip_graph: 0 = the sequence call by call, 1 = one recorded hipGraph launch")
     ap.add_argument("--split", type=int, default=-1, help="option split_streams of the handle (GOP groups on a stream each; default: the library's)")
     args = ap.parse_args()
@@ -40,11 +41,13 @@ def main():
     base = None
     for world, graph in [(w, gph) for w in args.world for gph in args.graph]:
         for rank in sorted({0, world // 2}):                      # the output rank (one neighbour + final assembly) and an inner rank
-            enc = M.Mpeg2Encoder(7, 7, 3, 2)
+            enc = M.Mpeg2Encoder(7, 7, 3, 2, debug=bool(args.ablate))
+            if args.ablate:
+                enc.set_option("ablate", args.ablate)
             enc.set_option("strip_graph", graph)
             if args.split >= 0:
                 enc.set_option("split_streams", args.split)
-            cbase = M.StripComm.solo(world, rccl=bool(args.rccl)) if world > 1 else None
+            cbase = M.StripComm.solo(world, rccl=bool(args.rccl), debug=bool(args.ablate)) if world > 1 else None
             comm = M.StripComm.peer(cbase, rank, 0) if (cbase is not None and args.peer) else cbase
             try:
                 run = lambda: M.parallel.encode_strips_native(enc, comm, rank, world, clip, 128, 128, pf, out if rank == 0 else None)   # noqa: E731
