@@ -302,9 +302,12 @@ void run_step_edges_fused(m2v_enc *e, hipStream_t s, size_t j, uint8_t *up, uint
 
 // strip mode, peer transport: GOP step j of the WHOLE strip as one launch each for the I and the P frames of the step (edge rows first
 // in dispatch order; k_mb<.., EDGE, PEER>).  ps: the counters and the budget; n_edge is filled in here.
-void run_step_peer(m2v_enc *e, hipStream_t s, size_t j, uint8_t *put_up, uint8_t *put_down, const uint8_t *got_up, const uint8_t *got_down, PeerStep ps)
+void run_step_peer(m2v_enc *e, hipStream_t s, size_t j, int group, uint8_t *put_up, uint8_t *put_down, const uint8_t *got_up, const uint8_t *got_down, PeerStep ps)
 {
     const m2v_enc::Step &st = e->plan_steps[j];
+    // group >= 0: only the frames of that GOP group (plan_chunk's cut_i / cut_p); -1: the whole step
+    const int i0 = group < 0 ? 0 : st.cut_i[group], i1 = group < 0 ? st.n_i : st.cut_i[group + 1];
+    const int p0 = group < 0 ? 0 : st.cut_p[group], p1 = group < 0 ? st.n_p : st.cut_p[group + 1];
     Geom gg = e->g;
     const int r0 = e->g.row0, r1 = e->g.row1, nrows = r1 - r0 >= 2 ? 2 : 1;
     gg.rstride = nrows == 2 ? r1 - 1 - r0 : 1;
@@ -312,8 +315,8 @@ void run_step_peer(m2v_enc *e, hipStream_t s, size_t j, uint8_t *put_up, uint8_t
     gg.edge_bot = r1 - 1;
     geom_finish(gg);
     ps.n_edge = (unsigned int)(nrows * gg.mbw);
-    launch_mb_peer<false>(e, s, e->d_lists.p + st.off_i, st.n_i, gg, put_up, put_down, nullptr, nullptr, ps);      // an I frame has no reference
-    launch_mb_peer<true>(e, s, e->d_lists.p + st.off_p, st.n_p, gg, put_up, put_down, got_up, got_down, ps);
+    launch_mb_peer<false>(e, s, e->d_lists.p + st.off_i + i0, i1 - i0, gg, put_up, put_down, nullptr, nullptr, ps);      // an I frame has no reference
+    launch_mb_peer<true>(e, s, e->d_lists.p + st.off_p + p0, p1 - p0, gg, put_up, put_down, got_up, got_down, ps);
 }
 
 void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_stream, bool advance)
@@ -540,6 +543,8 @@ int m2v_reset(m2v_enc *e)
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
     e->plan_steps.clear();
     e->plan_nf = 0;
+    e->ctl_init = 0;
+    e->scan_peer_gaveup = nullptr;
     e->g.row0 = 0; e->g.row1 = e->g.mbh; e->g.strip = 0;
     geom_finish(e->g);
     e->timed.clear(); e->ev_used = 0; e->chain_ev = nullptr;

@@ -148,6 +148,12 @@ struct m2v_enc {
     DevBuf<int> d_lists;
     DevBuf<FrameJob> d_joblist;           // the jobs again, in launch-list order (k_mb reads its frame's job with ONE dependent scalar load)
     DevBuf<StreamCtl> d_ctl;
+    int ctl_init = 0;                     // how the next k_frame_scan sets the control word up (ctl_begin): 0 leaves it, 1 new stream, 2 continues
+    unsigned long long ctl_cap = 0;
+    // strip mode, peer transport: what the next k_frame_scan does about the give-up word and the next sequence's arrival counters (PeerScan)
+    unsigned int *scan_peer_gaveup = nullptr, *scan_peer_clear = nullptr;
+    int scan_peer_lines = 0;
+    unsigned long long scan_peer_mark = 0;
     std::vector<uint8_t *> rec_pool;      // reconstruction buffers (4:2:0 planar), each ysz + 2*csz
     size_t rec_bytes = 0;
     size_t rec_pool_bytes = 0;            // allocation size of every buffer in rec_pool
@@ -232,7 +238,7 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
 void run_step(m2v_enc *e, hipStream_t s, size_t j);
 void run_step_rows(m2v_enc *e, hipStream_t s, size_t j, int r0, int r1);
 void run_step_edges_fused(m2v_enc *e, hipStream_t s, size_t j, uint8_t *up, uint8_t *down, const uint8_t *nb_up, const uint8_t *nb_down);
-void run_step_peer(m2v_enc *e, hipStream_t s, size_t j, uint8_t *put_up, uint8_t *put_down, const uint8_t *got_up, const uint8_t *got_down, PeerStep ps);
+void run_step_peer(m2v_enc *e, hipStream_t s, size_t j, int group, uint8_t *put_up, uint8_t *put_down, const uint8_t *got_up, const uint8_t *got_down, PeerStep ps);
 void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_stream, bool advance = false);
 void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool first, bool last, uint32_t last_valid_beats,
                   uint8_t *d_stream, bool advance = false);
@@ -277,15 +283,14 @@ template <bool P> void launch_mb_peer(m2v_enc *e, hipStream_t s, const int *d_li
                                       const uint8_t *got_up, const uint8_t *got_down, const PeerStep &ps);
 extern template void launch_mb_peer<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *, const PeerStep &);
 extern template void launch_mb_peer<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *, const PeerStep &);
-void launch_peer_verdict(m2v_enc *e, hipStream_t s, const unsigned int *gaveup, int nf, unsigned long long mark);
 extern template void launch_mb<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &);
 extern template void launch_mb<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &);
 extern template void launch_mb_edges<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *);
 extern template void launch_mb_edges<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *);
-// start of a chunk: the bytes of the sequence that precede it are the previous chunk's prior + total (still in *ctl: one stream, in
-// order); only the padding rule needs them.  A one-thread kernel, not a host-to-device copy (a copy engine round trip in front of
-// the first kernel)
-void launch_ctl_chain(m2v_enc *e, hipStream_t s, unsigned long long cap, bool first);
+// start of a chunk's stream: the bytes of the sequence that precede it are the previous chunk's prior + total (still in *ctl: one
+// stream, in order); only the padding rule needs them.  No launch and no copy: the chunk's k_frame_scan sets the control word up
+// itself (its ctl_init argument), this only notes how
+void ctl_begin(m2v_enc *e, unsigned long long cap, bool first);
 // neighbour-dependent codes + bit offsets of the slices of frames [f0, f1) of the chunk (one block per slice)
 void launch_slice_scan(m2v_enc *e, hipStream_t s, const Geom &g, int f0, int f1);
 void launch_frame_scan(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, bool advance, uint8_t *d_stream);
@@ -294,7 +299,7 @@ void launch_halo_pack(m2v_enc *e, hipStream_t s, const int *d_list, int count, u
 void launch_halo_unpack(m2v_enc *e, hipStream_t s, const int *d_list, int count, const uint8_t *from_up, const uint8_t *from_down);
 // strip mode, output rank: where every (frame, rank) piece goes + the copy itself, headers and trailer (k_strip_layout, k_strip_assemble)
 void launch_strip_assemble(m2v_enc *e, hipStream_t s, const Geom &g, uint32_t gop, size_t nf, int nranks, const StripSrc &src,
-                           const unsigned long long *d_all_off, uint8_t *d_out);
+                           const unsigned long long *d_all_off, uint8_t *d_out, unsigned long long cap);
 int debug_table(int which, int i, int j);
 
 }  // namespace m2v

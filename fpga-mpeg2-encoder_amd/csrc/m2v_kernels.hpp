@@ -2151,24 +2151,40 @@ __device__ __forceinline__ uint32_t frame_header_bytes(int i_frame)
 
 // One block; thread t owns K consecutive (frame, slice) items, an item = a slice preceded by its frame's
 // headers when it is the first slice of the frame: local sums -> block scan -> offsets.
+// ctl_init: the control word starts here instead of in a kernel of its own (a launch in front of every chunk - and, in strip mode, on the
+// tail of every sequence): 1 = a new stream (nothing precedes this chunk), 2 = this chunk's bytes leave in a buffer of their own but
+// continue the previous chunk's stream (the port path: prior = everything so far, only the final padding rule needs it), 0 = the word is
+// as the previous chunk of this call left it.  ctl_cap: capacity of the output buffer (modes 1, 2).
+// px (strip mode, peer transport; all null / 0 otherwise): a sequence in which some wait ran out of budget is marked in the strip's size
+// table ("encode it again, the ordinary way") where every rank sees it after the all-gather; the give-up word is cleared for the next
+// sequence, and so are the arrival counters of the NEXT sequence's set (nobody touches those before this rank has contributed to this
+// sequence's all-gather, which comes behind this kernel on the stream).
+struct PeerScan { unsigned int *gaveup; unsigned int *clear; int clear_lines; unsigned long long mark; };
+
 __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict__ jobs, Geom g, int nframes, int first, int last,
                                                      const uint32_t *__restrict__ slice_bytes,
                                                      unsigned long long *__restrict__ slice_off,
                                                      unsigned long long *__restrict__ frame_off, StreamCtl *ctl,
-                                                     int advance, uint32_t *__restrict__ out32)
+                                                     int advance, uint32_t *__restrict__ out32, int ctl_init, unsigned long long ctl_cap, PeerScan px)
 {
     __shared__ unsigned long long s_base;
     __shared__ unsigned long long s_wtot[16];
     const int tid = threadIdx.x;
     // requested with everything else: this single workgroup is pure latency, and these were a round trip of their own after the scan
-    const unsigned long long c_prior = ctl->prior_bytes, c_cap = ctl->cap_bytes;
-    const uint32_t c_ov = ctl->overflow;
+    unsigned long long c_prior = 0, c_cap = ctl_cap & ~3ull;
+    uint32_t c_ov = 0;
+    if (ctl_init == 0) { c_prior = ctl->prior_bytes; c_cap = ctl->cap_bytes; c_ov = ctl->overflow; }
+    else if (ctl_init == 2) c_prior = ctl->prior_bytes + ctl->total_bytes;
     if (tid == 0) {
         // advance = this chunk continues the stream of the previous one in the same buffer: base = previous total
-        unsigned long long b = ctl->base_bytes;
-        if (advance && !ctl->overflow) { b = ctl->total_bytes; ctl->base_bytes = b; }
+        unsigned long long b = 0;
+        if (ctl_init == 0) {
+            b = ctl->base_bytes;
+            if (advance && !ctl->overflow) { b = ctl->total_bytes; ctl->base_bytes = b; }
+        }
         s_base = b;
     }
+    for (int i = tid; i < px.clear_lines; i += 1024) px.clear[i * 32] = 0u;        // one counter per 128-byte line
     const int rows = g.row1 - g.row0;
     const int S = nframes * rows;
     const int K = (S + 1023) / 1024;
@@ -2252,6 +2268,11 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict_
     __syncthreads();                                          // every thread has read ctl->overflow / cap before they change
     if (tid == 1023) {
         frame_off[nframes] = all_frames;                      // one past the end (strip mode reads the sizes back)
+        if (px.gaveup) {
+            if (*px.gaveup) frame_off[nframes] = px.mark;
+            *px.gaveup = 0u;
+        }
+        if (ctl_init) { ctl->base_bytes = 0; ctl->cap_bytes = c_cap; ctl->prior_bytes = c_prior; ctl->pad = 0; }
         ctl->total_bytes = total;
         ctl->overflow = ov ? 1u : 0u;
         if (!ov && last && !g.strip)
@@ -2314,10 +2335,10 @@ __global__ void k_halo_unpack(const FrameJob *__restrict__ jobs, const int *__re
 constexpr int kLayoutThreads = 256;
 
 // all_off: [nranks][nframes + 1] byte offsets of every frame inside its rank's strip buffer.  Outputs: segs[f * nranks + r],
-// frame_pos[f] = where frame f's own headers start, ctl->total_bytes / overflow (cap is read from ctl->cap_bytes).
+// frame_pos[f] = where frame f's own headers start, the control word (total_bytes, overflow against `cap`).
 __global__ __launch_bounds__(kLayoutThreads) void k_strip_layout(const unsigned long long *__restrict__ all_off, int nranks, int nframes, uint32_t gop,
                                                                    StripSrc src, CopySeg *__restrict__ segs,
-                                                                   unsigned long long *__restrict__ frame_pos, StreamCtl *ctl)
+                                                                   unsigned long long *__restrict__ frame_pos, StreamCtl *ctl, unsigned long long cap)
 {
     __shared__ unsigned long long s_scan[kLayoutThreads];
     __shared__ unsigned long long s_carry;
@@ -2360,7 +2381,10 @@ __global__ __launch_bounds__(kLayoutThreads) void k_strip_layout(const unsigned 
         frame_pos[nframes] = body;
         ctl->base_bytes = 0;
         ctl->total_bytes = total;
-        ctl->overflow = total > ctl->cap_bytes ? 1u : 0u;
+        ctl->cap_bytes = cap & ~3ull;
+        ctl->prior_bytes = 0;
+        ctl->overflow = total > (cap & ~3ull) ? 1u : 0u;
+        ctl->pad = 0;
     }
 }
 

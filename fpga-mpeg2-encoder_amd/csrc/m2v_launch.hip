@@ -240,33 +240,13 @@ template void launch_mb_edges<true>(m2v_enc *, hipStream_t, const int *, int, co
 template void launch_mb_peer<false>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *, const PeerStep &);
 template void launch_mb_peer<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *, const PeerStep &);
 
-// peer transport: a sequence in which some wait ran out of budget is marked in the strip's size table ("encode it again, the ordinary
-// way"), where every rank sees it after the all-gather - on the device, because the host does not look before that
-__global__ void k_peer_verdict(const unsigned int *gaveup, unsigned long long *frame_off, int nf, unsigned long long mark)
-{
-    if (*gaveup) frame_off[nf] = mark;
-}
 
-void launch_peer_verdict(m2v_enc *e, hipStream_t s, const unsigned int *gaveup, int nf, unsigned long long mark)
-{
-    hipLaunchKernelGGL(k_peer_verdict, dim3(1), dim3(1), 0, s, gaveup, e->d_frame_off.p, nf, mark);
-}
-
-__global__ void k_ctl_chain(StreamCtl *ctl, unsigned long long cap, int first)
-{
-    const unsigned long long prior = first ? 0ull : ctl->prior_bytes + ctl->total_bytes;
-    ctl->base_bytes = 0;
-    ctl->total_bytes = 0;
-    ctl->cap_bytes = cap & ~3ull;
-    ctl->prior_bytes = prior;
-    ctl->overflow = 0;
-    ctl->pad = 0;
-}
-
-void launch_ctl_chain(m2v_enc *e, hipStream_t s, unsigned long long cap, bool first)
+// The control word of a chunk's stream starts inside k_frame_scan (ctl_init): what the next launch_frame_scan on this handle tells it.
+void ctl_begin(m2v_enc *e, unsigned long long cap, bool first)
 {
     e->d_ctl.ensure(1);
-    hipLaunchKernelGGL(k_ctl_chain, dim3(1), dim3(1), 0, s, e->d_ctl.p, cap, first ? 1 : 0);
+    e->ctl_init = first ? 1 : 2;
+    e->ctl_cap = cap;
 }
 
 void launch_slice_scan(m2v_enc *e, hipStream_t s, const Geom &g, int f0, int f1)
@@ -280,8 +260,15 @@ void launch_slice_scan(m2v_enc *e, hipStream_t s, const Geom &g, int f0, int f1)
 // offsets of every frame and slice, stream length, and the tail (end code + padding) cleared
 void launch_frame_scan(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, bool advance, uint8_t *d_stream)
 {
+    PeerScan px{};
+    if (e->scan_peer_gaveup) {
+        px.gaveup = e->scan_peer_gaveup; px.clear = e->scan_peer_clear; px.clear_lines = e->scan_peer_lines; px.mark = e->scan_peer_mark;
+        e->scan_peer_gaveup = nullptr;
+    }
     hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(1024), 0, s, e->d_jobs.p, g, (int)nf, first ? 1 : 0, last ? 1 : 0,
-                       e->d_slice_bytes.p, e->d_slice_off.p, e->d_frame_off.p, e->d_ctl.p, advance ? 1 : 0, (uint32_t *)d_stream);
+                       e->d_slice_bytes.p, e->d_slice_off.p, e->d_frame_off.p, e->d_ctl.p, advance ? 1 : 0, (uint32_t *)d_stream,
+                       e->ctl_init, e->ctl_cap, px);
+    e->ctl_init = 0;
 }
 
 // slices, and with them the headers and the sequence end code
@@ -304,11 +291,11 @@ void launch_halo_unpack(m2v_enc *e, hipStream_t s, const int *d_list, int count,
 }
 
 void launch_strip_assemble(m2v_enc *e, hipStream_t s, const Geom &g, uint32_t gop, size_t nf, int nranks, const StripSrc &src,
-                           const unsigned long long *d_all_off, uint8_t *d_out)
+                           const unsigned long long *d_all_off, uint8_t *d_out, unsigned long long cap)
 {
     const size_t nsegs = nf * (size_t)nranks;
     hipLaunchKernelGGL(k_strip_layout, dim3(1), dim3(kLayoutThreads), 0, s, d_all_off, nranks, (int)nf, gop, src, (CopySeg *)e->d_segs.p,
-                       e->d_frame_pos.p, e->d_ctl.p);
+                       e->d_frame_pos.p, e->d_ctl.p, cap);
     // every segment cut into `split` parts so that the launch has one to two thousand blocks whatever the number of ranks
     const int split = (int)std::max<size_t>(1, std::min<size_t>(32, 2048 / std::max<size_t>(nsegs, 1)));
     const unsigned blocks = (unsigned)(nsegs * (size_t)split + (nf + kCopyThreads - 1) / kCopyThreads + 1);

@@ -124,7 +124,7 @@ void flush_buffered(m2v_enc *e, bool last)
     const size_t cap = nf * ((size_t)g.mbs * 1216 + (size_t)g.mbh * 8 + 64) + 256;
     h.d_out.ensure(cap);
     e->d_ctl.ensure(1);
-    launch_ctl_chain(e, s, (unsigned long long)cap, e->first_chunk);
+    ctl_begin(e, (unsigned long long)cap, e->first_chunk);
     encode_chunk(e, s, h.d_in.p, nf, e->first_chunk, last, e->last_frame_valid_beats, h.d_out.p);
     HIPCHK(hipMemcpyAsync(h.h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(h.ev_ctl, s));

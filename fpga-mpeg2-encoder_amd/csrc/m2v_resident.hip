@@ -38,9 +38,9 @@ static int resident_impl(m2v_enc *e, void *argp)
     for (auto &st : e->stats) st = KStat{};
     const Geom &g = e->g;
     const size_t fb = (size_t)g.ysz * 3;
-    // the control word starts from a one-thread kernel, not from a host-to-device copy (a copy engine round trip in front of the first kernel)
+    // the control word is set up by the first chunk's k_frame_scan (no launch, no copy in front of the first kernel)
     if (!e->st().h_ctl) HIPCHK(hipHostMalloc((void **)&e->st().h_ctl, 2 * sizeof(StreamCtl)));
-    launch_ctl_chain(e, s, (unsigned long long)a->cap, true);
+    ctl_begin(e, (unsigned long long)a->cap, true);
     const size_t chunk = std::max<size_t>(1, e->batch_frames);
     // align chunks to GOP boundaries so every chunk starts with an I frame where possible
     const size_t gop = e->pframes + 1u;

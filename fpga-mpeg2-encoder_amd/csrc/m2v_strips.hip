@@ -31,6 +31,7 @@ static int strip_begin_impl(m2v_enc *e, void *argp)
     e->persist_slot = -1;
     for (auto &st : e->stats) st = KStat{};
     e->strip_stream = a->s ? a->s : e->stream;
+    e->scan_peer_gaveup = nullptr;                          // (left behind by a sequence that failed before its scans: not this one's)
     plan_chunk(e, e->strip_stream, a->d_in, a->n, true, g.ysz / 4);
     e->strip_active = true;
     return M2V_OK;
@@ -139,7 +140,7 @@ static void strip_finish_enqueue(m2v_enc *e, uint8_t *d_strip, size_t cap)
     const size_t nf = e->plan_nf;
     e->chain_ev = nullptr;
     e->d_ctl.ensure(1);
-    launch_ctl_chain(e, s, (unsigned long long)cap, true);
+    ctl_begin(e, (unsigned long long)cap, true);
     finish_chunk(e, s, false, false, d_strip);
     ensure_pinned(e->h_strip, e->h_strip_cap, (nf + 1) * sizeof(unsigned long long) + sizeof(StreamCtl));
     HIPCHK(hipMemcpyAsync(e->h_strip, e->d_frame_off.p, (nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -207,9 +208,8 @@ static void strip_assemble_enqueue(m2v_enc *e, hipStream_t s, const Geom &g, uin
     StripSrc src{};
     for (int r = 0; r < nranks; ++r) src.strip[r] = (const uint8_t *)strips[r];
     e->chain_ev = nullptr;
-    launch_ctl_chain(e, s, (unsigned long long)cap, true);
     Timer t(e, s, 2, (double)nf * g.ysz);
-    launch_strip_assemble(e, s, g, gop, nf, nranks, src, d_all_off, d_out);
+    launch_strip_assemble(e, s, g, gop, nf, nranks, src, d_all_off, d_out, (unsigned long long)cap);
     HIPCHK(hipGetLastError());
     t.stop();
 }
@@ -341,23 +341,12 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
     };
     hipStream_t side = q.world > 1 ? e->side[0] : nullptr;
     if (q.world > 1 && !q.peer) local([&] { HIPCHK(hipEventRecord(e->ev_done, s)); });          // the plan's uploads
-    if (q.peer) {
-        // this sequence's counters were cleared by the previous peer sequence (or by the allocation); clear the NEXT one's - nobody
-        // adds to those before this rank has contributed to this sequence's all-gather, which is behind this memset on the stream -
-        // and this rank's own give-up word
-        PeerState &ps = *q.peer;
-        local([&] {
-            HIPCHK(hipMemsetAsync(ps.block + PeerState::off_cnt((unsigned)((ps.seq + 1) & 1), 0), 0,
-                                  (size_t)std::max(1, halo_frames_of_step(q.nf, q.gop, 0)) * 2 * PeerState::kCntBytes, s));
-            HIPCHK(hipMemsetAsync(ps.gaveup(), 0, sizeof(unsigned int), s));
-        });
-    }
     for (int j = 0; j < q.steps; ++j) {
         const int n_h = halo_frames_of_step(q.nf, q.gop, j);
         const bool xchg = q.world > 1 && n_h > 0 && (q.up || q.down);
         const size_t nbytes = (size_t)n_h * (size_t)(3 * e->VL) * (size_t)q.W;
         if (q.peer) {
-            // ONE launch per frame type for the whole strip; the rows of step j land in the neighbours' buffers of parity j & 1, the
+            // ONE launch per frame type and GOP group for the whole strip; the rows of step j land in the neighbours' buffers of parity j & 1, the
             // neighbours' rows of step j - 1 are read from this rank's buffers of the other parity once the GOP's counter says that
             // every block of the neighbour's row has delivered.  Why two parities are enough: a block stores into a neighbour's
             // buffer (at its GOP's place) only after it has seen that neighbour's count for the GOP's frame of step j - 1 complete,
@@ -371,9 +360,29 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
             k.seen_down = ps.seen(1, set);
             k.gaveup = ps.gaveup();
             k.budget = ps.budget;
+            // The GOPs of the sequence as `plan_groups` independent chains on a stream each (option split_streams, as the whole-frame
+            // entry does): a strip's launch is two and a half rounds of the GPU's wave slots, its start and its drain are a quarter of
+            // its time, and the other chain's launch fills them.  Nothing orders the chains against each other: a GOP's frames depend
+            // on each other only, and so do its arrival counters and its place in the landing buffers.
             local([&] {
-                run_step_peer(e, s, (size_t)j, xchg && q.up ? ps.put(0, par) : nullptr, xchg && q.down ? ps.put(1, par) : nullptr,
-                              q.up ? ps.got(0, par ^ 1u) : nullptr, q.down ? ps.got(1, par ^ 1u) : nullptr, k);
+                const int G = e->profile ? 1 : e->plan_groups;
+                if (j == 0 && G > 1) {
+                    if (!e->ev_fork) HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(e->ev_fork, s));
+                    for (int gk = 1; gk < G; ++gk) {
+                        if (!e->side[gk - 1]) HIPCHK(hipStreamCreateWithFlags(&e->side[gk - 1], hipStreamNonBlocking));
+                        if (!e->ev_join[gk - 1]) HIPCHK(hipEventCreateWithFlags(&e->ev_join[gk - 1], hipEventDisableTiming));
+                        HIPCHK(hipStreamWaitEvent(e->side[gk - 1], e->ev_fork, 0));
+                    }
+                }
+                for (int gk = 0; gk < G; ++gk)
+                    run_step_peer(e, gk == 0 ? s : e->side[gk - 1], (size_t)j, G > 1 ? gk : -1, xchg && q.up ? ps.put(0, par) : nullptr,
+                                  xchg && q.down ? ps.put(1, par) : nullptr, q.up ? ps.got(0, par ^ 1u) : nullptr, q.down ? ps.got(1, par ^ 1u) : nullptr, k);
+                if (j + 1 == q.steps && G > 1)
+                    for (int gk = 1; gk < G; ++gk) {
+                        HIPCHK(hipEventRecord(e->ev_join[gk - 1], e->side[gk - 1]));
+                        HIPCHK(hipStreamWaitEvent(s, e->ev_join[gk - 1], 0));
+                    }
             });
             continue;
         }
@@ -433,13 +442,21 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
     // ---- this strip's slices, their sizes; everybody's sizes ----
     local([&] {
         e->chain_ev = nullptr;
-        launch_ctl_chain(e, s, (unsigned long long)q.strip_cap, true);
+        ctl_begin(e, (unsigned long long)q.strip_cap, true);
+        if (q.peer) {
+            // this strip's k_frame_scan also settles the peer form's accounts (PeerScan): the retry mark, the give-up word, the NEXT
+            // sequence's arrival counters
+            PeerState &ps = *q.peer;
+            e->scan_peer_gaveup = ps.gaveup();
+            e->scan_peer_clear = (unsigned int *)(ps.block + PeerState::off_cnt((unsigned)((ps.seq + 1) & 1), 0));
+            e->scan_peer_lines = 2 * std::max(1, halo_frames_of_step(q.nf, q.gop, 0));
+            e->scan_peer_mark = kStripRetry;
+        }
         finish_chunk(e, s, false, false, e->d_strip_own.p);
         e->frames_total -= q.nf;                            // (host state is the caller's business: a recorded sequence is replayed without this code)
         HIPCHK(hipMemcpyAsync(e->h_strip, e->d_frame_off.p, (q.nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(e->h_strip + (q.nf + 1) * sizeof(unsigned long long), e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
     });
-    if (q.peer) local([&] { launch_peer_verdict(e, s, q.peer->gaveup(), (int)q.nf, kStripRetry); HIPCHK(hipGetLastError()); });
     if (q.world > 1) {
         if (fail) (void)hipMemsetAsync(e->d_frame_off.p, 0xFF, (q.nf + 1) * sizeof(unsigned long long), s);        // the mark
         q.comm->allgather_u64(q.rank, e->d_frame_off.p, e->d_alloff.p, q.nf + 1, s);
@@ -687,6 +704,9 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     break;
     }   // attempt
     if (failed_rank >= 0) {
+        // (a rank that did not get as far as its scans has not cleared the next sequence's arrival counters either: the peer form is
+        // off for this communicator from here on - on every rank, they all read the same table)
+        if (pst) pst->degraded = true;
         (void)hipStreamSynchronize(s);
         collect_timers(e);
         if (fail) { e->set_err("m2v_strip_encode: %s", fail_text.c_str()); return fail; }
