@@ -367,7 +367,7 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
     # RCCL - and for one rank, which has nothing to exchange.  parallel.encode_strips (the Python statement of the same call
     # order, point-to-point ops through torch.distributed) is what the 1-GPU test hook (gloo, shared device) runs, and the
     # agreed fallback should librccl refuse to initialise.
-    loop, comm, why = "native", None, None
+    loop, comm, why, base_comm = "native", None, None, None
     if os.environ.get("M2V_STRIP_LOOP") == "python" or (world > 1 and backend != "nccl"):
         loop, why = "python", "M2V_STRIP_LOOP=python" if os.environ.get("M2V_STRIP_LOOP") == "python" else "backend %s" % backend
     elif world > 1:
@@ -386,6 +386,23 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
             if comm is not None:
                 comm.close()
                 comm = None
+        elif args.transport == "peer":
+            # the peer transport on top of the RCCL communicator (which keeps moving sizes and strips, and the halo if a wait ever runs
+            # out of budget); creating it is collective (the landing blocks' IPC handles are all-gathered through RCCL).  A rank that
+            # cannot - the vote again - leaves every rank on plain RCCL.
+            ok = 1
+            try:
+                peer_comm = M.StripComm.peer(comm, rank, local_rank, halo_bytes=args.gops * 9 * VL // 3 * Ws + 4096)
+            except Exception as ex:  # noqa: BLE001
+                ok, peer_why = 0, "m2v_comm_init_peer: %s" % ex
+            t = torch.tensor([ok], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 1:
+                base_comm, comm = comm, peer_comm
+            else:
+                why = peer_why if not ok else "another rank could not set the peer transport up"
+                if ok:
+                    peer_comm.close()
     torch.cuda.synchronize()
     out = None
     if loop == "native":
@@ -402,6 +419,8 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
         """what this rank was running, for the failure path of ANY rank (stderr: rank 0's stdout carries the JSON line only)"""
         d = {"rank": rank, "ranks_seen": dist.get_world_size() if dist is not None else 1, "strip_loop": loop, "strip_loop_why": why,
              "transport": comm.kind if comm is not None else None, "dist_backend": backend, "device": dev}
+        if base_comm is not None:
+            d["peer"] = comm.peer_stats()
         if loop == "native":
             try:
                 d["strip_graph"] = enc.strip_graph_stats()
@@ -473,6 +492,9 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
                        "baseline": "FPGA Kintex-7 268 MPixels/s (README.md:22)",
                        "strip_loop": loop, "strip_loop_why": why, "dist_backend": backend,
                        "transport": comm.kind if comm is not None else None,
+                       "transport_asked_for": args.transport if world > 1 else None,
+                       "peer": comm.peer_stats() if base_comm is not None else None,
+                       "gop_steps_ran_as": enc.strip_last_form() if loop == "native" else "python loop",
                        "strip_graph": graph_stats,
                        "launched_by": os.environ.get("M2V_BENCH_LAUNCHED_BY", "caller")},
             "roofline": {"bound": "hbm", "kernel": "k_mb<3,true> on rank 0's strip (%d macroblock rows), P-frame launches of one step" % (rows[1] - rows[0]),
@@ -509,9 +531,13 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
             line["rtl_sim"] = rtl_sim_probe()
         print(json.dumps(line))
         sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()                               # nobody frees a landing block a neighbour may still be storing into
     enc.close()
     if comm is not None:
         comm.close()
+    if base_comm is not None:
+        base_comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -653,6 +679,10 @@ def main():
                          "enqueued with m2v_encode_resident_begin and collected with _end when its handle comes round again; 1 = one "
                          "handle, every step a synchronous m2v_encode_resident call (what rounds 1 and 2 timed)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling aid: skip kernel phases (output invalid), see Geom::ablate")
+    ap.add_argument("--transport", choices=["rccl", "peer"], default=os.environ.get("M2V_STRIP_TRANSPORT", "rccl"),
+                    help="--mode strips, N > 1: how the halo rows travel.  rccl (default): ncclSend / ncclRecv per GOP step.  peer: the edge-row "
+                         "kernel stores them straight into the neighbour's landing block (hipIpc-mapped) and counts their arrival - one launch "
+                         "per GOP step, no exchange step; sizes and strips still through RCCL.  Never run between two GPUs yet: opt-in")
     ap.add_argument("--mode", choices=["sequences", "strips"], default="sequences",
                     help="sequences (default): config c3 / c4, one 1920x1152 sequence per GPU, no collective; "
                          "strips: config c5, ONE 2048x2048 sequence cut into macroblock-row strips, RCCL halo exchange")

@@ -94,3 +94,28 @@ def test_terminating_the_launcher_ends_its_ranks(tmp_path):
     p.send_signal(signal.SIGTERM)
     assert p.wait(timeout=60) != 0
     assert not _alive(pid)
+
+
+def test_more_ranks_than_visible_gpus_is_refused_before_anything_starts():
+    """`bench.py --gpus 8` on a node that shows fewer GPUs must not start eight processes that then fight over them: the launcher counts
+    the visible devices WITHOUT touching the HIP runtime (the *_VISIBLE_DEVICES list, else the KFD topology) and says what it found"""
+    r, lines = run(["--gpus", "4", "--steps", "1"], {"HIP_VISIBLE_DEVICES": "0,1"}, timeout=60)
+    assert r.returncode != 0 and not lines
+    assert "--gpus 4 but 2 GPU(s) visible" in r.stderr and "nothing was started" in r.stderr
+
+
+def test_visible_gpus_and_sensors_read_without_the_runtime(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "3,5,6")
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    n = bench.visible_gpus()                       # the KFD topology of this host (no GPU here: 0, or None where /sys/class/kfd is absent)
+    assert n is None or n >= 0
+    s = bench.gpu_sensors(99)
+    assert s is None                               # no such card: nothing invented

@@ -131,3 +131,70 @@ def test_bench_sequences_on_two_gpus():
     assert r.returncode == 0, r.stderr[-3000:]
     d = lines[-1]
     assert d["n_gpus"] == 2 and d["parity_check"]["identical_to_oracle"] is True
+
+
+@need2
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_transport_with_ranks_on_two_devices(world):
+    """The peer transport's first contact with a second GPU: ranks = threads, rank r on GPU r % 2, every landing block in fine-grained
+    memory of its own device, the neighbours' blocks reached through hipDeviceEnablePeerAccess; the edge blocks of one GPU store
+    into the memory of the other (write-through, system scope) and count their arrival there.  Byte-identical to the oracle, three
+    sequences; what the communicator says about waits that ran out of budget is printed (none are expected: every rank has a GPU
+    or at least a stream of its own)."""
+    import threading
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    W, H, pf, n = 256, 256, 4, 15
+    clip = M.synth.clip(W, H, n, clip_index=311, scene_len=6)
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
+    devs = [r % 2 for r in range(world)]
+    d_clips = [torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:%d" % d) for d in range(2)]
+    out = torch.empty(M.parallel.strip_output_bound(n, W, H), dtype=torch.uint8, device="cuda:0")
+    for d in range(2):
+        torch.cuda.synchronize(d)
+    encs = [M.Mpeg2Encoder(7, 7, 3, 2, device=devs[r]) for r in range(world)]
+    base = M.StripComm.local(world)
+    peers, got, errs = [None] * world, [], []
+
+    def work(r):
+        try:
+            peers[r] = M.StripComm.peer(base, r, devs[r])
+            for _ in range(3):
+                o = M.parallel.encode_strips_native(encs[r], peers[r], r, world, d_clips[devs[r]], W // 16, H // 16, pf, out if r == 0 else None)
+                if r == 0:
+                    got.append(o.cpu().numpy().tobytes())
+        except Exception as ex:  # noqa: BLE001
+            errs.append((r, ex))
+    try:
+        th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in th), "a rank is stuck"
+        assert not errs, errs
+        assert got == [want] * 3
+        stats = [p.peer_stats() for p in peers]
+        print("peer transport across two devices:", stats[0])
+        assert all(s == stats[0] for s in stats) and stats[0]["peer_sequences"] >= 1
+    finally:
+        for p in peers:
+            if p is not None:
+                p.close()
+        for e in encs:
+            e.close()
+        base.close()
+
+
+@need2
+def test_bench_strips_on_two_gpus_with_the_peer_transport():
+    """config c5 over two devices, one process per GPU: landing blocks mapped through hipIpc handles (all-gathered over RCCL), the
+    halo rows stored across xGMI by the edge-row kernel itself; sizes and strips through RCCL.  The stream is the oracle's."""
+    r, lines = _bench(["--gpus", "2", "--mode", "strips", "--transport", "peer", "--steps", "3", "--warmup", "1", "--prewarm", "0.2", "--gops", "2"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = lines[-1]
+    assert d["n_gpus"] == 2 and d["config"]["strip_loop"] == "native" and d["config"]["transport"] == "peer+rccl", d["config"]
+    assert d["parity_check"]["identical_to_oracle"] is True
+    print("bench --transport peer on two GPUs:", d["config"]["peer"], d["config"]["gop_steps_ran_as"], d["value"])

@@ -19,12 +19,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_peer_threads(M, d_clip, W, H, pf, VL, world, calls=1, halo_bytes=0, debug=False, before=None):
+def run_peer_threads(M, d_clip, W, H, pf, VL, world, calls=1, halo_bytes=0, debug=False, before=None, Q=2):
     """`world` handles, one host thread each, all on GPU 0, a local communicator underneath and a peer communicator per rank on
     top.  -> (stream bytes of every call, [peer_stats of every rank], [strip_last_form of every rank])"""
     import threading
     import torch
-    encs = [M.Mpeg2Encoder(7, 7, VL, 2, debug=debug) for _ in range(world)]
+    encs = [M.Mpeg2Encoder(7, 7, VL, Q, debug=debug) for _ in range(world)]
     base = M.StripComm.local(world, debug=debug)
     out = torch.empty(M.parallel.strip_output_bound(int(d_clip.shape[0]), W, H), dtype=torch.uint8, device="cuda:0")
     torch.cuda.synchronize()
@@ -194,13 +194,23 @@ def test_one_rank_of_n_alone_peer_equals_the_other_solo_transports():
         assert len(set(res["copy"] + res["peer"])) == 1 and len(res["copy"][0]) > 1000, (world, rank)
 
 
-def test_config_c5_geometry_peer_transport_8_ranks_as_threads():
-    """the real size: 2048x2048, one GOP of 1 I + 8 P, 8 ranks x 16 macroblock rows as threads on one GPU.  Eight ranks' launches on
-    the hardware queues of ONE GPU can keep each other from being scheduled (the waiting blocks of one hold the wave slots another
-    needs): a fallback is legitimate here - the stream has to be the oracle's either way."""
+def test_config_c5_geometry_peer_transport_8_ranks_as_threads(tmp_path):
+    """the real size: 2048x2048, one GOP of 1 I + 8 P (and the first frames of a second one), 8 ranks x 16 macroblock rows as threads
+    on one GPU, in a process that asks for a hardware queue per rank - with the default four, eight ranks' launches wait behind each
+    other's waiting blocks, a wait runs out of budget and the sequence falls back (legitimately: the stream is the oracle's either
+    way, which the second half of this test checks in this process)."""
+    import json
     import torch
     import m2v_load
     from oracle import m2v_oracle_ctypes as orc
+    script = tmp_path / "child.py"
+    script.write_text(PEER_THREADS_CHILD.replace("n = 2 * (pf + 1) + 1", "n = pf + 3"))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    r = subprocess.run([sys.executable, str(script), ROOT, json.dumps([(8, 2048, 2048, 8, 3)])], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])[0]
+    print("c5, 8 ranks as threads, sixteen hardware queues:", res)
+    assert res["identical"] and res["agree"]
     M = m2v_load.load()
     W = H = 2048
     pf, n = 8, 9
@@ -208,7 +218,7 @@ def test_config_c5_geometry_peer_transport_8_ranks_as_threads():
     want = orc.encode(d_clip.cpu().numpy(), 128, 128, pf, 7, 7, 3, 2)
     got, stats, forms = run_peer_threads(M, d_clip, W, H, pf, 3, 8, calls=2)
     assert got == [want, want]
-    print("c5, 8 ranks as threads on one GPU:", stats[0], forms)
+    print("c5, 8 ranks as threads, the process's default queues:", stats[0], forms)
 
 
 def test_a_rank_whose_own_work_fails_with_the_peer_transport():
