@@ -422,28 +422,6 @@ __device__ __forceinline__ void idct_col(const int a[8], int r[8])
     r[7] = (x7 - x1) >> 14;
 }
 
-// 10-way argmin with the RTL's tree tie-breaks (RTL:804-840).  The inputs are wave-uniform, non-negative and < 2^17.
-// Written without booleans: "a < b" is the sign bit of a - b and a selection is a multiply-add, so that the whole tree stays
-// integer arithmetic on the scalar unit (an i1 lives in a lane-mask register pair and turns into v_cndmask + v_readfirstlane
-// as soon as it is needed as a number).
-__device__ __forceinline__ int find_min_in_10_values(const int v[10])
-{
-    auto lt = [](int a, int b) { return (int)((uint32_t)(a - b) >> 31); };      // a < b as 0 / 1
-    auto mn = [](int a, int b) { return a < b ? a : b; };
-    const int wi1 = lt(v[1], v[0]), w01 = mn(v[1], v[0]);
-    const int wi3 = lt(v[3], v[2]), w23 = mn(v[3], v[2]);
-    const int wi5 = lt(v[5], v[4]), w45 = mn(v[5], v[4]);
-    const int wi7 = lt(v[7], v[6]), w67 = mn(v[7], v[6]);
-    const int wi9 = lt(v[9], v[8]), w89 = mn(v[9], v[8]);
-    const int xi23 = lt(w23, w01), x0123 = mn(w23, w01);
-    const int xi67 = lt(w67, w45), x4567 = mn(w67, w45);
-    const int a = wi1 + xi23 * (2 + wi3 - wi1);                  // argmin of 0..3
-    const int b = 4 + wi5 + xi67 * (2 + wi7 - wi5);              // argmin of 4..7
-    const int ab = b + lt(x0123, x4567) * (a - b);
-    const int use89 = (1 - lt(x0123, w89)) & (1 - lt(x4567, w89));   // w89 <= both
-    return sgpr(ab + use89 * (8 + wi9 - ab));
-}
-
 
 // ----------------------------------------------------------------------------------------------
 // VLC helpers shared by k_mb (coefficients) and k_slice_scan / k_assemble (neighbour-dependent codes)
@@ -704,6 +682,30 @@ constexpr int kQuadSearch0 = kQuadsLaneK, kQuadMfma0 = kQuadSearch0 + kQuadsSear
 constexpr int kQuadConst0 = kQuadMfma0 + kQuadsMfma;                 // 1 KB: c_dct32 | c_dct | c_dct_neg | d_cbp_code
 constexpr int kConstDct32 = 0, kConstDct = 256, kConstCbp = 384;     // kConstDct: 8 rows of [8 basis bytes | their 8 negatives]
 constexpr int kConstDcLuma = 512;            // 12 dwords: dct_dc_size_luminance code | length << 16 (read by the SCALAR unit, dc_code_uniform)
+// the half-pel decision's dead candidates (RTL:1757-1760) as ready-made words, read by the SCALAR unit: entry F = no_l | no_r << 1 |
+// no_u << 2 | no_d << 3, five dwords each - one per packed pair of half-pel SAD totals (candidates 0|1, 2|3, 4|5, 6|7, 8|-), bit 12
+// set where the pair's low candidate is dead, bit 28 where its high one is (hp_dead_word below; the host fills the table with it)
+constexpr int kConstHpDead = 576, kHpDeadStride = 20;
+static_assert(kConstHpDead + 16 * kHpDeadStride <= 1024, "inside the constants' KB");
+__host__ __device__ constexpr uint32_t hp_dead_bit(int k, int F)      // is half-pel candidate k = 3 (hy + 1) + (hx + 1) dead under F?
+{
+    return (uint32_t)(((k % 3 == 0) && (F & 1)) || ((k % 3 == 2) && (F & 2)) || ((k / 3 == 0) && (F & 4)) || ((k / 3 == 2) && (F & 8)));
+}
+__host__ __device__ constexpr uint32_t hp_dead_word(int pair, int F)
+{
+    return (hp_dead_bit(2 * pair, F) << 12) | (pair < 4 ? hp_dead_bit(2 * pair + 1, F) << 28 : 0u);
+}
+// The RTL's 10-way argmin (find_min_in_10_values, RTL:804-840) is the minimum of (value, rank): among equal values candidate 8 wins, then
+// 9, then 4, 5, 6, 7, then 0, 1, 2, 3 (the tree compares the pairs with "<", the two halves 0-3 / 4-7 so that 4-7 win a tie, and 8-9 with "<="
+// against both) - proved against the tree over every tie pattern in tests/test_host_logic.py.  kHpRank[k]: the rank of candidate k;
+// kHpRankHy / kHpRankHx: (hy + 1, hx + 1) of the candidate of rank r, two bits each (rank 1 = intra: centre)
+constexpr int kHpRank[10] = {6, 7, 8, 9, 2, 3, 4, 5, 0, 1};
+constexpr uint32_t hp_rank_table(bool y, int r = 0)
+{
+    // candidate of rank r: 8, 9, 4, 5, 6, 7, 0, 1, 2, 3
+    return r == 10 ? 0u : ((uint32_t)((r == 0 ? 8 : r == 1 ? 4 : r < 6 ? r + 2 : r - 6) / (y ? 3 : 1) % 3) << (2 * r)) | hp_rank_table(y, r + 1);
+}
+constexpr uint32_t kHpRankHy = hp_rank_table(true), kHpRankHx = hp_rank_table(false);
 constexpr int kQuadAc0 = kQuadConst0 + 1;                            // d_ac_code2
 constexpr int kQuadsPerBlock = kQuadAc0 + (2 * 2 * 33 * 41 + 1023) / 1024;
 static_assert(kQuadConst0 == 11 && kQuadAc0 == 12, "k_mb's second table base points at quad 12");
@@ -1272,11 +1274,21 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         hp[0] = avg4<CONF>(L0, C0, L1, C1);  hp[1] = avg2x4(C0, C1);  hp[2] = avg4<CONF>(C0, R0, C1, R1);
         hp[3] = avg2x4(L1, C1);          hp[4] = C1;              hp[5] = avg2x4(C1, R1);
         hp[6] = avg4<CONF>(L1, C1, L2, C2);  hp[7] = avg2x4(C1, C2);  hp[8] = avg4<CONF>(C1, R1, C2, R2);
-        int v10[10] = {4096, 4096, 4096, 4096, 0, 4096, 4096, 4096, 4096, 4095};
+        // The decision (RTL:1784-1816): the ten costs as KEYS (cost << 16 | rank) whose minimum IS the RTL's tree with its tie-breaks (kHpRank
+        // above).  A cost that the RTL caps at 4096 ("over", RTL:1784-1785) never wins - the intra cost is at most 4095 - so it is left
+        // as it is, and a dead candidate just gets bit 12 set: five ORs on the packed pairs of totals, from a table word per pair.
+        uint32_t best = 2u;                                     // (search-less debug runs: the centre candidate at cost 0)
         if (!(kDebug && (g.ablate & 2))) {
             // "intra cost" accumulates the absolute deviation from the mean on top of the pixel sum, 16-bit wrap
             // (RTL:1744, 1774-1777, 1791): the pixel sum S (formed in front of the search), then the deviation rides along with the nine SADs
             const uint32_t m = (S >> 8) & 255u;
+            // half-pel candidates that would reach outside the frame or beyond the search range are dead (RTL:1757-1760)
+            // as 0 / 1 integers by sign-bit arithmetic: fx + YR - 1 is negative exactly for fx = -YR, and so on
+            const int no_l = (in_l ^ 1) | (int)((uint32_t)(fx + YR - 1) >> 31), no_r = (in_r ^ 1) | (int)((uint32_t)(YR - 1 - fx) >> 31);
+            const int no_u = (in_u ^ 1) | (int)((uint32_t)(fy + YR - 1) >> 31), no_d = (in_d ^ 1) | (int)((uint32_t)(YR - 1 - fy) >> 31);
+            typedef const __attribute__((address_space(4))) uint32_t *sld;
+            const sld dtab = (sld)(ltab2 - 1024 + kConstHpDead + (uint32_t)sgpr(no_l | (no_r << 1) | (no_u << 2) | (no_d << 3)) * (uint32_t)kHpDeadStride);
+            const uint32_t d0 = dtab[0], d1 = dtab[1], d2 = dtab[2], d3 = dtab[3], d4 = dtab[4];
             // ten sums as five packed pairs (each total <= 65280; v_sad_hi_u8 packs for free), four of them reduced
             // together by wave_sum4
             uint32_t pk[5];
@@ -1285,34 +1297,33 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                 pk[k] = __builtin_amdgcn_sad_hi_u8(cur4, hp[2 * k + 1], __builtin_amdgcn_sad_u8(cur4, hp[2 * k], 0u));
             pk[4] = __builtin_amdgcn_sad_hi_u8(cur4, m * 0x01010101u, __builtin_amdgcn_sad_u8(cur4, hp[8], 0u));
             const int q4 = wave_sum4((int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]);
-            const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane(q4, 15), t23 = (uint32_t)__builtin_amdgcn_readlane(q4, 47);
-            const uint32_t t45 = (uint32_t)__builtin_amdgcn_readlane(q4, 31), t67 = (uint32_t)__builtin_amdgcn_readlane(q4, 63);
+            const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane(q4, 15) | d0, t23 = (uint32_t)__builtin_amdgcn_readlane(q4, 47) | d1;
+            const uint32_t t45 = (uint32_t)__builtin_amdgcn_readlane(q4, 31) | d2, t67 = (uint32_t)__builtin_amdgcn_readlane(q4, 63) | d3;
             const uint32_t t8d = (uint32_t)wave_sum((int)pk[4]);
-            const int tot[9] = {(int)(t01 & 0xFFFFu), (int)(t01 >> 16), (int)(t23 & 0xFFFFu), (int)(t23 >> 16), (int)(t45 & 0xFFFFu),
-                                (int)(t45 >> 16), (int)(t67 & 0xFFFFu), (int)(t67 >> 16), (int)(t8d & 0xFFFFu)};
-            // half-pel candidates that would reach outside the frame or beyond the search range are dead (RTL:1757-1760)
-            // as 0 / 1 integers by sign-bit arithmetic: fx + YR - 1 is negative exactly for fx = -YR, and so on
-            const int no_l = (in_l ^ 1) | (int)((uint32_t)(fx + YR - 1) >> 31), no_r = (in_r ^ 1) | (int)((uint32_t)(YR - 1 - fx) >> 31);
-            const int no_u = (in_u ^ 1) | (int)((uint32_t)(fy + YR - 1) >> 31), no_d = (in_d ^ 1) | (int)((uint32_t)(YR - 1 - fy) >> 31);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int khy = k / 3 - 1, khx = k % 3 - 1;
-                const int dead = (khx < 0 ? no_l : 0) | (khx > 0 ? no_r : 0) | (khy < 0 ? no_u : 0) | (khy > 0 ? no_d : 0);
-                const int t = tot[k] | (dead << 12);                   // totals are < 2^16: a dead candidate reads >= 4096
-                v10[k] = t < 4096 ? t : 4096;                          // {over, diff}: only "over" matters (RTL:1784-1785)
-            }
-            const uint32_t S2 = (S + (t8d >> 16)) & 0xFFFFu;
-            v10[9] = (S2 >> 12) == 0 ? (int)S2 : 0xFFF;
+            // key = cost << 16 | rank: ONE scalar instruction per candidate (s_pack_ll / s_pack_lh take the low / high half of the pair)
+#define M2V_KLO(p, k) ([](uint32_t pp) { uint32_t d; asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(d) : "n"(kHpRank[k]), "s"(pp)); return d; }(p))
+#define M2V_KHI(p, k) ([](uint32_t pp) { uint32_t d; asm("s_pack_lh_b32_b16 %0, %1, %2" : "=s"(d) : "n"(kHpRank[k]), "s"(pp)); return d; }(p))
+            const uint32_t S2 = (S + (t8d >> 16)) & 0xFFFFu;       // the intra cost, capped at 0xFFF (RTL:1791)
+            const uint32_t k9 = M2V_KLO(umin32(S2, 0xFFFu), 9);
+            // (every two-way minimum pinned to the scalar unit: left alone the compiler folds them into v_min3_u32, which only the vector
+            // ALU has, with a v_mov per operand and a v_readfirstlane behind)
+            auto smin = [](uint32_t x, uint32_t y) { return (uint32_t)sgpr((int)umin32(x, y)); };
+            const uint32_t a = smin(smin(M2V_KLO(t01, 0), M2V_KHI(t01, 1)), smin(M2V_KLO(t23, 2), M2V_KHI(t23, 3)));
+            const uint32_t b = smin(smin(M2V_KLO(t45, 4), M2V_KHI(t45, 5)), smin(M2V_KLO(t67, 6), M2V_KHI(t67, 7)));
+            best = smin(smin(a, b), smin(M2V_KLO(t8d | d4, 8), k9));
+#undef M2V_KLO
+#undef M2V_KHI
         }
-        const int idx = find_min_in_10_values(v10);
-        inter = idx != 9;
+        const uint32_t rk = 2u * (best & 15u);                   // twice the winner's rank
+        inter = (int)(rk != 2u);
         int hy = 0, hx = 0;
         if (inter) {
-            hy = idx / 3 - 1; hx = idx % 3 - 1;
+            const int hy1 = (int)((kHpRankHy >> rk) & 3u), hx1 = (int)((kHpRankHx >> rk) & 3u);
+            hy = hy1 - 1; hx = hx1 - 1;
             // the winner is wave-uniform: the register is picked by VGPR index mode (s_set_gpr_idx_on, one v_mov), not by a jump tree
             typedef uint32_t u32x9_t __attribute__((ext_vector_type(9)));
             const u32x9_t hv = {hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8]};
-            pred4 = hv[sgpr(idx)];
+            pred4 = hv[sgpr(2 * hy1 + hy1 + hx1)];
         }
         mvy = 2 * fy + hy;                                      // RTL:1827-1828
         mvx = 2 * fx + hx;

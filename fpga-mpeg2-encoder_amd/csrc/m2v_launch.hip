@@ -118,6 +118,10 @@ void upload_tables_now()
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dct_pn, sizeof dct_pn, cst + kConstDct));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), kCbpCode, sizeof kCbpCode, cst + kConstCbp));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), dcl, sizeof dcl, cst + kConstDcLuma));
+            uint32_t hpd[16][kHpDeadStride / 4];
+            for (int F = 0; F < 16; ++F)
+                for (int pr = 0; pr < kHpDeadStride / 4; ++pr) hpd[F][pr] = hp_dead_word(pr, F);
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), hpd, sizeof hpd, cst + kConstHpDead));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(d_lanetab), ac2, ac2_bytes, blk + (size_t)kQuadAc0 * 64 * 16));
         }
     HIPCHK(hipDeviceSynchronize());         // the copies read stack arrays: complete before they go out of scope

@@ -1,4 +1,6 @@
 """Host-side arithmetic and scheduling facts the HIP kernels rely on (no GPU needed)."""
+import os
+
 import numpy as np
 
 import m2v_load
@@ -125,3 +127,70 @@ def test_inverse_quantisers_never_reach_their_clamps():
             assert x.max() < (1 << 16) and x.max() <= 2047, (w, Q)
             xn = (-prod) << (Q - 3) if Q >= 3 else (-prod) >> (3 - Q)       # negative levels: arithmetic shift floors (RTL:2143)
             assert xn.min() >= -2047
+
+
+def test_keyed_minimum_is_the_rtl_decision_tree():
+    """k_mb's half-pel decision takes the minimum of ten KEYS (cost << 16 | rank) instead of walking find_min_in_10_values' tree
+    (RTL:804-840): the tree compares pairs with "<", the halves 0-3 / 4-7 so that 4-7 win a tie, and 8-9 with "<=" against both - i.e. among
+    equal costs candidate 8 wins, then 9, 4, 5, 6, 7, 0, 1, 2, 3 (csrc/m2v_kernels.hpp kHpRank).  Checked against the tree (the
+    second reading's, tests/rtl_stage_f.py) over EVERY pattern of ties and orders: all 10-tuples over four cost levels (4^10 ~ 1 M),
+    vectorised; plus the two facts the kernel leans on - a cost the RTL caps at 4096 never wins because the intra cost (index 9) is at
+    most 4095, so leaving it uncapped / marking a dead candidate by bit 12 changes nothing - over random costs with caps and dead bits."""
+    import itertools
+    from rtl_stage_f import find_min_in_10_values
+    rank = np.array([6, 7, 8, 9, 2, 3, 4, 5, 0, 1])
+    # the tree, vectorised (same comparisons as rtl_stage_f.find_min_in_10_values; that one is the scalar cross-check below)
+    def tree(v):
+        wi1 = v[:, 1] < v[:, 0]; w01 = np.where(wi1, v[:, 1], v[:, 0])
+        wi3 = v[:, 3] < v[:, 2]; w23 = np.where(wi3, v[:, 3], v[:, 2])
+        wi5 = v[:, 5] < v[:, 4]; w45 = np.where(wi5, v[:, 5], v[:, 4])
+        wi7 = v[:, 7] < v[:, 6]; w67 = np.where(wi7, v[:, 7], v[:, 6])
+        wi9 = v[:, 9] < v[:, 8]; w89 = np.where(wi9, v[:, 9], v[:, 8])
+        xi23 = w23 < w01; x0123 = np.where(xi23, w23, w01)
+        xi67 = w67 < w45; x4567 = np.where(xi67, w67, w45)
+        a = np.where(xi23, 2 + wi3, wi1.astype(np.int64))
+        b = np.where(xi67, 6 + wi7, 4 + wi5)
+        return np.where((w89 <= x0123) & (w89 <= x4567), 8 + wi9, np.where(x0123 < x4567, a, b))
+    def keyed(v):
+        return np.argmin((v.astype(np.int64) << 16) | rank[None, :], axis=1)
+    levels = np.array(list(itertools.product(range(4), repeat=10)), dtype=np.int64)
+    assert np.array_equal(tree(levels), keyed(levels))
+    rng = np.random.default_rng(5)
+    for row in levels[rng.integers(0, len(levels), 300)]:
+        assert find_min_in_10_values(list(row)) == tree(row[None, :])[0]
+    # the kernel's costs: nine totals < 2^16, capped at 4096 by the RTL, dead ones forced to 4096; the intra cost <= 4095
+    tot = rng.integers(0, 1 << 16, size=(400000, 9))
+    tot[:, :] = np.where(rng.random(tot.shape) < 0.5, rng.integers(0, 4200, size=tot.shape), tot)      # plenty of costs around the cap
+    tot[:100000] = rng.integers(4090, 4100, size=(100000, 9))
+    dead = rng.random(tot.shape) < 0.3
+    intra = rng.integers(0, 4096, size=(tot.shape[0], 1))
+    intra[:50000] = 4095
+    rtl = np.concatenate([np.minimum(tot | (dead.astype(np.int64) << 12), 4096), intra], axis=1)
+    mine = np.concatenate([tot | (dead.astype(np.int64) << 12), intra], axis=1)                          # uncapped, dead = bit 12 set
+    assert np.array_equal(tree(rtl), keyed(mine))
+    # (hy + 1, hx + 1) of the candidate of rank r, two bits each: the kernel's decode constants
+    cand_of_rank = [8, 4, 4, 5, 6, 7, 0, 1, 2, 3]                                                        # rank 1 = intra: the centre, unused
+    hy = sum((c // 3) << (2 * r) for r, c in enumerate(cand_of_rank))
+    hx = sum((c % 3) << (2 * r) for r, c in enumerate(cand_of_rank))
+    for k in range(9):
+        r = int(rank[k])
+        assert ((hy >> (2 * r)) & 3, (hx >> (2 * r)) & 3) == (k // 3, k % 3)
+    src = open(os.path.join(os.path.dirname(__file__), "..", "fpga-mpeg2-encoder_amd", "csrc", "m2v_kernels.hpp")).read()
+    assert "kHpRank[10] = {6, 7, 8, 9, 2, 3, 4, 5, 0, 1}" in src
+
+
+def test_half_pel_dead_words_match_the_rtl_rule():
+    """the table word per packed pair of half-pel totals (hp_dead_word, read by the scalar unit): bit 12 / bit 28 set exactly where the
+    pair's low / high candidate reaches outside the frame or beyond the search range (RTL:1757-1760) - rebuilt here from the rule"""
+    for F in range(16):
+        no_l, no_r, no_u, no_d = F & 1, (F >> 1) & 1, (F >> 2) & 1, (F >> 3) & 1
+        dead = []
+        for k in range(9):
+            hy, hx = k // 3 - 1, k % 3 - 1
+            dead.append(int((hx < 0 and no_l) or (hx > 0 and no_r) or (hy < 0 and no_u) or (hy > 0 and no_d)))
+        for pair in range(5):
+            want = (dead[2 * pair] << 12) | ((dead[2 * pair + 1] << 28) if pair < 4 else 0)
+            # hp_dead_bit / hp_dead_word of csrc/m2v_kernels.hpp, restated
+            bit = lambda kk: int(bool(((kk % 3 == 0) and (F & 1)) or ((kk % 3 == 2) and (F & 2)) or ((kk // 3 == 0) and (F & 4)) or ((kk // 3 == 2) and (F & 8))))
+            got = (bit(2 * pair) << 12) | ((bit(2 * pair + 1) << 28) if pair < 4 else 0)
+            assert got == want
