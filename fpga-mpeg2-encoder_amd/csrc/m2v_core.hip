@@ -482,6 +482,7 @@ void m2v_destroy(m2v_enc *e)
     e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
     e->d_jobs.release(); e->d_lists.release(); e->d_joblist.release(); e->d_ctl.release(); e->d_segs.release();
     for (auto p : e->rec_pool) (void)hipFree(p);
+    for (auto &c : e->mbmaps) { if (c.ev) (void)hipEventDestroy(c.ev); c.d.release(); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto &h : e->hs) {
         h.d_out.release();

@@ -147,6 +147,10 @@ struct m2v_enc {
     DevBuf<FrameJob> d_jobs;
     DevBuf<int> d_lists;
     DevBuf<FrameJob> d_joblist;           // the jobs again, in launch-list order (k_mb reads its frame's job with ONE dependent scalar load)
+    // block -> macroblock tables of the k_mb launches (MbMap), one per launch shape seen, built by the launch functions (m2v_launch.hip)
+    struct MbMapKey { int row0, row1, mbw, mbh, cu_pack, mode, rstride, n_edge; };
+    struct MbMapCache { MbMapKey key; DevBuf<MbMap> d; hipStream_t filled_on = nullptr; hipEvent_t ev = nullptr; std::vector<hipStream_t> waited; };
+    std::deque<MbMapCache> mbmaps;
     DevBuf<StreamCtl> d_ctl;
     int ctl_init = 0;                     // how the next k_frame_scan sets the control word up (ctl_begin): 0 leaves it, 1 new stream, 2 continues
     unsigned long long ctl_cap = 0;

@@ -746,7 +746,7 @@ __device__ __forceinline__ void peer_wait(const unsigned int *seen, unsigned int
 }
 
 template <int VL, bool P, bool CONF = false, bool MFMA = false, bool FILL = false, bool EDGE = false, bool PEER = false>
-__global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs, const int *__restrict__ frame_list,
+__global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs, const MbMap *__restrict__ mbmap,
                                            Geom g, uint32_t *__restrict__ mbinfo, MbAux *__restrict__ mbaux,
                                            uint32_t *__restrict__ slots_small, uint32_t *__restrict__ slots,
                                            int16_t *__restrict__ coef_dbg, uint8_t *__restrict__ halo_up = nullptr,
@@ -906,36 +906,20 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     if constexpr (!P && !kMfmaChroma) M2V_REQUEST_BASIS();     // (the matrix-core transform needs none of them)
     // grid = (macroblocks of one frame's share, frames of the launch list): the frame comes from blockIdx.y, no division for it
     const uint32_t li = blockIdx.y;                                            // which frame of the launch list
-    uint32_t local;
-    if constexpr (PEER) {
-        // the edge rows take the launch's first n_edge blocks - they go first in dispatch order, so their rows are on their way to the
-        // neighbours while the rows in between are encoded -, each part with its own XCD-aware permutation
-        local = edge_blk ? xcd_remap(blockIdx.x, ps.n_edge, 0u) : xcd_remap(blockIdx.x - ps.n_edge, gridDim.x - ps.n_edge, (uint32_t)g.cu_pack);
-    } else {
-        local = xcd_remap(blockIdx.x, gridDim.x, EDGE ? 0u : (uint32_t)g.cu_pack);
-    }
+    // block -> macroblock: the host's table for this launch shape (MbMap: the XCD-aware permutation, and for the strip kernels the edge
+    // rows first), one scalar load beside the job's
+    const MbMap me = mbmap[blockIdx.x];
     const FrameJob job = jobs[li];                 // `jobs` = the launch list as jobs: one dependent scalar load, not list -> job
     const int fidx = (int)job.fidx;
-    int mb, by, bx;
-    if (EDGE && edge_blk) {
-        // two local rows: the strip's first macroblock row and, rstride rows below, its last
-        const uint32_t lrow = udiv_magic(local, (uint32_t)g.mbw, g.magic_mbw);
-        bx = (int)(local - lrow * (uint32_t)g.mbw);
-        by = g.row0 + (int)lrow * g.rstride;
-        mb = by * g.mbw + bx;
-    } else {
-        mb = (g.row0 + (PEER ? 1 : 0)) * g.mbw + (int)local;      // (the peer form's other blocks: the rows behind the strip's first)
-        by = (int)udiv_magic((uint32_t)mb, (uint32_t)g.mbw, g.magic_mbw);
-        bx = mb - by * g.mbw;
-    }
+    const int mb = (int)(me.mb & 0xFFFFFFu), by = (int)(me.byx >> 16), bx = (int)(me.byx & 0xFFFFu);
     const int W = g.W;
     const uint32_t tile = (uint32_t)mb + (uint32_t)by;           // by * (mbw + 1) + bx: the reconstruction tile (luma and chroma) whose right half this macroblock fills
     const int r = lane >> 2, c4 = lane & 3;
-    // 1 = the macroblock has a neighbour on that side (left, right, up, down).  Sign-bit arithmetic, not compares: these
+    // 1 = the macroblock has a neighbour on that side (left, right, up, down), from the host's table.  Integers, not compares: these
     // wave-uniform flags feed range limits and candidate masks that must stay on the scalar unit, and a compare that is
     // also needed as a lane mask somewhere gets computed by the vector ALU - with everything downstream of it.
-    const int in_l = sgpr((int)((uint32_t)-bx >> 31)), in_r = sgpr((int)((uint32_t)(bx + 1 - g.mbw) >> 31));
-    const int in_u = sgpr((int)((uint32_t)-by >> 31)), in_d = sgpr((int)((uint32_t)(by + 1 - g.mbh) >> 31));
+    const int in_l = sgpr((int)((me.mb >> 24) & 1u)), in_r = sgpr((int)((me.mb >> 25) & 1u));
+    const int in_u = sgpr((int)((me.mb >> 26) & 1u)), in_d = sgpr((int)((me.mb >> 27) & 1u));
 
     // ---- stages A..E: current macroblock; 4:4:4 -> 4:2:0 with two-stage rounding -------------
     // (RTL:1086-1089 horizontal mean2, RTL:1167-1170 vertical mean2 of the two means)

@@ -130,7 +130,7 @@ void upload_tables_now()
     {
         Geom g0{};
         const dim3 one(1), wave(64);
-#define M2V_FILL(VLV, PV) hipLaunchKernelGGL((k_mb<VLV, PV, false, false, true>), one, wave, 0, 0, (const FrameJob *)nullptr, (const int *)nullptr, g0, \
+#define M2V_FILL(VLV, PV) hipLaunchKernelGGL((k_mb<VLV, PV, false, false, true>), one, wave, 0, 0, (const FrameJob *)nullptr, (const MbMap *)nullptr, g0, \
                                              (uint32_t *)nullptr, (MbAux *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int16_t *)nullptr)
         M2V_FILL(1, false); M2V_FILL(1, true); M2V_FILL(2, false); M2V_FILL(2, true); M2V_FILL(3, false); M2V_FILL(3, true);
 #undef M2V_FILL
@@ -147,6 +147,71 @@ void upload_tables(int device)
     else upload_tables_now();
 }
 
+// Block -> macroblock table of a k_mb launch (MbMap, m2v_types.hpp), filled once per launch shape by a small kernel on the launch's own
+// stream (no host copy: nothing here waits for anything, and another rank's waiting kernels cannot hold it up) and kept with the handle.
+// mode 0: the rows [row0, row1) through xcd_remap (option cu_pack); 1: the strip's two edge rows only (row0 and row0 + rstride; g.row1 -
+// g.row0 = 1 or 2 local rows); 2: the peer form - the edge rows first (the launch's first n_edge blocks), then the rows in between.
+__host__ __device__ inline MbMap mbmap_entry(uint32_t b, uint32_t n, const Geom &g, int mode, uint32_t n_edge)
+{
+    int by, bx, edge = mode == 1;
+    if (mode == 2 && b < n_edge) edge = 1;
+    if (edge) {
+        const uint32_t local = xcd_remap(b, mode == 1 ? n : n_edge, 0u), lrow = local / (uint32_t)g.mbw;
+        bx = (int)(local - lrow * (uint32_t)g.mbw);
+        by = g.row0 + (int)lrow * g.rstride;
+    } else {
+        const uint32_t local = mode == 2 ? xcd_remap(b - n_edge, n - n_edge, (uint32_t)g.cu_pack) : xcd_remap(b, n, (uint32_t)g.cu_pack);
+        const int mb = (g.row0 + (mode == 2 ? 1 : 0)) * g.mbw + (int)local;      // (the peer form's other blocks: the rows behind the strip's first)
+        by = mb / g.mbw;
+        bx = mb - by * g.mbw;
+    }
+    MbMap m;
+    m.mb = (uint32_t)(by * g.mbw + bx) | (bx > 0 ? 1u << 24 : 0u) | (bx + 1 < g.mbw ? 1u << 25 : 0u) | (by > 0 ? 1u << 26 : 0u) |
+           (by + 1 < g.mbh ? 1u << 27 : 0u) | (edge ? 1u << 28 : 0u);
+    m.byx = ((uint32_t)by << 16) | (uint32_t)bx;
+    return m;
+}
+
+__global__ void k_mbmap_fill(MbMap *out, uint32_t n, Geom g, int mode, uint32_t n_edge)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n) out[b] = mbmap_entry(b, n, g, mode, n_edge);
+}
+
+static const MbMap *mbmap_for(m2v_enc *e, hipStream_t s, const Geom &g, int mode, int n_edge = 0)
+{
+    const m2v_enc::MbMapKey key{g.row0, g.row1, g.mbw, g.mbh, mode == 1 ? 0 : g.cu_pack, mode, g.rstride, n_edge};
+    for (auto &c : e->mbmaps)
+        if (!memcmp(&c.key, &key, sizeof key)) {
+            // a table filled on ANOTHER stream of the handle (the GOP groups run on a stream each): this stream waits for the fill once
+            if (c.filled_on != s && std::find(c.waited.begin(), c.waited.end(), s) == c.waited.end()) {
+                HIPCHK(hipStreamWaitEvent(s, c.ev, 0));
+                c.waited.push_back(s);
+            }
+            return c.d.p;
+        }
+    const uint32_t n = (uint32_t)((g.row1 - g.row0) * g.mbw);
+    if (e->mbmaps.size() >= 24) {                           // (a recorded graph that still points at it is invalidated by the release: alloc_generation)
+        (void)hipStreamSynchronize(e->mbmaps.front().filled_on);
+        if (e->mbmaps.front().ev) (void)hipEventDestroy(e->mbmaps.front().ev);
+        e->mbmaps.front().d.release();
+        e->mbmaps.pop_front();
+    }
+    e->mbmaps.emplace_back();
+    auto &c = e->mbmaps.back();
+    c.key = key;
+    c.d.ensure(n);
+    Geom gg = g;
+    if (mode == 1) gg.cu_pack = 0;
+    hipLaunchKernelGGL(k_mbmap_fill, dim3((n + 255) / 256), dim3(256), 0, s, c.d.p, n, gg, mode, (uint32_t)n_edge);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c.ev, s));
+    c.filled_on = s;
+    e->chain_ev = nullptr;
+    return c.d.p;
+}
+
 // strip mode, m2v_strip_encode: the strip's first and last macroblock row in ONE launch of the EDGE instantiation, which also
 // writes their outer rows of the reconstruction into the halo buffers (no pack kernel).  gg: row0 = first row, rstride = distance
 // to the last one, row1 - row0 = 1 or 2 local rows.
@@ -156,11 +221,12 @@ void launch_mb_edges(m2v_enc *e, hipStream_t s, const int *d_list, int count, co
 {
     if (count <= 0) return;
     const dim3 grid((unsigned)((g.row1 - g.row0) * g.mbw), (unsigned)count), block(64);
+    const MbMap *const mm = mbmap_for(e, s, g, 1);
     Timer t(e, s, P ? 0 : 1, (double)count * (g.row1 - g.row0) * g.mbw * 256.0);
     int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
     const FrameJob *const jl = e->d_joblist.p + (d_list - e->d_lists.p);
 #define M2V_LAUNCH_EDGE(VLV) \
-    hipLaunchKernelGGL((k_mb<VLV, P, false, true, false, true>), grid, block, 0, s, jl, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
+    hipLaunchKernelGGL((k_mb<VLV, P, false, true, false, true>), grid, block, 0, s, jl, mm, g, e->d_mbinfo.p, e->d_mbaux.p, \
                        e->d_slots_small.p, e->d_slots.p, dbg, up, down, nb_up, nb_down)
     switch (e->VL) {
         case 1: M2V_LAUNCH_EDGE(1); break;
@@ -182,10 +248,11 @@ void launch_mb_peer(m2v_enc *e, hipStream_t s, const int *d_list, int count, con
 {
     if (count <= 0) return;
     const dim3 grid((unsigned)((g.row1 - g.row0) * g.mbw), (unsigned)count), block(64);
+    const MbMap *const mm = mbmap_for(e, s, g, 2, (int)ps.n_edge);
     Timer t(e, s, P ? 0 : 1, (double)count * (g.row1 - g.row0) * g.mbw * 256.0);
     const FrameJob *const jl = e->d_joblist.p + (d_list - e->d_lists.p);
 #define M2V_LAUNCH_PEER(VLV) \
-    hipLaunchKernelGGL((k_mb<VLV, P, false, true, false, true, true>), grid, block, 0, s, jl, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
+    hipLaunchKernelGGL((k_mb<VLV, P, false, true, false, true, true>), grid, block, 0, s, jl, mm, g, e->d_mbinfo.p, e->d_mbaux.p, \
                        e->d_slots_small.p, e->d_slots.p, (int16_t *)nullptr, put_up, put_down, got_up, got_down, ps)
     switch (e->VL) {
         case 1: M2V_LAUNCH_PEER(1); break;
@@ -202,16 +269,17 @@ void launch_mb(m2v_enc *e, hipStream_t s, const int *d_list, int count, const Ge
 {
     if (count <= 0) return;
     const dim3 grid((unsigned)((g.row1 - g.row0) * g.mbw), (unsigned)count), block(64);      // one wavefront per macroblock; y = frame of the launch list
+    const MbMap *const mm = mbmap_for(e, s, g, 0);
     Timer t(e, s, P ? 0 : 1, (double)count * g.ysz);
     int16_t *dbg = e->keep_recon ? e->d_coef.p : nullptr;
     const FrameJob *const jl = e->d_joblist.p + (d_list - e->d_lists.p);      // the same launch list, as jobs
 #define M2V_LAUNCH_MB(VLV, PV, CV) \
     do { \
         if (e->dct_mfma && !(CV)) \
-            hipLaunchKernelGGL((k_mb<VLV, PV, false, true>), grid, block, 0, s, jl, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
+            hipLaunchKernelGGL((k_mb<VLV, PV, false, true>), grid, block, 0, s, jl, mm, g, e->d_mbinfo.p, e->d_mbaux.p, \
                                e->d_slots_small.p, e->d_slots.p, dbg); \
         else \
-            hipLaunchKernelGGL((k_mb<VLV, PV, CV, false>), grid, block, 0, s, jl, d_list, g, e->d_mbinfo.p, e->d_mbaux.p, \
+            hipLaunchKernelGGL((k_mb<VLV, PV, CV, false>), grid, block, 0, s, jl, mm, g, e->d_mbinfo.p, e->d_mbaux.p, \
                                e->d_slots_small.p, e->d_slots.p, dbg); \
     } while (0)
     if (P) {

@@ -636,6 +636,9 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         sg.launches++;
     } else {
         strip_enqueue_sequence(e, s, q, false, fail, fail_text, e->profile && !q.peer ? &marks : nullptr, &us_in_comm);
+        // what this call allocated on the way (the launches' block tables on a shape's first call) belongs to the shape that was seen:
+        // the next call of it finds everything in place and records
+        if (graph_ok && !fail && !sg.seen.empty()) sg.seen[0] = alloc_generation().load();
     }
     // host state the sequence leaves behind, recorded or not
     if (e->strip_active) {

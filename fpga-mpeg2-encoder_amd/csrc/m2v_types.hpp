@@ -51,6 +51,16 @@ inline void geom_finish(Geom &g)
     g.magic_mbw = g.mbw > 1 ? (uint32_t)(0x100000000ull / (uint32_t)g.mbw) : 0xFFFFFFFFu;
 }
 
+// Which macroblock a block of a k_mb launch works on, worked out by the HOST once per launch shape (m2v_launch.hip, mbmap_for) and read
+// with one scalar load: the XCD / CU permutation (xcd_remap), the row / column split and the neighbour flags were ~60 scalar
+// instructions at the head of every macroblock, on a scalar unit that four SIMDs share and that is as busy as the vector ALUs
+// (profiles/r04_experiments.txt item 19).
+struct MbMap {
+    uint32_t mb;            // bits 0-23: macroblock index by * mbw + bx; bit 24 / 25 / 26 / 27: it has a neighbour on the left / right / above / below
+                            // (inside the FRAME); bit 28: the block is one of the strip's edge rows (k_mb<.., EDGE>)
+    uint32_t byx;           // by << 16 | bx
+};
+
 struct FrameJob {           // one per frame of the chunk (device memory)
     const uint8_t *in;      // 4:4:4 planar frame: Y, U, V planes of W*H bytes
     const uint8_t *ref;     // reconstruction of the previous frame (4:2:0 planar) or nullptr

@@ -109,7 +109,7 @@ def test_peer_transport_many_ranks_with_a_hardware_queue_each(tmp_path):
     import json
     script = tmp_path / "child.py"
     script.write_text(PEER_THREADS_CHILD)
-    cases = [(4, 64, 64, 3, 3), (8, 64, 128, 2, 3), (8, 256, 256, 4, 3)]
+    cases = [(2, 256, 256, 4, 3), (4, 64, 64, 3, 3), (8, 64, 128, 2, 3), (8, 256, 256, 4, 3)]
     env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
     r = subprocess.run([sys.executable, str(script), ROOT, json.dumps(cases)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -117,22 +117,8 @@ def test_peer_transport_many_ranks_with_a_hardware_queue_each(tmp_path):
     for c in res:
         print("peer transport, sixteen hardware queues:", c)
         assert c["identical"] and c["agree"], c
-
-
-def test_peer_transport_two_ranks_really_run_the_peer_form():
-    """two ranks on two streams of one process: the launches run side by side, no wait gives up, all three sequences in the peer form"""
-    import torch
-    import m2v_load
-    from oracle import m2v_oracle_ctypes as orc
-    M = m2v_load.load()
-    W, H, pf, n = 256, 256, 4, 15
-    clip = M.synth.clip(W, H, n, clip_index=310, scene_len=6)
-    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
-    d_clip = torch.from_numpy(np.ascontiguousarray(clip)).to("cuda:0")
-    got, stats, forms = run_peer_threads(M, d_clip, W, H, pf, 3, 2, calls=3)
-    assert all(g == want for g in got)
-    assert stats[0] == {"peer_sequences": 3, "giveups": 0, "fell_back": False} and stats[0] == stats[1], stats
-    assert forms == ["peer", "peer"]
+    # two ranks (four streams) in a fresh process with sixteen queues: every sequence really ran in the peer form, no wait gave up
+    assert res[0]["stats"] == {"peer_sequences": 3, "giveups": 0, "fell_back": False} and res[0]["forms"] == ["peer", "peer"], res[0]
 
 
 def test_a_wait_out_of_budget_falls_back_to_the_base_communicator():
