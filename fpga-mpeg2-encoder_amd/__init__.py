@@ -36,7 +36,7 @@ EXPORTS = [
     "m2v_comm_unique_id", "m2v_comm_init_rccl", "m2v_comm_init_local", "m2v_comm_init_solo", "m2v_comm_destroy", "m2v_comm_last_error", "m2v_comm_selftest",
     "m2v_comm_init_solo_rccl", "m2v_comm_selftest_captured", "m2v_strip_graph_stats",
     "m2v_comm_init_callbacks", "m2v_comm_init_peer", "m2v_comm_peer_export", "m2v_comm_peer_connect", "m2v_comm_peer_connect_all",
-    "m2v_comm_peer_stats", "m2v_comm_kind", "m2v_strip_last_form",
+    "m2v_comm_peer_stats", "m2v_comm_kind", "m2v_strip_last_form", "m2v_upload_wait",
 ]
 
 PEER_DESC_BYTES = 128          # M2V_PEER_DESC_BYTES
@@ -137,6 +137,7 @@ def lib(debug=False):
             L.m2v_comm_kind.restype = ctypes.c_char_p
             L.m2v_comm_kind.argtypes = [vp]
             L.m2v_strip_last_form.argtypes = [vp]
+            L.m2v_upload_wait.argtypes = [vp]
         except AttributeError:
             # an OLDER build handed in through M2V_LIB for a same-box A/B (tools/ab.sh) may lack the newer entry points; the library of
             # this tree must have every one of them (tests/test_abi.py)
@@ -219,6 +220,10 @@ class Mpeg2Encoder:
         self._chk(self._L.m2v_push_frames(self._h, xsize16, ysize16, pframes_count, f.ctypes.data,
                                           f.size // (3 * W * H)), "m2v_push_frames")
 
+    def upload_wait(self):
+        """option direct_upload = 2: returns when every frame handed to push_frames so far has been read"""
+        self._chk(self._L.m2v_upload_wait(self._h), "m2v_upload_wait")
+
     def sequence_stop(self):
         self._chk(self._L.m2v_sequence_stop(self._h), "m2v_sequence_stop")
 
@@ -228,10 +233,21 @@ class Mpeg2Encoder:
 
     def pull(self, max_bytes=1 << 20):
         """-> (bytes, last)"""
-        buf = np.empty(max_bytes & ~31, np.uint8)
+        # one buffer per handle, kept: a fresh 16 MB numpy array per call is a fresh mapping whose pages fault in one by one
+        buf = getattr(self, "_pullbuf", None)
+        if buf is None or buf.size < (max_bytes & ~31):
+            buf = self._pullbuf = np.empty(max_bytes & ~31, np.uint8)
         last = ctypes.c_int(0)
-        n = self._chk(self._L.m2v_pull(self._h, buf.ctypes.data, buf.size, ctypes.byref(last)), "m2v_pull")
+        n = self._chk(self._L.m2v_pull(self._h, buf.ctypes.data, max_bytes & ~31, ctypes.byref(last)), "m2v_pull")
         return buf[:n].tobytes(), bool(last.value)
+
+    def pull_into(self, dst, offset=0):
+        """m2v_pull straight into the caller's uint8 array (from `offset` on, whole 32-byte words): -> (bytes written, last).  What a
+        C caller does: no intermediate object."""
+        assert dst.dtype == np.uint8 and dst.flags["C_CONTIGUOUS"]
+        last = ctypes.c_int(0)
+        n = self._chk(self._L.m2v_pull(self._h, dst.ctypes.data + offset, (dst.size - offset) & ~31, ctypes.byref(last)), "m2v_pull")
+        return n, bool(last.value)
 
     def pull_all(self):
         out = []

@@ -246,13 +246,14 @@ void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, b
     if (!on_device) {
         memcpy(e->st().h_jobs, jobs.data(), nf * sizeof(FrameJob));
         memcpy(e->st().h_lists, lists.data(), lists.size() * sizeof(int));
-        HIPCHK(hipMemcpyAsync(e->d_jobs.p, e->st().h_jobs, nf * sizeof(FrameJob), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(e->d_lists.p, e->st().h_lists, lists.size() * sizeof(int), hipMemcpyHostToDevice, s));
         for (size_t i = 0; i < lists.size(); ++i) {
             e->st().h_joblist[i] = jobs[(size_t)lists[i]];
             e->st().h_joblist[i].fidx = (uint32_t)lists[i];
         }
-        HIPCHK(hipMemcpyAsync(e->d_joblist.p, e->st().h_joblist, lists.size() * sizeof(FrameJob), hipMemcpyHostToDevice, s));
+        // The plan goes up through ONE small kernel that reads the pinned staging itself (host memory is mapped into the device's
+        // address space), not through three copy-engine transfers: on the port path those queue on the engine behind the NEXT chunk's
+        // frames - a millisecond of upload - before this chunk's first kernel can start.
+        launch_plan_upload(e, s, e->st().h_jobs, nf, e->st().h_lists, e->st().h_joblist, lists.size());
         e->dev_jobs = jobs;
         e->dev_lists = lists;
         e->dev_jobs_p = e->d_jobs.p; e->dev_lists_p = e->d_lists.p; e->dev_joblist_p = e->d_joblist.p;
@@ -476,6 +477,7 @@ void m2v_destroy(m2v_enc *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
     if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
+    if (e->up_stream2) (void)hipStreamSynchronize(e->up_stream2);
     for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
     (void)hipGetLastError();            // (a caller's stream that no longer exists: tolerated above, and not left behind as HIP's last error)
     e->d_coef.release(); e->d_mbaux.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
@@ -508,12 +510,15 @@ void m2v_destroy(m2v_enc *e)
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     e->d_frame_pos.release(); e->d_alloff.release(); e->d_halo.release(); e->d_strip_own.release(); e->d_gather.release();
     if (e->strip_graph.exec) (void)hipGraphExecDestroy(e->strip_graph.exec);
+    for (auto ev : e->ev_upl) if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_up2) (void)hipEventDestroy(e->ev_up2);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     for (auto ev : e->ev_join) if (ev) (void)hipEventDestroy(ev);
     for (auto sd : e->side) if (sd) (void)hipStreamDestroy(sd);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->up_stream) (void)hipStreamDestroy(e->up_stream);
+    if (e->up_stream2) (void)hipStreamDestroy(e->up_stream2);
     delete e;
 }
 
@@ -526,6 +531,7 @@ int m2v_reset(m2v_enc *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
     if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
+    if (e->up_stream2) (void)hipStreamSynchronize(e->up_stream2);
     for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
     if (e->strip_stream && e->strip_stream != e->stream) (void)hipStreamSynchronize(e->strip_stream);
     (void)hipGetLastError();            // (a caller's stream that no longer exists: the next launch must not trip over this)
@@ -546,6 +552,7 @@ int m2v_reset(m2v_enc *e)
     e->plan_nf = 0;
     e->ctl_init = 0;
     e->scan_peer_gaveup = nullptr;
+    e->upl_pending[0] = e->upl_pending[1] = false;
     e->g.row0 = 0; e->g.row1 = e->g.mbh; e->g.strip = 0;
     geom_finish(e->g);
     e->timed.clear(); e->ev_used = 0; e->chain_ev = nullptr;
@@ -609,7 +616,14 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
         return M2V_OK;
     }
     if (!strcmp(name, "cu_pack")) { if (value < 0 || value > 8) return M2V_E_PARAM; e->cu_pack = (int)value; return M2V_OK; }
-    if (!strcmp(name, "direct_upload")) { e->direct_upload = value != 0; return M2V_OK; }
+    if (!strcmp(name, "direct_upload")) {
+        if (value < 0 || value > 2) return M2V_E_PARAM;
+        if (e->up_stream && (e->upl_pending[0] || e->upl_pending[1])) { (void)hipStreamSynchronize(e->up_stream); if (e->up_stream2) (void)hipStreamSynchronize(e->up_stream2); }
+        e->upl_pending[0] = e->upl_pending[1] = false;
+        e->direct_upload = value != 0;
+        e->direct_upload_deferred = value == 2;
+        return M2V_OK;
+    }
     if (!strcmp(name, "copy_threads")) { if (value < 1 || value > 64) return M2V_E_PARAM; e->copy_threads = (int)value; return M2V_OK; }
     if (kDebug) {       // libm2v_mi355x_dbg.so only (-DM2V_DEBUG): the shipped library does not know these names
         if (!strcmp(name, "keep_recon")) { e->keep_recon = value != 0; return M2V_OK; }

@@ -121,11 +121,16 @@ struct m2v_enc {
     bool conformant = false;      // option "conformant": ISO reconstruction loop instead of the RTL's (NOT byte-identical to the reference)
     int copy_threads = 8;         // option "copy_threads": threads that copy m2v_push_frames input into pinned memory
     bool direct_upload = true;    // option "direct_upload": page-locked caller memory is uploaded without the staging copy
+    bool direct_upload_deferred = false;   // ... = 2: and m2v_push_frames returns while its frames are still being read (see include/m2v_mi355x.h)
+    hipEvent_t ev_upl[2] = {nullptr, nullptr}, ev_up2 = nullptr;
+    bool upl_pending[2] = {false, false};
+    int up_parity = 0;
     int split_streams = 2;        // GOP segments of a chunk run as this many independent groups on as many streams (encode_chunk)
     static constexpr int kMaxSplit = 8;
     hipStream_t side[kMaxSplit - 1] = {};            // group 0 runs on the caller's stream
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSplit - 1] = {};
     hipStream_t up_stream = nullptr;     // host -> device uploads of the port path
+    hipStream_t up_stream2 = nullptr;    // ... the second one of option direct_upload = 2
     bool async = true;            // option "async": 0 = every chunk is completed before m2v_push_* returns
     hipStream_t copy_stream = nullptr;   // stream read-back, concurrent with the next chunk's kernels
     size_t buffered = 0;          // complete frames waiting in st().h_in
@@ -295,6 +300,7 @@ extern template void launch_mb_edges<true>(m2v_enc *, hipStream_t, const int *, 
 // stream, in order); only the padding rule needs them.  No launch and no copy: the chunk's k_frame_scan sets the control word up
 // itself (its ctl_init argument), this only notes how
 void ctl_begin(m2v_enc *e, unsigned long long cap, bool first);
+void launch_plan_upload(m2v_enc *e, hipStream_t s, const FrameJob *h_jobs, size_t nf, const int *h_lists, const FrameJob *h_joblist, size_t nlist);
 // neighbour-dependent codes + bit offsets of the slices of frames [f0, f1) of the chunk (one block per slice)
 void launch_slice_scan(m2v_enc *e, hipStream_t s, const Geom &g, int f0, int f1);
 void launch_frame_scan(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, bool advance, uint8_t *d_stream);

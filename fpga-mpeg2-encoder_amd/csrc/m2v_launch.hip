@@ -313,6 +313,27 @@ template void launch_mb_peer<false>(m2v_enc *, hipStream_t, const int *, int, co
 template void launch_mb_peer<true>(m2v_enc *, hipStream_t, const int *, int, const Geom &, uint8_t *, uint8_t *, const uint8_t *, const uint8_t *, const PeerStep &);
 
 
+// the chunk's plan from pinned host memory (read by the kernel itself, over PCIe) into the device arrays the kernels index
+__global__ __launch_bounds__(256) void k_plan_upload(uint32_t *__restrict__ d_jobs, const uint32_t *__restrict__ h_jobs, uint32_t n_jobs,
+                                                     uint32_t *__restrict__ d_lists, const uint32_t *__restrict__ h_lists, uint32_t n_lists,
+                                                     uint32_t *__restrict__ d_joblist, const uint32_t *__restrict__ h_joblist, uint32_t n_joblist)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint32_t k = i; k < n_jobs; k += stride) d_jobs[k] = h_jobs[k];
+    for (uint32_t k = i; k < n_lists; k += stride) d_lists[k] = h_lists[k];
+    for (uint32_t k = i; k < n_joblist; k += stride) d_joblist[k] = h_joblist[k];
+}
+
+void launch_plan_upload(m2v_enc *e, hipStream_t s, const FrameJob *h_jobs, size_t nf, const int *h_lists, const FrameJob *h_joblist, size_t nlist)
+{
+    static_assert(sizeof(FrameJob) % 4 == 0, "copied as dwords");
+    const uint32_t n1 = (uint32_t)(nf * sizeof(FrameJob) / 4), n2 = (uint32_t)nlist, n3 = (uint32_t)(nlist * sizeof(FrameJob) / 4);
+    const uint32_t blocks = std::min<uint32_t>(64u, (std::max(n1, n3) + 255u) / 256u);
+    hipLaunchKernelGGL(k_plan_upload, dim3(std::max(1u, blocks)), dim3(256), 0, s, (uint32_t *)e->d_jobs.p, (const uint32_t *)h_jobs, n1,
+                       (uint32_t *)e->d_lists.p, (const uint32_t *)h_lists, n2, (uint32_t *)e->d_joblist.p, (const uint32_t *)h_joblist, n3);
+    HIPCHK(hipGetLastError());
+}
+
 // The control word of a chunk's stream starts inside k_frame_scan (ctl_init): what the next launch_frame_scan on this handle tells it.
 void ctl_begin(m2v_enc *e, unsigned long long cap, bool first)
 {

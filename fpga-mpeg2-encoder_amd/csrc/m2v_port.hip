@@ -59,7 +59,11 @@ bool event_reached(hipEvent_t ev, bool block)
 
 // Move submitted chunks forward, oldest first.  block = wait for every step; until >= 0 = return as soon
 // as that stage is free again.
-void progress(m2v_enc *e, bool block, int until = -1)
+// m2v_pull's destination while it moves chunks forward: a completed chunk's whole 32-byte words go straight from the pinned read-back
+// buffer to the caller when nothing is waiting in the FIFO in front of them (one copy instead of two); the residue takes the FIFO
+struct PullSink { uint8_t *dst; size_t cap, used; };
+
+void progress(m2v_enc *e, bool block, int until = -1, PullSink *sink = nullptr)
 {
     while (!e->pending.empty()) {
         const int idx = e->pending.front();
@@ -81,7 +85,13 @@ void progress(m2v_enc *e, bool block, int until = -1)
             h.stage = 2;
         }
         if (!event_reached(h.ev_out, block)) return;
-        e->fifo.insert(e->fifo.end(), h.h_out, h.h_out + h.bytes);
+        size_t direct = 0;
+        if (sink && e->fifo_rd == e->fifo.size() && sink->cap - sink->used >= 32) {
+            direct = std::min(h.bytes, sink->cap - sink->used) & ~(size_t)31;
+            memcpy(sink->dst + sink->used, h.h_out, direct);
+            sink->used += direct;
+        }
+        e->fifo.insert(e->fifo.end(), h.h_out + direct, h.h_out + h.bytes);
         e->stream_bytes += h.bytes;
         if (h.last) e->end_pending = true;
         h.stage = 0;
@@ -307,7 +317,24 @@ static int push_frames_impl(m2v_enc *e, void *argp)
             if (h.uploaded < e->buffered)           // frames staged on the host earlier in this chunk go first
                 HIPCHK(hipMemcpyAsync(h.d_in.p + h.uploaded * fb, h.h_in + h.uploaded * fb, (e->buffered - h.uploaded) * fb,
                                       hipMemcpyHostToDevice, e->up_stream));
-            HIPCHK(hipMemcpyAsync(h.d_in.p + e->buffered * fb, a->frames + k * fb, take * fb, hipMemcpyHostToDevice, e->up_stream));
+            // (deferred completion: the calls' transfers alternate between two upload streams - the copy engine sets the next one up while
+            // the running one drains, which one in-order stream does not allow; measured: one stream 47.6 GB/s, no better than blocking)
+            hipStream_t ups = e->up_stream;
+            if (e->direct_upload_deferred && e->up_parity) {
+                // (which copy engine a stream's transfers run on is the runtime's choice: the two streams overlap each other's set-up when
+                // they are dealt different engines - 53 GB/s from one caller in a fresh process, 93 % of the plain copy - and behave like
+                // one stream when they are not - 49 GB/s, seen in bench.py's process with its dozen streams; a stream of another
+                // PRIORITY, which never shares a hardware queue, did not change that)
+                if (!e->up_stream2) HIPCHK(hipStreamCreateWithFlags(&e->up_stream2, hipStreamNonBlocking));
+                ups = e->up_stream2;
+            }
+            HIPCHK(hipMemcpyAsync(h.d_in.p + e->buffered * fb, a->frames + k * fb, take * fb, hipMemcpyHostToDevice, ups));
+            if (ups != e->up_stream) {
+                // the chunk's kernels (enqueued on the handle's stream by flush_buffered, possibly a few lines below) come behind these frames
+                if (!e->ev_up2) HIPCHK(hipEventCreateWithFlags(&e->ev_up2, hipEventDisableTiming));
+                HIPCHK(hipEventRecord(e->ev_up2, ups));
+                HIPCHK(hipStreamWaitEvent(e->stream, e->ev_up2, 0));
+            }
             h.uploaded = e->buffered + take;
             direct_pending = true;
         } else {
@@ -317,7 +344,22 @@ static int push_frames_impl(m2v_enc *e, void *argp)
         k += take;
         if (e->buffered == e->batch_frames) flush_buffered(e, false);
     }
-    if (direct_pending) HIPCHK(hipStreamSynchronize(e->up_stream));     // the caller may reuse its buffer when this returns
+    if (direct_pending) {
+        if (e->direct_upload_deferred) {
+            // option direct_upload = 2: this call's frames are still being read when it returns; what is waited for here is the
+            // PREVIOUS call's upload (its frames are free from now on).  The copy engine then always has the next transfer queued
+            // behind the one it is working on: no idle link between two pushes of one caller.
+            const int k = e->up_parity;
+            if (!e->ev_upl[k]) HIPCHK(hipEventCreateWithFlags(&e->ev_upl[k], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(e->ev_upl[k], k && e->up_stream2 ? e->up_stream2 : e->up_stream));
+            if (e->upl_pending[k ^ 1]) { HIPCHK(hipEventSynchronize(e->ev_upl[k ^ 1])); e->upl_pending[k ^ 1] = false; }
+            e->upl_pending[k] = true;
+            e->up_parity ^= 1;
+        } else {
+            HIPCHK(hipStreamSynchronize(e->up_stream));     // the caller may reuse its buffer when this returns
+            e->upl_pending[0] = e->upl_pending[1] = false;
+        }
+    }
     progress(e, false);
     return M2V_OK;
 }
@@ -330,8 +372,26 @@ int m2v_push_frames(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pfr
     return guard(e, push_frames_impl, &a);
 }
 
+static int upload_wait_impl(m2v_enc *e, void *)
+{
+    if (e->up_stream && (e->upl_pending[0] || e->upl_pending[1])) {
+        HIPCHK(hipStreamSynchronize(e->up_stream));
+        if (e->up_stream2) HIPCHK(hipStreamSynchronize(e->up_stream2));
+    }
+    e->upl_pending[0] = e->upl_pending[1] = false;
+    return M2V_OK;
+}
+
+int m2v_upload_wait(m2v_enc *e)
+{
+    if (!e) return M2V_E_PARAM;
+    return guard(e, upload_wait_impl, nullptr);
+}
+
 static int stop_impl(m2v_enc *e, void *)
 {
+    const int r = upload_wait_impl(e, nullptr);         // every frame handed in has been read: the caller's buffers are free when this returns
+    if (r < 0) return r;
     if (e->state == m2v_enc::DURING) do_stop(e);       // no effect while idle / already ending (RTL:1090)
     return M2V_OK;
 }
@@ -344,10 +404,10 @@ int m2v_sequence_stop(m2v_enc *e)
 
 int m2v_busy(const m2v_enc *e) { return e && e->state != m2v_enc::IDLE; }
 
-static int pull_progress_impl(m2v_enc *e, void *)
+static int pull_progress_impl(m2v_enc *e, void *argp)
 {
     // chunks still in flight: take what is complete; once the sequence has been stopped wait for the rest
-    progress(e, e->state == m2v_enc::ENDED);
+    progress(e, e->state == m2v_enc::ENDED, -1, (PullSink *)argp);
     return M2V_OK;
 }
 
@@ -355,15 +415,17 @@ long long m2v_pull(m2v_enc *e, uint8_t *dst, size_t cap, int *last)
 {
     if (!e || (!dst && cap)) return M2V_E_PARAM;
     if (last) *last = 0;
+    PullSink sink{dst, cap, 0};
     if (!e->pending.empty()) {
-        const int r = guard(e, pull_progress_impl, nullptr);
+        const int r = guard(e, pull_progress_impl, &sink);
         if (r < 0) return r;
     }
     const size_t avail = e->fifo.size() - e->fifo_rd;
     // only whole 32-byte words leave; the residue waits for more data or for the end of the sequence
-    size_t n = std::min(avail, cap) & ~(size_t)31;
-    if (n) memcpy(dst, e->fifo.data() + e->fifo_rd, n);
+    size_t n = std::min(avail, cap - sink.used) & ~(size_t)31;
+    if (n) memcpy(dst + sink.used, e->fifo.data() + e->fifo_rd, n);
     e->fifo_rd += n;
+    n += sink.used;
     if (e->fifo_rd > (1u << 20) && e->fifo_rd * 2 > e->fifo.size()) {      // compact
         e->fifo.erase(e->fifo.begin(), e->fifo.begin() + (long)e->fifo_rd);
         e->fifo_rd = 0;

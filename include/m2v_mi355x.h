@@ -86,6 +86,8 @@ int m2v_push_frames(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pfr
 /* `i_sequence_stop` pulse with i_en = 0 (RTL:1090-1091; SIM/tb_mpeg2encoder.v:249-252). A frame
  * in progress is completed with black pixels (RTL:1048-1056). No effect while idle. */
 int m2v_sequence_stop(m2v_enc *e);
+/* Option "direct_upload" = 2 only (a no-op otherwise): waits until every frame handed to m2v_push_frames so far has been read. */
+int m2v_upload_wait(m2v_enc *e);
 
 /* `o_sequence_busy` (RTL:1095): 1 from the first beat until the `last` word has been pulled. */
 int m2v_busy(const m2v_enc *e);
@@ -299,7 +301,11 @@ int m2v_strip_graph_stats(const m2v_enc *e, int *last_call_was_graph, int *recor
  * "copy_threads" (default 8: threads m2v_push_frames uses to copy large inputs into pinned memory),
  * "direct_upload" (default 1: frames handed to m2v_push_frames in page-locked host memory - hipHostMalloc / hipHostRegister -
  * are uploaded straight from the caller's buffer, without the copy into the handle's pinned staging; the call returns when
- * the upload of its frames has completed, the encoding continues asynchronously),
+ * the upload of its frames has completed, the encoding continues asynchronously.  2 = the same with the completion DEFERRED: the
+ * call returns while its frames are still being read, and what it waits for is the PREVIOUS call's upload - the caller keeps a
+ * pushed range unchanged until the next m2v_push_frames, m2v_sequence_stop or m2v_upload_wait on the handle has returned; the copy
+ * engine then always has the next transfer queued behind the running one, which is what a single caller needs to keep the link
+ * busy.  0 = always through the staging copy),
  * "split_streams" (default 2; 1..8 = the closed GOPs of a chunk are encoded as this many independent groups on as many
  * HIP streams, so that the partially filled tail of one group's launch overlaps with another group's next launch;
  * 1 = a single stream; ignored while "profile" is on, which times every launch with in-band events on one stream),

@@ -282,3 +282,37 @@ def test_page_locked_frames_are_uploaded_directly_and_mix_with_beats():
                 assert b"".join(out) == want, "batch_frames=%d direct_upload=%d" % (batch, direct)
             finally:
                 enc.close()
+
+
+def test_deferred_upload_and_pull_into_give_the_same_stream():
+    """option direct_upload = 2 (m2v_push_frames returns while its frames are still being read; the next push / stop / m2v_upload_wait
+    releases them) and m2v_pull straight into the caller's buffer: byte-identical to the blocking path, GOP after GOP from page-locked
+    memory, with a push that crosses a chunk boundary, three sequences on one handle."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    W, H, pf, n = 192, 128, 3, 22
+    clip = M.synth.clip(W, H, n, clip_index=95, scene_len=6)
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
+    pinned = torch.from_numpy(np.ascontiguousarray(clip)).pin_memory().numpy()
+    out = np.zeros(len(want) + 4096, np.uint8)
+    enc = M.Mpeg2Encoder(7, 7, 3, 2)
+    try:
+        enc.set_option("batch_frames", 8)
+        for mode in (2, 1, 2):
+            enc.set_option("direct_upload", mode)
+            pos = 0
+            for k in range(0, n, 5):                          # 5 frames per push, 8 per chunk: pushes that straddle chunks
+                enc.push_frames(W // 16, H // 16, pf, pinned[k:k + 5])
+                pos += enc.pull_into(out, pos)[0]
+            enc.upload_wait()                                 # (what a caller that wants to overwrite its frames now would do)
+            enc.sequence_stop()
+            last = False
+            while not last:
+                m, last = enc.pull_into(out, pos)
+                pos += m
+            assert out[:pos].tobytes() == want, "direct_upload = %d" % mode
+            assert not enc.busy
+    finally:
+        enc.close()

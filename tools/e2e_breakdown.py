@@ -16,29 +16,45 @@ gop = PF + 1
 clip = M.synth.clip_torch(W, H, n, clip_index=0, device="cuda:0").cpu()
 pinned_t = clip.pin_memory()
 frames = pinned_t.numpy()
-enc = M.Mpeg2Encoder(7, 7, 3, 2)
-enc.set_option("batch_frames", 2 * gop)
-for rep in range(4):
+import hashlib
+for batch, into, deferred in ((2 * gop, False, 0), (2 * gop, True, 0), (2 * gop, True, 1), (gop, True, 1), (2 * gop, True, 0), (2 * gop, True, 1)):
+  enc = M.Mpeg2Encoder(7, 7, 3, 2)
+  enc.set_option("batch_frames", batch)
+  enc.set_option("direct_upload", 2 if deferred else 1)
+  outbuf = np.empty(n * W * H * 3 // 2, np.uint8)
+  for rep in range(4):
     t = {"push": 0.0, "pull": 0.0, "stop": 0.0, "drain": 0.0}
     t0 = time.perf_counter()
-    out = []
+    out, pos = [], 0
     for k in range(0, n, gop):
         a = time.perf_counter()
         enc.push_frames(W // 16, H // 16, PF, frames[k:k + gop])
         b = time.perf_counter()
-        out.append(enc.pull(1 << 24)[0])
+        if into:
+            pos += enc.pull_into(outbuf, pos)[0]
+        else:
+            out.append(enc.pull(1 << 24)[0])
         c = time.perf_counter()
         t["push"] += b - a
         t["pull"] += c - b
     a = time.perf_counter()
     enc.sequence_stop()
     b = time.perf_counter()
-    out.append(enc.pull_all())
+    if into:
+        last = False
+        while not last:
+            m, last = enc.pull_into(outbuf, pos)
+            pos += m
+    else:
+        out.append(enc.pull_all())
     c = time.perf_counter()
     t["stop"], t["drain"] = b - a, c - b
     total = c - t0
-    print("total %.2f ms (%.1f GB/s of input)  " % (total * 1e3, n * W * H * 3 / total * 1e-9) + "  ".join("%s %.2f" % (k, v * 1e3) for k, v in t.items()),
-          " bytes", sum(len(o) for o in out))
+    data = outbuf[:pos].tobytes() if into else b"".join(out)
+    print("%s batch_frames %2d %s total %.2f ms (%.1f GB/s of input)  " % ("deferred" if deferred else "blocking", batch, "pull_into" if into else "pull     ", total * 1e3, n * W * H * 3 / total * 1e-9) + "  ".join("%s %.2f" % (k, v * 1e3) for k, v in t.items()),
+          " bytes", len(data), hashlib.sha1(data).hexdigest()[:10])
+  enc.close()
+enc = M.Mpeg2Encoder(7, 7, 3, 2)
 dev = torch.empty_like(pinned_t, device="cuda")
 dev.copy_(pinned_t, non_blocking=True)
 torch.cuda.synchronize()

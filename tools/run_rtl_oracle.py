@@ -9,7 +9,9 @@ SIM/tb_mpeg2encoder.v: one beat per clock, stop pulse with i_en=0, o_data byte 0
 `iverilog -g2001` + `vvp -n` (SIM/tb_run_iverilog.bat:2-3) - or, where only Verilator (>= 5) is installed, `verilator --binary
 --timing` -, (4) compares the .m2v byte for byte with the CPU oracle and reports clocks/s, and (5) where a GPU and the built product
 are at hand, drives the product's own testbench counterpart (m2v_tb, the same files through the C-ABI) and prints ONE three-way verdict
-line:  RTL == oracle == product.  The two hand-derived 160-byte known-answer streams (tests/golden/) go first: a
+line:  RTL == oracle == product.  The generated testbench also writes one line per macroblock at the moment the RTL's stage T latches it
+(frame, row, column, inter flag, vector, coded flags - hierarchical references to g_inter, g_mvx, g_mvy, s_nzflags at s_en_blk,
+RTL:2630-2637), which is compared with the oracle's dump: on first contact a mismatch is localised to a STAGE, not to a byte offset.  The two hand-derived 160-byte known-answer streams (tests/golden/) go first: a
 simulator whose `$fwrite("%c")` drops the 0x00 bytes of the start codes fails there, before anything is concluded
 from the seeded clips.  Without a simulator or without the RTL file it prints "RTL oracle unavailable" and exits 0 (this is the case in
 the build image and on the GPU box).  The last stdout line is a JSON object (bench.py copies it into its `rtl_sim` entry).
@@ -71,8 +73,18 @@ initial begin
     end
   join
   $fclose(fo);
+  $fclose(fd);
   $display("CLOCKS %%0d", clocks);
   $finish;
+end
+// One line per macroblock at the moment stage T latches it (RTL:2630-2637: s_en_blk in PUT_IDLE): frame, row, column, inter flag, the
+// transmitted vector, the six coded flags - so that a first mismatch is localised to a STAGE (decision / vector / coded pattern), not to a byte
+// offset.  Hierarchical references into the module under test (Verilator: --public-flat-rw).
+integer fd, mbf;
+initial begin fd = $fopen("%(DUMP)s", "w"); mbf = -1; end
+always @(posedge clk) if (dut.s_en_blk) begin
+  if (dut.g_y16 == 0 && dut.g_x16 == 0) mbf = mbf + 1;
+  $fdisplay(fd, "MB %%0d %%0d %%0d %%0d %%0d %%0d %%0d", mbf, dut.g_y16, dut.g_x16, dut.g_inter, $signed(dut.g_mvx), $signed(dut.g_mvy), dut.s_nzflags);
 end
 endmodule
 """
@@ -101,7 +113,7 @@ def find_simulator():
     if ver:
         def build(tb, rtl, work, tag):
             obj = os.path.join(work, "obj_" + tag)
-            subprocess.check_call([ver, "--binary", "--timing", "-Wno-fatal", "-Wno-lint", "-Wno-style", "--top-module", "tb", "--Mdir", obj,
+            subprocess.check_call([ver, "--binary", "--timing", "--public-flat-rw", "-Wno-fatal", "-Wno-lint", "-Wno-style", "--top-module", "tb", "--Mdir", obj,
                                    "-o", "sim", tb, rtl], stdout=subprocess.DEVNULL)
             return [os.path.join(obj, "sim")]
         return "verilator", build
@@ -141,6 +153,40 @@ def product_possible():
     return False
 
 
+def compare_mb_dump(path, dump, W, H, limit=5):
+    """The RTL's per-macroblock lines (the generated testbench's $fdisplay at s_en_blk) against the oracle's dump of the same
+    sequence: -> (macroblocks compared, [first mismatches as text]).  A macroblock's vector is compared only when it is inter
+    (the RTL's g_mvx / g_mvy hold the search result for intra macroblocks too; nothing of it is transmitted)."""
+    mbw = W // 16
+    bad, n = [], 0
+    if not os.path.exists(path):
+        return 0, ["no per-macroblock dump was written (simulator without hierarchical references?)"]
+    for ln in open(path):
+        t = ln.split()
+        if len(t) != 8 or t[0] != "MB":
+            continue
+        f, y, x, inter, mvx, mvy, nz = (int(v) for v in t[1:])
+        if f < 0 or f >= dump["mb_inter"].shape[0] or y * mbw + x >= dump["mb_inter"].shape[1]:
+            bad.append("macroblock (frame %d, row %d, column %d) outside the oracle's sequence" % (f, y, x))
+            continue
+        i = y * mbw + x
+        n += 1
+        o_inter, o_cbp = int(dump["mb_inter"][f, i]), int(dump["mb_cbp"][f, i])
+        o_mv = (int(dump["mb_mvx"][f, i]), int(dump["mb_mvy"][f, i]))
+        what = []
+        if inter != o_inter:
+            what.append("intra/inter decision (stage F, RTL:1790-1816): RTL %d, oracle %d" % (inter, o_inter))
+        elif inter and (mvx, mvy) != o_mv:
+            what.append("motion vector (stage F, RTL:1634-1829): RTL (%d, %d), oracle (%d, %d)" % (mvx, mvy, o_mv[0], o_mv[1]))
+        if nz != o_cbp:
+            what.append("coded flags (stages G-S, RTL:1972-2468): RTL %s, oracle %s" % (format(nz, "06b"), format(o_cbp, "06b")))
+        if what and len(bad) < limit:
+            bad.append("frame %d, macroblock row %d column %d: %s" % (f, y, x, "; ".join(what)))
+        elif what:
+            bad.append(None)
+    return n, bad
+
+
 def main():
     import json
     ap = argparse.ArgumentParser()
@@ -160,7 +206,7 @@ def main():
     def simulate(clip, W, H, nf, pf, XL, YL, VL, Q, nbeats, tag):
         fin, fout, ftb = (os.path.join(tmp, "%s.%s" % (tag, e)) for e in ("yuv", "m2v", "v"))
         clip.tofile(fin)
-        open(ftb, "w").write(TB % dict(XL=XL, YL=YL, W=W, H=H, NF=nf, NBEATS=nbeats, VL=VL, Q=Q, PF=pf, IN=fin, OUT=fout))
+        open(ftb, "w").write(TB % dict(XL=XL, YL=YL, W=W, H=H, NF=nf, NBEATS=nbeats, VL=VL, Q=Q, PF=pf, IN=fin, OUT=fout, DUMP=os.path.join(tmp, tag + ".mb")))
         argv = build(ftb, args.rtl, tmp, tag)
         t0 = time.time()
         log = subprocess.run(argv, capture_output=True, text=True).stdout
@@ -179,16 +225,21 @@ def main():
         print("known answer %-5s 64x64: RTL under %s %d bytes -> %s%s" % (kind, simname, len(got), "IDENTICAL" if same else "DIFFERENT",
               "" if same else "  (if only the 0x00 bytes are missing: this simulator drops NUL on %c - SURVEY.md 8(c))"))
     # 2. seeded clips, three ways
-    bad_oracle = bad_product = product_cases = 0
+    bad_oracle = bad_product = product_cases = mb_total = mb_wrong = 0
     px = secs = 0.0
     for ci, (W, H, nf, pf, XL, YL, VL, Q, stop) in enumerate(CASES):
         clip = M.synth.clip(W, H, nf, clip_index=100 + ci, scene_len=3)
         nbeats = nf * W * H // 4 if stop is None else stop
         got, dt, clocks, fin = simulate(clip, W, H, nf, pf, XL, YL, VL, Q, nbeats, "c%d" % ci)
-        want = orc.encode(clip, W // 16, H // 16, pf, XL, YL, VL, Q, nbeats=nbeats)
+        want, dump = orc.encode(clip, W // 16, H // 16, pf, XL, YL, VL, Q, nbeats=nbeats, dump=True)
         prod = product_bytes(fin, W, H, pf, XL, YL, VL, Q, nf, tmp, "c%d" % ci) if stop is None else None
         ok = got == want
         bad_oracle += not ok
+        mb_n, mb_bad = compare_mb_dump(os.path.join(tmp, "c%d.mb" % ci), dump, W, H)
+        mb_total += mb_n
+        mb_wrong += len(mb_bad)
+        for line in [b for b in mb_bad if b][:5]:
+            print("    first differences by stage: " + line)
         if prod is not None:
             product_cases += 1
             bad_product += prod != got
@@ -201,6 +252,7 @@ def main():
     verdict = {"available": True, "simulator": simname, "known_answers_identical": kat_ok, "cases": len(CASES),
                "rtl_equals_oracle": bad_oracle == 0 and kat_ok, "product_cases": product_cases,
                "rtl_equals_product": (bad_product == 0) if product_cases else None,
+               "macroblocks_compared_by_stage": mb_total, "macroblocks_differing_by_stage": mb_wrong,
                "rtl_sim_MPixels_per_s": round(px / secs * 1e-6, 5) if secs > 0 else None, "cores": 1}
     print("three-way verdict: RTL %s oracle; RTL %s product (%d of %d cases through m2v_tb); simulator %s"
           % ("==" if verdict["rtl_equals_oracle"] else "!=", "==" if verdict["rtl_equals_product"] else ("!=" if product_cases else "?="),
