@@ -324,17 +324,6 @@ void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_s
 {
     const Geom &g = e->g;
     const size_t nf = e->plan_nf;
-    if (e->fused_tail && nf <= 1024) {
-        // scans, headers and slice assembly in ONE launch (k_assemble<true>; every block reads the entries of the frames in front of
-        // its own: chunks of more than 1024 frames take the three-launch form)
-        Timer t(e, s, 3, (double)nf * g.ysz);
-        launch_assemble_fused(e, s, g, nf, first, last, advance, d_stream);
-        HIPCHK(hipGetLastError());
-        t.stop();
-        e->slice_scan_done = false;
-        e->frames_total += nf;
-        return;
-    }
     {
         Timer t(e, s, 4, (double)nf * g.ysz);
         if (!e->slice_scan_done) launch_slice_scan(e, s, g, 0, (int)nf);
@@ -380,11 +369,9 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
         }
         // every group scans its own slices right behind its last macroblock kernel (nothing in k_slice_scan looks beyond a
         // slice): the group that finishes first does it while the others still encode; only k_frame_scan and k_assemble need all
-        if (!(e->fused_tail && nf <= 1024)) {
-            for (int k = 0; k < G; ++k) launch_slice_scan(e, k == 0 ? s : e->side[k - 1], e->g, e->plan_gf[k], e->plan_gf[k + 1]);
-            HIPCHK(hipGetLastError());
-            e->slice_scan_done = true;
-        }
+        for (int k = 0; k < G; ++k) launch_slice_scan(e, k == 0 ? s : e->side[k - 1], e->g, e->plan_gf[k], e->plan_gf[k + 1]);
+        HIPCHK(hipGetLastError());
+        e->slice_scan_done = true;
         for (int k = 1; k < G; ++k) {
             HIPCHK(hipEventRecord(e->ev_join[k - 1], e->side[k - 1]));
             HIPCHK(hipStreamWaitEvent(s, e->ev_join[k - 1], 0));
@@ -494,7 +481,7 @@ void m2v_destroy(m2v_enc *e)
     for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
     (void)hipGetLastError();            // (a caller's stream that no longer exists: tolerated above, and not left behind as HIP's last error)
     e->d_coef.release(); e->d_mbaux.release(); e->d_slots.release(); e->d_slots_small.release(); e->d_mbinfo.release(); e->d_mblen.release();
-    e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release(); e->d_scan.release();
+    e->d_slice_bytes.release(); e->d_slice_off.release(); e->d_frame_off.release();
     e->d_jobs.release(); e->d_lists.release(); e->d_joblist.release(); e->d_ctl.release(); e->d_segs.release();
     for (auto p : e->rec_pool) (void)hipFree(p);
     for (auto &c : e->mbmaps) { if (c.ev) (void)hipEventDestroy(c.ev); c.d.release(); }
@@ -610,7 +597,6 @@ int m2v_set_option(m2v_enc *e, const char *name, long long value)
         return M2V_OK;
     }
     if (!strcmp(name, "dct_mfma")) { e->dct_mfma = value != 0; return M2V_OK; }
-    if (!strcmp(name, "fused_tail")) { e->fused_tail = value != 0; return M2V_OK; }
     if (!strcmp(name, "strip_graph")) { e->strip_graph_opt = value < 0 ? -1 : value != 0; return M2V_OK; }
     if (!strcmp(name, "stream_priority")) {
         // the handle's own stream again, at another priority (-1 low, 0 normal, 1 high).  HIP keeps the hardware queues of different

@@ -149,8 +149,6 @@ struct m2v_enc {
     DevBuf<uint32_t> d_slots_small;       // compact 128-byte slots (kSmallSlotWords each): the common case
     DevBuf<uint32_t> d_mbinfo, d_mblen, d_slice_bytes;
     DevBuf<unsigned long long> d_slice_off, d_frame_off;
-    DevBuf<unsigned long long> d_scan;    // option fused_tail: ticket, one look-back entry per slice, a completion count (k_assemble<true>); all zero between launches
-    bool fused_tail = true;               // option "fused_tail": scans inside k_assemble (one launch) instead of k_slice_scan + k_frame_scan + k_assemble
     DevBuf<FrameJob> d_jobs;
     DevBuf<int> d_lists;
     DevBuf<FrameJob> d_joblist;           // the jobs again, in launch-list order (k_mb reads its frame's job with ONE dependent scalar load)
@@ -307,7 +305,6 @@ void launch_plan_upload(m2v_enc *e, hipStream_t s, const FrameJob *h_jobs, size_
 void launch_slice_scan(m2v_enc *e, hipStream_t s, const Geom &g, int f0, int f1);
 void launch_frame_scan(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, bool advance, uint8_t *d_stream);
 void launch_assemble(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, uint8_t *d_stream);
-void launch_assemble_fused(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, bool advance, uint8_t *d_stream);
 void launch_halo_pack(m2v_enc *e, hipStream_t s, const int *d_list, int count, uint8_t *up, uint8_t *down);
 void launch_halo_unpack(m2v_enc *e, hipStream_t s, const int *d_list, int count, const uint8_t *from_up, const uint8_t *from_down);
 // strip mode, output rank: where every (frame, rank) piece goes + the copy itself, headers and trailer (k_strip_layout, k_strip_assemble)

@@ -1966,33 +1966,6 @@ __device__ __forceinline__ const uint32_t *compact_slot(const uint32_t *slots_sm
                                                  : slots_small + mb * kSmallSlotWords;
 }
 
-__device__ __forceinline__ uint32_t frame_header_bytes(int i_frame)
-{
-    return (i_frame == 0 ? kGopHeaderBytes + 17u : 18u);     // RTL:2670-2682
-}
-
-// ctl_init: the control word starts here instead of in a kernel of its own (a launch in front of every chunk - and, in strip mode, on the
-// tail of every sequence): 1 = a new stream (nothing precedes this chunk), 2 = this chunk's bytes leave in a buffer of their own but
-// continue the previous chunk's stream (the port path: prior = everything so far, only the final padding rule needs it), 0 = the word is
-// as the previous chunk of this call left it.  ctl_cap: capacity of the output buffer (modes 1, 2).
-// px (strip mode, peer transport; all null / 0 otherwise): a sequence in which some wait ran out of budget is marked in the strip's size
-// table ("encode it again, the ordinary way") where every rank sees it after the all-gather; the give-up word is cleared for the next
-// sequence, and so are the arrival counters of the NEXT sequence's set (nobody touches those before this rank has contributed to this
-// sequence's all-gather, which comes behind this kernel on the stream).
-struct PeerScan { unsigned int *gaveup; unsigned int *clear; int clear_lines; unsigned long long mark; };
-
-
-// FUSED = the scans inside (option "fused_tail"): no k_slice_scan, no k_frame_scan - one launch behind the last macroblock kernel instead
-// of three.  A block takes a ticket (= its slice, in stream order: whoever holds a lower ticket has started), adds up its slice's bits as
-// before, PUBLISHES its size - one word per slice, and the same bytes added to a word per frame whose upper bits count the frame's slices
-// (one atomic: bytes and count cannot be seen apart) - and only then looks at the others': the frames in front of its own (complete when
-// the count says so), the slices of its own frame in front of it.  No block waits for a block that is waiting (a first version chained
-// prefixes through 6 480 slices, Merrill-Garland fashion: 64 slices per hop, a hundred hops, 148 us instead of 58).  Every entry is one
-// 8-byte word moved by agent-scope atomics: the data IS the flag (the guide's "granule"), no fence.  The staging loads of the slice's slots
-// are in flight meanwhile.  The last slice's block does what k_frame_scan's last thread did (stream length, final-word rule
-// RTL:2932-2937, overflow, control word, the peer form's accounts); the block that is LAST to know its offset (a count tells) clears
-// tickets, entries and count for the next launch.  Layout of the scratch words: [0] ticket, [1] count, [2 .. 2 + frames) frames, then slices.
-
 constexpr int kAsmThreads = 128;          // >= macroblocks per row (W <= 2048)
 constexpr int kAsmImageWords = 1024;      // 4 KB image: a P-frame slice in one pass, an I-frame slice in a few (LDS bounds the occupancy
                                           // of this latency-bound kernel: 9 KB per workgroup = 16 workgroups, all 32 wavefronts, per CU)
@@ -2011,44 +1984,24 @@ __device__ __forceinline__ void asm_put(uint32_t *img, int nw, int pos, uint32_t
     if (w + 1 < nw && lo) atomicOr(&img[w + 1], lo);
 }
 
-template <bool FUSED>
 __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__restrict__ jobs, Geom g, int nframes,
                                                  const uint32_t *__restrict__ mbinfo, const MbAux *__restrict__ mbaux,
                                                  const uint32_t *__restrict__ slots_small, const uint32_t *__restrict__ slots,
                                                  const unsigned long long *__restrict__ slice_off,
-                                                 uint32_t *__restrict__ out32, StreamCtl *ctl,
-                                                 int first, int last, unsigned long long *frame_off,
-                                                 const uint32_t *__restrict__ slice_bytes,
-                                                 /* FUSED only: */ int advance, int ctl_init, unsigned long long ctl_cap, PeerScan px,
-                                                 unsigned long long *lb, uint32_t *__restrict__ mb_len)
+                                                 uint32_t *__restrict__ out32, const StreamCtl *__restrict__ ctl,
+                                                 int first, int last, const unsigned long long *__restrict__ frame_off,
+                                                 const uint32_t *__restrict__ slice_bytes)
 {
     __shared__ uint32_t s_img[kAsmImageWords];
     __shared__ uint32_t s_slot[kAsmStageWords];
     __shared__ uint32_t s_nw[kAsmThreads];                 // stored words of every macroblock (compact slots only)
     __shared__ uint32_t s_so[kAsmThreads];                 // where its chunks start in s_slot (inclusive scan of the chunk words)
     __shared__ uint32_t s_wave0, s_bits[2];
-    __shared__ uint32_t s_ticket;
-    __shared__ unsigned long long s_excl;
     static_assert(kAsmThreads == 128, "two wavefronts: the scans below");
     static_assert(kAsmThreads * 5 <= kAsmImageWords, "the neighbour exchange borrows the image");
-    typedef __attribute__((address_space(1))) unsigned long long *gu64p;
     const int tid = threadIdx.x;
     const int rows = g.row1 - g.row0;
-    uint32_t slice = blockIdx.x;
-    // the previous state of the control word, read by EVERY block before it publishes anything (the last block rewrites the word at its
-    // end, when every other block is past this point)
-    unsigned long long c_prior = 0, c_cap = ctl_cap & ~3ull, c_base = 0;
-    uint32_t c_ov = 0;
-    if constexpr (FUSED) {
-        if (tid == 0) s_ticket = atomicAdd((unsigned int *)lb, 1u);
-        if (ctl_init == 0) {
-            c_prior = ctl->prior_bytes; c_cap = ctl->cap_bytes; c_ov = ctl->overflow;
-            c_base = (advance && !c_ov) ? ctl->total_bytes : ctl->base_bytes;
-        } else if (ctl_init == 2) c_prior = ctl->prior_bytes + ctl->total_bytes;
-        __syncthreads();
-        slice = s_ticket;
-    }
-    const int f = (int)(slice / (uint32_t)rows), by = g.row0 + (int)(slice % (uint32_t)rows);
+    const int f = blockIdx.x / rows, by = g.row0 + (int)(blockIdx.x % rows);
     if (f >= nframes) return;
     const size_t base = ((size_t)f * g.mbh + by) * g.mbw;
     const bool have = tid < g.mbw;
@@ -2056,12 +2009,8 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
     MbAux aux{0, 0, 0, 0};
     if (have) { info = mbinfo[base + tid]; aux = mbaux[base + tid]; }
     const int i_frame = jobs[f].i_frame;
-    unsigned long long q = 0;
-    bool overflow = false;
-    if constexpr (!FUSED) {
-        q = (ctl->base_bytes + slice_off[(size_t)f * g.mbh + by]) * 8ull;
-        overflow = ctl->overflow != 0;
-    }
+    const unsigned long long q = (ctl->base_bytes + slice_off[(size_t)f * g.mbh + by]) * 8ull;
+    const bool overflow = ctl->overflow != 0;
     // the left neighbour's word and record, through LDS (the image is not in use yet): the neighbour-dependent codes - motion vector
     // deltas, DC differentials (RTL:2736-2748, 2808-2821) - are formed here, as k_slice_scan formed them for their lengths
     uint32_t *const s_x = s_img;
@@ -2090,21 +2039,6 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
     __syncthreads();
     const uint32_t off = bscan - mylen + (tid >= 64 ? s_bits[0] : 0u);
     const uint32_t total = s_bits[0] + s_bits[1];          // the slice's bits
-    // FUSED: this slice's bytes (the next header aligns, RTL:2940-2943) and, in front of a frame's first slice, the frame's headers
-    const uint32_t my_bytes = (total + 7u) >> 3;
-    uint32_t hdr = 0;
-    if constexpr (FUSED) {
-        if (!g.strip && by == g.row0) hdr = frame_header_bytes(i_frame) + (first && f == 0 ? kSeqHeaderBytes : 0u);
-        if (have) mb_len[base + tid] = mylen;
-        if (tid == 0) {
-            // (the control word has been READ before anything is published - the last slice's block rewrites it when every block has
-            // published: its loads are in front of this statement, which the compiler cannot move memory accesses across, and complete)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            // this slice's size (+ 1: published), and the same bytes added to its frame's entry together with a count of 1
-            __hip_atomic_store((gu64p)(lb + 2 + nframes + slice), (unsigned long long)(hdr + my_bytes) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add((gu64p)(lb + 2 + f), (1ull << 40) | (unsigned long long)(hdr + my_bytes), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     // stage the compact slots: up to kSlotChunks chunks of 16 bytes per macroblock, only the filled ones, packed.  All loads of a
     // thread are issued before the first LDS store (one memory round trip, not one per chunk).
     {
@@ -2120,89 +2054,12 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
             const uint32_t *const src = compact_slot(slots_small, g, base + m, nwm);
             v[i] = take ? *(const uint4 *)(src + 4 * c) : uint4{0, 0, 0, 0};
         }
-        if constexpr (FUSED) {
-            // where the slice starts, by the block's first wavefront, while the loads above are in flight: the complete frames in front of
-            // this one (64 entries per read: bytes in the low 40 bits, slices counted above them - complete when the count is `rows`),
-            // then the slices of this frame in front of this one.  Nothing here waits for a block that is itself waiting: every
-            // block publishes its size before it looks at anybody else's.
-            if (tid < 64) {
-                auto sum64 = [](unsigned long long val) {       // three parts of 21 bits: their wavefront sums cannot wrap
-                    return (unsigned long long)(uint32_t)wave_sum((int)(val & 0x1FFFFFull)) +
-                           ((unsigned long long)(uint32_t)wave_sum((int)((val >> 21) & 0x1FFFFFull)) << 21) +
-                           ((unsigned long long)(uint32_t)wave_sum((int)(val >> 42)) << 42);
-                };
-                unsigned long long sum = 0;
-                for (int f0 = 0; f0 < f; f0 += 64) {
-                    const int ff = f0 + tid;
-                    unsigned long long v = 0;
-                    for (;;) {
-                        if (ff < f) v = __hip_atomic_load((gu64p)(lb + 2 + ff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (!ballot(ff < f && (v >> 40) != (unsigned long long)rows)) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    sum += sum64(ff < f ? v & ((1ull << 40) - 1ull) : 0ull);
-                }
-                const int r = by - g.row0;
-                for (int r0 = 0; r0 < r; r0 += 64) {
-                    const int rr = r0 + tid;
-                    unsigned long long v = 1;
-                    for (;;) {
-                        if (rr < r) v = __hip_atomic_load((gu64p)(lb + 2 + nframes + (size_t)f * rows + rr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (!ballot(v == 0ull)) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    sum += sum64(v - 1ull);
-                }
-                if (tid == 0) {
-                    s_excl = sum;
-                    // whoever finishes LAST (not necessarily the last slice) clears tickets, entries and this count for the next launch
-                    s_ticket = atomicAdd((unsigned int *)(lb + 1), 1u) == (unsigned int)(nframes * rows) - 1u ? 1u : 0u;
-                }
-            }
-        }
 #pragma unroll
         for (int i = 0; i < kIter; ++i)
             if (dst[i] != 0xFFFFFFFFu) {
                 uint32_t *d = &s_slot[dst[i]];
                 d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
             }
-    }
-    unsigned long long excl = 0;                            // FUSED: bytes of the chunk in front of this slice's own headers
-    if constexpr (FUSED) {
-        __syncthreads();
-        excl = s_excl;
-        if (s_ticket)       // every block has found its prefix: nobody looks at the tickets, the entries or the count any more
-            for (uint32_t i = tid; i < (uint32_t)(nframes * rows + nframes) + 2u; i += kAsmThreads) lb[i] = 0ull;
-        q = (c_base + excl + hdr) * 8ull;
-        // a slice that would end beyond the buffer is not written (the stream is then reported as too large by the last slice's block)
-        overflow = c_ov != 0 || c_base + excl + hdr + my_bytes > c_cap;
-        if (tid == 0 && by == g.row0) frame_off[f] = excl + (!g.strip && first && f == 0 ? kSeqHeaderBytes : 0u);     // the frame's own headers start here
-        if (slice == (uint32_t)(nframes * rows) - 1u) {
-            // ---- the last slice of the chunk: what k_frame_scan's last thread did ----
-            const unsigned long long all_frames = excl + hdr + my_bytes;
-            unsigned long long tot = c_base + all_frames;
-            if (last) {
-                tot += 4;                                             // sequence_end_code (RTL:2621-2628)
-                const unsigned long long all = c_prior + tot;
-                tot = (all / 32ull + 1ull) * 32ull - c_prior;         // final word always leaves (RTL:2932-2937)
-            }
-            const bool ov = tot > c_cap || c_ov;
-            overflow = overflow || ov;
-            for (int i = tid; i < px.clear_lines; i += kAsmThreads) px.clear[i * 32] = 0u;
-            if (tid == 0) {
-                frame_off[nframes] = all_frames;
-                if (px.gaveup) {
-                    if (*px.gaveup) frame_off[nframes] = px.mark;
-                    *px.gaveup = 0u;
-                }
-                ctl->base_bytes = c_base; ctl->cap_bytes = c_cap; ctl->prior_bytes = c_prior; ctl->pad = 0;
-                ctl->total_bytes = tot;
-                ctl->overflow = ov ? 1u : 0u;
-                if (!ov && last && !g.strip)
-                    for (unsigned long long w = (c_base + all_frames) >> 2; w < (tot + 3ull) >> 2; ++w) out32[w] = 0u;      // end code + padding: cleared, the end code follows below
-            }
-        }
-        if (overflow) return;
     }
     const int sh = (int)(q & 31ull);
     const unsigned long long w0 = q >> 5;
@@ -2266,13 +2123,13 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
     // stores by one thread.  A header byte may share a dword with a slice's boundary word; that dword was cleared by
     // k_frame_scan, the atomic OR above only adds the slice's own bits and the byte store only touches its byte.
     if (!g.strip && tid == 0) {
-        uint8_t *const out8 = (uint8_t *)out32 + (FUSED ? c_base : ctl->base_bytes);
+        uint8_t *const out8 = (uint8_t *)out32 + ctl->base_bytes;
         if (by == g.row0) {
             if (first && f == 0) write_sequence_headers(out8, g);
-            write_frame_headers(out8 + (FUSED ? excl + (first && f == 0 ? kSeqHeaderBytes : 0u) : frame_off[f]), jobs[f]);
+            write_frame_headers(out8 + frame_off[f], jobs[f]);
         }
         if (last && f == nframes - 1 && by == g.row1 - 1) {
-            uint8_t *e = FUSED ? out8 + excl + hdr + my_bytes : out8 + slice_off[(size_t)f * g.mbh + by] + slice_bytes[(size_t)f * g.mbh + by];
+            uint8_t *e = out8 + slice_off[(size_t)f * g.mbh + by] + slice_bytes[(size_t)f * g.mbh + by];
             e[0] = 0x00; e[1] = 0x00; e[2] = 0x01; e[3] = 0xB7;       // sequence_end_code (RTL:2625-2628)
         }
     }
@@ -2282,9 +2139,23 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
 // k_frame_scan: byte offsets of frames and slices inside the chunk; total stream length
 // ----------------------------------------------------------------------------------------------
 
+__device__ __forceinline__ uint32_t frame_header_bytes(int i_frame)
+{
+    return (i_frame == 0 ? kGopHeaderBytes + 17u : 18u);     // RTL:2670-2682
+}
 
 // One block; thread t owns K consecutive (frame, slice) items, an item = a slice preceded by its frame's
 // headers when it is the first slice of the frame: local sums -> block scan -> offsets.
+// ctl_init: the control word starts here instead of in a kernel of its own (a launch in front of every chunk - and, in strip mode, on the
+// tail of every sequence): 1 = a new stream (nothing precedes this chunk), 2 = this chunk's bytes leave in a buffer of their own but
+// continue the previous chunk's stream (the port path: prior = everything so far, only the final padding rule needs it), 0 = the word is
+// as the previous chunk of this call left it.  ctl_cap: capacity of the output buffer (modes 1, 2).
+// px (strip mode, peer transport; all null / 0 otherwise): a sequence in which some wait ran out of budget is marked in the strip's size
+// table ("encode it again, the ordinary way") where every rank sees it after the all-gather; the give-up word is cleared for the next
+// sequence, and so are the arrival counters of the NEXT sequence's set (nobody touches those before this rank has contributed to this
+// sequence's all-gather, which comes behind this kernel on the stream).
+struct PeerScan { unsigned int *gaveup; unsigned int *clear; int clear_lines; unsigned long long mark; };
+
 __global__ __launch_bounds__(1024) void k_frame_scan(const FrameJob *__restrict__ jobs, Geom g, int nframes, int first, int last,
                                                      const uint32_t *__restrict__ slice_bytes,
                                                      unsigned long long *__restrict__ slice_off,

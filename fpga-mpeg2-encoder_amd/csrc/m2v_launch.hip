@@ -368,30 +368,9 @@ void launch_frame_scan(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool
 void launch_assemble(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, uint8_t *d_stream)
 {
     const size_t rows = (size_t)(g.row1 - g.row0);
-    hipLaunchKernelGGL(k_assemble<false>, dim3((unsigned)(nf * rows)), dim3(kAsmThreads), 0, s, e->d_jobs.p, g, (int)nf,
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)(nf * rows)), dim3(kAsmThreads), 0, s, e->d_jobs.p, g, (int)nf,
                        e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, e->d_slice_off.p,
-                       (uint32_t *)d_stream, e->d_ctl.p, first ? 1 : 0, last ? 1 : 0, e->d_frame_off.p, e->d_slice_bytes.p,
-                       0, 0, 0ull, PeerScan{}, (unsigned long long *)nullptr, (uint32_t *)nullptr);
-}
-
-// the same with the scans inside (k_assemble<true>): ONE launch behind the last macroblock kernel
-void launch_assemble_fused(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, bool advance, uint8_t *d_stream)
-{
-    const size_t rows = (size_t)(g.row1 - g.row0), S = nf * rows;
-    if (e->d_scan.n < S + nf + 2) {
-        e->d_scan.ensure(S + nf + 2 + 1024);
-        HIPCHK(hipMemsetAsync(e->d_scan.p, 0, e->d_scan.n * sizeof(unsigned long long), s));      // (every launch leaves it cleared)
-    }
-    PeerScan px{};
-    if (e->scan_peer_gaveup) {
-        px.gaveup = e->scan_peer_gaveup; px.clear = e->scan_peer_clear; px.clear_lines = e->scan_peer_lines; px.mark = e->scan_peer_mark;
-        e->scan_peer_gaveup = nullptr;
-    }
-    hipLaunchKernelGGL(k_assemble<true>, dim3((unsigned)S), dim3(kAsmThreads), 0, s, e->d_jobs.p, g, (int)nf,
-                       e->d_mbinfo.p, e->d_mbaux.p, e->d_slots_small.p, e->d_slots.p, (const unsigned long long *)nullptr,
-                       (uint32_t *)d_stream, e->d_ctl.p, first ? 1 : 0, last ? 1 : 0, e->d_frame_off.p, (const uint32_t *)nullptr,
-                       advance ? 1 : 0, e->ctl_init, e->ctl_cap, px, e->d_scan.p, e->d_mblen.p);
-    e->ctl_init = 0;
+                       (uint32_t *)d_stream, e->d_ctl.p, first ? 1 : 0, last ? 1 : 0, e->d_frame_off.p, e->d_slice_bytes.p);
 }
 
 void launch_halo_pack(m2v_enc *e, hipStream_t s, const int *d_list, int count, uint8_t *up, uint8_t *down)
