@@ -884,7 +884,19 @@ def main():
         fn = run_steps if submission == "in_flight" else sync_steps
         per = max(2 * nh, int(0.5 / max(dt / args.steps, 1e-6)))
         s0 = gpu_sensors(local_rank)
+        # the sensors again every 0.1 s WHILE the loop runs, from a thread of their own (read between two windows the GPU has just gone
+        # idle and shows its idle clock)
+        import threading
+        samples, stop_sampling = [], threading.Event()
+
+        def sampler():
+            while not stop_sampling.wait(0.1):
+                x = gpu_sensors(local_rank)
+                if x:
+                    samples.append(x)
+        th = threading.Thread(target=sampler, daemon=True)
         barrier()
+        th.start()
         wins, t_begin = [], time.perf_counter()
         while time.perf_counter() - t_begin < args.sustain:
             t0 = time.perf_counter()
@@ -893,13 +905,20 @@ def main():
             wins.append(time.perf_counter() - t0)
             assert nb == nbytes
         t_all = time.perf_counter() - t_begin
+        stop_sampling.set()
+        th.join(timeout=2.0)
         s1 = gpu_sensors(local_rank)
+
+        def spread(key):
+            v = [x[key] for x in samples if x.get(key) is not None]
+            return {"min": min(v), "max": max(v), "mean": round(sum(v) / len(v), 1), "samples": len(v)} if v else None
         rate = [per * nframes * W * H / w * 1e-6 for w in wins]
         sustained = {"seconds": round(t_all, 2), "sequences": per * len(wins), "sequences_per_window": per, "windows": len(wins),
                      "value": round(per * len(wins) * nframes * W * H / sum(wins) * 1e-6, 2), "unit": "MPixels/s (this rank)",
                      "window_min": round(min(rate), 2), "window_max": round(max(rate), 2),
                      "first_window": round(rate[0], 2), "last_window": round(rate[-1], 2),
                      "submission": submission, "sensors_start": s0, "sensors_end": s1,
+                     "sensors_during": {"sclk_mhz": spread("sclk_mhz"), "power_w": spread("power_w"), "every_s": 0.1},
                      "sensors_source": "amdgpu sysfs (pp_dpm_sclk / pp_dpm_mclk / hwmon)" if (s0 or s1) else "not readable on this host"}
     # second pass, same K steps, for the per-kernel numbers: option "profile" brackets every launch with HIP events on the
     # launch stream and keeps the whole chunk on ONE stream, so that a launch's duration is the kernel alone on the GPU
