@@ -120,3 +120,31 @@ def test_communicator_constructors_validate_without_a_gpu(L):
     assert L.m2v_comm_selftest(None, 0, None, None, 0, None) == -1
     assert L.m2v_strip_encode(None, None, 0, 1, 0, 4, 4, 0, None, 0, None, 0, None, None) == -1
     L.m2v_comm_destroy(None)                                      # like free(NULL)
+
+
+def test_communicator_constructors_validate_their_arguments_without_a_gpu(L):
+    """m2v_comm_init_callbacks / m2v_comm_init_peer and friends: what can be refused before anything touches HIP is refused there, with a text"""
+    err = ctypes.c_int(0)
+    assert not L.m2v_comm_init_callbacks(2, None, ctypes.byref(err)) and err.value == -1
+    cb = M.CommCallbacks(M.CommCallbacks.HALO(lambda *a: 0), M.CommCallbacks.ALLGATHER(lambda *a: 0), M.CommCallbacks.GATHER(), None)
+    assert not L.m2v_comm_init_callbacks(2, ctypes.byref(cb), ctypes.byref(err)) and err.value == -1        # a function is missing
+    assert b"all three functions" in L.m2v_comm_last_error()
+    cb = M.CommCallbacks(M.CommCallbacks.HALO(lambda *a: 0), M.CommCallbacks.ALLGATHER(lambda *a: 0), M.CommCallbacks.GATHER(lambda *a: 0), None)
+    assert not L.m2v_comm_init_callbacks(17, ctypes.byref(cb), ctypes.byref(err)) and err.value == -1       # at most 16 strips
+    c = L.m2v_comm_init_callbacks(3, ctypes.byref(cb), ctypes.byref(err))
+    assert c and err.value == 0
+    try:
+        assert L.m2v_comm_kind(c) == b"callbacks" and L.m2v_comm_kind(None) == b""
+        assert L.m2v_comm_peer_stats(c, None, None) == -1                                                   # not a peer communicator
+        buf = ctypes.create_string_buffer(M.PEER_DESC_BYTES)
+        assert L.m2v_comm_peer_export(c, buf, M.PEER_DESC_BYTES) == -1 and b"not a peer communicator" in L.m2v_comm_last_error()
+        assert L.m2v_comm_peer_connect(c, None, None) == -1 and L.m2v_comm_peer_connect_all(c) == -1
+        assert not L.m2v_comm_init_peer(None, 0, 0, 0, ctypes.byref(err)) and err.value == -1
+        assert not L.m2v_comm_init_peer(c, 3, 0, 0, ctypes.byref(err)) and err.value == -1                  # rank outside the base communicator
+        assert not L.m2v_comm_init_peer(c, -1, 0, 0, ctypes.byref(err)) and err.value == -1
+        import torch
+        if not torch.cuda.is_available():
+            assert not L.m2v_comm_init_peer(c, 0, 0, 0, ctypes.byref(err)) and err.value == -2              # M2V_E_NODEVICE: no landing block without a GPU
+    finally:
+        L.m2v_comm_destroy(c)
+    assert L.m2v_upload_wait(None) == -1 and L.m2v_strip_last_form(None) == -1
