@@ -382,49 +382,64 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
     # RCCL - and for one rank, which has nothing to exchange.  parallel.encode_strips (the Python statement of the same call
     # order, point-to-point ops through torch.distributed) is what the 1-GPU test hook (gloo, shared device) runs, and the
     # agreed fallback should librccl refuse to initialise.
-    loop, comm, why, base_comm = "native", None, None, None
+    # Sequences in flight on this rank (--strip-inflight K): K stacks of (handle, communicator[, peer communicator on top]), one host thread each
+    # in the timed loop - while one thread sits in its host waits (the sizes, the final sync) the others' kernels run.  Stack 0 is the one every
+    # other leg of this function uses.  Collective calls are made stack by stack, in the same order on every rank.
+    K = max(1, args.strip_inflight)
+    loop, why = "native", None
+    stacks = []                                   # [enc, comm, base_comm]
     if os.environ.get("M2V_STRIP_LOOP") == "python" or (world > 1 and backend != "nccl"):
         loop, why = "python", "M2V_STRIP_LOOP=python" if os.environ.get("M2V_STRIP_LOOP") == "python" else "backend %s" % backend
-    elif world > 1:
+        K = 1
+    for k in range(K):
+        stacks.append([enc if k == 0 else M.Mpeg2Encoder(7, 7, VL, Q, device=local_rank), None, None])
+    if loop == "native" and world > 1:
         # (StripComm.rccl is collective: a failure to make the id on rank 0 reaches every rank through its broadcast and all of them
         # land in the except branch together; a rank stuck in ncclCommInitRank because another one never arrived ends its process
         # after init_timeout, and the launcher tears the job down.  The vote below runs after every rank has returned from it.)
         ok = 1
         try:
-            comm = M.StripComm.rccl(rank, world, local_rank, dist, init_timeout=float(os.environ.get("M2V_RCCL_INIT_TIMEOUT", "180")))
+            for st in stacks:
+                st[1] = M.StripComm.rccl(rank, world, local_rank, dist, init_timeout=float(os.environ.get("M2V_RCCL_INIT_TIMEOUT", "180")))
         except Exception as ex:  # noqa: BLE001
             ok, why = 0, "m2v_comm_init_rccl: %s" % ex
         t = torch.tensor([ok], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if int(t.item()) == 0:
             loop, why = "python", why or "another rank could not initialise RCCL natively"
-            if comm is not None:
-                comm.close()
-                comm = None
+            for st in stacks:
+                if st[1] is not None:
+                    st[1].close()
+                    st[1] = None
+            K = 1
         elif args.transport == "peer":
             # the peer transport on top of the RCCL communicator (which keeps moving sizes and strips, and the halo if a wait ever runs
             # out of budget); creating it is collective (the landing blocks' IPC handles are all-gathered through RCCL).  A rank that
             # cannot - the vote again - leaves every rank on plain RCCL.
-            ok = 1
+            ok, made, peer_why = 1, [], None
             try:
-                peer_comm = M.StripComm.peer(comm, rank, local_rank, halo_bytes=args.gops * 9 * VL // 3 * Ws + 4096)
+                for st in stacks:
+                    made.append(M.StripComm.peer(st[1], rank, local_rank, halo_bytes=args.gops * 9 * VL // 3 * Ws + 4096))
             except Exception as ex:  # noqa: BLE001
                 ok, peer_why = 0, "m2v_comm_init_peer: %s" % ex
             t = torch.tensor([ok], dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             if int(t.item()) == 1:
-                base_comm, comm = comm, peer_comm
+                for st, pc in zip(stacks, made):
+                    st[2], st[1] = st[1], pc
             else:
                 why = peer_why if not ok else "another rank could not set the peer transport up"
-                if ok:
-                    peer_comm.close()
+                for pc in made:
+                    pc.close()
+    comm, base_comm = stacks[0][1], stacks[0][2]
     torch.cuda.synchronize()
     out = None
     if loop == "native":
-        d_out = torch.empty(M.parallel.strip_output_bound(nframes, Ws, Hs), dtype=torch.uint8, device=dev) if rank == 0 else None
+        d_outs = [torch.empty(M.parallel.strip_output_bound(nframes, Ws, Hs), dtype=torch.uint8, device=dev) if rank == 0 else None for _ in stacks]
+        d_out = d_outs[0]
 
-        def step(timings=None):
-            return M.parallel.encode_strips_native(enc, comm, rank, world, clip, 128, 128, PFRAMES, d_out)
+        def step(timings=None, k=0):
+            return M.parallel.encode_strips_native(stacks[k][0], stacks[k][1], rank, world, clip, 128, 128, PFRAMES, d_outs[k])
     else:
         eng = M.parallel.GpuStripEngine(enc, clip, 128, 128, PFRAMES, dev)
 
@@ -467,6 +482,33 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
         out = guarded(step)
     barrier()
     dt = time.perf_counter() - t0
+    # the same K steps with --strip-inflight sequences in flight: thread k runs steps k, k + K, ... on stack k (the same split on every rank:
+    # a stack's collectives pair up across the ranks)
+    dt_fly = None
+    if K > 1 and loop == "native":
+        import threading
+        errs = []
+
+        def worker(k, count):
+            try:
+                for _ in range(count):
+                    step(None, k)
+            except BaseException as ex:  # noqa: BLE001
+                errs.append((k, ex))
+        for phase in ("warm", "timed"):
+            counts = [len(range(k, args.steps if phase == "timed" else max(4 * K, args.warmup), K)) for k in range(K)]
+            th = [threading.Thread(target=worker, args=(k, counts[k])) for k in range(K)]
+            barrier()
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            barrier()
+            dt_fly = time.perf_counter() - t0
+            if errs:
+                sys.stderr.write("bench.py --mode strips: rank %d, sequences in flight: %r\n  state: %s\n" % (rank, errs, json.dumps(describe())))
+                raise errs[0][1]
     graph_stats = enc.strip_graph_stats() if loop == "native" else None      # the timed steps: one recorded hipGraph launch each?
     host_us_timed = enc.strip_stats().get("host_us_per_step") if loop == "native" else None
     # one more pass with per-launch HIP events (option profile) and the exchange bracketed by events on the engine's stream
@@ -484,10 +526,11 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
     enc.set_option("profile", 0)
     host_us, host_out = timings.get("host_us_per_step"), timings.get("host_us_per_step_outside_comm")
     if dist is not None:
-        t = torch.tensor([dt, timings.get("halo_exposed", 0.0), timings.get("halo_total", 0.0), timings.get("gather", 0.0)],
+        t = torch.tensor([dt, timings.get("halo_exposed", 0.0), timings.get("halo_total", 0.0), timings.get("gather", 0.0), dt_fly or 0.0],
                          dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, timings["halo_exposed"], timings["halo_total"], timings["gather"] = (float(v) for v in t.tolist())
+        dt, timings["halo_exposed"], timings["halo_total"], timings["gather"], dt_fly_max = (float(v) for v in t.tolist())
+        dt_fly = dt_fly_max if dt_fly is not None else None
     if rank == 0:
         px = nframes * Ws * Hs
         rows = M.parallel.partition_rows(128, world)[0]
@@ -495,11 +538,15 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
         alg_bytes = args.gops * ((PFRAMES - 1) * 6.0 + 4.5) * strip_px          # this rank's P-frame launches of one step
         achieved = alg_bytes / (ms_p * 1e-3) * 1e-9 if ms_p > 0 else 0.0
         line = {
-            "metric": "MPixels/s encoded, 2048x2048 I+P, macroblock-row strips", "value": round(args.steps * px / dt * 1e-6, 2),
+            "metric": "MPixels/s encoded, 2048x2048 I+P, macroblock-row strips", "value": round(args.steps * px / (dt_fly or dt) * 1e-6, 2),
             "unit": "MPixels/s", "n_gpus": dist.get_world_size() if dist is not None else 1,
             "ranks_seen": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": round(args.steps * px / dt * 1e-6 / FPGA_MPIXELS, 3), "dtype": "u8", "data": "synthetic",
+            "ms_per_step": round((dt_fly or dt) / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": round(args.steps * px / (dt_fly or dt) * 1e-6 / FPGA_MPIXELS, 3), "dtype": "u8", "data": "synthetic",
+            # `value`: the K steps with `sequences_in_flight` of them under way on every rank (one host thread, handle and communicator stack each);
+            # one sequence at a time - what earlier rounds reported - beside it
+            "sequences_in_flight": K if dt_fly is not None else 1,
+            "one_sequence_at_a_time": {"value": round(args.steps * px / dt * 1e-6, 2), "ms_per_step": round(dt / args.steps * 1e3, 3)},
             "config": {"workload": "c5: ONE 2048x2048 yuv444p sequence, %d GOPs of 1 I + %d P, VECTOR_LEVEL=3 Q_LEVEL=2, "
                                    "%d strips of macroblock rows, halo = 9 rows x 2048 B per frame per direction"
                                    % (args.gops, PFRAMES, world), "frames": nframes,
@@ -548,11 +595,12 @@ def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()                               # nobody frees a landing block a neighbour may still be storing into
-    enc.close()
-    if comm is not None:
-        comm.close()
-    if base_comm is not None:
-        base_comm.close()
+    for st in stacks:
+        st[0].close()
+        if st[1] is not None:
+            st[1].close()
+        if st[2] is not None:
+            st[2].close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -694,6 +742,9 @@ def main():
                          "enqueued with m2v_encode_resident_begin and collected with _end when its handle comes round again; 1 = one "
                          "handle, every step a synchronous m2v_encode_resident call (what rounds 1 and 2 timed)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling aid: skip kernel phases (output invalid), see Geom::ablate")
+    ap.add_argument("--strip-inflight", type=int, default=1,
+                    help="--mode strips: sequences in flight per rank in the timed loop (that many host threads, each with a handle and a communicator "
+                         "stack of its own).  1 (default): one blocking m2v_strip_encode after the other, as in earlier rounds")
     ap.add_argument("--transport", choices=["rccl", "peer"], default=os.environ.get("M2V_STRIP_TRANSPORT", "rccl"),
                     help="--mode strips, N > 1: how the halo rows travel.  rccl (default): ncclSend / ncclRecv per GOP step.  peer: the edge-row "
                          "kernel stores them straight into the neighbour's landing block (hipIpc-mapped) and counts their arrival - one launch "
