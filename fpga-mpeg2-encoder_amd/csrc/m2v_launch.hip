@@ -192,7 +192,7 @@ static const MbMap *mbmap_for(m2v_enc *e, hipStream_t s, const Geom &g, int mode
         }
     const uint32_t n = (uint32_t)((g.row1 - g.row0) * g.mbw);
     if (e->mbmaps.size() >= 24) {                           // (a recorded graph that still points at it is invalidated by the release: alloc_generation)
-        (void)hipStreamSynchronize(e->mbmaps.front().filled_on);
+        (void)hipDeviceSynchronize();                       // launches on ANY of the handle's streams may still be reading the oldest table (rare: 24 shapes)
         if (e->mbmaps.front().ev) (void)hipEventDestroy(e->mbmaps.front().ev);
         e->mbmaps.front().d.release();
         e->mbmaps.pop_front();
