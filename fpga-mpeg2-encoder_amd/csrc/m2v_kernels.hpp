@@ -57,16 +57,18 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 // The six 8x8 tiles of a macroblock (Y00 Y01 Y10 Y11 U V = tiles 0 .. 5) sit in the coefficient buffers of k_mb (s_t, s_zig) in SLOTS:
 // tile 0 in slot 0, U in slot 1, tile 1 in slot 2, tile 3 in slot 3, V in slot 4, tile 2 in slot 5.  The matrix-core transform leaves the
-// coefficients of luma tile 2 (g >> 1) + (c >> 3) in lane (g, c); run on the chroma block [U 0; 0 V] it leaves U where tile 0's are and V
-// where tile 3's are - with this order the chroma pass stores through the luma pass's lane addresses plus ONE constant (one slot).
+// coefficients of luma tile 2 (c >> 3) + (g >> 1) in lane (g, c) (the block TRANSPOSED: a lane's four are neighbours in a row); run on the
+// chroma block [U 0; 0 V] it leaves U where tile 0's are and V where tile 3's are - with this order the chroma pass stores through the
+// luma pass's lane addresses plus ONE constant (one slot).
 __host__ __device__ constexpr int slot_of_tile(int t) { return t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 5 : t == 3 ? 3 : t == 4 ? 1 : 4; }
 __host__ __device__ constexpr int tile_of_slot(int s) { return s == 0 ? 0 : s == 1 ? 4 : s == 2 ? 1 : s == 3 ? 3 : s == 4 ? 5 : 2; }
 static_assert(slot_of_tile(4) == slot_of_tile(0) + 1 && slot_of_tile(5) == slot_of_tile(3) + 1 && tile_of_slot(slot_of_tile(2)) == 2 && tile_of_slot(slot_of_tile(1)) == 1, "chroma one slot behind luma tiles 0 and 3");
 constexpr int kMfmaCpOff = 704;      // k_mb's kOffCp (static_assert there): the host fills MfmaLane::a1c with absolute LDS addresses
 struct MfmaLane {        // three quads: b1, a, a1c | zoff | the intra quantiser's reciprocals
     uint32_t b1[2];      // pass 1 B operand: +-basis row (c & 7) for the k group that matches c's tile column, else 0
-    uint32_t a2;         // pass 2 A operand: a = basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1, else 0; the
-                         // kernel forms the pair {a, 0} (multiplies the low dword of a B operand) and the pair {0, a} (the high dword)
+    uint32_t a2;         // pass 2 basis operand: a = basis[c & 7][4 (g & 1) .. + 3] where the tile row of c matches g >> 1, else 0; the
+                         // kernel forms the pair {a, 0} (multiplies the low dword of the limb operand) and the pair {0, a} (the high dword).
+                         // It is the B operand (the limbs of pass 1 are A): the product is the coefficient block transposed
     uint32_t a1c;        // pass 1 A operand of the CHROMA block [U 0; 0 V]: LDS address of s_cp[4 + (c >> 3)][c & 7][8 (g >> 1)] (kMfmaCpOff = k_mb's kOffCp)
     uint32_t zoff[4];    // byte offset of coefficient v inside s_zig: slot * 128 + zigzag position * 2
     uint32_t irecip[4];  // intra macroblocks only: ceil(2^21 / W) of the lane's four coefficients (the intra words share two otherwise
@@ -661,7 +663,7 @@ struct LaneK {
     uint32_t cpc_st;                // &s_cp[4][r >> 1][2 c4]
     uint32_t cpred_st, cpc2_st;     // &s_pred[4 + pl][yc << 3 | xc], &s_cp[4 + pl][yc][8 + xc]
     uint32_t cwin_rd;               // &s_cwin[pl][(yc + UR) * 4]: the lane part of the chroma prediction fetch
-    uint32_t xc4;                   // xc + 4
+    uint32_t row_st;                // row pass of the inverse transform: &s_t[slot][row * 8] of the lane's row (matrix-core transform: luma rows in lanes 0-15 / 32-47, chroma in 16-31; else unused)
     uint32_t cp_rd;                 // &s_cp[0][lane >> 3][0]
     uint32_t a1;                    // pass-1 A operand of the matrix-core transform
     uint32_t xrow;                  // &s_t[..] of the lane's first accumulator register (dequantised coefficients, raster order)
@@ -813,12 +815,16 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         k.cpred_st = lds_off(&s_pred[4 + pl][(yc << 3) | xc]);
         k.cpc2_st = lds_off(&s_cp[4 + pl][yc][8 + xc]);
         k.cwin_rd = lds_off(&s_cwin[0][0] + pl * (CROWS * 4) + (yc + UR) * 4);
-        k.xc4 = (uint32_t)(xc + 4);
+        {
+            const int mg = lane >> 4, mc = lane & 15;
+            const int rslot = (mg & 1) ? slot_of_tile(4 + (mc >> 3)) : slot_of_tile(((mc >> 3) << 1) | (mg >> 1));
+            k.row_st = lds_off(&s_t[rslot][(mc & 7) << 3]);
+        }
         const int di = lane >> 3;
         k.cp_rd = lds_off(&s_cp[0][di][0]);
         const int mg = lane >> 4, mc = lane & 15;
         k.a1 = lds_off(&s_cp[((mc >> 3) << 1) | (mg & 1)][mc & 7][8 * (mg >> 1)]);
-        k.xrow = lds_off(&s_t[slot_of_tile(((mg >> 1) << 1) | (mc >> 3))][((mg & 1) << 5) | (mc & 7)]);
+        k.xrow = lds_off(&s_t[slot_of_tile(((mc >> 3) << 1) | (mg >> 1))][((mc & 7) << 3) | ((mg & 1) << 2)]);
         k.zz2 = 2u * c_zigzag[lane];
         const int ct = lane < 48 ? lane >> 3 : 5;               // column pass: 48 lanes, lane group = SLOT of the coefficient buffer
         k.col_rd = lds_off(&s_t[ct][lane & 7]);
@@ -871,7 +877,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     u32x3_t kq4 = {0, 0, 0};
 #define M2V_REQUEST_G3()                                                                                             \
     do {                                                                                                             \
-        kq2 = M2V_LANEK4(xc4); kq3 = M2V_LANEK4(zz2);                                                                \
+        kq2 = M2V_LANEK4(row_st); kq3 = M2V_LANEK4(zz2);                                                                \
         /* only the words that are used: a dead register of a wide load is reused at once, and the write-after-write   \
            wait then stalls the wavefront for the whole round trip */                                                  \
         if constexpr (EDGE) { if (edge_blk) kq4 = *(const __attribute__((address_space(1))) u32x3_t *)&M2V_LANEK4(crec_r); }   /* halo rows only */ \
@@ -1386,8 +1392,9 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     // transforms are B16 . Z . B16^T in place (tools/ubench/mfma_dct_check.hip checks this formulation on its own).
     //   pass 1  T = Z . B16^T: ONE v_mfma_i32_16x16x32_i8, K = 16 current columns (+B16) and 16 prediction columns (-B16);
     //           A = a row of signed bytes straight from s_cp, B = per-lane constant
-    //   pass 2  Y = B16 . T: T is 19 bit, i8 operands: three signed byte limbs (T + 0x808080) ^ 0x808080, the accumulator
-    //           layout of pass 1 (rows 4g .. 4g+3 of column c) IS the B layout of a K = 4g .. 4g+3 slice, a 4x4 byte transpose
+    //   pass 2  Y^T = T^T . B16^T: T is 19 bit, i8 operands: three signed byte limbs (T + 0x808080) ^ 0x808080, the accumulator
+    //           layout of pass 1 (rows 4g .. 4g+3 of column c) IS the A layout of T^T for a K = 4g .. 4g+3 slice (and equally the B
+    //           layout of T: which of the two operands the limbs are decides whether Y or Y^T comes out), a 4x4 byte transpose
     //           (7 v_perm) sorts the limbs, one MFMA per limb, recombined by two shift-adds per coefficient.
     // The two chroma tiles go through the same four instructions as the block [U x; x V]: A row c < 8 = row c of U in both halves of
     // K, row c >= 8 = row c - 8 of V; B16 being block diagonal, the quadrants beside the diagonal (x: U, V again) only reach output
@@ -1398,6 +1405,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     constexpr int kRound = P ? 2048 + (2 << 12) : 2048;        // an I frame has no non-intra macroblock: just the transform's rounding
     int yacc[4] = {0, 0, 0, 0}, yacc_c[4] = {0, 0, 0, 0};
     typedef int v4i_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4i_t *LdsW4i;
     // (matrix-core lane = (g = lane >> 4, c = lane & 15); its LDS slots come from the lane table)
     if constexpr (kMfmaLuma) {
         const long b1 = mf_b1, a2lo = mf_a2lo, a2hi = mf_a2hi;
@@ -1417,10 +1425,14 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
             uint32_t junk;
             asm volatile("" : "=v"(junk));
             const long b01 = (long)(((unsigned long long)w1 << 32) | w0), b2 = (long)(((unsigned long long)junk << 32) | w2);
-            const v4i_t y0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2lo, b01, zero4, 0, 0, 0);
+            // The limbs of T as the A operand, the basis as B: the product is Y TRANSPOSED, Y^T = T^T . B16^T - lane (g, c) ends up with
+            // Y[c][4g .. 4g+3], four neighbouring coefficients of ONE ROW of tile 2 (c >> 3) + (g >> 1): half of what one lane of the
+            // inverse transform's row pass needs, the other half is in lane (g ^ 1, c) - the dequantised luma values never go through LDS
+            // (profiles/r05_experiments.txt item 12)
+            const v4i_t y0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(b01, a2lo, zero4, 0, 0, 0);
             const v4i_t round4 = {kRound >> 8, kRound >> 8, kRound >> 8, kRound >> 8};
-            const v4i_t y1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2hi, b01, round4, 0, 0, 0);
-            const v4i_t y2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2lo, b2, zero4, 0, 0, 0);
+            const v4i_t y1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(b01, a2hi, round4, 0, 0, 0);
+            const v4i_t y2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(b2, a2lo, zero4, 0, 0, 0);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 // two v_lshl_add_u32.  Both are left to the compiler: an instruction that reads a matrix-core result needs wait
@@ -1453,6 +1465,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     const size_t mbidx = (size_t)fidx * g.mbs + mb;
     const bool need_rec = job.rec != nullptr && !(kDebug && (g.ablate & 8));
     int cbp = 0;
+    v4i_t xl4 = {0, 0, 0, 0};           // matrix-core transform: the lane's four dequantised luma coefficients (row mc, columns 4 mg ..)
     const bool chroma_lane = ((((uint32_t)lane >> 5) ^ ((uint32_t)lane >> 3)) & 1u) == 0u;     // matrix-core layout: g >> 1 == c >> 3
     if (kDebug && (g.ablate & 16)) {
         for (int t = 0; t < 6; ++t) s_zig[t][lane] = 0;
@@ -1460,13 +1473,13 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     } else if (inter) {
         const int qneg = sgpr(-(((1 << (4 + Q)) - 5) << 12));      // MINUS the bias of a negative value (it multiplies the sign mask)
         if constexpr (kMfmaLuma) {
-            // the four luma tiles in accumulator layout: lane (g, c) owns rows 4g .. 4g+3 of column c of the 16x16 block,
-            // i.e. four coefficients of tile 2 (g >> 1) + (c >> 3); their s_zig slots come from the lane table, their
-            // raster slots in s_t are 32 bytes apart
+            // the four luma tiles in (transposed) accumulator layout: lane (g, c) owns columns 4g .. 4g+3 of row c of the 16x16 block,
+            // i.e. four coefficients of tile 2 (c >> 3) + (g >> 1); their s_zig slots come from the lane table, their
+            // raster slots in s_t are neighbours
             const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
-            int32_t *const xrow = (int32_t *)(__attribute__((address_space(3))) int32_t *)(uintptr_t)kq2.w;   // &s_t[slot of tile ((mg >> 1) << 1) | (mc >> 3)][((mg & 1) << 5) | (mc & 7)]
-            // four coefficients of one pass of the transform: levels to s_zig (+ zadd bytes), dequantised values to s_t (+ xadd dwords)
-            auto quant4 = [&](const int (&ya)[4], const uint32_t zadd, const int xadd) {
+            const uint32_t xrow = kq2.w;                     // &s_t[slot of tile ((mc >> 3) << 1) | (mg >> 1)][((mc & 7) << 3) | ((mg & 1) << 2)]
+            // four coefficients of one pass of the transform: levels to s_zig (+ zadd bytes), dequantised values to s_t (+ xadd BYTES)
+            auto quant4 = [&](const int (&ya)[4], const uint32_t zadd, const uint32_t xadd) {
                 int nzor = 0, qv[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -1478,24 +1491,27 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     qv[v] = q;
                 }
                 if (need_rec) {                     // one test for the four coefficients
+                    v4i_t x4;
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         // RTL:2134-2137 clamps to +-2047; the clamp cannot bind here: |q| <= 16322 >> (4 + Q), so (2 |q| + 1) << Q <= 2044
                         // for every Q_LEVEL (tests/test_host_logic.py::test_inverse_quantisers_never_reach_their_clamps)
-                        xrow[v * 8 + xadd] = (2 * qv[v] + sign_of(qv[v])) << Q;
+                        x4[v] = (2 * qv[v] + sign_of(qv[v])) << Q;
                     }
+                    if (xadd == 0u) xl4 = x4;                       // luma: the row pass takes them from the registers
+                    else *(LdsW4i)(uintptr_t)(xrow + xadd) = x4;    // chroma block of an I frame: four neighbours of a row, ONE store
                 }
                 return nzor;
             };
-            // coded flags of the four luma tiles: tile 2 ty + tx lives in lanes 32 ty + 16 h + 8 tx + (0 .. 7), h = 0, 1
-            const unsigned long long nzm = ballot(quant4(yacc, 0u, 0) != 0);
+            // coded flags of the four luma tiles: tile 2 ty + tx lives in lanes 32 tx + 16 h + 8 ty + (0 .. 7), h = 0, 1
+            const unsigned long long nzm = ballot(quant4(yacc, 0u, 0u) != 0);
             const uint32_t lo = (uint32_t)sgpr((int)(uint32_t)nzm), hi = (uint32_t)sgpr((int)(uint32_t)(nzm >> 32));
-            cbp = ((lo & 0x00FF00FFu) ? 8 : 0) | ((lo & 0xFF00FF00u) ? 4 : 0) | ((hi & 0x00FF00FFu) ? 2 : 0) | (int)(((hi & 0xFF00FF00u) | (0u - (hi & 0xFF00FF00u))) >> 31);
+            cbp = ((lo & 0x00FF00FFu) ? 8 : 0) | ((hi & 0x00FF00FFu) ? 4 : 0) | ((lo & 0xFF00FF00u) ? 2 : 0) | (int)(((hi & 0xFF00FF00u) | (0u - (hi & 0xFF00FF00u))) >> 31);
             // the chroma block: U where luma tile 0 is (g < 2, c < 8: lanes 0-7, 16-23), V where tile 3 is (lanes 40-47, 56-63), one slot
             // further in both buffers; the other lanes hold the quadrants nobody wants
             if constexpr (kMfmaChroma) {
                 int nzor_c = 0;
-                if (chroma_lane) nzor_c = quant4(yacc_c, 128u, kTileStride);
+                if (chroma_lane) nzor_c = quant4(yacc_c, 128u, 4u * kTileStride);
                 const unsigned long long nzc = ballot(nzor_c != 0);
                 cbp = (cbp << 2) | ((uint32_t)sgpr((int)(uint32_t)nzc) ? 2 : 0) | ((uint32_t)sgpr((int)(uint32_t)(nzc >> 32)) ? 1 : 0);
             }
@@ -1536,14 +1552,15 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         if constexpr (kMfmaLuma) {
             const uint32_t zo[4] = {mf_zoff.x, mf_zoff.y, mf_zoff.z, mf_zoff.w};
             const uint32_t ml_wq = iq_w.y, ml_recip[4] = {iq_recip.x, iq_recip.y, iq_recip.z, iq_recip.w};
-            int32_t *const xrow = (int32_t *)(__attribute__((address_space(3))) int32_t *)(uintptr_t)kq2.w;
+            const uint32_t xrow = kq2.w;
             // (the chroma block's coefficients sit at the raster positions of the lane's luma coefficients: same weights, same DC lane)
-            auto quant4 = [&](const int (&ya)[4], const uint32_t zadd, const int xadd) {
+            auto quant4 = [&](const int (&ya)[4], const uint32_t zadd, const uint32_t xadd) {
+                v4i_t x4 = {0, 0, 0, 0};
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int wv = (int)((ml_wq >> (8 * v)) & 255u);
                     const uint32_t qo = __umul24((uint32_t)wv, (3u << Q) + 2u) >> 3;
-                    const bool is_dc = v == 0 && (lane & 0x17) == 0;           // row 0 of a tile (g even, v = 0), column 0 of a tile
+                    const bool is_dc = v == 0 && (lane & 0x17) == 0;           // column 0 of a tile (g even, v = 0), row 0 of a tile
                     const int C = (ya[v] >> 12) - (kRound >> 12);          // ya carries kRound
                     const int sg = C >> 31;
                     uint32_t a = (uint32_t)((C ^ sg) - sg) & 0xFFFFu;
@@ -1564,12 +1581,16 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                         } else {
                             x = 2 * q;
                         }
-                        xrow[v * 8 + xadd] = x;
+                        x4[v] = x;
                     }
                 }
+                if (need_rec) {
+                    if (xadd == 0u) xl4 = x4;
+                    else *(LdsW4i)(uintptr_t)(xrow + xadd) = x4;
+                }
             };
-            quant4(yacc, 0u, 0);
-            if constexpr (kMfmaChroma) { if (chroma_lane) quant4(yacc_c, 128u, kTileStride); }
+            quant4(yacc, 0u, 0u);
+            if constexpr (kMfmaChroma) { if (chroma_lane) quant4(yacc_c, 128u, 4u * kTileStride); }
         }
 #pragma unroll
         for (int t = kT0; t < 6; ++t) {
@@ -1687,7 +1708,30 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
     if (need_rec) {
         keep_alive(kq3);
         if constexpr (EDGE) keep_alive(kq4);
-        if (lane < 48) {                                // rows: lane = slot*8 + row (RTL:2159-2189), in place
+        if constexpr (kMfmaLuma) {
+            // rows (RTL:2159-2189).  A luma row is split over lanes (g, c) and (g ^ 1, c), columns 0-3 and 4-7: one v_permlane16_swap per
+            // register hands the odd rows' halves to the even rows (the register that receives them needs no content, the odd rows'
+            // own copies are dead) - lanes 0-15 and 32-47 then hold the 32 luma rows.  Lanes 16-31 fetch the 16 chroma rows from s_t.
+            typedef __attribute__((address_space(3))) v4i_t *LdsV4;
+            int a[8], o[8];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                int junk;
+                asm volatile("" : "=v"(junk));
+                const auto sw = __builtin_amdgcn_permlane16_swap((uint32_t)xl4[v], (uint32_t)junk, false, false);
+                a[v] = (int)sw[0]; a[4 + v] = (int)sw[1];
+            }
+            if (lane < 48) {
+                if (lane & 16) {
+                    const v4i_t lo = *(LdsV4)(uintptr_t)kq2.x, hi = *(LdsV4)(uintptr_t)(kq2.x + 16u);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { a[k] = lo[k]; a[4 + k] = hi[k]; }
+                }
+                idct_row(a, o);
+                *(LdsV4)(uintptr_t)kq2.x = v4i_t{o[0], o[1], o[2], o[3]};
+                *(LdsV4)(uintptr_t)(kq2.x + 16u) = v4i_t{o[4], o[5], o[6], o[7]};
+            }
+        } else if (lane < 48) {                         // rows: lane = slot*8 + row (RTL:2159-2189), in place
             const int t = lane >> 3, row = lane & 7;
             int a[8], o[8];
 #pragma unroll

@@ -57,11 +57,11 @@ void upload_tables_now()
             }
         if ((c >> 3) == (g >> 1))
             for (int b = 0; b < 4; ++b) m.a2 |= (uint32_t)(uint8_t)kDctBasis[(c & 7) * 8 + 4 * (g & 1) + b] << (8 * b);
-        const int tile = ((g >> 1) << 1) | (c >> 3);
+        const int tile = ((c >> 3) << 1) | (g >> 1);            // the second pass leaves Y transposed: lane (g, c) = row c, columns 4g .. 4g+3
         m.a1c = (uint32_t)(kMfmaCpOff + ((4 + (c >> 3)) * 8 + (c & 7)) * 16 + 8 * (g >> 1));        // &s_cp[4 + (c >> 3)][c & 7][8 (g >> 1)]
         uint32_t wq4 = 0;
         for (int v = 0; v < 4; ++v) {
-            const int raster = (4 * (g & 1) + v) * 8 + (c & 7);
+            const int raster = (c & 7) * 8 + 4 * (g & 1) + v;
             m.zoff[v] = (uint32_t)(slot_of_tile(tile) * 128 + kZigzagPos[raster] * 2);
             wq4 |= (uint32_t)kIntraW[raster] << (8 * v);
             m.irecip[v] = recip[raster];
