@@ -198,10 +198,10 @@ def end_to_end(M, clip_np, want_bytes):
 
     outbuf = np.empty(clip_np.shape[0] * W * H * 3 // 2 + 4096, np.uint8)      # the caller's own output buffer: m2v_pull writes into it
 
-    def run(frames, best_of=4, deferred=False):
+    def run(frames, best_of=4, deferred=False, one_call=False):
         enc = M.Mpeg2Encoder(XL, YL, VL, Q)
         try:
-            enc.set_option("batch_frames", 2 * gop)
+            enc.set_option("batch_frames", gop)
             if deferred:
                 enc.set_option("direct_upload", 2)
             best, data = 1e9, b""
@@ -209,8 +209,11 @@ def end_to_end(M, clip_np, want_bytes):
                 t0 = time.perf_counter()
                 pos = 0
                 for k in range(0, n, gop):
-                    enc.push_frames(XS16, YS16, PFRAMES, frames[k:k + gop])
-                    pos += enc.pull_into(outbuf, pos)[0]
+                    if one_call:
+                        pos += enc.push_frames_pull(XS16, YS16, PFRAMES, frames[k:k + gop], outbuf, pos)[0]
+                    else:
+                        enc.push_frames(XS16, YS16, PFRAMES, frames[k:k + gop])
+                        pos += enc.pull_into(outbuf, pos)[0]
                 enc.sequence_stop()
                 last = False
                 while not last:
@@ -227,6 +230,7 @@ def end_to_end(M, clip_np, want_bytes):
     pinned = pinned_t.numpy()
     t_pin, d_pin = run(pinned)
     t_def, d_def = run(pinned, deferred=True)
+    t_one, d_one = run(pinned, one_call=True)
 
     def run_two(best_of=6):
         """two callers at once - two threads, a handle and a page-locked copy of the clip each: one caller's turn-around between its
@@ -237,7 +241,7 @@ def end_to_end(M, clip_np, want_bytes):
         res, best = [b"", b""], 1e9
         try:
             for e in encs:
-                e.set_option("batch_frames", 2 * gop)
+                e.set_option("batch_frames", gop)
 
             def caller(i):
                 out = []
@@ -277,8 +281,9 @@ def end_to_end(M, clip_np, want_bytes):
     return {"value": round(px / t_pin * 1e-6, 1), "unit": "MPixels/s", "frames": n, "best_of": 4,
             "input_GBps": round(px * 3 / t_pin * 1e-9, 2), "identical_to_resident_stream": d_pin == want_bytes and d_page == want_bytes,
             "path": "m2v_push_frames -> m2v_pull (into the caller's output buffer), frames in page-locked host memory uploaded straight from "
-                    "the caller's buffer (hipMemcpyAsync on an upload stream; the call returns when its frames have been read), stream bytes back "
-                    "to the host; chunk k+1 uploads while chunk k encodes, batch_frames=%d" % (2 * gop),
+                    "the caller's buffer (hipMemcpyAsync on an upload stream; the call returns when its frames have been read; the chunk's kernels "
+                    "queue behind a gate kernel the call opens then), stream bytes back to the host by a kernel; chunk k+1 uploads while chunk k "
+                    "encodes, batch_frames=%d" % gop,
             "pageable_source": {"value": round(px / t_page * 1e-6, 1), "input_GBps": round(px * 3 / t_page * 1e-9, 2),
                                 "path": "the same from a plain numpy array: copied into the handle's pinned staging by 8 threads first"},
             "two_callers": {"value": round(2 * px / t_two * 1e-6, 1), "input_GBps": round(2 * px * 3 / t_two * 1e-9, 2),
@@ -290,6 +295,10 @@ def end_to_end(M, clip_np, want_bytes):
             "deferred_upload": {"value": round(px / t_def * 1e-6, 1), "input_GBps": round(px * 3 / t_def * 1e-9, 2), "identical": d_def == want_bytes,
                                 "fraction_of_measured_h2d": round(px * 3 / t_def / h2d, 3),
                                 "path": "the same loop with option direct_upload = 2"},
+            # both port groups in one call (m2v_push_frames_pull): the stream bytes of completed chunks are copied into the caller's buffer while
+            # the call's frames cross the link - the same loop, one call per GOP instead of two
+            "one_call": {"value": round(px / t_one * 1e-6, 1), "input_GBps": round(px * 3 / t_one * 1e-9, 2), "identical": d_one == want_bytes,
+                         "fraction_of_measured_h2d": round(px * 3 / t_one / h2d, 3), "path": "m2v_push_frames_pull per GOP, then stop and drain"},
             "pcie_bound_MPixels": round(63e9 / 3 * 1e-6, 0),
             "h2d_copy_measured_GBps": round(h2d * 1e-9, 1), "fraction_of_measured_h2d": round(px * 3 / t_pin / h2d, 3)}
 

@@ -27,7 +27,7 @@ LIB_DBG_PATH = os.environ.get("M2V_LIB_DBG") or os.path.join(_HERE, "libm2v_mi35
 _libs = {}
 
 EXPORTS = [
-    "m2v_version", "m2v_create", "m2v_destroy", "m2v_reset", "m2v_push_beats", "m2v_push_packed", "m2v_push_frames",
+    "m2v_version", "m2v_create", "m2v_destroy", "m2v_reset", "m2v_push_beats", "m2v_push_packed", "m2v_push_frames", "m2v_push_frames_pull",
     "m2v_sequence_stop", "m2v_busy", "m2v_pull", "m2v_geometry", "m2v_encode_resident", "m2v_encode_resident_begin",
     "m2v_encode_resident_end", "m2v_set_option",
     "m2v_kernel_stats", "m2v_debug_read", "m2v_last_error", "m2v_debug_table",
@@ -138,6 +138,8 @@ def lib(debug=False):
             L.m2v_comm_kind.argtypes = [vp]
             L.m2v_strip_last_form.argtypes = [vp]
             L.m2v_upload_wait.argtypes = [vp]
+            L.m2v_push_frames_pull.restype = ctypes.c_longlong
+            L.m2v_push_frames_pull.argtypes = [vp, u32, u32, u32, vp, sz, vp, sz, ctypes.POINTER(ci)]
         except AttributeError:
             # an OLDER build handed in through M2V_LIB for a same-box A/B (tools/ab.sh) may lack the newer entry points; the library of
             # this tree must have every one of them (tests/test_abi.py)
@@ -219,6 +221,18 @@ class Mpeg2Encoder:
         assert f.size % (3 * W * H) == 0
         self._chk(self._L.m2v_push_frames(self._h, xsize16, ysize16, pframes_count, f.ctypes.data,
                                           f.size // (3 * W * H)), "m2v_push_frames")
+
+    def push_frames_pull(self, xsize16, ysize16, pframes_count, frames444, dst, offset=0):
+        """m2v_push_frames_pull: push_frames + pull_into(dst, offset) in one call, the stream bytes copied while the frames upload:
+        -> (bytes written, last)"""
+        W, H = self.geometry(xsize16, ysize16)
+        f = np.ascontiguousarray(frames444, np.uint8).reshape(-1)
+        assert f.size % (3 * W * H) == 0
+        assert dst.dtype == np.uint8 and dst.flags["C_CONTIGUOUS"]
+        last = ctypes.c_int(0)
+        n = self._chk(self._L.m2v_push_frames_pull(self._h, xsize16, ysize16, pframes_count, f.ctypes.data, f.size // (3 * W * H),
+                                                   dst.ctypes.data + offset, (dst.size - offset) & ~31, ctypes.byref(last)), "m2v_push_frames_pull")
+        return n, bool(last.value)
 
     def upload_wait(self):
         """option direct_upload = 2: returns when every frame handed to push_frames so far has been read"""

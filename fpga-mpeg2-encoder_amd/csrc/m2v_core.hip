@@ -472,6 +472,7 @@ void m2v_destroy(m2v_enc *e)
     (void)hipSetDevice(e->device);
     // a resident sequence enqueued on a CALLER's stream (m2v_encode_resident_begin with hip_stream != NULL) still reads and writes the
     // handle's work buffers: nothing is released under running kernels
+    if (e->gate_open && e->h_gate) { if (e->up_stream) (void)hipStreamSynchronize(e->up_stream); *(volatile unsigned int *)e->h_gate = e->gate_seq; e->gate_open = false; }
     if (e->resident_inflight && e->resident_stream) (void)hipStreamSynchronize(e->resident_stream);
     if (e->strip_stream && e->strip_stream != e->stream) (void)hipStreamSynchronize(e->strip_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -501,6 +502,7 @@ void m2v_destroy(m2v_enc *e)
     }
     if (e->ev_asm) { (void)hipEventSynchronize(e->ev_asm); (void)hipEventDestroy(e->ev_asm); }
     if (e->h_asm) (void)hipHostFree(e->h_asm);
+    if (e->h_gate) (void)hipHostFree(e->h_gate);
     if (e->ev_strip) { (void)hipEventSynchronize(e->ev_strip); (void)hipEventDestroy(e->ev_strip); }
     if (e->h_strip) (void)hipHostFree(e->h_strip);
     if (e->comm_stream) { (void)hipStreamSynchronize(e->comm_stream); (void)hipStreamDestroy(e->comm_stream); }
@@ -526,6 +528,8 @@ int m2v_reset(m2v_enc *e)
 {
     if (!e) return M2V_E_PARAM;
     (void)hipSetDevice(e->device);
+    // (a call that failed between queueing a gate kernel and releasing it: the handle's stream would sit behind it for the gate's budget)
+    if (e->gate_open && e->h_gate) { if (e->up_stream) (void)hipStreamSynchronize(e->up_stream); *(volatile unsigned int *)e->h_gate = e->gate_seq; e->gate_open = false; }
     // (a resident sequence on a caller's stream: its kernels use the work buffers the next call rewrites)
     if (e->resident_inflight && e->resident_stream) (void)hipStreamSynchronize(e->resident_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -553,6 +557,7 @@ int m2v_reset(m2v_enc *e)
     e->ctl_init = 0;
     e->scan_peer_gaveup = nullptr;
     e->upl_pending[0] = e->upl_pending[1] = false;
+    e->up_unsynced = false;
     e->g.row0 = 0; e->g.row1 = e->g.mbh; e->g.strip = 0;
     geom_finish(e->g);
     e->timed.clear(); e->ev_used = 0; e->chain_ev = nullptr;

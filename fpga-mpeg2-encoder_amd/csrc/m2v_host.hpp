@@ -125,6 +125,14 @@ struct m2v_enc {
     hipEvent_t ev_upl[2] = {nullptr, nullptr}, ev_up2 = nullptr;
     bool upl_pending[2] = {false, false};
     int up_parity = 0;
+    // Blocking m2v_push_frames from page-locked memory: the chunk's kernels are queued behind a GATE kernel that waits for a word in
+    // pinned host memory, which the call writes once it has waited for its transfer (m2v_port.hip: open_gate / release_gate) - instead
+    // of an event behind the copy, which the call's own wait would then sit behind as well.
+    bool up_unsynced = false;            // a direct upload has been issued and not yet waited for on the host
+    unsigned int *h_gate = nullptr;      // pinned: the sequence number of the last released gate
+    unsigned int gate_seq = 0;           // ... of the last gate queued
+    bool gate_open = false;              // a gate kernel is queued whose number has not been written yet
+    void *call_sink = nullptr;           // m2v_push_frames_pull: the call's destination (a PullSink), seen by every progress() inside the call
     int split_streams = 2;        // GOP segments of a chunk run as this many independent groups on as many streams (encode_chunk)
     static constexpr int kMaxSplit = 8;
     hipStream_t side[kMaxSplit - 1] = {};            // group 0 runs on the caller's stream

@@ -57,6 +57,47 @@ bool event_reached(hipEvent_t ev, bool block)
     return true;
 }
 
+// 16 bytes per lane: a chunk's stream bytes into the pinned read-back buffer.  By a kernel, not by the copy engine: a read-back the copy
+// engine is working on when the NEXT upload arrives delays that upload by most of its own duration (+45 us per 3.4 MB on this box, every
+// second m2v_push_frames call; nothing when a kernel writes the bytes - profiles/r05_experiments.txt item 13)
+__global__ __launch_bounds__(256) void k_readback(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+// The gate in front of a chunk's kernels (see m2v_enc::h_gate): one lane waits until the host has written this gate's number - it does so
+// when it has waited for the chunk's transfer.  Bounded (wall clock, 100 MHz): a host that never gets there (a failed call that is not
+// followed by m2v_reset / m2v_destroy, which write the number) stalls the handle's stream for two seconds, not for ever.
+__global__ void k_gate(const unsigned int *flag, unsigned int want)
+{
+    typedef const __attribute__((address_space(1))) unsigned int *gu32;
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load((gu32)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+        if (wall_clock64() - t0 > 200000000ll) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+
+// queue a gate on the handle's stream
+static void open_gate(m2v_enc *e)
+{
+    if (!e->h_gate) { HIPCHK(hipHostMalloc((void **)&e->h_gate, 64)); *e->h_gate = 0; e->gate_seq = 0; }
+    ++e->gate_seq;
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, e->stream, (const unsigned int *)e->h_gate, e->gate_seq);
+    HIPCHK(hipGetLastError());
+    e->gate_open = true;
+}
+
+// every direct upload issued so far has arrived: wait for the copy itself (the upload stream's last command), then let the kernels go
+static void release_gate(m2v_enc *e)
+{
+    if (e->up_unsynced) { HIPCHK(hipStreamSynchronize(e->up_stream)); e->up_unsynced = false; }
+    if (e->gate_open) {
+        __atomic_store_n(e->h_gate, e->gate_seq, __ATOMIC_RELEASE);
+        e->gate_open = false;
+    }
+}
+
 // Move submitted chunks forward, oldest first.  block = wait for every step; until >= 0 = return as soon
 // as that stage is free again.
 // m2v_pull's destination while it moves chunks forward: a completed chunk's whole 32-byte words go straight from the pinned read-back
@@ -65,6 +106,7 @@ struct PullSink { uint8_t *dst; size_t cap, used; };
 
 void progress(m2v_enc *e, bool block, int until = -1, PullSink *sink = nullptr)
 {
+    if (!sink) sink = (PullSink *)e->call_sink;
     while (!e->pending.empty()) {
         const int idx = e->pending.front();
         m2v_enc::HostStage &h = e->hs[idx];
@@ -80,16 +122,25 @@ void progress(m2v_enc *e, bool block, int until = -1, PullSink *sink = nullptr)
                 h.h_out_cap = h.bytes + 4096;
             }
             // the kernels that wrote d_out are complete (ev_ctl follows them): no cross-stream wait needed
-            HIPCHK(hipMemcpyAsync(h.h_out, h.d_out.p, h.bytes, hipMemcpyDeviceToHost, e->copy_stream));
+            if (h.bytes) {
+                hipLaunchKernelGGL(k_readback, dim3(32), dim3(256), 0, e->copy_stream, (uint4 *)h.h_out, (const uint4 *)h.d_out.p, (h.bytes + 15) / 16);
+                HIPCHK(hipGetLastError());
+            }
             HIPCHK(hipEventRecord(h.ev_out, e->copy_stream));
             h.stage = 2;
         }
         if (!event_reached(h.ev_out, block)) return;
         size_t direct = 0;
-        if (sink && e->fifo_rd == e->fifo.size() && sink->cap - sink->used >= 32) {
-            direct = std::min(h.bytes, sink->cap - sink->used) & ~(size_t)31;
-            memcpy(sink->dst + sink->used, h.h_out, direct);
-            sink->used += direct;
+        const size_t waiting = e->fifo.size() - e->fifo_rd;            // less than a word: the residue of the chunk before
+        if (sink && waiting < 32 && sink->cap - sink->used >= 32 && waiting + h.bytes >= 32) {
+            // the residue first, then this chunk's bytes straight from the read-back buffer - whole words in all
+            const size_t whole = std::min(waiting + h.bytes, sink->cap - sink->used) & ~(size_t)31;
+            memcpy(sink->dst + sink->used, e->fifo.data() + e->fifo_rd, waiting);
+            direct = whole - waiting;
+            memcpy(sink->dst + sink->used + waiting, h.h_out, direct);
+            sink->used += whole;
+            e->fifo.clear();
+            e->fifo_rd = 0;
         }
         e->fifo.insert(e->fifo.end(), h.h_out + direct, h.h_out + h.bytes);
         e->stream_bytes += h.bytes;
@@ -124,12 +175,24 @@ void flush_buffered(m2v_enc *e, bool last)
     // the stage's own device buffer, filled on the upload stream: the copy of chunk k+1 crosses PCIe while the kernels
     // of chunk k run (the stage is only refilled after its previous chunk has completed, see the end of this function)
     h.d_in.ensure(std::max(nf, h.uploaded ? e->batch_frames : (size_t)0) * frame_bytes);
-    if (h.uploaded < nf)
+    // a gate queued by an earlier chunk of this call: released before anything below can wait for that chunk (and with it every upload so far)
+    if (e->gate_open) release_gate(e);
+    const bool staged = h.uploaded < nf;
+    if (staged)
         HIPCHK(hipMemcpyAsync(h.d_in.p + h.uploaded * frame_bytes, h.h_in + h.uploaded * frame_bytes, (nf - h.uploaded) * frame_bytes,
                               hipMemcpyHostToDevice, e->up_stream));
     h.uploaded = 0;
-    HIPCHK(hipEventRecord(h.ev_up, e->up_stream));
-    HIPCHK(hipStreamWaitEvent(s, h.ev_up, 0));
+    if (staged || e->direct_upload_deferred || e->upl_pending[0] || e->upl_pending[1]) {
+        // the chunk's kernels behind its uploads, by an event (option direct_upload = 2: this call's own transfer is not waited for on the host)
+        HIPCHK(hipEventRecord(h.ev_up, e->up_stream));
+        HIPCHK(hipStreamWaitEvent(s, h.ev_up, 0));
+    } else if (e->up_unsynced) {
+        // Only the blocking call's own direct transfer is outstanding, and the call waits for it on the host before it returns: the kernels
+        // go behind a gate that the call opens then.  (An event would be a packet of its own behind the copy on the upload stream, and the
+        // call's wait for that stream a wait for the packet: +30 us per chunk on this box, tools/ubench/h2d_kernel.hip.)
+        if (e->async && !e->profile && !last) open_gate(e);
+        else release_gate(e);           // (this chunk is waited for before the function returns: its frames first, no gate)
+    }
     // worst case ~1.2 KB per macroblock; typical streams are ~100x smaller
     const size_t cap = nf * ((size_t)g.mbs * 1216 + (size_t)g.mbh * 8 + 64) + 256;
     h.d_out.ensure(cap);
@@ -281,7 +344,7 @@ int m2v_push_packed(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pfr
     return M2V_OK;
 }
 
-struct PushFramesArgs { uint32_t xs, ys, pf; const uint8_t *frames; size_t n; };
+struct PushFramesArgs { uint32_t xs, ys, pf; const uint8_t *frames; size_t n; PullSink *sink; };
 
 static int push_frames_impl(m2v_enc *e, void *argp)
 {
@@ -337,6 +400,7 @@ static int push_frames_impl(m2v_enc *e, void *argp)
             }
             h.uploaded = e->buffered + take;
             direct_pending = true;
+            if (!e->direct_upload_deferred) e->up_unsynced = true;
         } else {
             parallel_copy(h.h_in + e->buffered * fb, a->frames + k * fb, take * fb, e->copy_threads);
         }
@@ -344,6 +408,8 @@ static int push_frames_impl(m2v_enc *e, void *argp)
         k += take;
         if (e->buffered == e->batch_frames) flush_buffered(e, false);
     }
+    // m2v_push_frames_pull: completed chunks leave for the caller's buffer HERE, while this call's frames cross the link
+    if (a->sink) progress(e, false, -1, a->sink);
     if (direct_pending) {
         if (e->direct_upload_deferred) {
             // option direct_upload = 2: this call's frames are still being read when it returns; what is waited for here is the
@@ -356,20 +422,54 @@ static int push_frames_impl(m2v_enc *e, void *argp)
             e->upl_pending[k] = true;
             e->up_parity ^= 1;
         } else {
-            HIPCHK(hipStreamSynchronize(e->up_stream));     // the caller may reuse its buffer when this returns
+            release_gate(e);                                // waits for the transfer: the caller may reuse its buffer when this returns
             e->upl_pending[0] = e->upl_pending[1] = false;
         }
     }
-    progress(e, false);
+    progress(e, false, -1, a->sink);
     return M2V_OK;
+}
+
+// a call that failed behind open_gate: the gate is let go (best effort) so that nothing later waits out its budget behind it
+static int push_frames_guarded(m2v_enc *e, PushFramesArgs *a)
+{
+    const int r = guard(e, push_frames_impl, a);
+    if (r < 0 && e->gate_open && e->h_gate) {
+        if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
+        __atomic_store_n(e->h_gate, e->gate_seq, __ATOMIC_RELEASE);
+        e->gate_open = false;
+        e->up_unsynced = false;
+    }
+    return r;
 }
 
 int m2v_push_frames(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const uint8_t *frames444,
                     size_t nframes)
 {
     if (!e || (nframes && !frames444)) return M2V_E_PARAM;
-    PushFramesArgs a{xsize16, ysize16, pframes_count, frames444, nframes};
-    return guard(e, push_frames_impl, &a);
+    PushFramesArgs a{xsize16, ysize16, pframes_count, frames444, nframes, nullptr};
+    return push_frames_guarded(e, &a);
+}
+
+static long long pull_tail(m2v_enc *e, uint8_t *dst, size_t cap, const PullSink &sink, int *last);
+static int pull_progress_impl(m2v_enc *e, void *argp);
+
+long long m2v_push_frames_pull(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const uint8_t *frames444,
+                               size_t nframes, uint8_t *dst, size_t cap, int *last)
+{
+    if (!e || (nframes && !frames444) || (!dst && cap)) return M2V_E_PARAM;
+    if (last) *last = 0;
+    PullSink sink{dst, cap, 0};
+    PushFramesArgs a{xsize16, ysize16, pframes_count, frames444, nframes, &sink};
+    e->call_sink = &sink;
+    int r = push_frames_guarded(e, &a);
+    e->call_sink = nullptr;
+    if (r < 0) return r;
+    if (e->state == m2v_enc::ENDED && !e->pending.empty()) {        // (frames are dropped while the sequence ends; the pull half waits like m2v_pull)
+        r = guard(e, pull_progress_impl, &sink);
+        if (r < 0) return r;
+    }
+    return pull_tail(e, dst, cap, sink, last);
 }
 
 static int upload_wait_impl(m2v_enc *e, void *)
@@ -420,6 +520,12 @@ long long m2v_pull(m2v_enc *e, uint8_t *dst, size_t cap, int *last)
         const int r = guard(e, pull_progress_impl, &sink);
         if (r < 0) return r;
     }
+    return pull_tail(e, dst, cap, sink, last);
+}
+
+// what m2v_pull and m2v_push_frames_pull end with: the FIFO's whole words behind what went to the caller directly, the end of the sequence
+static long long pull_tail(m2v_enc *e, uint8_t *dst, size_t cap, const PullSink &sink, int *last)
+{
     const size_t avail = e->fifo.size() - e->fifo_rd;
     // only whole 32-byte words leave; the residue waits for more data or for the end of the sequence
     size_t n = std::min(avail, cap - sink.used) & ~(size_t)31;

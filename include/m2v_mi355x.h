@@ -101,6 +101,15 @@ int m2v_busy(const m2v_enc *e);
  * waiting; after the stop it waits for the rest.
  */
 long long m2v_pull(m2v_enc *e, uint8_t *dst, size_t cap, int *last);
+/*
+ * Both port groups in ONE call, as the module drives them in the same clock (input beats RTL:15-21 while o_en / o_data run,
+ * RTL:35-37; the testbench's producer and consumer blocks, SIM/tb_mpeg2encoder.v:206-266 and :268-281): m2v_push_frames followed by
+ * m2v_pull into dst, with the same results and return value as that pair - except that the words of completed chunks are
+ * copied into dst WHILE this call's frames cross the link, not between two transfers.  For a caller with one thread and frames in
+ * page-locked memory the link then only idles for the caller's own turn-around.
+ */
+long long m2v_push_frames_pull(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
+                               const uint8_t *frames444, size_t nframes, uint8_t *dst, size_t cap, int *last);
 
 /* Clamped geometry the module would use for (xsize16, ysize16) (RTL:985-1006). */
 int m2v_geometry(const m2v_enc *e, uint32_t xsize16, uint32_t ysize16, int *width, int *height);

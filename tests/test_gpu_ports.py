@@ -316,3 +316,74 @@ def test_deferred_upload_and_pull_into_give_the_same_stream():
             assert not enc.busy
     finally:
         enc.close()
+
+
+def test_push_frames_pull_is_push_then_pull():
+    """m2v_push_frames_pull (both port groups in one call): byte-identical to the oracle from page-locked and from pageable memory, with
+    pushes that complete a chunk exactly (the gate-kernel path of a blocking direct upload), pushes that span several chunks, a push
+    per frame, and a destination so small that words queue up in the FIFO behind it; the handle is reused for all of them."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    W, H, pf, n = 192, 128, 3, 24
+    clip = M.synth.clip(W, H, n, clip_index=96, scene_len=7)
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
+    pinned = torch.from_numpy(np.ascontiguousarray(clip)).pin_memory().numpy()
+    enc = M.Mpeg2Encoder(7, 7, 3, 2)
+    try:
+        for src, batch, per_push, cap in ((pinned, 4, 4, None), (pinned, 4, 12, None), (pinned, 8, 1, None), (clip, 4, 4, None),
+                                          (pinned, 4, 4, 64), (pinned, 4, 2, 4096), (clip, 8, 5, 96)):
+            enc.set_option("batch_frames", batch)
+            out = np.zeros(len(want) + 4096, np.uint8)
+            pos, last = 0, False
+            for k in range(0, n, per_push):
+                window = out if cap is None else out[:min(out.size, pos + cap)]
+                m, last = enc.push_frames_pull(W // 16, H // 16, pf, src[k:k + per_push], window, pos)
+                pos += m
+                assert not last
+            enc.sequence_stop()
+            while not last:
+                m, last = enc.pull_into(out, pos)
+                pos += m
+            assert out[:pos].tobytes() == want, (batch, per_push, cap)
+            assert not enc.busy
+    finally:
+        enc.close()
+
+
+def test_deferred_upload_chunk_completed_by_the_call_itself():
+    """option direct_upload = 2 with pushes that complete a chunk exactly and frames large enough that the transfer is still under way when
+    the chunk's kernels are queued: the kernels must wait for THIS call's transfer although the call does not (the chunk's first launch
+    sits behind an event on the upload stream; a missing event shows here as a stream encoded from the frames of the sequence before -
+    two different clips take turns, so what is left in the device buffers is never what is wanted)."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    W, H, pf, n = 1280, 720, 3, 12
+    clips = [M.synth.clip(W, H, n, clip_index=97 + i, scene_len=5) for i in range(2)]
+    wants = [orc.encode(c, W // 16, H // 16, pf, 7, 7, 2, 2) for c in clips]
+    pinned = [torch.from_numpy(np.ascontiguousarray(c)).pin_memory().numpy() for c in clips]
+    out = np.zeros(max(len(w) for w in wants) + 4096, np.uint8)
+    enc = M.Mpeg2Encoder(7, 7, 2, 2)
+    try:
+        enc.set_option("batch_frames", 4)
+        rnd = 0
+        for mode in (2, 1, 2):
+            enc.set_option("direct_upload", mode)
+            for rep in range(2):
+                src, want = pinned[rnd & 1], wants[rnd & 1]
+                rnd += 1
+                pos = 0
+                for k in range(0, n, 4):
+                    enc.push_frames(W // 16, H // 16, pf, src[k:k + 4])
+                    pos += enc.pull_into(out, pos)[0]
+                enc.sequence_stop()
+                last = False
+                while not last:
+                    m, last = enc.pull_into(out, pos)
+                    pos += m
+                assert out[:pos].tobytes() == want, "direct_upload = %d, sequence %d" % (mode, rnd)
+    finally:
+        enc.close()
