@@ -2028,7 +2028,9 @@ __device__ __forceinline__ void asm_put(uint32_t *img, int nw, int pos, uint32_t
     if (w + 1 < nw && lo) atomicOr(&img[w + 1], lo);
 }
 
-__global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__restrict__ jobs, Geom g, int nframes,
+// (eight wavefronts per SIMD = 16 workgroups per CU: 51 registers with the staging in two rounds; one round of eight 16-byte loads per thread
+// needs 74 = six wavefronts, and fits eight only by spilling - 40 / 44 / 48 us per sequence in the profiled pass, item 14)
+__global__ __launch_bounds__(kAsmThreads, 8) void k_assemble(const FrameJob *__restrict__ jobs, Geom g, int nframes,
                                                  const uint32_t *__restrict__ mbinfo, const MbAux *__restrict__ mbaux,
                                                  const uint32_t *__restrict__ slots_small, const uint32_t *__restrict__ slots,
                                                  const unsigned long long *__restrict__ slice_off,
@@ -2083,27 +2085,30 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(const FrameJob *__rest
     __syncthreads();
     const uint32_t off = bscan - mylen + (tid >= 64 ? s_bits[0] : 0u);
     const uint32_t total = s_bits[0] + s_bits[1];          // the slice's bits
-    // stage the compact slots: up to kSlotChunks chunks of 16 bytes per macroblock, only the filled ones, packed.  All loads of a
-    // thread are issued before the first LDS store (one memory round trip, not one per chunk).
+    // stage the compact slots: up to kSlotChunks chunks of 16 bytes per macroblock, only the filled ones, packed.  The loads of a
+    // round are issued before its first LDS store (two memory round trips, not one per chunk).
     {
-        constexpr int kIter = kSlotChunks;                  // 128 macroblocks x kSlotChunks chunks / 128 threads
-        uint4 v[kIter];
-        uint32_t dst[kIter];
+        constexpr int kRounds = 2, kIter = kSlotChunks / kRounds;     // 128 macroblocks x kSlotChunks chunks / 128 threads, in two rounds (registers: see the launch bounds)
 #pragma unroll
-        for (int i = 0; i < kIter; ++i) {
-            const int idx = tid + i * kAsmThreads, m = idx / kSlotChunks, c = idx % kSlotChunks;
-            const uint32_t nwm = s_nw[m], end = s_so[m];   // end: one past the macroblock's last staged word
-            const bool take = m < g.mbw && (uint32_t)(4 * c) < nwm && end <= (uint32_t)kAsmStageWords;
-            dst[i] = take ? end - ((nwm + 3u) & ~3u) + 4u * (uint32_t)c : 0xFFFFFFFFu;
-            const uint32_t *const src = compact_slot(slots_small, g, base + m, nwm);
-            v[i] = take ? *(const uint4 *)(src + 4 * c) : uint4{0, 0, 0, 0};
-        }
+        for (int h = 0; h < kRounds; ++h) {
+            uint4 v[kIter];
+            uint32_t dst[kIter];
 #pragma unroll
-        for (int i = 0; i < kIter; ++i)
-            if (dst[i] != 0xFFFFFFFFu) {
-                uint32_t *d = &s_slot[dst[i]];
-                d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+            for (int i = 0; i < kIter; ++i) {
+                const int idx = tid + (h * kIter + i) * kAsmThreads, m = idx / kSlotChunks, c = idx % kSlotChunks;
+                const uint32_t nwm = s_nw[m], end = s_so[m];   // end: one past the macroblock's last staged word
+                const bool take = m < g.mbw && (uint32_t)(4 * c) < nwm && end <= (uint32_t)kAsmStageWords;
+                dst[i] = take ? end - ((nwm + 3u) & ~3u) + 4u * (uint32_t)c : 0xFFFFFFFFu;
+                const uint32_t *const src = compact_slot(slots_small, g, base + m, nwm);
+                v[i] = take ? *(const uint4 *)(src + 4 * c) : uint4{0, 0, 0, 0};
             }
+#pragma unroll
+            for (int i = 0; i < kIter; ++i)
+                if (dst[i] != 0xFFFFFFFFu) {
+                    uint32_t *d = &s_slot[dst[i]];
+                    d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+                }
+        }
     }
     const int sh = (int)(q & 31ull);
     const unsigned long long w0 = q >> 5;
