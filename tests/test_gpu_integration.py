@@ -3,6 +3,7 @@
 * integration/port_caller.c (gcc, C99, only include/m2v_mi355x.h): the per-clock call sequence of the DPI-C shim
   integration/mpeg2encoder_mi355x.sv - one beat per m2v_push_beats, one word per m2v_pull, stop pulse - must write the
   oracle's bytes.
+* integration/frames_caller.c: the testbench's file loop with m2v_push_frames_pull (both port groups in one call).
 * the HIP encoder's stream through the ISO/IEC 13818-2 decoder (fpga-mpeg2-encoder_amd/decoder.py,
   which shares no table or code with the encoder): parses to the last bit, decoded picture close to the source, and
   with the RTL's documented deviations switched on equal to the oracle's reconstruction."""
@@ -38,6 +39,33 @@ def test_plain_c_caller_drives_the_port_contract(tmp_path, bubble):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "last=1" in r.stdout
     assert out.read_bytes() == orc.encode(clip, W // 16, H // 16, pf, 6, 5, 2, 3)
+
+
+@pytest.mark.parametrize("per_call,pageable", [(0, 0), (3, 0), (0, 1)])
+def test_plain_c_caller_pushes_and_pulls_in_one_call(tmp_path, per_call, pageable):
+    """integration/frames_caller.c (gcc, C99; include/m2v_mi355x.h + hipHostMalloc for its frame buffers): the testbench's file loop with
+    m2v_push_frames_pull - a GOP per call from page-locked memory, calls that do not end on a chunk boundary, and pageable memory - must
+    write the oracle's bytes."""
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    M.build()
+    libdir = os.path.join(ROOT, "fpga-mpeg2-encoder_amd")
+    exe = str(tmp_path / "frames_caller")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+           os.path.join(ROOT, "integration", "frames_caller.c"), "-L" + libdir, "-lm2v_mi355x", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    W, H, n, pf = 320, 192, 14, 3
+    clip = M.synth.clip(W, H, n, clip_index=134, scene_len=6)
+    (tmp_path / "in.yuv").write_bytes(clip.tobytes() + b"\x22" * 777)       # trailing partial frame is ignored (TB:220)
+    out = tmp_path / "out.m2v"
+    r = subprocess.run([exe, str(tmp_path / "in.yuv"), str(W), str(H), str(out), str(pf), str(per_call), str(pageable)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "%d frames" % n in r.stdout and "last=1" in r.stdout
+    assert out.read_bytes() == orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
 
 
 @pytest.mark.parametrize("W,H,n,pf,VL,Q,ci", [(96, 64, 5, 4, 3, 2, 131), (64, 80, 4, 1, 1, 4, 132), (80, 64, 3, 0, 2, 1, 133)])
