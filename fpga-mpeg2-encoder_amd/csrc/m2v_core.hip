@@ -70,10 +70,11 @@ hipEvent_t pool_event(m2v_enc *e)
 
 void collect_timers(m2v_enc *e)
 {
+    e->open_t.on = false;       // (an interval nobody closed before the wait that led here would include that wait: dropped)
     for (auto &t : e->timed) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
-            e->stats[t.kernel].launches++;
+            e->stats[t.kernel].launches += t.count;
             e->stats[t.kernel].ms += ms;
             e->stats[t.kernel].units += t.units;
         }
@@ -92,7 +93,7 @@ void collect_timers(m2v_enc *e)
 // ---------------------------------------------------------------------------------------------
 void plan_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf, bool last, uint32_t last_valid_beats)
 {
-    e->chain_ev = nullptr;                  // copies are enqueued below: the next timer records its own start event
+    timer_break(e);                  // copies are enqueued below: the next timer records its own start event
     const Geom &g = e->g;
     const size_t frame_bytes = (size_t)g.ysz * 3;
     const uint32_t bpf = g.ysz / 4;
@@ -338,6 +339,7 @@ void finish_chunk(m2v_enc *e, hipStream_t s, bool first, bool last, uint8_t *d_s
         HIPCHK(hipGetLastError());
         t.stop();
     }
+    timer_break(e);             // what follows on this stream (control word read-back, events) is not the assembly's
     e->frames_total += nf;
 }
 
@@ -377,7 +379,10 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
             HIPCHK(hipStreamWaitEvent(s, e->ev_join[k - 1], 0));
         }
     } else {
+        e->timer_merge = true;          // (option profile: the steps' launches of one kind as one timed interval)
         for (size_t j = 0; j < e->plan_steps.size(); ++j) run_step(e, s, j);
+        e->timer_merge = false;
+        timer_break(e);
     }
     finish_chunk(e, s, first, last, d_stream, advance);
 }
@@ -560,7 +565,7 @@ int m2v_reset(m2v_enc *e)
     e->up_unsynced = false;
     e->g.row0 = 0; e->g.row1 = e->g.mbh; e->g.strip = 0;
     geom_finish(e->g);
-    e->timed.clear(); e->ev_used = 0; e->chain_ev = nullptr;
+    e->timed.clear(); e->ev_used = 0; e->chain_ev = nullptr; e->open_t.on = false;
     e->err.clear();
     return M2V_OK;
 }

@@ -62,7 +62,7 @@ struct DevBuf {
 struct KStat { int launches = 0; double ms = 0, units = 0; };
 
 
-struct TimedLaunch { hipEvent_t a, b; int kernel; double units; };
+struct TimedLaunch { hipEvent_t a, b; int kernel; double units; int count; };
 
 }  // namespace m2v
 
@@ -233,6 +233,11 @@ struct m2v_enc {
     size_t ev_used = 0;
     hipEvent_t chain_ev = nullptr;        // stop event of the previous timer while nothing else was enqueued after it
     hipStream_t chain_stream = nullptr;
+    // the timer that stopped last and has not recorded its stop event yet: consecutive launches of ONE kind on one stream are timed as
+    // one interval (an event between two kernels costs the second one ~3 us: the eight P launches of a sequence read 110.8 us each with
+    // an event in every gap and 107 under rocprofv3)
+    struct { bool on = false; hipEvent_t a = nullptr; int kernel = 0; double units = 0; int count = 0; hipStream_t s = nullptr; } open_t;
+    bool timer_merge = false;             // only where launches follow each other on one stream with nothing in between (encode_chunk's step loop)
 
     void set_err(const char *fmt, ...)
     {
@@ -267,11 +272,31 @@ int guard(m2v_enc *e, int (*fn)(m2v_enc *, void *), void *arg);
 // HIP-event timers of option "profile": events come from a pool that lives as long as the handle, and a timer
 // that starts right where the previous one stopped (same stream, nothing enqueued in between) reuses that
 // event, so a step of n back-to-back launches costs n + 1 event records and no create / destroy.
+// closes the open timer: its stop event goes into its stream HERE (call it before anything untimed is enqueued there)
+inline void timer_close(m2v_enc *e)
+{
+    if (!e->open_t.on) return;
+    hipEvent_t b = pool_event(e);
+    HIPCHK(hipEventRecord(b, e->open_t.s));
+    e->timed.push_back(TimedLaunch{e->open_t.a, b, e->open_t.kernel, e->open_t.units, e->open_t.count});
+    e->chain_ev = b;
+    e->chain_stream = e->open_t.s;
+    e->open_t.on = false;
+}
+// ... and the next timer records a start event of its own (untimed work follows)
+inline void timer_break(m2v_enc *e)
+{
+    if (e->profile) timer_close(e);
+    e->chain_ev = nullptr;
+}
+
 struct Timer {
-    m2v_enc *e; hipStream_t s; int kernel; double units; hipEvent_t a = nullptr, b = nullptr;
+    m2v_enc *e; hipStream_t s; int kernel; double units; hipEvent_t a = nullptr; bool merged = false;
     Timer(m2v_enc *e_, hipStream_t s_, int k, double u) : e(e_), s(s_), kernel(k), units(u)
     {
         if (e->profile) {
+            if (e->open_t.on && e->open_t.kernel == kernel && e->open_t.s == s) { merged = true; return; }     // one more launch of the open interval
+            timer_close(e);
             if (e->chain_ev && e->chain_stream == s) a = e->chain_ev;
             else { a = pool_event(e); HIPCHK(hipEventRecord(a, s)); }
             e->chain_ev = nullptr;
@@ -280,11 +305,9 @@ struct Timer {
     void stop()
     {
         if (e->profile) {
-            b = pool_event(e);
-            HIPCHK(hipEventRecord(b, s));
-            e->timed.push_back(TimedLaunch{a, b, kernel, units});
-            e->chain_ev = b;
-            e->chain_stream = s;
+            if (merged) { e->open_t.units += units; ++e->open_t.count; return; }
+            e->open_t.on = true; e->open_t.a = a; e->open_t.kernel = kernel; e->open_t.units = units; e->open_t.count = 1; e->open_t.s = s;
+            if (!e->timer_merge) timer_close(e);        // everywhere else the stop event follows its launch at once
         }
     }
 };

@@ -208,7 +208,7 @@ static const MbMap *mbmap_for(m2v_enc *e, hipStream_t s, const Geom &g, int mode
     HIPCHK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
     HIPCHK(hipEventRecord(c.ev, s));
     c.filled_on = s;
-    e->chain_ev = nullptr;
+    timer_break(e);
     return c.d.p;
 }
 

@@ -73,7 +73,7 @@ static int strip_step_impl(m2v_enc *e, void *argp)
         return st.n_h;
     }
     if (st.n_h > 0 && (a->up || a->down)) {
-        e->chain_ev = nullptr;
+        timer_break(e);
         launch_halo_pack(e, e->strip_stream, e->d_lists.p + st.off_h, st.n_h, e->g.row0 > 0 ? a->up : nullptr, e->g.row1 < e->g.mbh ? a->down : nullptr);
         HIPCHK(hipGetLastError());
     }
@@ -107,7 +107,7 @@ static int strip_halo_in_impl(m2v_enc *e, void *argp)
     if (!e->strip_active || a->j < 0 || a->j >= (int)e->plan_steps.size()) return M2V_E_STATE;
     const m2v_enc::Step &st = e->plan_steps[a->j];
     if (st.n_h > 0 && (a->from_up || a->from_down)) {
-        e->chain_ev = nullptr;
+        timer_break(e);
         launch_halo_unpack(e, e->strip_stream, e->d_lists.p + st.off_h, st.n_h, e->g.row0 > 0 ? a->from_up : nullptr,
                            e->g.row1 < e->g.mbh ? a->from_down : nullptr);
         HIPCHK(hipGetLastError());
@@ -138,7 +138,7 @@ static void strip_finish_enqueue(m2v_enc *e, uint8_t *d_strip, size_t cap)
 {
     hipStream_t s = e->strip_stream;
     const size_t nf = e->plan_nf;
-    e->chain_ev = nullptr;
+    timer_break(e);
     e->d_ctl.ensure(1);
     ctl_begin(e, (unsigned long long)cap, true);
     finish_chunk(e, s, false, false, d_strip);
@@ -207,7 +207,7 @@ static void strip_assemble_enqueue(m2v_enc *e, hipStream_t s, const Geom &g, uin
     e->d_ctl.ensure(1);
     StripSrc src{};
     for (int r = 0; r < nranks; ++r) src.strip[r] = (const uint8_t *)strips[r];
-    e->chain_ev = nullptr;
+    timer_break(e);
     Timer t(e, s, 2, (double)nf * g.ysz);
     launch_strip_assemble(e, s, g, gop, nf, nranks, src, d_all_off, d_out, (unsigned long long)cap);
     HIPCHK(hipGetLastError());
@@ -329,7 +329,7 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
     auto mark = [&](hipStream_t on) {
         if (!marks || fail) return;
         hipEvent_t ev = pool_event(e);
-        e->chain_ev = nullptr;
+        timer_break(e);
         HIPCHK(hipEventRecord(ev, on));
         marks->push_back(ev);
     };
@@ -414,7 +414,7 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
                 HIPCHK(hipStreamWaitEvent(side, e->ev_done, 0));    // the previous step, neighbour rows included
                 run_step_rows(e, s, (size_t)j, q.row0, q.row0 + 1);
                 if (q.row1 - q.row0 >= 2) run_step_rows(e, s, (size_t)j, q.row1 - 1, q.row1);
-                e->chain_ev = nullptr;
+                timer_break(e);
                 launch_halo_pack(e, s, e->d_lists.p + e->plan_steps[(size_t)j].off_h, n_h, q.up ? q.send_up : nullptr, q.down ? q.send_down : nullptr);
                 HIPCHK(hipGetLastError());
                 mark(s);
@@ -430,7 +430,7 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
                 HIPCHK(hipStreamWaitEvent(s, e->ev_halo, 0));
                 HIPCHK(hipStreamWaitEvent(s, e->ev_interior, 0));
                 mark(s);
-                e->chain_ev = nullptr;
+                timer_break(e);
                 launch_halo_unpack(e, s, e->d_lists.p + e->plan_steps[(size_t)j].off_h, n_h, q.up ? q.recv_up : nullptr, q.down ? q.recv_down : nullptr);
                 HIPCHK(hipGetLastError());
             });
@@ -441,7 +441,7 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
     }
     // ---- this strip's slices, their sizes; everybody's sizes ----
     local([&] {
-        e->chain_ev = nullptr;
+        timer_break(e);
         ctl_begin(e, (unsigned long long)q.strip_cap, true);
         if (q.peer) {
             // this strip's k_frame_scan also settles the peer form's accounts (PeerScan): the retry mark, the give-up word, the NEXT
@@ -653,7 +653,7 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     e->strip_stats.host_us_per_step = std::chrono::duration<double, std::micro>(clk::now() - t_loop).count() / std::max(1, q.steps);
     e->strip_stats.comm_us_per_step = us_in_comm / std::max(1, q.steps);
     g0 = g1 = nullptr;
-    if (e->profile && !fail) { g0 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g0, s)); }     // from here: gather, final assembly
+    if (e->profile && !fail) { g0 = pool_event(e); timer_break(e); HIPCHK(hipEventRecord(g0, s)); }     // from here: gather, final assembly
 
     // ---- the one host wait; strips to the output rank; final assembly ----
     for (auto &sp : strips) sp = nullptr;
@@ -719,10 +719,10 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     size_t out_bytes = 0;
     if (rank == a->dst) {
         strip_assemble_enqueue(e, s, full, a->pf, nf, world, strips, d_all, a->d_out, a->cap);
-        if (e->profile) { g1 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g1, s)); }
+        if (e->profile) { g1 = pool_event(e); timer_break(e); HIPCHK(hipEventRecord(g1, s)); }
         if (!e->st().h_ctl) HIPCHK(hipHostMalloc((void **)&e->st().h_ctl, 2 * sizeof(StreamCtl)));
         HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
-    } else if (e->profile) { g1 = pool_event(e); e->chain_ev = nullptr; HIPCHK(hipEventRecord(g1, s)); }
+    } else if (e->profile) { g1 = pool_event(e); timer_break(e); HIPCHK(hipEventRecord(g1, s)); }
     HIPCHK(hipStreamSynchronize(s));
     {
         const StreamCtl *c = (const StreamCtl *)(e->h_strip + (nf + 1) * sizeof(unsigned long long));

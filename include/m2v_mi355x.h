@@ -303,7 +303,7 @@ int m2v_strip_last_form(const m2v_enc *e);
 int m2v_strip_graph_stats(const m2v_enc *e, int *last_call_was_graph, int *recordings, int *launches);
 
 /* Options: "batch_frames" (frames buffered before the GPU is kicked, default 96; 1 .. 65536, M2V_E_PARAM beyond),
- * "profile" (1 = time the per-kernel launches with HIP events),
+ * "profile" (1 = time the launches with HIP events: one interval per run of consecutive launches of one kernel on one stream),
  * "async" (default 1: the port path keeps two chunks in flight - while one chunk is uploaded, encoded and
  * read back, m2v_push_* fills the pinned staging of the next one; 0 = a chunk is complete when the push
  * that filled it returns.  The bytes are the same either way),
