@@ -67,13 +67,16 @@ __global__ __launch_bounds__(256) void k_readback(uint4 *__restrict__ dst, const
 
 // The gate in front of a chunk's kernels (see m2v_enc::h_gate): one lane waits until the host has written this gate's number - it does so
 // when it has waited for the chunk's transfer.  Bounded (wall clock, 100 MHz): a host that never gets there (a failed call that is not
-// followed by m2v_reset / m2v_destroy, which write the number) stalls the handle's stream for two seconds, not for ever.
+// followed by m2v_reset / m2v_destroy, which write the number) stalls the handle's stream for ten seconds, not for ever.  The bound is
+// far above what a chunk's transfer can take (a gate waits for at most the chunk being uploaded: 1.2 GB at the largest frame size and
+// the default chunk = 21 ms on this link); a host that is merely slow to notice the transfer's end costs time, not correctness - the
+// frames are there when it does.
 __global__ void k_gate(const unsigned int *flag, unsigned int want)
 {
     typedef const __attribute__((address_space(1))) unsigned int *gu32;
     const long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load((gu32)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
-        if (wall_clock64() - t0 > 200000000ll) break;
+        if (wall_clock64() - t0 > 1000000000ll) break;
         __builtin_amdgcn_s_sleep(16);
     }
 }
