@@ -347,6 +347,7 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
                   uint32_t last_valid_beats, uint8_t *d_stream, bool advance)
 {
     plan_chunk(e, s, d_frames, nf, last, last_valid_beats);
+    gate_if_wanted(e, s);       // the port path's gate (m2v_port.hip): behind the plan and its allocations, in front of every launch that reads the frames
     if (e->plan_groups > 1 && !e->profile && e->plan_steps.size() > 1) {
         // The GOP segments of the chunk as `plan_groups` independent groups, one stream each: a launch of 86 400
         // wavefronts ends with a partially filled GPU (10.55 rounds of 8 192 wave slots) and the next step of the

@@ -31,9 +31,9 @@ void parallel_copy(uint8_t *dst, const uint8_t *src, size_t bytes, int threads)
     for (auto &t : pool) t.join();
 }
 
-void ensure_staging(m2v_enc *e)
+void ensure_staging(m2v_enc *e, int idx = -1)
 {
-    m2v_enc::HostStage &h = e->st();
+    m2v_enc::HostStage &h = idx < 0 ? e->st() : e->hs[idx];
     const size_t want = e->batch_frames * (size_t)e->g.ysz * 3;
     if (!h.h_ctl) HIPCHK(hipHostMalloc((void **)&h.h_ctl, 2 * sizeof(StreamCtl)));
     if (!h.ev_ctl) HIPCHK(hipEventCreateWithFlags(&h.ev_ctl, hipEventDisableTiming));
@@ -65,36 +65,17 @@ __global__ __launch_bounds__(256) void k_readback(uint4 *__restrict__ dst, const
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
-// The gate in front of a chunk's kernels (see m2v_enc::h_gate): one lane waits until the host has written this gate's number - it does so
-// when it has waited for the chunk's transfer.  Bounded (wall clock, 100 MHz): a host that never gets there (a failed call that is not
-// followed by m2v_reset / m2v_destroy, which write the number) stalls the handle's stream for ten seconds, not for ever.  The bound is
-// far above what a chunk's transfer can take (a gate waits for at most the chunk being uploaded: 1.2 GB at the largest frame size and
-// the default chunk = 21 ms on this link); a host that is merely slow to notice the transfer's end costs time, not correctness - the
-// frames are there when it does.
-__global__ void k_gate(const unsigned int *flag, unsigned int want)
-{
-    typedef const __attribute__((address_space(1))) unsigned int *gu32;
-    const long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load((gu32)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
-        if (wall_clock64() - t0 > 1000000000ll) break;
-        __builtin_amdgcn_s_sleep(16);
-    }
-}
-
-// queue a gate on the handle's stream
-static void open_gate(m2v_enc *e)
-{
-    if (!e->h_gate) { HIPCHK(hipHostMalloc((void **)&e->h_gate, 64)); *e->h_gate = 0; e->gate_seq = 0; }
-    ++e->gate_seq;
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, e->stream, (const unsigned int *)e->h_gate, e->gate_seq);
-    HIPCHK(hipGetLastError());
-    e->gate_open = true;
-}
-
+// The gate in front of a chunk's macroblock kernels (m2v_enc::h_gate; the kernel and the place it is queued: m2v_launch.hip, gate_if_wanted).
+// RULE: while a gate is wanted or open, this thread neither waits for the device nor allocates or frees anything - a spinning kernel
+// holds up every later packet of its hardware queue, which other streams of the process may share, and hipFree / hipHostFree wait for
+// the whole device.  flush_buffered therefore does its waiting and allocating FIRST, the gate is queued behind the chunk's plan, and the
+// only thing waited for until it is released is the upload - issued before it.  (With GPU_MAX_HW_QUEUES=1 every violation of the rule is
+// a ten-second stall: tests/test_gpu_ports.py::test_one_hardware_queue_does_not_stall_the_gate.)
 // every direct upload issued so far has arrived: wait for the copy itself (the upload stream's last command), then let the kernels go
 static void release_gate(m2v_enc *e)
 {
     if (e->up_unsynced) { HIPCHK(hipStreamSynchronize(e->up_stream)); e->up_unsynced = false; }
+    e->gate_wanted = false;             // (a chunk without a macroblock launch: nothing was queued)
     if (e->gate_open) {
         __atomic_store_n(e->h_gate, e->gate_seq, __ATOMIC_RELEASE);
         e->gate_open = false;
@@ -175,11 +156,22 @@ void flush_buffered(m2v_enc *e, bool last)
         return;
     }
     m2v_enc::HostStage &h = e->st();
-    // the stage's own device buffer, filled on the upload stream: the copy of chunk k+1 crosses PCIe while the kernels
-    // of chunk k run (the stage is only refilled after its previous chunk has completed, see the end of this function)
-    h.d_in.ensure(std::max(nf, h.uploaded ? e->batch_frames : (size_t)0) * frame_bytes);
+    const int idx = e->cur, other = idx ^ 1;
+    const bool overlapped = e->async && !e->profile && !last;      // the caller goes on filling the other stage while this chunk encodes
     // a gate queued by an earlier chunk of this call: released before anything below can wait for that chunk (and with it every upload so far)
-    if (e->gate_open) release_gate(e);
+    if (e->gate_open || e->gate_wanted) release_gate(e);
+    // Everything that may wait for the device or (re)allocate comes first (see the rule at release_gate): the other stage must be free
+    // before it is refilled, its staging must exist, this chunk's buffers must exist.
+    if (overlapped) {
+        if (e->hs[other].stage != 0) progress(e, true, other);
+        ensure_staging(e, other);
+    }
+    // the stage's own device buffer, filled on the upload stream: the copy of chunk k+1 crosses PCIe while the kernels of chunk k run
+    h.d_in.ensure(std::max(nf, h.uploaded ? e->batch_frames : (size_t)0) * frame_bytes);
+    // worst case ~1.2 KB per macroblock; typical streams are ~100x smaller
+    const size_t cap = nf * ((size_t)g.mbs * 1216 + (size_t)g.mbh * 8 + 64) + 256;
+    h.d_out.ensure(cap);
+    e->d_ctl.ensure(1);
     const bool staged = h.uploaded < nf;
     if (staged)
         HIPCHK(hipMemcpyAsync(h.d_in.p + h.uploaded * frame_bytes, h.h_in + h.uploaded * frame_bytes, (nf - h.uploaded) * frame_bytes,
@@ -190,41 +182,52 @@ void flush_buffered(m2v_enc *e, bool last)
         HIPCHK(hipEventRecord(h.ev_up, e->up_stream));
         HIPCHK(hipStreamWaitEvent(s, h.ev_up, 0));
     } else if (e->up_unsynced) {
-        // Only the blocking call's own direct transfer is outstanding, and the call waits for it on the host before it returns: the kernels
-        // go behind a gate that the call opens then.  (An event would be a packet of its own behind the copy on the upload stream, and the
-        // call's wait for that stream a wait for the packet: +30 us per chunk on this box, tools/ubench/h2d_kernel.hip.)
-        if (e->async && !e->profile && !last) open_gate(e);
-        else release_gate(e);           // (this chunk is waited for before the function returns: its frames first, no gate)
+        // Only the blocking call's own direct transfer is outstanding, and the call waits for it on the host before it returns: the
+        // macroblock kernels go behind a gate that the call opens then.  (An event would be a packet of its own behind the copy on the
+        // upload stream, and the call's wait for that stream a wait for the packet: +30 us per chunk on this box, tools/ubench/h2d_kernel.hip.)
+        if (overlapped) {                               // queued by encode_chunk behind the chunk's plan and its allocations
+            if (!e->h_gate) { HIPCHK(hipHostMalloc((void **)&e->h_gate, 64)); *e->h_gate = 0; e->gate_seq = 0; }
+            e->gate_wanted = true;
+        }
+        else release_gate(e);                           // (this chunk is waited for before the function returns: its frames first, no gate)
     }
-    // worst case ~1.2 KB per macroblock; typical streams are ~100x smaller
-    const size_t cap = nf * ((size_t)g.mbs * 1216 + (size_t)g.mbh * 8 + 64) + 256;
-    h.d_out.ensure(cap);
-    e->d_ctl.ensure(1);
     ctl_begin(e, (unsigned long long)cap, e->first_chunk);
     encode_chunk(e, s, h.d_in.p, nf, e->first_chunk, last, e->last_frame_valid_beats, h.d_out.p);
     HIPCHK(hipMemcpyAsync(h.h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(h.ev_ctl, s));
     h.stage = 1;
     h.last = last;
-    e->pending.push_back(e->cur);
+    e->pending.push_back(idx);
     e->buffered = 0;
     e->first_chunk = false;
-    if (!e->async || e->profile || last) {
+    if (!overlapped) {
         // profile: the HIP-event timers of a chunk are read before the next one is queued
         // last:    the caller pulls next; nothing is left to overlap with
         progress(e, true);
         return;
     }
-    e->cur ^= 1;
-    if (e->st().stage != 0) progress(e, true, e->cur);     // the other stage must be free before it is refilled
-    ensure_staging(e);
-    progress(e, false);
+    e->cur = other;
+    if (!e->gate_open && !e->gate_wanted) progress(e, false);      // (with a gate up the caller's m2v_push_frames does this once it has let it go)
 }
 
 void start_sequence(m2v_enc *e, uint32_t xs, uint32_t ys, uint32_t pf)
 {
-    if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-    if (!e->up_stream) HIPCHK(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
+    // The upload and the read-back stream at another PRIORITY than the handle's kernel stream: streams of different priorities never share
+    // a hardware queue (profiles/r04_queue_ab.txt), and whatever these two put into theirs - a small transfer done by a kernel, the packet
+    // behind a wait for the stream - must never sit behind the gate kernel that the kernel stream carries while a transfer is under way
+    // (see release_gate: in a shared queue the call's wait for its transfer would wait for the gate that waits for the call)
+    int least = 0, greatest = 0, mine = 0, theirs = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(hipStreamGetPriority(e->stream, &mine));
+    const int want = mine == greatest ? least : greatest;      // (option stream_priority may have put the kernel stream at the top)
+    for (hipStream_t *ps : {&e->copy_stream, &e->up_stream, &e->up_stream2}) {
+        if (*ps && (hipStreamGetPriority(*ps, &theirs) != hipSuccess || theirs == mine)) {      // the kernel stream has moved since
+            (void)hipStreamSynchronize(*ps);
+            (void)hipStreamDestroy(*ps);
+            *ps = nullptr;
+        }
+        if (!*ps && ps != &e->up_stream2) HIPCHK(hipStreamCreateWithPriority(ps, hipStreamNonBlocking, want));
+    }
     e->g = make_geom(e, xs, ys);            // latched on the first beat (RTL:1060-1065)
     e->pframes = pf & 0xFFu;
     e->state = m2v_enc::DURING;
@@ -376,6 +379,7 @@ static int push_frames_impl(m2v_enc *e, void *argp)
     const bool pinned = e->direct_upload && page_locked(a->frames) && page_locked(a->frames + a->n * fb - 1);
     bool direct_pending = false;
     for (size_t k = 0; k < a->n;) {
+        if (e->gate_open || e->gate_wanted) release_gate(e);        // (the chunk before, completed by this call: let go before another transfer is queued)
         m2v_enc::HostStage &h = e->st();
         const size_t take = std::min(a->n - k, e->batch_frames - e->buffered);
         if (pinned) {
@@ -391,7 +395,11 @@ static int push_frames_impl(m2v_enc *e, void *argp)
                 // they are dealt different engines - 53 GB/s from one caller in a fresh process, 93 % of the plain copy - and behave like
                 // one stream when they are not - 49 GB/s, seen in bench.py's process with its dozen streams; a stream of another
                 // PRIORITY, which never shares a hardware queue, did not change that)
-                if (!e->up_stream2) HIPCHK(hipStreamCreateWithFlags(&e->up_stream2, hipStreamNonBlocking));
+                if (!e->up_stream2) {
+                    int pr = 0;
+                    HIPCHK(hipStreamGetPriority(e->up_stream, &pr));
+                    HIPCHK(hipStreamCreateWithPriority(&e->up_stream2, hipStreamNonBlocking, pr));
+                }
                 ups = e->up_stream2;
             }
             HIPCHK(hipMemcpyAsync(h.d_in.p + e->buffered * fb, a->frames + k * fb, take * fb, hipMemcpyHostToDevice, ups));
@@ -404,6 +412,9 @@ static int push_frames_impl(m2v_enc *e, void *argp)
             h.uploaded = e->buffered + take;
             direct_pending = true;
             if (!e->direct_upload_deferred) e->up_unsynced = true;
+            // m2v_push_frames_pull: completed chunks leave for the caller's buffer HERE, while this call's frames cross the link (and before
+            // a chunk of this call puts a gate up: nothing that can wait or allocate runs behind one)
+            if (a->sink) progress(e, false, -1, a->sink);
         } else {
             parallel_copy(h.h_in + e->buffered * fb, a->frames + k * fb, take * fb, e->copy_threads);
         }
@@ -411,8 +422,7 @@ static int push_frames_impl(m2v_enc *e, void *argp)
         k += take;
         if (e->buffered == e->batch_frames) flush_buffered(e, false);
     }
-    // m2v_push_frames_pull: completed chunks leave for the caller's buffer HERE, while this call's frames cross the link
-    if (a->sink) progress(e, false, -1, a->sink);
+    if (a->sink && !direct_pending) progress(e, false, -1, a->sink);
     if (direct_pending) {
         if (e->direct_upload_deferred) {
             // option direct_upload = 2: this call's frames are still being read when it returns; what is waited for here is the

@@ -2,8 +2,12 @@
 
 Mirrors what SIM/tb_mpeg2encoder.v exercises (three sequences back to back on one instance, TB:150) and the
 cases SURVEY.md 8(f1) lists: mid-frame stop / black fill, size clamp, pframes 0..255, bubbles."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -391,3 +395,51 @@ def test_deferred_upload_chunk_completed_by_the_call_itself():
                 assert out[:pos].tobytes() == want, "direct_upload = %d, sequence %d" % (mode, rnd)
     finally:
         enc.close()
+
+
+def test_one_hardware_queue_does_not_stall_the_gate():
+    """The gate kernel in front of a chunk's macroblock launches (blocking m2v_push_frames from page-locked memory) holds up every later
+    packet of its hardware queue until the call lets it go.  With GPU_MAX_HW_QUEUES=1 all streams of the process share ONE queue: any
+    wait for the device or any (re)allocation between queueing the gate and releasing it then costs the gate's ten-second bound.  A fresh
+    process with one queue runs the shapes that exercise it - chunks completed by a call, calls spanning chunks, no pulls in between
+    (the stage-reuse wait), the combined call, a second larger geometry (buffers grow) - and must finish in seconds, bytes identical."""
+    import subprocess
+    import sys
+    import time
+    code = r'''
+import sys, time
+sys.path.insert(0, %r)
+import numpy as np, torch, m2v_load
+from oracle import m2v_oracle_ctypes as orc
+M = m2v_load.load()
+enc = M.Mpeg2Encoder(7, 7, 3, 2)
+t0 = time.perf_counter()
+for (W, H, n, pf, batch, per_push, pull) in ((192, 128, 24, 3, 4, 4, 1), (192, 128, 24, 3, 4, 12, 0), (320, 192, 20, 4, 5, 5, 2), (192, 128, 16, 3, 8, 3, 0)):
+    clip = M.synth.clip(W, H, n, clip_index=140 + n, scene_len=5)
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
+    src = torch.from_numpy(np.ascontiguousarray(clip)).pin_memory().numpy()
+    enc.set_option("batch_frames", batch)
+    out = np.zeros(len(want) + 4096, np.uint8)
+    pos = 0
+    for k in range(0, n, per_push):
+        if pull == 2:
+            pos += enc.push_frames_pull(W // 16, H // 16, pf, src[k:k + per_push], out, pos)[0]
+        else:
+            enc.push_frames(W // 16, H // 16, pf, src[k:k + per_push])
+            if pull == 1:
+                pos += enc.pull_into(out, pos)[0]
+    enc.sequence_stop()
+    last = False
+    while not last:
+        m, last = enc.pull_into(out, pos)
+        pos += m
+    assert out[:pos].tobytes() == want, (W, H, batch, per_push, pull)
+enc.close()
+print("SECONDS %%.2f" %% (time.perf_counter() - t0))
+''' % ROOT
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    secs = float(r.stdout.split("SECONDS")[1])
+    assert secs < 8.0, "the port path stalled (%.1f s for four small sequences): something waits behind an open gate" % secs
