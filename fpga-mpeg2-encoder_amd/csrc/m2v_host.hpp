@@ -132,6 +132,7 @@ struct m2v_enc {
     unsigned int *h_gate = nullptr;      // pinned: the sequence number of the last released gate
     unsigned int gate_seq = 0;           // ... of the last gate queued
     bool gate_open = false;              // a gate kernel is queued whose number has not been written yet
+    bool gate_ok = false;                // the upload stream could be given another priority than the kernel stream (start_sequence)
     bool gate_wanted = false;            // the chunk being queued wants one in front of its first macroblock launch (gate_if_wanted)
     void *call_sink = nullptr;           // m2v_push_frames_pull: the call's destination (a PullSink), seen by every progress() inside the call
     int split_streams = 2;        // GOP segments of a chunk run as this many independent groups on as many streams (encode_chunk)

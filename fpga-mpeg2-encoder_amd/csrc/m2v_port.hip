@@ -177,7 +177,7 @@ void flush_buffered(m2v_enc *e, bool last)
         HIPCHK(hipMemcpyAsync(h.d_in.p + h.uploaded * frame_bytes, h.h_in + h.uploaded * frame_bytes, (nf - h.uploaded) * frame_bytes,
                               hipMemcpyHostToDevice, e->up_stream));
     h.uploaded = 0;
-    if (staged || e->direct_upload_deferred || e->upl_pending[0] || e->upl_pending[1]) {
+    if (staged || e->direct_upload_deferred || e->upl_pending[0] || e->upl_pending[1] || (e->up_unsynced && !e->gate_ok)) {
         // the chunk's kernels behind its uploads, by an event (option direct_upload = 2: this call's own transfer is not waited for on the host)
         HIPCHK(hipEventRecord(h.ev_up, e->up_stream));
         HIPCHK(hipStreamWaitEvent(s, h.ev_up, 0));
@@ -220,6 +220,7 @@ void start_sequence(m2v_enc *e, uint32_t xs, uint32_t ys, uint32_t pf)
     HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIPCHK(hipStreamGetPriority(e->stream, &mine));
     const int want = mine == greatest ? least : greatest;      // (option stream_priority may have put the kernel stream at the top)
+    e->gate_ok = least != greatest;                            // one priority level only: no gates, the event behind the transfer instead
     for (hipStream_t *ps : {&e->copy_stream, &e->up_stream, &e->up_stream2}) {
         if (*ps && (hipStreamGetPriority(*ps, &theirs) != hipSuccess || theirs == mine)) {      // the kernel stream has moved since
             (void)hipStreamSynchronize(*ps);
