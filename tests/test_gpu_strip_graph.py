@@ -89,7 +89,10 @@ def test_one_rank_of_n_recorded_equals_call_by_call(world, rank, rccl, general):
     ref, st0 = _solo_bytes(M, d_clip, W, H, pf, world, rank, rccl, False, 2, general)
     assert ref[0] == ref[1] and len(ref[0]) > 1000 and st0["launches"] == 0
     got, st = _solo_bytes(M, d_clip, W, H, pf, world, rank, rccl, True, 5, general)
-    if general:         # enqueued call by call whatever the option says (see m2v_strip_encode)
+    import os
+    if general or os.environ.get("GPU_MAX_HW_QUEUES") == "1":
+        # general: enqueued call by call whatever the option says (see m2v_strip_encode); one hardware queue: no recording of a form with
+        # parallel branches (hipGraphLaunch of one crashes inside the runtime there)
         assert st["recordings"] == 0 and st["launches"] == 0
     else:
         assert st["recordings"] == 1 and st["launches"] == 4 and st["last_call_was_graph"]
