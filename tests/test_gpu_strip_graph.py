@@ -154,4 +154,5 @@ def test_config_c5_geometry_one_rank_of_eight_recorded():
     d_clip = M.synth.clip_torch(W, H, n, clip_index=57, device="cuda:0", scene_len=5)
     ref, _ = _solo_bytes(M, d_clip, W, H, pf, 8, 3, True, False, 1)
     got, st = _solo_bytes(M, d_clip, W, H, pf, 8, 3, True, True, 4)
-    assert st["launches"] == 3 and all(g == ref[0] for g in got)
+    import os
+    assert st["launches"] == (0 if os.environ.get("GPU_MAX_HW_QUEUES") == "1" else 3) and all(g == ref[0] for g in got)      # (one queue: never recorded)
