@@ -220,7 +220,10 @@ void start_sequence(m2v_enc *e, uint32_t xs, uint32_t ys, uint32_t pf)
     HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIPCHK(hipStreamGetPriority(e->stream, &mine));
     const int want = mine == greatest ? least : greatest;      // (option stream_priority may have put the kernel stream at the top)
-    e->gate_ok = least != greatest;                            // one priority level only: no gates, the event behind the transfer instead
+    // no gates (the event behind the transfer instead) with one priority level only, and under the runtime's debugging switches that make a
+    // launch wait for its kernel - the gate's kernel ends when the call that launched it goes on
+    auto env_on = [](const char *n) { const char *v = getenv(n); return v && atoi(v) != 0; };
+    e->gate_ok = least != greatest && !env_on("HIP_LAUNCH_BLOCKING") && !env_on("AMD_SERIALIZE_KERNEL") && !env_on("CUDA_LAUNCH_BLOCKING");
     for (hipStream_t *ps : {&e->copy_stream, &e->up_stream, &e->up_stream2}) {
         if (*ps && (hipStreamGetPriority(*ps, &theirs) != hipSuccess || theirs == mine)) {      // the kernel stream has moved since
             (void)hipStreamSynchronize(*ps);
