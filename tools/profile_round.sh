@@ -17,18 +17,18 @@ timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/raw_sta
 grep -h '^{' $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
 python3 tools/summarize_rocprof.py $RAW/raw_stats/s_kernel_stats.csv $OUT/kernel_stats.csv
 step raw_f
-timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/raw_f -o f -- python3 bench.py --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/raw_f -o f -- python3 bench.py --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline --no-e2e --sustain 0 > /dev/null 2>&1
 step raw_w
-timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/raw_w -o w -- python3 bench.py --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/raw_w -o w -- python3 bench.py --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline --no-e2e --sustain 0 > /dev/null 2>&1
 python3 tools/summarize_pmc.py $RAW/raw_f $RAW/raw_w > $OUT/pmc_hbm.json
 # config c2 (640x480, I frames only): kernel stats and HBM counters of the I-frame kernel
 step raw_c2
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/raw_c2 -o s -- python3 bench.py --config c2 --inflight 1 --split 1 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/c2_bench_under_rocprof.log 2>&1
 python3 tools/summarize_rocprof.py $RAW/raw_c2/s_kernel_stats.csv $OUT/c2_kernel_stats.csv
 step raw_c2f
-timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/raw_c2f -o f -- python3 bench.py --config c2 --gops 128 --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/raw_c2f -o f -- python3 bench.py --config c2 --gops 128 --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline --no-e2e --sustain 0 > /dev/null 2>&1
 step raw_c2w
-timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/raw_c2w -o w -- python3 bench.py --config c2 --gops 128 --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > /dev/null 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/raw_c2w -o w -- python3 bench.py --config c2 --gops 128 --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline --no-e2e --sustain 0 > /dev/null 2>&1
 python3 tools/summarize_pmc.py $RAW/raw_c2f $RAW/raw_c2w > $OUT/c2_pmc_hbm.json
 python3 tools/make_pmc_traffic.py $OUT/pmc_hbm.json $OUT/c2_pmc_hbm.json $HEAD > $OUT/pmc_traffic.json
 step sq
