@@ -160,36 +160,40 @@ void flush_buffered(m2v_enc *e, bool last)
     const bool overlapped = e->async && !e->profile && !last;      // the caller goes on filling the other stage while this chunk encodes
     // a gate queued by an earlier chunk of this call: released before anything below can wait for that chunk (and with it every upload so far)
     if (e->gate_open || e->gate_wanted) release_gate(e);
-    // Everything that may wait for the device or (re)allocate comes first (see the rule at release_gate): the other stage must be free
-    // before it is refilled, its staging must exist, this chunk's buffers must exist.
-    if (overlapped) {
+    const bool staged = h.uploaded < nf;
+    // will this chunk's kernels go behind a gate?  Only the blocking call's own direct transfer outstanding, and the call goes on afterwards
+    const bool gate = overlapped && e->gate_ok && !staged && !e->direct_upload_deferred && !e->upl_pending[0] && !e->upl_pending[1] && e->up_unsynced;
+    // With a gate, everything that may wait for the device or (re)allocate comes FIRST (see the rule at release_gate): the other stage must be
+    // free before it is refilled, its staging must exist, this chunk's buffers must exist.  (Without one it comes last, as it always did: a
+    // chunk staged through pinned memory is uploaded HERE, and waiting for the chunk before it in front of that transfer leaves the link idle
+    // - 50.7 -> 41 GB/s from pageable memory when this order was the same for both.)
+    auto free_other_stage = [&] {
         if (e->hs[other].stage != 0) progress(e, true, other);
         ensure_staging(e, other);
-    }
+    };
+    if (gate) free_other_stage();
     // the stage's own device buffer, filled on the upload stream: the copy of chunk k+1 crosses PCIe while the kernels of chunk k run
     h.d_in.ensure(std::max(nf, h.uploaded ? e->batch_frames : (size_t)0) * frame_bytes);
     // worst case ~1.2 KB per macroblock; typical streams are ~100x smaller
     const size_t cap = nf * ((size_t)g.mbs * 1216 + (size_t)g.mbh * 8 + 64) + 256;
     h.d_out.ensure(cap);
     e->d_ctl.ensure(1);
-    const bool staged = h.uploaded < nf;
     if (staged)
         HIPCHK(hipMemcpyAsync(h.d_in.p + h.uploaded * frame_bytes, h.h_in + h.uploaded * frame_bytes, (nf - h.uploaded) * frame_bytes,
                               hipMemcpyHostToDevice, e->up_stream));
     h.uploaded = 0;
-    if (staged || e->direct_upload_deferred || e->upl_pending[0] || e->upl_pending[1] || (e->up_unsynced && !e->gate_ok)) {
+    if (gate) {
+        // The macroblock kernels go behind a gate that the call opens when it has waited for its transfer.  (An event would be a packet of its
+        // own behind the copy on the upload stream, and the call's wait for that stream a wait for the packet: +30 us per chunk on this box,
+        // tools/ubench/h2d_kernel.hip.)  Queued by encode_chunk behind the chunk's plan and its allocations.
+        if (!e->h_gate) { HIPCHK(hipHostMalloc((void **)&e->h_gate, 64)); *e->h_gate = 0; e->gate_seq = 0; }
+        e->gate_wanted = true;
+    } else if (staged || e->direct_upload_deferred || e->upl_pending[0] || e->upl_pending[1] || (e->up_unsynced && overlapped)) {
         // the chunk's kernels behind its uploads, by an event (option direct_upload = 2: this call's own transfer is not waited for on the host)
         HIPCHK(hipEventRecord(h.ev_up, e->up_stream));
         HIPCHK(hipStreamWaitEvent(s, h.ev_up, 0));
     } else if (e->up_unsynced) {
-        // Only the blocking call's own direct transfer is outstanding, and the call waits for it on the host before it returns: the
-        // macroblock kernels go behind a gate that the call opens then.  (An event would be a packet of its own behind the copy on the
-        // upload stream, and the call's wait for that stream a wait for the packet: +30 us per chunk on this box, tools/ubench/h2d_kernel.hip.)
-        if (overlapped) {                               // queued by encode_chunk behind the chunk's plan and its allocations
-            if (!e->h_gate) { HIPCHK(hipHostMalloc((void **)&e->h_gate, 64)); *e->h_gate = 0; e->gate_seq = 0; }
-            e->gate_wanted = true;
-        }
-        else release_gate(e);                           // (this chunk is waited for before the function returns: its frames first, no gate)
+        release_gate(e);                                // (this chunk is waited for before the function returns: its frames first)
     }
     ctl_begin(e, (unsigned long long)cap, e->first_chunk);
     encode_chunk(e, s, h.d_in.p, nf, e->first_chunk, last, e->last_frame_valid_beats, h.d_out.p);
@@ -207,7 +211,10 @@ void flush_buffered(m2v_enc *e, bool last)
         return;
     }
     e->cur = other;
-    if (!e->gate_open && !e->gate_wanted) progress(e, false);      // (with a gate up the caller's m2v_push_frames does this once it has let it go)
+    if (!gate) {                                                   // (with a gate up both were done in front, and the caller's m2v_push_frames
+        free_other_stage();                                        // moves the chunks on once it has let the gate go)
+        progress(e, false);
+    }
 }
 
 void start_sequence(m2v_enc *e, uint32_t xs, uint32_t ys, uint32_t pf)
