@@ -1081,7 +1081,7 @@ def main():
                                   "note": "256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz; every unit the macroblock kernel touches is 65-90 % busy "
                                           "(vector ALU 85-89 %, SQ_ACTIVE_INST_VALU; LDS ~70 %, scalar unit ~69 %): the full-pel search is ~30 % of its "
                                           "vector cycles (52 v_qsad_pk_u16_u8 = 832 of ~2 800) at 81 % of the instruction's candidate slots "
-                                          "(169 of 208 live) - DESIGN.md section 4, profiles/r04_final_pmc_sq.json"}
+                                          "(169 of 208 live) - DESIGN.md section 4, profiles/r05_final_pmc_sq.json"}
         out["roofline"]["timed_in"] = ("profiled_pass (one stream; HIP events on the launch stream around every RUN of consecutive launches of one kernel - the eight P launches of "
                                        "a sequence are one interval, duration / launches: an event in every gap costs the next launch ~3 us)")
         if rank_parity is not None:
