@@ -281,8 +281,8 @@ def end_to_end(M, clip_np, want_bytes):
     return {"value": round(px / t_pin * 1e-6, 1), "unit": "MPixels/s", "frames": n, "best_of": 4,
             "input_GBps": round(px * 3 / t_pin * 1e-9, 2), "identical_to_resident_stream": d_pin == want_bytes and d_page == want_bytes,
             "path": "m2v_push_frames -> m2v_pull (into the caller's output buffer), frames in page-locked host memory uploaded straight from "
-                    "the caller's buffer (hipMemcpyAsync on an upload stream; the call returns when its frames have been read; the chunk's kernels "
-                    "queue behind a gate kernel the call opens then), stream bytes back to the host by a kernel; chunk k+1 uploads while chunk k "
+                    "the caller's buffer (hipMemcpyAsync on an upload stream; the call returns when its frames have been read: it waits for the fence-free "
+                    "event the chunk's kernels wait for), stream bytes back to the host by a kernel; chunk k+1 uploads while chunk k "
                     "encodes, batch_frames=%d" % gop,
             "pageable_source": {"value": round(px / t_page * 1e-6, 1), "input_GBps": round(px * 3 / t_page * 1e-9, 2),
                                 "path": "the same from a plain numpy array: copied into the handle's pinned staging by 8 threads first"},

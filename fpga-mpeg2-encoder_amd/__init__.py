@@ -167,6 +167,7 @@ class Mpeg2Encoder:
 
     def __init__(self, XL=6, YL=6, VECTOR_LEVEL=3, Q_LEVEL=2, device=0, debug=False):
         self.params = (XL, YL, VECTOR_LEVEL, Q_LEVEL)
+        self._geom = {}
         err = ctypes.c_int(0)
         self._L = lib(debug)
         self._h = self._L.m2v_create(XL, YL, VECTOR_LEVEL, Q_LEVEL, device, ctypes.byref(err))
@@ -192,9 +193,20 @@ class Mpeg2Encoder:
         self._chk(self._L.m2v_set_option(self._h, name.encode(), int(value)), "m2v_set_option(%s)" % name)
 
     def geometry(self, xsize16, ysize16):
-        w, h = ctypes.c_int(), ctypes.c_int()
-        self._chk(self._L.m2v_geometry(self._h, xsize16, ysize16, ctypes.byref(w), ctypes.byref(h)), "m2v_geometry")
-        return w.value, h.value
+        # (a handle's clamps are fixed at creation: asked once per size - the per-call bindings below are on a caller's critical path)
+        got = self._geom.get((xsize16, ysize16))
+        if got is None:
+            w, h = ctypes.c_int(), ctypes.c_int()
+            self._chk(self._L.m2v_geometry(self._h, xsize16, ysize16, ctypes.byref(w), ctypes.byref(h)), "m2v_geometry")
+            got = self._geom[(xsize16, ysize16)] = (w.value, h.value)
+        return got
+
+    @staticmethod
+    def _flat_u8(a):
+        """the array as contiguous bytes: itself when it already is (no copy, no new object beyond a view)"""
+        if isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]:
+            return a
+        return np.ascontiguousarray(a, np.uint8)
 
     # ---- port-level interface ----
     def push_beats(self, xsize16, ysize16, pframes_count, y4, u4, v4, stop_with_last=False):
@@ -217,7 +229,7 @@ class Mpeg2Encoder:
 
     def push_frames(self, xsize16, ysize16, pframes_count, frames444):
         W, H = self.geometry(xsize16, ysize16)
-        f = np.ascontiguousarray(frames444, np.uint8).reshape(-1)
+        f = self._flat_u8(frames444)
         assert f.size % (3 * W * H) == 0
         self._chk(self._L.m2v_push_frames(self._h, xsize16, ysize16, pframes_count, f.ctypes.data,
                                           f.size // (3 * W * H)), "m2v_push_frames")
@@ -226,7 +238,7 @@ class Mpeg2Encoder:
         """m2v_push_frames_pull: push_frames + pull_into(dst, offset) in one call, the stream bytes copied while the frames upload:
         -> (bytes written, last)"""
         W, H = self.geometry(xsize16, ysize16)
-        f = np.ascontiguousarray(frames444, np.uint8).reshape(-1)
+        f = self._flat_u8(frames444)
         assert f.size % (3 * W * H) == 0
         assert dst.dtype == np.uint8 and dst.flags["C_CONTIGUOUS"]
         last = ctypes.c_int(0)

@@ -347,7 +347,6 @@ void encode_chunk(m2v_enc *e, hipStream_t s, const uint8_t *d_frames, size_t nf,
                   uint32_t last_valid_beats, uint8_t *d_stream, bool advance)
 {
     plan_chunk(e, s, d_frames, nf, last, last_valid_beats);
-    gate_if_wanted(e, s);       // the port path's gate (m2v_port.hip): behind the plan and its allocations, in front of every launch that reads the frames
     if (e->plan_groups > 1 && !e->profile && e->plan_steps.size() > 1) {
         // The GOP segments of the chunk as `plan_groups` independent groups, one stream each: a launch of 86 400
         // wavefronts ends with a partially filled GPU (10.55 rounds of 8 192 wave slots) and the next step of the
@@ -478,7 +477,6 @@ void m2v_destroy(m2v_enc *e)
     (void)hipSetDevice(e->device);
     // a resident sequence enqueued on a CALLER's stream (m2v_encode_resident_begin with hip_stream != NULL) still reads and writes the
     // handle's work buffers: nothing is released under running kernels
-    if (e->gate_open && e->h_gate) { if (e->up_stream) (void)hipStreamSynchronize(e->up_stream); *(volatile unsigned int *)e->h_gate = e->gate_seq; e->gate_open = false; }
     if (e->resident_inflight && e->resident_stream) (void)hipStreamSynchronize(e->resident_stream);
     if (e->strip_stream && e->strip_stream != e->stream) (void)hipStreamSynchronize(e->strip_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -508,7 +506,6 @@ void m2v_destroy(m2v_enc *e)
     }
     if (e->ev_asm) { (void)hipEventSynchronize(e->ev_asm); (void)hipEventDestroy(e->ev_asm); }
     if (e->h_asm) (void)hipHostFree(e->h_asm);
-    if (e->h_gate) (void)hipHostFree(e->h_gate);
     if (e->ev_strip) { (void)hipEventSynchronize(e->ev_strip); (void)hipEventDestroy(e->ev_strip); }
     if (e->h_strip) (void)hipHostFree(e->h_strip);
     if (e->comm_stream) { (void)hipStreamSynchronize(e->comm_stream); (void)hipStreamDestroy(e->comm_stream); }
@@ -534,8 +531,6 @@ int m2v_reset(m2v_enc *e)
 {
     if (!e) return M2V_E_PARAM;
     (void)hipSetDevice(e->device);
-    // (a call that failed between queueing a gate kernel and releasing it: the handle's stream would sit behind it for the gate's budget)
-    if (e->gate_open && e->h_gate) { if (e->up_stream) (void)hipStreamSynchronize(e->up_stream); *(volatile unsigned int *)e->h_gate = e->gate_seq; e->gate_open = false; }
     // (a resident sequence on a caller's stream: its kernels use the work buffers the next call rewrites)
     if (e->resident_inflight && e->resident_stream) (void)hipStreamSynchronize(e->resident_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);

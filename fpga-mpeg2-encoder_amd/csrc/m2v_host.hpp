@@ -125,15 +125,10 @@ struct m2v_enc {
     hipEvent_t ev_upl[2] = {nullptr, nullptr}, ev_up2 = nullptr;
     bool upl_pending[2] = {false, false};
     int up_parity = 0;
-    // Blocking m2v_push_frames from page-locked memory: the chunk's kernels are queued behind a GATE kernel that waits for a word in
-    // pinned host memory, which the call writes once it has waited for its transfer (m2v_port.hip: open_gate / release_gate) - instead
-    // of an event behind the copy, which the call's own wait would then sit behind as well.
+    // Blocking m2v_push_frames from page-locked memory: the chunk's kernels wait for the upload through an event WITHOUT system fence, and
+    // the call waits for that event itself (not for the upload stream) - m2v_port.hip, flush_buffered
     bool up_unsynced = false;            // a direct upload has been issued and not yet waited for on the host
-    unsigned int *h_gate = nullptr;      // pinned: the sequence number of the last released gate
-    unsigned int gate_seq = 0;           // ... of the last gate queued
-    bool gate_open = false;              // a gate kernel is queued whose number has not been written yet
-    bool gate_ok = false;                // the upload stream could be given another priority than the kernel stream (start_sequence)
-    bool gate_wanted = false;            // the chunk being queued wants one in front of its first macroblock launch (gate_if_wanted)
+    hipEvent_t up_wait_ev = nullptr;     // the event behind the LAST transfer issued on the upload stream, if one was recorded there (else: wait for the stream)
     void *call_sink = nullptr;           // m2v_push_frames_pull: the call's destination (a PullSink), seen by every progress() inside the call
     int split_streams = 2;        // GOP segments of a chunk run as this many independent groups on as many streams (encode_chunk)
     static constexpr int kMaxSplit = 8;
@@ -338,7 +333,6 @@ void launch_plan_upload(m2v_enc *e, hipStream_t s, const FrameJob *h_jobs, size_
 void launch_slice_scan(m2v_enc *e, hipStream_t s, const Geom &g, int f0, int f1);
 void launch_frame_scan(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, bool advance, uint8_t *d_stream);
 void launch_assemble(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, uint8_t *d_stream);
-void gate_if_wanted(m2v_enc *e, hipStream_t s);      // the port path's gate kernel (m2v_port.hip: release_gate), queued here if the chunk wants one
 void launch_halo_pack(m2v_enc *e, hipStream_t s, const int *d_list, int count, uint8_t *up, uint8_t *down);
 void launch_halo_unpack(m2v_enc *e, hipStream_t s, const int *d_list, int count, const uint8_t *from_up, const uint8_t *from_down);
 // strip mode, output rank: where every (frame, rank) piece goes + the copy itself, headers and trailer (k_strip_layout, k_strip_assemble)

@@ -191,7 +191,7 @@ static const MbMap *mbmap_for(m2v_enc *e, hipStream_t s, const Geom &g, int mode
             return c.d.p;
         }
     const uint32_t n = (uint32_t)((g.row1 - g.row0) * g.mbw);
-    if (e->mbmaps.size() >= 24 && !e->gate_open) {          // (not behind an open gate of the port path: the wait below would sit behind it)                           // (a recorded graph that still points at it is invalidated by the release: alloc_generation)
+    if (e->mbmaps.size() >= 24) {                           // (a recorded graph that still points at it is invalidated by the release: alloc_generation)                           // (a recorded graph that still points at it is invalidated by the release: alloc_generation)
         (void)hipDeviceSynchronize();                       // launches on ANY of the handle's streams may still be reading the oldest table (rare: 24 shapes)
         if (e->mbmaps.front().ev) (void)hipEventDestroy(e->mbmaps.front().ev);
         e->mbmaps.front().d.release();
@@ -365,34 +365,6 @@ void launch_frame_scan(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool
 }
 
 // slices, and with them the headers and the sequence end code
-// The gate in front of a chunk's macroblock kernels (m2v_port.hip): one lane waits until the host has written this gate's number into a word
-// of pinned host memory - it does so when it has waited for the chunk's transfer.  Bounded (wall clock, 100 MHz): a host that never gets
-// there (a failed call that is not followed by m2v_reset / m2v_destroy, which write the number) stalls the handle's stream for ten seconds,
-// not for ever.  The bound is far above what a chunk's transfer can take (a gate waits for at most the chunk being uploaded: 1.2 GB at the
-// largest frame size and the default chunk = 21 ms on this link); a host that is merely slow to notice the transfer's end costs time, not
-// correctness - the frames are there when it does.
-__global__ void k_gate(const unsigned int *flag, unsigned int want)
-{
-    typedef const __attribute__((address_space(1))) unsigned int *gu32;
-    const long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load((gu32)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
-        if (wall_clock64() - t0 > 1000000000ll) break;
-        __builtin_amdgcn_s_sleep(16);
-    }
-}
-
-// called by encode_chunk behind the chunk's plan (its allocations, its plan upload) and in front of everything that reads the chunk's
-// frames - the fork of the GOP groups' streams included: a chunk that wants a gate gets it here
-void gate_if_wanted(m2v_enc *e, hipStream_t s)
-{
-    if (!e->gate_wanted) return;
-    e->gate_wanted = false;
-    ++e->gate_seq;
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, (const unsigned int *)e->h_gate, e->gate_seq);
-    HIPCHK(hipGetLastError());
-    e->gate_open = true;
-}
-
 void launch_assemble(m2v_enc *e, hipStream_t s, const Geom &g, size_t nf, bool first, bool last, uint8_t *d_stream)
 {
     const size_t rows = (size_t)(g.row1 - g.row0);

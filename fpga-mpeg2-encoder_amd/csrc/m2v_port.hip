@@ -38,7 +38,7 @@ void ensure_staging(m2v_enc *e, int idx = -1)
     if (!h.h_ctl) HIPCHK(hipHostMalloc((void **)&h.h_ctl, 2 * sizeof(StreamCtl)));
     if (!h.ev_ctl) HIPCHK(hipEventCreateWithFlags(&h.ev_ctl, hipEventDisableTiming));
     if (!h.ev_out) HIPCHK(hipEventCreateWithFlags(&h.ev_out, hipEventDisableTiming));
-    if (!h.ev_up) HIPCHK(hipEventCreateWithFlags(&h.ev_up, hipEventDisableTiming));
+    if (!h.ev_up) HIPCHK(hipEventCreateWithFlags(&h.ev_up, hipEventDisableTiming | hipEventDisableSystemFence));      // (nothing to release to the host behind an upload)
     if (h.h_in && h.h_in_cap >= want) return;
     if (h.h_in) (void)hipHostFree(h.h_in);
     h.h_in = nullptr;
@@ -65,21 +65,20 @@ __global__ __launch_bounds__(256) void k_readback(uint4 *__restrict__ dst, const
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
-// The gate in front of a chunk's macroblock kernels (m2v_enc::h_gate; the kernel and the place it is queued: m2v_launch.hip, gate_if_wanted).
-// RULE: while a gate is wanted or open, this thread neither waits for the device nor allocates or frees anything - a spinning kernel
-// holds up every later packet of its hardware queue, which other streams of the process may share, and hipFree / hipHostFree wait for
-// the whole device.  flush_buffered therefore does its waiting and allocating FIRST, the gate is queued behind the chunk's plan, and the
-// only thing waited for until it is released is the upload - issued before it.  (With GPU_MAX_HW_QUEUES=1 every violation of the rule is
-// a ten-second stall: tests/test_gpu_ports.py::test_one_hardware_queue_does_not_stall_the_gate.)
-// every direct upload issued so far has arrived: wait for the copy itself (the upload stream's last command), then let the kernels go
-static void release_gate(m2v_enc *e)
+// The blocking call's wait for its direct uploads.  An event behind the last transfer (flush_buffered records one for the chunk's kernels)
+// is waited for ITSELF: the wait for the upload stream behind such an event takes ~30 us longer than the transfer, the wait for the event
+// ~15 (tools/ubench/h2d_kernel.hip; the event carries no system fence - an upload leaves nothing to release to the host).  Without an event
+// behind it the stream's last command is the transfer, and the wait for the stream costs nothing extra.
+// (Round 5 also had a GATE here - the kernels queued behind a one-lane kernel polling a host word, released by the call after its wait for
+// the bare transfer: 10 us better still, and unusable: a spinning kernel holds up its hardware queue, and in a process with several threads
+// another thread's hipFree waits for the device inside the runtime while this thread needs the runtime to get to its release - ten-second
+// stalls in tools/stress_threads.py.  profiles/r05_experiments.txt items 13, 16, 17.)
+static void wait_uploads(m2v_enc *e)
 {
-    if (e->up_unsynced) { HIPCHK(hipStreamSynchronize(e->up_stream)); e->up_unsynced = false; }
-    e->gate_wanted = false;             // (a chunk without a macroblock launch: nothing was queued)
-    if (e->gate_open) {
-        __atomic_store_n(e->h_gate, e->gate_seq, __ATOMIC_RELEASE);
-        e->gate_open = false;
-    }
+    if (!e->up_unsynced) return;
+    if (e->up_wait_ev) HIPCHK(hipEventSynchronize(e->up_wait_ev));
+    else HIPCHK(hipStreamSynchronize(e->up_stream));
+    e->up_unsynced = false;
 }
 
 // Move submitted chunks forward, oldest first.  block = wait for every step; until >= 0 = return as soon
@@ -156,89 +155,49 @@ void flush_buffered(m2v_enc *e, bool last)
         return;
     }
     m2v_enc::HostStage &h = e->st();
-    const int idx = e->cur, other = idx ^ 1;
-    const bool overlapped = e->async && !e->profile && !last;      // the caller goes on filling the other stage while this chunk encodes
-    // a gate queued by an earlier chunk of this call: released before anything below can wait for that chunk (and with it every upload so far)
-    if (e->gate_open || e->gate_wanted) release_gate(e);
-    const bool staged = h.uploaded < nf;
-    // will this chunk's kernels go behind a gate?  Only the blocking call's own direct transfer outstanding, and the call goes on afterwards
-    const bool gate = overlapped && e->gate_ok && !staged && !e->direct_upload_deferred && !e->upl_pending[0] && !e->upl_pending[1] && e->up_unsynced;
-    // With a gate, everything that may wait for the device or (re)allocate comes FIRST (see the rule at release_gate): the other stage must be
-    // free before it is refilled, its staging must exist, this chunk's buffers must exist.  (Without one it comes last, as it always did: a
-    // chunk staged through pinned memory is uploaded HERE, and waiting for the chunk before it in front of that transfer leaves the link idle
-    // - 50.7 -> 41 GB/s from pageable memory when this order was the same for both.)
-    auto free_other_stage = [&] {
-        if (e->hs[other].stage != 0) progress(e, true, other);
-        ensure_staging(e, other);
-    };
-    if (gate) free_other_stage();
-    // the stage's own device buffer, filled on the upload stream: the copy of chunk k+1 crosses PCIe while the kernels of chunk k run
+    // the stage's own device buffer, filled on the upload stream: the copy of chunk k+1 crosses PCIe while the kernels
+    // of chunk k run (the stage is only refilled after its previous chunk has completed, see the end of this function)
     h.d_in.ensure(std::max(nf, h.uploaded ? e->batch_frames : (size_t)0) * frame_bytes);
-    // worst case ~1.2 KB per macroblock; typical streams are ~100x smaller
-    const size_t cap = nf * ((size_t)g.mbs * 1216 + (size_t)g.mbh * 8 + 64) + 256;
-    h.d_out.ensure(cap);
-    e->d_ctl.ensure(1);
+    const bool staged = h.uploaded < nf;
     if (staged)
         HIPCHK(hipMemcpyAsync(h.d_in.p + h.uploaded * frame_bytes, h.h_in + h.uploaded * frame_bytes, (nf - h.uploaded) * frame_bytes,
                               hipMemcpyHostToDevice, e->up_stream));
     h.uploaded = 0;
-    if (gate) {
-        // The macroblock kernels go behind a gate that the call opens when it has waited for its transfer.  (An event would be a packet of its
-        // own behind the copy on the upload stream, and the call's wait for that stream a wait for the packet: +30 us per chunk on this box,
-        // tools/ubench/h2d_kernel.hip.)  Queued by encode_chunk behind the chunk's plan and its allocations.
-        if (!e->h_gate) { HIPCHK(hipHostMalloc((void **)&e->h_gate, 64)); *e->h_gate = 0; e->gate_seq = 0; }
-        e->gate_wanted = true;
-    } else if (staged || e->direct_upload_deferred || e->upl_pending[0] || e->upl_pending[1] || (e->up_unsynced && overlapped)) {
-        // the chunk's kernels behind its uploads, by an event (option direct_upload = 2: this call's own transfer is not waited for on the host)
-        HIPCHK(hipEventRecord(h.ev_up, e->up_stream));
-        HIPCHK(hipStreamWaitEvent(s, h.ev_up, 0));
-    } else if (e->up_unsynced) {
-        release_gate(e);                                // (this chunk is waited for before the function returns: its frames first)
-    }
+    // the chunk's kernels behind its uploads (on both upload streams of option direct_upload = 2: the second one's are ordered into
+    // the kernel stream by m2v_push_frames itself)
+    HIPCHK(hipEventRecord(h.ev_up, e->up_stream));
+    HIPCHK(hipStreamWaitEvent(s, h.ev_up, 0));
+    e->up_wait_ev = h.ev_up;            // (what a blocking m2v_push_frames waits for: see wait_uploads)
+    // worst case ~1.2 KB per macroblock; typical streams are ~100x smaller
+    const size_t cap = nf * ((size_t)g.mbs * 1216 + (size_t)g.mbh * 8 + 64) + 256;
+    h.d_out.ensure(cap);
+    e->d_ctl.ensure(1);
     ctl_begin(e, (unsigned long long)cap, e->first_chunk);
     encode_chunk(e, s, h.d_in.p, nf, e->first_chunk, last, e->last_frame_valid_beats, h.d_out.p);
     HIPCHK(hipMemcpyAsync(h.h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(h.ev_ctl, s));
     h.stage = 1;
     h.last = last;
-    e->pending.push_back(idx);
+    e->pending.push_back(e->cur);
     e->buffered = 0;
     e->first_chunk = false;
-    if (!overlapped) {
+    if (!e->async || e->profile || last) {
         // profile: the HIP-event timers of a chunk are read before the next one is queued
         // last:    the caller pulls next; nothing is left to overlap with
         progress(e, true);
         return;
     }
-    e->cur = other;
-    if (!gate) {                                                   // (with a gate up both were done in front, and the caller's m2v_push_frames
-        free_other_stage();                                        // moves the chunks on once it has let the gate go)
-        progress(e, false);
-    }
+    e->cur ^= 1;
+    if (e->st().stage != 0) progress(e, true, e->cur);     // the other stage must be free before it is refilled
+    ensure_staging(e);
+    progress(e, false);
 }
 
 void start_sequence(m2v_enc *e, uint32_t xs, uint32_t ys, uint32_t pf)
 {
-    // The upload and the read-back stream at another PRIORITY than the handle's kernel stream: streams of different priorities never share
-    // a hardware queue (profiles/r04_queue_ab.txt), and whatever these two put into theirs - a small transfer done by a kernel, the packet
-    // behind a wait for the stream - must never sit behind the gate kernel that the kernel stream carries while a transfer is under way
-    // (see release_gate: in a shared queue the call's wait for its transfer would wait for the gate that waits for the call)
-    int least = 0, greatest = 0, mine = 0, theirs = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIPCHK(hipStreamGetPriority(e->stream, &mine));
-    const int want = mine == greatest ? least : greatest;      // (option stream_priority may have put the kernel stream at the top)
-    // no gates (the event behind the transfer instead) with one priority level only, and under the runtime's debugging switches that make a
-    // launch wait for its kernel - the gate's kernel ends when the call that launched it goes on
-    auto env_on = [](const char *n) { const char *v = getenv(n); return v && atoi(v) != 0; };
-    e->gate_ok = least != greatest && !env_on("HIP_LAUNCH_BLOCKING") && !env_on("AMD_SERIALIZE_KERNEL") && !env_on("CUDA_LAUNCH_BLOCKING");
-    for (hipStream_t *ps : {&e->copy_stream, &e->up_stream, &e->up_stream2}) {
-        if (*ps && (hipStreamGetPriority(*ps, &theirs) != hipSuccess || theirs == mine)) {      // the kernel stream has moved since
-            (void)hipStreamSynchronize(*ps);
-            (void)hipStreamDestroy(*ps);
-            *ps = nullptr;
-        }
-        if (!*ps && ps != &e->up_stream2) HIPCHK(hipStreamCreateWithPriority(ps, hipStreamNonBlocking, want));
-    }
+    if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    if (!e->up_stream) HIPCHK(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
+    e->up_wait_ev = nullptr;
     e->g = make_geom(e, xs, ys);            // latched on the first beat (RTL:1060-1065)
     e->pframes = pf & 0xFFu;
     e->state = m2v_enc::DURING;
@@ -390,7 +349,6 @@ static int push_frames_impl(m2v_enc *e, void *argp)
     const bool pinned = e->direct_upload && page_locked(a->frames) && page_locked(a->frames + a->n * fb - 1);
     bool direct_pending = false;
     for (size_t k = 0; k < a->n;) {
-        if (e->gate_open || e->gate_wanted) release_gate(e);        // (the chunk before, completed by this call: let go before another transfer is queued)
         m2v_enc::HostStage &h = e->st();
         const size_t take = std::min(a->n - k, e->batch_frames - e->buffered);
         if (pinned) {
@@ -406,11 +364,7 @@ static int push_frames_impl(m2v_enc *e, void *argp)
                 // they are dealt different engines - 53 GB/s from one caller in a fresh process, 93 % of the plain copy - and behave like
                 // one stream when they are not - 49 GB/s, seen in bench.py's process with its dozen streams; a stream of another
                 // PRIORITY, which never shares a hardware queue, did not change that)
-                if (!e->up_stream2) {
-                    int pr = 0;
-                    HIPCHK(hipStreamGetPriority(e->up_stream, &pr));
-                    HIPCHK(hipStreamCreateWithPriority(&e->up_stream2, hipStreamNonBlocking, pr));
-                }
+                if (!e->up_stream2) HIPCHK(hipStreamCreateWithFlags(&e->up_stream2, hipStreamNonBlocking));
                 ups = e->up_stream2;
             }
             HIPCHK(hipMemcpyAsync(h.d_in.p + e->buffered * fb, a->frames + k * fb, take * fb, hipMemcpyHostToDevice, ups));
@@ -422,9 +376,8 @@ static int push_frames_impl(m2v_enc *e, void *argp)
             }
             h.uploaded = e->buffered + take;
             direct_pending = true;
-            if (!e->direct_upload_deferred) e->up_unsynced = true;
-            // m2v_push_frames_pull: completed chunks leave for the caller's buffer HERE, while this call's frames cross the link (and before
-            // a chunk of this call puts a gate up: nothing that can wait or allocate runs behind one)
+            if (!e->direct_upload_deferred && ups == e->up_stream) { e->up_unsynced = true; e->up_wait_ev = nullptr; }     // (no event behind this transfer yet)
+            // m2v_push_frames_pull: completed chunks leave for the caller's buffer HERE, while this call's frames cross the link
             if (a->sink) progress(e, false, -1, a->sink);
         } else {
             parallel_copy(h.h_in + e->buffered * fb, a->frames + k * fb, take * fb, e->copy_threads);
@@ -446,7 +399,7 @@ static int push_frames_impl(m2v_enc *e, void *argp)
             e->upl_pending[k] = true;
             e->up_parity ^= 1;
         } else {
-            release_gate(e);                                // waits for the transfer: the caller may reuse its buffer when this returns
+            wait_uploads(e);                                // the caller may reuse its buffer when this returns
             e->upl_pending[0] = e->upl_pending[1] = false;
         }
     }
@@ -454,25 +407,12 @@ static int push_frames_impl(m2v_enc *e, void *argp)
     return M2V_OK;
 }
 
-// a call that failed behind open_gate: the gate is let go (best effort) so that nothing later waits out its budget behind it
-static int push_frames_guarded(m2v_enc *e, PushFramesArgs *a)
-{
-    const int r = guard(e, push_frames_impl, a);
-    if (r < 0 && e->gate_open && e->h_gate) {
-        if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
-        __atomic_store_n(e->h_gate, e->gate_seq, __ATOMIC_RELEASE);
-        e->gate_open = false;
-        e->up_unsynced = false;
-    }
-    return r;
-}
-
 int m2v_push_frames(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const uint8_t *frames444,
                     size_t nframes)
 {
     if (!e || (nframes && !frames444)) return M2V_E_PARAM;
     PushFramesArgs a{xsize16, ysize16, pframes_count, frames444, nframes, nullptr};
-    return push_frames_guarded(e, &a);
+    return guard(e, push_frames_impl, &a);
 }
 
 static long long pull_tail(m2v_enc *e, uint8_t *dst, size_t cap, const PullSink &sink, int *last);
@@ -486,7 +426,7 @@ long long m2v_push_frames_pull(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, u
     PullSink sink{dst, cap, 0};
     PushFramesArgs a{xsize16, ysize16, pframes_count, frames444, nframes, &sink};
     e->call_sink = &sink;
-    int r = push_frames_guarded(e, &a);
+    int r = guard(e, push_frames_impl, &a);
     e->call_sink = nullptr;
     if (r < 0) return r;
     if (e->state == m2v_enc::ENDED && !e->pending.empty()) {        // (frames are dropped while the sequence ends; the pull half waits like m2v_pull)

@@ -324,7 +324,7 @@ def test_deferred_upload_and_pull_into_give_the_same_stream():
 
 def test_push_frames_pull_is_push_then_pull():
     """m2v_push_frames_pull (both port groups in one call): byte-identical to the oracle from page-locked and from pageable memory, with
-    pushes that complete a chunk exactly (the gate-kernel path of a blocking direct upload), pushes that span several chunks, a push
+    pushes that complete a chunk exactly (the call then waits for the chunk's upload event), pushes that span several chunks, a push
     per frame, and a destination so small that words queue up in the FIFO behind it; the handle is reused for all of them."""
     import torch
     import m2v_load
@@ -397,12 +397,12 @@ def test_deferred_upload_chunk_completed_by_the_call_itself():
         enc.close()
 
 
-def test_one_hardware_queue_does_not_stall_the_gate():
-    """The gate kernel in front of a chunk's macroblock launches (blocking m2v_push_frames from page-locked memory) holds up every later
-    packet of its hardware queue until the call lets it go.  With GPU_MAX_HW_QUEUES=1 all streams of the process share ONE queue: any
-    wait for the device or any (re)allocation between queueing the gate and releasing it then costs the gate's ten-second bound.  A fresh
-    process with one queue runs the shapes that exercise it - chunks completed by a call, calls spanning chunks, no pulls in between
-    (the stage-reuse wait), the combined call, a second larger geometry (buffers grow) - and must finish in seconds, bytes identical."""
+def test_one_hardware_queue_does_not_stall_the_port_path():
+    """With GPU_MAX_HW_QUEUES=1 every stream of the process shares ONE hardware queue: anything the port path queues that waits for the
+    host - round 5 tried a gate kernel in front of a chunk's launches, released by the call - or any wait of the host for something queued
+    behind such a thing shows as a stall of seconds.  A fresh process with one queue runs the shapes that would - chunks completed by a
+    call, calls spanning chunks, no pulls in between (the stage-reuse wait), the combined call, a second larger geometry (buffers grow) -
+    and must finish in seconds, bytes identical."""
     import subprocess
     import sys
     import time
@@ -442,4 +442,4 @@ print("SECONDS %%.2f" %% (time.perf_counter() - t0))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     secs = float(r.stdout.split("SECONDS")[1])
-    assert secs < 8.0, "the port path stalled (%.1f s for four small sequences): something waits behind an open gate" % secs
+    assert secs < 8.0, "the port path stalled (%.1f s for four small sequences)" % secs

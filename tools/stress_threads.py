@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Ad-hoc concurrency run: several host threads at once on ONE GPU, each with handles of its own - blocking resident calls, two
-handles taking turns with m2v_encode_resident_begin / _end, the port path (push / pull), and strip mode with an in-process
+handles taking turns with m2v_encode_resident_begin / _end, the port path (beats; frames from page-locked memory), and strip mode with an in-process
 communicator (whose ranks are further threads) - created, used and closed while the others run.  Every stream is checked against
 the oracle (computed beforehand, single-threaded).  usage (GPU box): python tools/stress_threads.py [threads] [rounds] [seed]"""
 import os
 import sys
 import threading
+import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -51,7 +52,8 @@ def worker(t):
     for it in range(R):
         c = cases[int(r.integers(0, len(cases)))]
         W, H, n, pf, VL, Q, clip, want = c
-        kind = int(r.integers(0, 4))
+        kind = int(r.integers(0, 5))
+        t_begin = time.perf_counter()
         try:
             if kind == 0:
                 ok = G.resident_encode(clip, W // 16, H // 16, pf, 7, 7, VL, Q, batch_frames=int(r.choice([2, 96]))) == want
@@ -71,6 +73,29 @@ def worker(t):
                     ok = e.encode(clip, W // 16, H // 16, pf) == want
                 finally:
                     e.close()
+            elif kind == 4:
+                # the port path from page-locked memory: blocking m2v_push_frames or m2v_push_frames_pull, chunk and call sizes at random, pulls or none in between
+                e = M.Mpeg2Encoder(7, 7, VL, Q)
+                try:
+                    src = torch.from_numpy(np.ascontiguousarray(clip)).pin_memory().numpy()
+                    e.set_option("batch_frames", int(r.choice([1, 2, 5, 96])))
+                    per, mode = int(r.choice([1, 2, 3, 7])), int(r.integers(0, 3))
+                    out = np.zeros(len(want) + 4096, np.uint8)
+                    pos, last = 0, False
+                    for k in range(0, n, per):
+                        if mode == 2:
+                            pos += e.push_frames_pull(W // 16, H // 16, pf, src[k:k + per], out, pos)[0]
+                        else:
+                            e.push_frames(W // 16, H // 16, pf, src[k:k + per])
+                            if mode == 1:
+                                pos += e.pull_into(out, pos)[0]
+                    e.sequence_stop()
+                    while not last:
+                        m, last = e.pull_into(out, pos)
+                        pos += m
+                    ok = out[:pos].tobytes() == want
+                finally:
+                    e.close()
             else:
                 world = int(r.integers(1, min(5, H // 16) + 1))
                 d = torch.from_numpy(np.ascontiguousarray(clip)).cuda()
@@ -79,6 +104,8 @@ def worker(t):
         except Exception as ex:  # noqa: BLE001
             ok = False
             print("thread %d round %d kind %d: %r" % (t, it, kind, ex), flush=True)
+        if time.perf_counter() - t_begin > 3.0:
+            print("thread %d round %d kind %d took %.1f s" % (t, it, kind, time.perf_counter() - t_begin), flush=True)
         with lock:
             done[0] += 1
             if not ok:

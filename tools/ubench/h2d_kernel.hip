@@ -91,7 +91,9 @@ int main(int argc, char **argv)
             CHK(hipMalloc((void **)&d2, back));
             hipEvent_t ev;
             CHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            for (int mode = 0; mode < 4; ++mode)
+            hipEvent_t ev_nf;
+            CHK(hipEventCreateWithFlags(&ev_nf, hipEventDisableTiming | hipEventDisableSystemFence));
+            for (int mode = 0; mode < 6; ++mode)
                 for (int rep = 0; rep < 2; ++rep) {
                     const double t0 = now();
                     double up = 0;
@@ -101,15 +103,18 @@ int main(int argc, char **argv)
                         CHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
                         if (mode == 2) CHK(hipMemcpyAsync(h2, d2, back, hipMemcpyDeviceToHost, s2));
                         if (mode == 3) { CHK(hipEventRecord(ev, s)); CHK(hipStreamWaitEvent(s2, ev, 0)); }
+                        if (mode == 4) { CHK(hipEventRecord(ev_nf, s)); CHK(hipStreamWaitEvent(s2, ev_nf, 0)); }
+                        if (mode == 5) { CHK(hipEventRecord(ev_nf, s)); CHK(hipStreamWaitEvent(s2, ev_nf, 0)); CHK(hipEventSynchronize(ev_nf)); }
                         CHK(hipStreamSynchronize(s));
                         up += now() - a;
                         CHK(hipStreamSynchronize(s2));
                     }
                     const double dt = (now() - t0) / K;
-                    static const char *const names[4] = {"upload alone", "3.4 MB read-back issued first", "3.4 MB read-back issued behind", "event behind the upload, stream waited for"};
+                    static const char *const names[6] = {"upload alone", "3.4 MB read-back issued first", "3.4 MB read-back issued behind", "event behind the upload, stream waited for",
+                                                                "... an event without system fence", "... the same, the EVENT waited for"};
                     if (rep) printf("%4zu MiB  %-44s upload %8.1f us  (both %8.1f us)\n", bytes >> 20, names[mode], up / K * 1e6, dt * 1e6);
                 }
-            CHK(hipEventDestroy(ev));
+            CHK(hipEventDestroy(ev)); CHK(hipEventDestroy(ev_nf));
             CHK(hipFree(d2)); CHK(hipHostFree(h2));
         }
         CHK(hipStreamDestroy(s2));
