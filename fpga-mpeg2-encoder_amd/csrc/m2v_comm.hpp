@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -450,13 +451,25 @@ struct PeerDesc {                    // what a rank tells its neighbours (m2v_co
     uint32_t magic, version;
     int32_t pid, device;
     unsigned long long ptr, bytes, cap;
+    unsigned long long nonce;        // drawn once per process: "the same process" is decided by this, not by the pid (ranks in a container each may all be pid 1)
     hipIpcMemHandle_t ipc;
-    uint8_t pad[M2V_PEER_DESC_BYTES - 40 - sizeof(hipIpcMemHandle_t)];
+    uint8_t pad[M2V_PEER_DESC_BYTES - 48 - sizeof(hipIpcMemHandle_t)];
 };
 static_assert(sizeof(PeerDesc) == M2V_PEER_DESC_BYTES, "the descriptor is M2V_PEER_DESC_BYTES of plain data");
 
+inline unsigned long long process_nonce()
+{
+    static const unsigned long long n = [] {
+        std::random_device rd;
+        unsigned long long v = ((unsigned long long)rd() << 32) ^ (unsigned long long)rd() ^ ((unsigned long long)getpid() << 17);
+        return v ? v : 1ull;
+    }();
+    return n;
+}
+
 struct PeerState {
     static constexpr uint32_t kMagic = 0x4D325650u;       // "M2VP"
+    static constexpr uint32_t kVersion = 2;               // 2: the descriptor carries the process nonce
     static constexpr size_t kCntBytes = (size_t)kPeerCntStride * 4 / 2;                                   // one counter's line: 128 bytes
     static constexpr size_t kCtl = 2 * (size_t)kPeerSlots * 2 * kCntBytes + 1024;                          // the counters, then the give-up word's KB
     int rank = 0, world = 1, device = 0;
@@ -471,6 +484,7 @@ struct PeerState {
     unsigned long long seq = 0;       // peer sequences so far (selects the counter set)
     unsigned int budget = 20000000u;  // bound of one wait in 10 ns ticks: 200 ms (M2V_PEER_BUDGET_US overrides)
     unsigned long long sequences = 0, giveups = 0;
+    int lines_used = 0;               // counter lines (2 per GOP) the longest sequence so far counted on: what a sequence clears of the next set
 
     static size_t off_cnt(unsigned set, int side) { return ((size_t)set * kPeerSlots * 2 + (size_t)side) * kCntBytes; }     // GOP 0's; GOP g: + g * 2 * kCntBytes
     static size_t off_gaveup() { return kCtl - 1024; }
@@ -500,8 +514,14 @@ struct PeerComm final : m2v_comm {
         st.fine = !(coarse && coarse[0] == '1');
         if (st.fine) M2V_COMM_HIP(hipExtMallocWithFlags((void **)&st.block, st.bytes, hipDeviceMallocFinegrained));
         else M2V_COMM_HIP(hipMalloc((void **)&st.block, st.bytes));
-        M2V_COMM_HIP(hipMemset(st.block, 0, st.bytes));
-        M2V_COMM_HIP(hipDeviceSynchronize());
+        try {                               // (no destructor runs for a constructor that throws: the block is given back here)
+            M2V_COMM_HIP(hipMemset(st.block, 0, st.bytes));
+            M2V_COMM_HIP(hipDeviceSynchronize());
+        } catch (...) {
+            (void)hipFree(st.block);
+            st.block = nullptr;
+            throw;
+        }
         if (const char *b_us = getenv("M2V_PEER_BUDGET_US")) {
             const long long us = atoll(b_us);
             st.budget = (unsigned int)std::min<long long>(std::max<long long>(us, 0) * 100, 0x7FFFFFFFll);
@@ -526,18 +546,19 @@ struct PeerComm final : m2v_comm {
     void export_desc(PeerDesc &d) const
     {
         memset(&d, 0, sizeof d);
-        d.magic = PeerState::kMagic; d.version = 1;
+        d.magic = PeerState::kMagic; d.version = PeerState::kVersion;
         d.pid = (int32_t)getpid(); d.device = st.device;
+        d.nonce = process_nonce();
         d.ptr = (unsigned long long)(uintptr_t)st.block; d.bytes = st.bytes; d.cap = st.cap;
         M2V_COMM_HIP(hipSetDevice(st.device));
         M2V_COMM_HIP(hipIpcGetMemHandle(&d.ipc, st.block));
     }
     uint8_t *map(const PeerDesc &d, bool &ipc)
     {
-        if (d.magic != PeerState::kMagic || d.version != 1) throw CommError("peer transport: not a landing-block descriptor");
+        if (d.magic != PeerState::kMagic || d.version != PeerState::kVersion) throw CommError("peer transport: not a landing-block descriptor");
         if (d.cap != st.cap || d.bytes != st.bytes) throw CommError("peer transport: the ranks were created with different halo capacities");
         M2V_COMM_HIP(hipSetDevice(st.device));
-        if (d.pid == (int32_t)getpid()) {                   // the same process: its pointer is good here
+        if (d.nonce == process_nonce() && d.pid == (int32_t)getpid()) {     // the same process (by its nonce; pids repeat across pid namespaces): its pointer is good here
             ipc = false;
             if (d.device != st.device) {
                 int can = 0;

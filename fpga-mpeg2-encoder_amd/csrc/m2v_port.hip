@@ -327,11 +327,18 @@ static int push_frames_impl(m2v_enc *e, void *argp)
     auto *a = (PushFramesArgs *)argp;
     if (e->strip_active) { e->set_err("m2v_push_*: a strip sequence is open (m2v_strip_finish or m2v_reset first)"); return M2V_E_STATE; }
     if (e->resident_inflight) { e->set_err("m2v_push_*: a resident sequence is in flight (m2v_encode_resident_end first)"); return M2V_E_STATE; }
-    if (e->state == m2v_enc::ENDED || a->n == 0) return M2V_OK;
+    // option direct_upload = 2 promises that a pushed range is free once the NEXT m2v_push_frames has returned - whatever that next
+    // call turns out to be: frames dropped while the sequence ends, no frames at all, or frames from ordinary memory (the staging path)
+    auto settle_deferred = [&] {
+        for (int k = 0; k < 2; ++k)
+            if (e->upl_pending[k]) { HIPCHK(hipEventSynchronize(e->ev_upl[k])); e->upl_pending[k] = false; }
+    };
+    if (e->state == m2v_enc::ENDED || a->n == 0) { settle_deferred(); return M2V_OK; }
     if (e->state == m2v_enc::IDLE) start_sequence(e, a->xs, a->ys, a->pf);
     const Geom &g = e->g;
     const size_t fb = (size_t)g.ysz * 3;
     if (e->beat_pos != 0) {
+        settle_deferred();
         e->set_err("m2v_push_frames: a frame is partially filled by m2v_push_beats");
         return M2V_E_STATE;
     }
@@ -400,8 +407,10 @@ static int push_frames_impl(m2v_enc *e, void *argp)
             e->up_parity ^= 1;
         } else {
             wait_uploads(e);                                // the caller may reuse its buffer when this returns
-            e->upl_pending[0] = e->upl_pending[1] = false;
+            settle_deferred();                              // (the option was switched off between two calls)
         }
+    } else {
+        settle_deferred();                                  // a call through the staging copy: the previous call's frames are free all the same
     }
     progress(e, false, -1, a->sink);
     return M2V_OK;
@@ -428,10 +437,22 @@ long long m2v_push_frames_pull(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, u
     e->call_sink = &sink;
     int r = guard(e, push_frames_impl, &a);
     e->call_sink = nullptr;
-    if (r < 0) return r;
+    if (r < 0) {
+        // chunks that completed inside the failed call went to dst already: back to the front of the FIFO with them, a later m2v_pull
+        // hands them out again (after an error only m2v_reset and m2v_pull are of any use, but nothing that was encoded is lost)
+        if (sink.used) {
+            try { e->fifo.insert(e->fifo.begin() + (long)e->fifo_rd, dst, dst + sink.used); } catch (...) { return M2V_E_NOMEM; }
+        }
+        return r;
+    }
     if (e->state == m2v_enc::ENDED && !e->pending.empty()) {        // (frames are dropped while the sequence ends; the pull half waits like m2v_pull)
         r = guard(e, pull_progress_impl, &sink);
-        if (r < 0) return r;
+        if (r < 0) {
+            if (sink.used) {
+                try { e->fifo.insert(e->fifo.begin() + (long)e->fifo_rd, dst, dst + sink.used); } catch (...) { return M2V_E_NOMEM; }
+            }
+            return r;
+        }
     }
     return pull_tail(e, dst, cap, sink, last);
 }

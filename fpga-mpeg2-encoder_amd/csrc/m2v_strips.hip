@@ -449,7 +449,10 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
             PeerState &ps = *q.peer;
             e->scan_peer_gaveup = ps.gaveup();
             e->scan_peer_clear = (unsigned int *)(ps.block + PeerState::off_cnt((unsigned)((ps.seq + 1) & 1), 0));
-            e->scan_peer_lines = 2 * std::max(1, halo_frames_of_step(q.nf, q.gop, 0));
+            // every line ANY earlier sequence of this communicator counted on: the set was last used two sequences ago, possibly by a
+            // sequence of more GOPs than this one (8 GOPs, 1 GOP, 8 GOPs: slots 1..7 of the first must not greet the third with old counts)
+            ps.lines_used = std::max(ps.lines_used, 2 * std::max(1, halo_frames_of_step(q.nf, q.gop, 0)));
+            e->scan_peer_lines = ps.lines_used;
             e->scan_peer_mark = kStripRetry;
         }
         finish_chunk(e, s, false, false, e->d_strip_own.p);

@@ -26,7 +26,8 @@ def run_peer_threads(M, d_clip, W, H, pf, VL, world, calls=1, halo_bytes=0, debu
     import torch
     encs = [M.Mpeg2Encoder(7, 7, VL, Q, debug=debug) for _ in range(world)]
     base = M.StripComm.local(world, debug=debug)
-    out = torch.empty(M.parallel.strip_output_bound(int(d_clip.shape[0]), W, H), dtype=torch.uint8, device="cuda:0")
+    clips = d_clip if isinstance(d_clip, (list, tuple)) else [d_clip]          # a list: call k encodes clips[k % len]
+    out = torch.empty(M.parallel.strip_output_bound(max(int(c.shape[0]) for c in clips), W, H), dtype=torch.uint8, device="cuda:0")
     torch.cuda.synchronize()
     peers, got, errs = [None] * world, [], []
 
@@ -36,7 +37,7 @@ def run_peer_threads(M, d_clip, W, H, pf, VL, world, calls=1, halo_bytes=0, debu
             for k in range(calls):
                 if before is not None:
                     before(r, k, encs[r], peers[r])
-                o = M.parallel.encode_strips_native(encs[r], peers[r], r, world, d_clip, W // 16, H // 16, pf, out if r == 0 else None)
+                o = M.parallel.encode_strips_native(encs[r], peers[r], r, world, clips[k % len(clips)], W // 16, H // 16, pf, out if r == 0 else None)
                 if r == 0:
                     got.append(o.cpu().numpy().tobytes())
         except Exception as ex:  # noqa: BLE001
@@ -78,6 +79,27 @@ def test_peer_transport_threads_equal_oracle(world, W, H, pf, VL):
     assert all(s["peer_sequences"] >= 1 for s in stats), stats
     assert len({(s["peer_sequences"], s["giveups"], s["fell_back"]) for s in stats}) == 1, "the ranks disagree about what happened: %r" % (stats,)
     print("peer transport, %d ranks as threads: %r, last form %r" % (world, stats[0], forms[0]))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_counter_sets_survive_sequences_of_different_gop_counts(world):
+    """8 GOPs, 1 GOP, 8 GOPs, 1 GOP, 8 GOPs on ONE peer communicator: a sequence clears the arrival counters of the NEXT sequence's set,
+    and that set was last used two sequences earlier - by a sequence of MORE GOPs than the one that clears it.  Every line any earlier
+    sequence counted on has to go, or GOP slots 1..7 of the third sequence start at the first one's final counts, its waits pass at
+    once and the edge rows read landing buffers the neighbour has not filled yet."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    W, H, pf, VL = 128, 128, 1, 3
+    long_clip = M.synth.clip(W, H, 16, clip_index=340 + world, scene_len=5)
+    short_clip = M.synth.clip(W, H, 2, clip_index=350 + world)
+    want = [orc.encode(c, W // 16, H // 16, pf, 7, 7, VL, 2) for c in (long_clip, short_clip)]
+    d = [torch.from_numpy(np.ascontiguousarray(c)).to("cuda:0") for c in (long_clip, short_clip)]
+    got, stats, forms = run_peer_threads(M, d, W, H, pf, VL, world, calls=5)
+    assert [g == want[k % 2] for k, g in enumerate(got)] == [True] * 5
+    assert len({(s["peer_sequences"], s["giveups"], s["fell_back"]) for s in stats}) == 1, stats
+    print("alternating GOP counts, %d ranks: %r, last form %r" % (world, stats[0], forms[0]))
 
 
 PEER_THREADS_CHILD = r'''
