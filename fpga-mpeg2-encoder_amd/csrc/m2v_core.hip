@@ -494,6 +494,8 @@ void m2v_destroy(m2v_enc *e)
     for (auto &h : e->hs) {
         h.d_out.release();
         h.d_in.release();
+        h.d_pk.release();
+        if (h.h_pk) (void)hipHostFree(h.h_pk);
         if (h.ev_up) (void)hipEventDestroy(h.ev_up);
         if (h.h_in) (void)hipHostFree(h.h_in);
         if (h.h_out) (void)hipHostFree(h.h_out);
@@ -540,7 +542,7 @@ int m2v_reset(m2v_enc *e)
     for (auto sd : e->side) if (sd) (void)hipStreamSynchronize(sd);
     if (e->strip_stream && e->strip_stream != e->stream) (void)hipStreamSynchronize(e->strip_stream);
     (void)hipGetLastError();            // (a caller's stream that no longer exists: the next launch must not trip over this)
-    for (auto &h : e->hs) { h.stage = 0; h.uploaded = 0; }
+    for (auto &h : e->hs) { h.stage = 0; h.uploaded = 0; h.pk.clear(); h.pk_used = h.pk_valid = h.pk_up = 0; }
     e->dev_jobs.clear(); e->dev_lists.clear(); e->dev_jobs_p = nullptr;
     e->resident_inflight = false; e->resident_empty = false;
     e->pending.clear();

@@ -105,6 +105,17 @@ struct m2v_enc {
         DevBuf<uint8_t> d_in;                 // the chunk's frames on the device: the upload of chunk k+1 (up_stream) runs
                                               // while the kernels of chunk k read the other stage's buffer
         DevBuf<uint8_t> d_out;                // chunk output when it goes to the host
+        // Frames that arrived as PACKED 4:4:4 samples (m2v_push_packed) keep the caller's byte order until they are on the device: one
+        // linear run of bytes per chunk, frame after frame in arrival order, staged in pinned memory (or uploaded straight from
+        // page-locked caller memory) and de-interleaved into d_in by k_unpack444 in front of the chunk's kernels
+        struct PkFrame { uint32_t frame; int layout; size_t off; };       // chunk frame index, M2V_PACKED_*, where its bytes start in h_pk / d_pk
+        std::vector<PkFrame> pk;
+        uint8_t *h_pk = nullptr;              // pinned staging (only when packed beats come from ordinary memory)
+        size_t h_pk_cap = 0;
+        DevBuf<uint8_t> d_pk;
+        size_t pk_used = 0;                   // bytes reserved for the packed frames of the chunk being filled (whole frames)
+        size_t pk_valid = 0;                  // ... of which the caller has delivered this many (the frame in progress ends here)
+        size_t pk_up = 0;                     // ... of which this many are on the device (or on their way) already
         hipEvent_t ev_ctl = nullptr, ev_out = nullptr, ev_up = nullptr;
         size_t uploaded = 0;                  // leading frames of the chunk being filled that are already in d_in (page-locked
                                               // caller memory goes to the device directly, without the pinned staging copy)
@@ -140,6 +151,8 @@ struct m2v_enc {
     hipStream_t copy_stream = nullptr;   // stream read-back, concurrent with the next chunk's kernels
     size_t buffered = 0;          // complete frames waiting in st().h_in
     size_t beat_pos = 0;          // beats received of the frame in progress
+    int cur_kind = 0;             // the form the frame in progress is kept in (that of its first beats): 0 = three planes in h_in, 1 + layout = packed
+    size_t cur_pk_off = 0;        // ... a packed one: where it starts in the stage's packed bytes
     uint32_t last_frame_valid_beats = 0;   // for a black-filled last frame
 
     // host output FIFO (32-byte words are handed out by m2v_pull)

@@ -65,6 +65,62 @@ __global__ __launch_bounds__(256) void k_readback(uint4 *__restrict__ dst, const
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
+// Packed 4:4:4 samples -> the three planes of the chunk's frames.  16 pixels per lane: STRIDE 16-byte loads (a wavefront's loads of one
+// kind cover a contiguous run between them), byte selection in registers (v_perm_b32 / v_bfe), one 16-byte store per plane.
+// src: frames of ysz * STRIDE bytes back to back; dst: frames of 3 * ysz bytes (Y plane, U plane, V plane).  HBM traffic 2 x the
+// frame's bytes - against a link that delivers them at a hundredth of the rate.
+template <int STRIDE, int OY, int OU, int OV>
+__global__ __launch_bounds__(256) void k_unpack444(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint32_t ysz, uint32_t nframes)
+{
+    const uint32_t per_frame = ysz >> 4;
+    for (uint32_t f = blockIdx.y; f < nframes; f += gridDim.y) {
+        const uint8_t *sf = src + (size_t)f * ysz * STRIDE;
+        uint8_t *df = dst + (size_t)f * ysz * 3;
+        for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < per_frame; t += gridDim.x * 256u) {
+            const uint4 *p = (const uint4 *)(sf + (size_t)t * 16 * STRIDE);
+            uint32_t w[4 * STRIDE];
+#pragma unroll
+            for (int k = 0; k < STRIDE; ++k) { const uint4 q = p[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+            auto byte = [&](int idx) -> uint32_t { return (w[idx >> 2] >> (8 * (idx & 3))) & 0xFFu; };
+            auto plane = [&](int off) {
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[j] = byte((4 * j) * STRIDE + off) | (byte((4 * j + 1) * STRIDE + off) << 8) | (byte((4 * j + 2) * STRIDE + off) << 16) |
+                           (byte((4 * j + 3) * STRIDE + off) << 24);
+                return make_uint4(o[0], o[1], o[2], o[3]);
+            };
+            ((uint4 *)df)[t] = plane(OY);
+            ((uint4 *)(df + ysz))[t] = plane(OU);
+            ((uint4 *)(df + 2 * (size_t)ysz))[t] = plane(OV);
+        }
+    }
+}
+
+struct PackedFmt { int stride, oy, ou, ov; };
+bool packed_fmt(int layout, PackedFmt &f)
+{
+    switch (layout) {
+    case M2V_PACKED_YUV24: f = {3, 0, 1, 2}; return true;
+    case M2V_PACKED_UYV24: f = {3, 1, 0, 2}; return true;
+    case M2V_PACKED_YUVX32: f = {4, 0, 1, 2}; return true;
+    case M2V_PACKED_AYUV32: f = {4, 1, 2, 3}; return true;
+    }
+    return false;
+}
+
+void launch_unpack(hipStream_t s, int layout, const uint8_t *src, uint8_t *dst, uint32_t ysz, uint32_t nframes)
+{
+    const dim3 grid(std::min<uint32_t>(((ysz >> 4) + 255u) / 256u, 1024u), std::min<uint32_t>(nframes, 32768u)), block(256);
+    switch (layout) {
+    case M2V_PACKED_YUV24: hipLaunchKernelGGL((k_unpack444<3, 0, 1, 2>), grid, block, 0, s, src, dst, ysz, nframes); break;
+    case M2V_PACKED_UYV24: hipLaunchKernelGGL((k_unpack444<3, 1, 0, 2>), grid, block, 0, s, src, dst, ysz, nframes); break;
+    case M2V_PACKED_YUVX32: hipLaunchKernelGGL((k_unpack444<4, 0, 1, 2>), grid, block, 0, s, src, dst, ysz, nframes); break;
+    default: hipLaunchKernelGGL((k_unpack444<4, 1, 2, 3>), grid, block, 0, s, src, dst, ysz, nframes); break;
+    }
+    HIPCHK(hipGetLastError());
+}
+
 // The blocking call's wait for its direct uploads.  An event behind the last transfer (flush_buffered records one for the chunk's kernels)
 // is waited for ITSELF: the wait for the upload stream behind such an event takes ~30 us longer than the transfer, the wait for the event
 // ~15 (tools/ubench/h2d_kernel.hip; the event carries no system fence - an upload leaves nothing to release to the host).  Without an event
@@ -158,16 +214,44 @@ void flush_buffered(m2v_enc *e, bool last)
     // the stage's own device buffer, filled on the upload stream: the copy of chunk k+1 crosses PCIe while the kernels
     // of chunk k run (the stage is only refilled after its previous chunk has completed, see the end of this function)
     h.d_in.ensure(std::max(nf, h.uploaded ? e->batch_frames : (size_t)0) * frame_bytes);
-    const bool staged = h.uploaded < nf;
-    if (staged)
-        HIPCHK(hipMemcpyAsync(h.d_in.p + h.uploaded * frame_bytes, h.h_in + h.uploaded * frame_bytes, (nf - h.uploaded) * frame_bytes,
-                              hipMemcpyHostToDevice, e->up_stream));
+    if (h.pk.empty()) {
+        if (h.uploaded < nf)
+            HIPCHK(hipMemcpyAsync(h.d_in.p + h.uploaded * frame_bytes, h.h_in + h.uploaded * frame_bytes, (nf - h.uploaded) * frame_bytes,
+                                  hipMemcpyHostToDevice, e->up_stream));
+    } else {
+        // some frames (usually all) came as packed samples: the planar ones in between go up run by run, the packed bytes that are
+        // still on the host in one piece; k_unpack444 below turns them into the planes of their frames
+        size_t k = h.uploaded, q = 0;
+        while (k < nf) {
+            while (q < h.pk.size() && h.pk[q].frame < k) ++q;
+            if (q < h.pk.size() && h.pk[q].frame == k) { ++k; continue; }
+            const size_t stop = q < h.pk.size() ? std::min<size_t>(h.pk[q].frame, nf) : nf;
+            HIPCHK(hipMemcpyAsync(h.d_in.p + k * frame_bytes, h.h_in + k * frame_bytes, (stop - k) * frame_bytes, hipMemcpyHostToDevice, e->up_stream));
+            k = stop;
+        }
+        if (h.pk_up < h.pk_valid)
+            HIPCHK(hipMemcpyAsync(h.d_pk.p + h.pk_up, h.h_pk + h.pk_up, h.pk_valid - h.pk_up, hipMemcpyHostToDevice, e->up_stream));
+    }
     h.uploaded = 0;
     // the chunk's kernels behind its uploads (on both upload streams of option direct_upload = 2: the second one's are ordered into
     // the kernel stream by m2v_push_frames itself)
     HIPCHK(hipEventRecord(h.ev_up, e->up_stream));
     HIPCHK(hipStreamWaitEvent(s, h.ev_up, 0));
     e->up_wait_ev = h.ev_up;            // (what a blocking m2v_push_frames waits for: see wait_uploads)
+    if (!h.pk.empty()) {
+        timer_break(e);
+        for (size_t a = 0; a < h.pk.size();) {          // runs of consecutive frames of one layout: one launch each
+            PackedFmt f{};
+            packed_fmt(h.pk[a].layout, f);
+            size_t b = a + 1;
+            while (b < h.pk.size() && h.pk[b].layout == h.pk[a].layout && h.pk[b].frame == h.pk[a].frame + (b - a) &&
+                   h.pk[b].off == h.pk[a].off + (b - a) * (size_t)g.ysz * (size_t)f.stride) ++b;
+            launch_unpack(s, h.pk[a].layout, h.d_pk.p + h.pk[a].off, h.d_in.p + (size_t)h.pk[a].frame * frame_bytes, g.ysz, (uint32_t)(b - a));
+            a = b;
+        }
+        h.pk.clear();
+        h.pk_used = h.pk_valid = h.pk_up = 0;
+    }
     // worst case ~1.2 KB per macroblock; typical streams are ~100x smaller
     const size_t cap = nf * ((size_t)g.mbs * 1216 + (size_t)g.mbh * 8 + 64) + 256;
     h.d_out.ensure(cap);
@@ -208,7 +292,7 @@ void start_sequence(m2v_enc *e, uint32_t xs, uint32_t ys, uint32_t pf)
     e->persist_slot = -1;
     e->end_pending = false;
     e->last_frame_valid_beats = e->g.ysz / 4;
-    for (auto &h : e->hs) h.uploaded = 0;
+    for (auto &h : e->hs) { h.uploaded = 0; h.pk.clear(); h.pk_used = h.pk_valid = h.pk_up = 0; }
     // the FIFO total counts stream bytes of THIS sequence (padding rule): must be empty
     e->fifo.clear();
     e->fifo_rd = 0;
@@ -223,12 +307,16 @@ void do_stop(m2v_enc *e)
     const uint32_t bpf = g.ysz / 4;
     if (e->beat_pos != 0) {
         // black-fill the frame in progress (RTL:1036-1056)
-        uint8_t *f = e->st().h_in + e->buffered * (size_t)g.ysz * 3;
-        const size_t done = e->beat_pos * 4;
-        memset(f + done, 0x00, g.ysz - done);
-        memset(f + g.ysz + done, 0x80, g.ysz - done);
-        memset(f + 2 * (size_t)g.ysz + done, 0x80, g.ysz - done);
-        e->last_frame_valid_beats = bpf;    // the fill is materialised on the host
+        if (e->cur_kind == 0) {
+            uint8_t *f = e->st().h_in + e->buffered * (size_t)g.ysz * 3;
+            const size_t done = e->beat_pos * 4;
+            memset(f + done, 0x00, g.ysz - done);
+            memset(f + g.ysz + done, 0x80, g.ysz - done);
+            memset(f + 2 * (size_t)g.ysz + done, 0x80, g.ysz - done);
+            e->last_frame_valid_beats = bpf;    // the fill is materialised on the host
+        } else {
+            e->last_frame_valid_beats = (uint32_t)e->beat_pos;      // a packed frame: the macroblock kernel fills (FrameJob::valid_beats)
+        }
         e->buffered++;
         e->beat_pos = 0;
     }
@@ -241,7 +329,61 @@ void do_stop(m2v_enc *e)
 
 extern "C" {
 
-struct PushBeatsArgs { uint32_t xs, ys, pf; const uint8_t *y, *u, *v; size_t n; int stop; };
+// Where the samples of a run of beats are: three arrays (stride 1; kind 0) or one interleaved array (kind 1 + M2V_PACKED_*)
+struct BeatSrc { const uint8_t *y, *u, *v; int stride, kind; };
+struct PushBeatsArgs { uint32_t xs, ys, pf; BeatSrc src; size_t n; int stop; };
+
+static bool page_locked_range(const void *p, size_t bytes)
+{
+    // the whole range must be page-locked, not just its first byte (a pointer near the end of a registered region)
+    auto one = [](const void *q) {
+        hipPointerAttribute_t attr;
+        const bool yes = hipPointerGetAttributes(&attr, q) == hipSuccess && attr.type == hipMemoryTypeHost;
+        if (!yes) (void)hipGetLastError();          // an ordinary pointer is "invalid value" to the query: not an error here
+        return yes;
+    };
+    return bytes && one(p) && one((const uint8_t *)p + bytes - 1);
+}
+
+// room for `bytes` more packed bytes in the stage being filled; false = the chunk has to leave first (a layout of more bytes per pixel
+// than the one the buffers were sized for arrived in the middle of a chunk)
+static bool pk_room(m2v_enc *e, m2v_enc::HostStage &h, size_t bytes, int stride)
+{
+    if (h.pk_used + bytes <= h.d_pk.n) return true;
+    if (h.pk_used != 0) return false;
+    h.d_pk.recorded = false;
+    h.d_pk.ensure(std::max(e->batch_frames * (size_t)e->g.ysz * (size_t)stride, bytes));
+    return true;
+}
+
+// the pinned staging of the packed bytes, as large as the device side (allocated with the first bytes that need it; when the device
+// side has grown since, nothing of the chunk being filled is in it)
+static void pk_staging(m2v_enc::HostStage &h)
+{
+    if (h.h_pk && h.h_pk_cap >= h.d_pk.n) return;
+    if (h.h_pk) (void)hipHostFree(h.h_pk);
+    h.h_pk = nullptr; h.h_pk_cap = 0;
+    HIPCHK(hipHostMalloc((void **)&h.h_pk, h.d_pk.n));
+    h.h_pk_cap = h.d_pk.n;
+}
+
+// `len` packed bytes of the caller at offset `off` of the stage's packed run: straight to the device from page-locked memory, else into
+// the pinned staging (uploaded when the chunk leaves).  Bytes arrive in order: off is where the previous piece ended.
+static void pk_put(m2v_enc *e, m2v_enc::HostStage &h, size_t off, const uint8_t *src, size_t len, bool pinned, bool &direct_pending)
+{
+    if (pinned) {
+        if (h.pk_up < off)                      // bytes staged on the host earlier in this chunk go first
+            HIPCHK(hipMemcpyAsync(h.d_pk.p + h.pk_up, h.h_pk + h.pk_up, off - h.pk_up, hipMemcpyHostToDevice, e->up_stream));
+        HIPCHK(hipMemcpyAsync(h.d_pk.p + off, src, len, hipMemcpyHostToDevice, e->up_stream));
+        h.pk_up = off + len;
+        e->up_unsynced = true; e->up_wait_ev = nullptr;
+        direct_pending = true;
+    } else {
+        pk_staging(h);
+        parallel_copy(h.h_pk + off, src, len, e->copy_threads);
+    }
+    h.pk_valid = off + len;
+}
 
 static int push_beats_impl(m2v_enc *e, void *argp)
 {
@@ -257,12 +399,67 @@ static int push_beats_impl(m2v_enc *e, void *argp)
     if (e->state == m2v_enc::IDLE) start_sequence(e, a->xs, a->ys, a->pf);
     const Geom &g = e->g;
     const size_t bpf = g.ysz / 4;
+    const BeatSrc &src = a->src;
+    PackedFmt sf{1, 0, 0, 0};
+    if (src.kind) packed_fmt(src.kind - 1, sf);
+    // packed samples in page-locked memory (capture buffers) cross PCIe from where they are
+    const bool pinned = src.kind != 0 && e->direct_upload && page_locked_range(src.y - sf.oy, a->n * 4 * (size_t)sf.stride);
+    bool direct_pending = false;
     while (i < a->n) {
-        uint8_t *f = e->st().h_in + e->buffered * (size_t)g.ysz * 3;
+        m2v_enc::HostStage &h = e->st();
+        if (e->beat_pos == 0 && src.kind != 0) {
+            // a frame begins, and it keeps the form its first beats come in: the caller's bytes as they are, de-interleaved on the
+            // device.  Whole frames of the call leave in one piece.
+            const size_t fbytes = (size_t)g.ysz * (size_t)sf.stride;
+            const size_t whole = std::min((a->n - i) / bpf, e->batch_frames - e->buffered);
+            const size_t nfr = std::max<size_t>(whole, 1);
+            if (!pk_room(e, h, nfr * fbytes, sf.stride)) { flush_buffered(e, false); continue; }      // (pk_used != 0: complete frames are buffered)
+            for (size_t k = 0; k < nfr; ++k) h.pk.push_back({(uint32_t)(e->buffered + k), src.kind - 1, h.pk_used + k * fbytes});
+            e->cur_kind = src.kind;
+            e->cur_pk_off = h.pk_used;
+            h.pk_used += nfr * fbytes;
+            if (whole >= 1) {
+                pk_put(e, h, e->cur_pk_off, src.y - sf.oy + i * 4 * (size_t)sf.stride, whole * fbytes, pinned, direct_pending);
+                i += whole * bpf;
+                e->buffered += whole;
+                if (e->buffered == e->batch_frames && !(a->stop && i == a->n)) flush_buffered(e, false);
+                continue;
+            }
+        } else if (e->beat_pos == 0) {
+            e->cur_kind = 0;
+        }
         const size_t take = std::min(a->n - i, bpf - e->beat_pos);
-        memcpy(f + e->beat_pos * 4, a->y + i * 4, take * 4);    // raster order: beat b = pixels 4b..4b+3
-        memcpy(f + g.ysz + e->beat_pos * 4, a->u + i * 4, take * 4);
-        memcpy(f + 2 * (size_t)g.ysz + e->beat_pos * 4, a->v + i * 4, take * 4);
+        if (e->cur_kind == 0 && src.kind == 0) {
+            uint8_t *f = h.h_in + e->buffered * (size_t)g.ysz * 3;
+            memcpy(f + e->beat_pos * 4, src.y + i * 4, take * 4);    // raster order: beat b = pixels 4b..4b+3
+            memcpy(f + g.ysz + e->beat_pos * 4, src.u + i * 4, take * 4);
+            memcpy(f + 2 * (size_t)g.ysz + e->beat_pos * 4, src.v + i * 4, take * 4);
+        } else if (e->cur_kind == src.kind) {
+            pk_put(e, h, e->cur_pk_off + e->beat_pos * 4 * (size_t)sf.stride, src.y - sf.oy + i * 4 * (size_t)sf.stride, take * 4 * (size_t)sf.stride,
+                   pinned, direct_pending);
+        } else {
+            // the frame in progress was begun in another form (a caller that mixes the entry points inside one frame): sample by
+            // sample into the form the frame has
+            PackedFmt df{1, 0, 0, 0};
+            uint8_t *dy, *du, *dv;
+            if (e->cur_kind == 0) {
+                uint8_t *f = h.h_in + e->buffered * (size_t)g.ysz * 3 + e->beat_pos * 4;
+                dy = f; du = f + g.ysz; dv = f + 2 * (size_t)g.ysz;
+            } else {
+                packed_fmt(e->cur_kind - 1, df);
+                const size_t off = e->cur_pk_off + e->beat_pos * 4 * (size_t)df.stride, len = take * 4 * (size_t)df.stride;
+                pk_staging(h);
+                if (df.stride == 4) memset(h.h_pk + off, 0, len);
+                dy = h.h_pk + off + df.oy; du = h.h_pk + off + df.ou; dv = h.h_pk + off + df.ov;
+                h.pk_valid = off + len;
+            }
+            const uint8_t *sy = src.y + i * 4 * (size_t)sf.stride, *su = src.u + i * 4 * (size_t)sf.stride, *sv = src.v + i * 4 * (size_t)sf.stride;
+            for (size_t k = 0; k < take * 4; ++k) {
+                dy[k * df.stride] = sy[k * sf.stride];
+                du[k * df.stride] = su[k * sf.stride];
+                dv[k * df.stride] = sv[k * sf.stride];
+            }
+        }
         e->beat_pos += take;
         i += take;
         if (e->beat_pos == bpf) {
@@ -271,6 +468,7 @@ static int push_beats_impl(m2v_enc *e, void *argp)
             if (e->buffered == e->batch_frames && !(a->stop && i == a->n)) flush_buffered(e, false);
         }
     }
+    if (direct_pending) wait_uploads(e);            // the caller may reuse its buffer when this returns
     if (a->stop) do_stop(e);
     else progress(e, false);
     return M2V_OK;
@@ -280,44 +478,22 @@ int m2v_push_beats(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pfra
                    const uint8_t *u4, const uint8_t *v4, size_t nbeats, int stop_with_last)
 {
     if (!e || (nbeats && (!y4 || !u4 || !v4))) return M2V_E_PARAM;
-    PushBeatsArgs a{xsize16, ysize16, pframes_count, y4, u4, v4, nbeats, stop_with_last};
+    PushBeatsArgs a{xsize16, ysize16, pframes_count, BeatSrc{y4, u4, v4, 1, 0}, nbeats, stop_with_last};
     return guard(e, push_beats_impl, &a);
 }
 
 // Packed 4:4:4 sources (capture cards, SDI/HDMI receivers hand out interleaved samples): the same beats, the
-// twelve port bytes of a beat simply arrive interleaved instead of on three arrays.
+// twelve port bytes of a beat simply arrive interleaved instead of on three arrays.  They stay interleaved until they are in HBM.
 int m2v_push_packed(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count, const uint8_t *pixels,
                     size_t nbeats, int layout, int stop_with_last)
 {
     if (!e || (nbeats && !pixels)) return M2V_E_PARAM;
-    int stride, oy, ou, ov;
-    switch (layout) {
-    case M2V_PACKED_YUV24: stride = 3; oy = 0; ou = 1; ov = 2; break;
-    case M2V_PACKED_UYV24: stride = 3; oy = 1; ou = 0; ov = 2; break;
-    case M2V_PACKED_YUVX32: stride = 4; oy = 0; ou = 1; ov = 2; break;
-    case M2V_PACKED_AYUV32: stride = 4; oy = 1; ou = 2; ov = 3; break;
-    default: e->set_err("m2v_push_packed: unknown layout %d", layout); return M2V_E_PARAM;
-    }
-    constexpr size_t kBlock = 4096;                     // beats per de-interleave block (48 KB of planar data: stays in L1/L2)
-    uint8_t y[kBlock * 4], u[kBlock * 4], v[kBlock * 4];
-    if (nbeats == 0) {
-        PushBeatsArgs a{xsize16, ysize16, pframes_count, y, u, v, 0, stop_with_last};
-        return guard(e, push_beats_impl, &a);
-    }
-    for (size_t done = 0; done < nbeats;) {
-        const size_t nb = std::min(kBlock, nbeats - done);
-        const uint8_t *src = pixels + done * 4 * (size_t)stride;
-        for (size_t i = 0; i < nb * 4; ++i) {
-            y[i] = src[i * stride + oy];
-            u[i] = src[i * stride + ou];
-            v[i] = src[i * stride + ov];
-        }
-        done += nb;
-        PushBeatsArgs a{xsize16, ysize16, pframes_count, y, u, v, nb, (stop_with_last && done == nbeats) ? 1 : 0};
-        const int r = guard(e, push_beats_impl, &a);
-        if (r < 0) return r;
-    }
-    return M2V_OK;
+    PackedFmt f{};
+    if (!packed_fmt(layout, f)) { e->set_err("m2v_push_packed: unknown layout %d", layout); return M2V_E_PARAM; }
+    static const uint8_t none[4] = {0, 0, 0, 0};
+    const uint8_t *p = pixels ? pixels : none;
+    PushBeatsArgs a{xsize16, ysize16, pframes_count, BeatSrc{p + f.oy, p + f.ou, p + f.ov, f.stride, 1 + layout}, nbeats, stop_with_last};
+    return guard(e, push_beats_impl, &a);
 }
 
 struct PushFramesArgs { uint32_t xs, ys, pf; const uint8_t *frames; size_t n; PullSink *sink; };

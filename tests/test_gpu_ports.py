@@ -215,6 +215,88 @@ def test_packed_444_layouts(env, layout):
         enc.close()
 
 
+def _packed_of(clip, layout):
+    y, u, v = clip[:, 0], clip[:, 1], clip[:, 2]
+    pad = np.full_like(y, 0x5A)
+    order = {"yuv24": (y, u, v), "uyv24": (u, y, v), "yuvx32": (y, u, v, pad), "ayuv32": (pad, y, u, v)}[layout]
+    return np.ascontiguousarray(np.stack(order, axis=-1)).reshape(-1), len(order)
+
+
+@pytest.mark.parametrize("layout,page_locked", [("yuv24", True), ("yuv24", False), ("ayuv32", True), ("uyv24", False)])
+def test_packed_frames_stay_packed_until_they_are_in_hbm(env, layout, page_locked):
+    """Whole frames per call, several chunks (batch_frames 4), from page-locked memory (uploaded as they are, k_unpack444 turns them
+    into planes on the device) and from ordinary memory (through the packed pinned staging); the caller's buffer is reused - and
+    overwritten - as soon as a call returns.  Then the same with a stop in the middle of a frame: a packed frame's black fill is the
+    macroblock kernel's (FrameJob::valid_beats), RTL:1036-1056."""
+    import torch
+    M, orc = env
+    W, H, n, pf = 96, 64, 11, 3
+    clip = M.synth.clip(W, H, n, clip_index=44)
+    want = orc.encode(clip, W // 16, H // 16, pf, 6, 6, 3, 2)
+    packed, bpp = _packed_of(clip, layout)
+    fbytes = W * H * bpp
+    enc = M.Mpeg2Encoder(6, 6, 3, 2)
+    try:
+        enc.set_option("batch_frames", 4)
+        scratch = torch.empty(3 * fbytes, dtype=torch.uint8)
+        scratch = (scratch.pin_memory() if page_locked else scratch).numpy()
+        k = 0
+        for take in (3, 1, 2, 3, 2):                                 # chunk boundaries inside and between the calls
+            scratch[:take * fbytes] = packed[k * fbytes:(k + take) * fbytes]
+            enc.push_packed(W // 16, H // 16, pf, scratch[:take * fbytes], layout)
+            scratch[:] = 0xEE                                        # the bytes have left the caller's buffer when the call returns
+            k += take
+        assert k == n
+        enc.sequence_stop()
+        assert enc.pull_all() == want
+        # stop inside frame 5 (beats of 2.5 rows of it delivered)
+        cut_beats = 5 * (W * H // 4) + (2 * W + W // 2) // 4
+        want_cut = orc.encode(clip[:6], W // 16, H // 16, pf, 6, 6, 3, 2, nbeats=cut_beats)
+        scratch2 = torch.empty(cut_beats * 4 * bpp, dtype=torch.uint8)
+        scratch2 = (scratch2.pin_memory() if page_locked else scratch2).numpy()
+        scratch2[:] = packed[:cut_beats * 4 * bpp]
+        enc.push_packed(W // 16, H // 16, pf, scratch2, layout, stop_with_last=True)
+        assert enc.pull_all() == want_cut
+    finally:
+        enc.close()
+
+
+def test_packed_and_planar_beats_mixed_inside_frames_and_chunks(env):
+    """Every mixture a caller can produce through the two beat entry points: a frame begun with planar beats and finished with packed
+    ones and the other way round, a 32-bit layout arriving in a chunk sized for a 24-bit one (the chunk leaves early), planar frames
+    between packed ones in one chunk, page-locked and ordinary sources in turn."""
+    import torch
+    M, orc = env
+    W, H, n, pf = 64, 64, 14, 4
+    clip = M.synth.clip(W, H, n, clip_index=45)
+    want = orc.encode(clip, W // 16, H // 16, pf, 6, 6, 2, 3)
+    bpf = W * H // 4
+    layouts = ["yuv24", "uyv24", "yuvx32", "ayuv32"]
+    packs = {l: _packed_of(clip, l) for l in layouts}
+    pinned = {l: torch.from_numpy(packs[l][0]).pin_memory().numpy() for l in layouts}
+    yb, ub, vb = (np.ascontiguousarray(clip[:, c]).reshape(-1) for c in range(3))
+    rng = np.random.default_rng(99)
+    enc = M.Mpeg2Encoder(6, 6, 2, 3)
+    try:
+        enc.set_option("batch_frames", 5)
+        b, total = 0, n * bpf
+        while b < total:
+            take = int(min(total - b, rng.choice([1, 7, bpf // 3, bpf, 2 * bpf + 5, 3 * bpf])))
+            kind = int(rng.integers(0, 9))
+            if kind == 0:
+                enc.push_beats(W // 16, H // 16, pf, yb[4 * b:4 * (b + take)], ub[4 * b:4 * (b + take)], vb[4 * b:4 * (b + take)])
+            else:
+                l = layouts[(kind - 1) % 4]
+                src = pinned[l] if kind > 4 else packs[l][0]
+                bpp = packs[l][1]
+                enc.push_packed(W // 16, H // 16, pf, src[4 * bpp * b:4 * bpp * (b + take)], l)
+            b += take
+        enc.sequence_stop()
+        assert enc.pull_all() == want
+    finally:
+        enc.close()
+
+
 def test_long_sequence_many_chunks_in_flight(env):
     """1500 frames through the double-buffered port path in 30 chunks (FIFO compaction, stage reuse, the padding rule
     against the whole-sequence byte count chained on the device), pulled in small pieces while pushing."""
