@@ -36,7 +36,7 @@ EXPORTS = [
     "m2v_comm_unique_id", "m2v_comm_init_rccl", "m2v_comm_init_local", "m2v_comm_init_solo", "m2v_comm_destroy", "m2v_comm_last_error", "m2v_comm_selftest",
     "m2v_comm_init_solo_rccl", "m2v_comm_selftest_captured", "m2v_strip_graph_stats",
     "m2v_comm_init_callbacks", "m2v_comm_init_peer", "m2v_comm_peer_export", "m2v_comm_peer_connect", "m2v_comm_peer_connect_all",
-    "m2v_comm_peer_stats", "m2v_comm_kind", "m2v_strip_last_form", "m2v_upload_wait",
+    "m2v_comm_peer_stats", "m2v_comm_kind", "m2v_strip_last_form", "m2v_upload_wait", "m2v_device_pci_bus_id",
 ]
 
 PEER_DESC_BYTES = 128          # M2V_PEER_DESC_BYTES
@@ -140,6 +140,7 @@ def lib(debug=False):
             L.m2v_upload_wait.argtypes = [vp]
             L.m2v_push_frames_pull.restype = ctypes.c_longlong
             L.m2v_push_frames_pull.argtypes = [vp, u32, u32, u32, vp, sz, vp, sz, ctypes.POINTER(ci)]
+            L.m2v_device_pci_bus_id.argtypes = [ci, ctypes.c_char_p, sz]
         except AttributeError:
             # an OLDER build handed in through M2V_LIB for a same-box A/B (tools/ab.sh) may lack the newer entry points; the library of
             # this tree must have every one of them (tests/test_abi.py)
@@ -151,6 +152,13 @@ def lib(debug=False):
 
 def build(force=False, verbose=False):
     return _build.build(force=force, verbose=verbose)
+
+
+def device_pci_bus_id(device=0):
+    """PCI address of HIP device `device` as sysfs spells it ("0000:c1:00.0"), or None (m2v_device_pci_bus_id)"""
+    buf = ctypes.create_string_buffer(64)
+    n = lib().m2v_device_pci_bus_id(int(device), buf, 64)
+    return buf.value.decode() if n > 0 else None
 
 
 def clamp_geometry(xsize16, ysize16, XL=7, YL=7):

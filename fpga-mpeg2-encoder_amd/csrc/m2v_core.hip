@@ -708,6 +708,17 @@ long long m2v_debug_read(m2v_enc *e, int what, void *dst, size_t cap)
     return r < 0 ? r : a.ret;
 }
 
+int m2v_device_pci_bus_id(int device, char *buf, size_t cap)
+{
+    if (!buf || cap < 16) return M2V_E_PARAM;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return M2V_E_NODEVICE; }
+    if (hipDeviceGetPCIBusId(buf, (int)std::min<size_t>(cap, 64), device) != hipSuccess) { (void)hipGetLastError(); return M2V_E_HIP; }
+    buf[cap - 1] = 0;
+    for (char *c = buf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');      // sysfs spells the address in lower case
+    return (int)strlen(buf);
+}
+
 const char *m2v_last_error(const m2v_enc *e) { return e ? e->err.c_str() : t_create_err.c_str(); }
 
 int m2v_debug_table(int which, int i, int j) { return debug_table(which, i, j); }

@@ -230,3 +230,66 @@ def strip_output_bound(nframes, W, H):
     """A safe capacity for the assembled stream of `nframes` frames (the library reports M2V_E_OVERFLOW beyond it):
     worst case 1216 bytes per macroblock + headers."""
     return nframes * ((W // 16) * (H // 16) * 1216 + (H // 16) * 8 + 64) + 256
+
+
+def dist_comm(StripComm, dist, world):
+    """A strip communicator over ANY initialised torch.distributed process group (m2v_comm_init_callbacks): sizes, strips and - when
+    nothing better is at hand - halo rows travel through `dist`, staged through host memory.  What m2v_strip_encode needs when librccl
+    cannot be used between the ranks (two processes on ONE GPU: RCCL refuses; a gloo-only job), and the base the peer transport sits on
+    there: with StripComm.peer on top the halo rows never come this way, only the once-per-sequence sizes and strips do.
+    Slow by construction (host staging, stream synchronised per call); the RCCL communicator is the one for a multi-GPU node."""
+    import ctypes
+    import torch
+    # the HIP runtime this process already holds (torch's copy): the same file again gives the same instance, never a second runtime
+    hip = ctypes.CDLL([ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln][0])
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    D2H, H2D = 2, 1
+
+    def down(ptr, n):
+        a = np.empty(n, np.uint8)
+        if hip.hipMemcpy(a.ctypes.data, ptr, n, D2H) != 0:
+            raise RuntimeError("hipMemcpy (device to host)")
+        return a
+
+    def up(ptr, a):
+        a = np.ascontiguousarray(a)
+        if hip.hipMemcpy(ptr, a.ctypes.data, a.nbytes, H2D) != 0:
+            raise RuntimeError("hipMemcpy (host to device)")
+
+    def halo(r, su, ru, sd, rd, n, stream):
+        hip.hipStreamSynchronize(stream)
+        ops, back = [], []
+        for s_, r_, peer in ((su, ru, r - 1), (sd, rd, r + 1)):
+            if s_:
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(down(s_, n)), peer))
+                t = torch.empty(n, dtype=torch.uint8)
+                back.append((r_, t))
+                ops.append(dist.P2POp(dist.irecv, t, peer))
+        for q in dist.batch_isend_irecv(ops) if ops else []:
+            q.wait()
+        for p_, t in back:
+            up(p_, t.numpy())
+        return 0
+
+    def allgather(r, src, dst, count, stream):
+        hip.hipStreamSynchronize(stream)
+        mine = torch.from_numpy(down(src, 8 * count))
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        up(dst, torch.cat(every).numpy())
+        return 0
+
+    def gather(r, dstrank, strip, sizes, bufs, stream):
+        hip.hipStreamSynchronize(stream)
+        if r != dstrank:
+            if sizes[r]:
+                dist.send(torch.from_numpy(down(strip, sizes[r])), dstrank)
+        else:
+            for k in range(world):
+                if k != dstrank and sizes[k]:
+                    t = torch.empty(sizes[k], dtype=torch.uint8)
+                    dist.recv(t, k)
+                    up(bufs[k], t.numpy())
+        return 0
+    return StripComm.callbacks(world, halo, allgather, gather)

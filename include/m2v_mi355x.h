@@ -45,6 +45,11 @@ const char *m2v_version(void);
 m2v_enc *m2v_create(int XL, int YL, int VECTOR_LEVEL, int Q_LEVEL, int device, int *err);
 void     m2v_destroy(m2v_enc *e);
 
+/* PCI address ("0000:c1:00.0") of HIP device `device`, NUL-terminated into buf: which card of /sys/class/drm a handle created on that
+ * ordinal runs on (sensors, topology).  Returns the string's length, M2V_E_NODEVICE for an ordinal out of range, M2V_E_PARAM for a
+ * buffer of less than 16 bytes.  No counterpart in the RTL: a host-side aid. */
+int m2v_device_pci_bus_id(int device, char *buf, size_t cap);
+
 /* `rstn` low (RTL:1028-1039): drop any sequence in flight, return to idle, discard output. */
 int m2v_reset(m2v_enc *e);
 
