@@ -37,6 +37,7 @@ EXPORTS = [
     "m2v_comm_init_solo_rccl", "m2v_comm_selftest_captured", "m2v_strip_graph_stats",
     "m2v_comm_init_callbacks", "m2v_comm_init_peer", "m2v_comm_peer_export", "m2v_comm_peer_connect", "m2v_comm_peer_connect_all",
     "m2v_comm_peer_stats", "m2v_comm_kind", "m2v_strip_last_form", "m2v_upload_wait", "m2v_device_pci_bus_id",
+    "m2v_strip_encode_begin", "m2v_strip_encode_end",
 ]
 
 PEER_DESC_BYTES = 128          # M2V_PEER_DESC_BYTES
@@ -141,6 +142,8 @@ def lib(debug=False):
             L.m2v_push_frames_pull.restype = ctypes.c_longlong
             L.m2v_push_frames_pull.argtypes = [vp, u32, u32, u32, vp, sz, vp, sz, ctypes.POINTER(ci)]
             L.m2v_device_pci_bus_id.argtypes = [ci, ctypes.c_char_p, sz]
+            L.m2v_strip_encode_begin.argtypes = [vp, vp, ci, ci, ci, u32, u32, u32, vp, sz, vp, sz, vp]
+            L.m2v_strip_encode_end.argtypes = [vp, ctypes.POINTER(sz)]
         except AttributeError:
             # an OLDER build handed in through M2V_LIB for a same-box A/B (tools/ab.sh) may lack the newer entry points; the library of
             # this tree must have every one of them (tests/test_abi.py)
@@ -364,6 +367,19 @@ class Mpeg2Encoder:
         n = ctypes.c_size_t(0)
         self._chk(self._L.m2v_strip_encode(self._h, comm.handle if comm is not None else None, rank, world, dst, xsize16, ysize16,
                                            pframes_count, d_frames_ptr, nframes, d_out_ptr, cap, ctypes.byref(n), stream), "m2v_strip_encode")
+        return n.value
+
+    def strip_encode_begin(self, comm, rank, world, d_frames_ptr, nframes, xsize16, ysize16, pframes_count, d_out_ptr=None, cap=0, dst=0, stream=0):
+        """m2v_strip_encode_begin: the sequence's GOP steps and this strip's slices are enqueued, nothing is waited for.  Two handles
+        (a peer communicator each, over ONE base communicator) taking turns from one thread keep two strip sequences in flight."""
+        self._chk(self._L.m2v_strip_encode_begin(self._h, comm.handle if comm is not None else None, rank, world, dst, xsize16, ysize16,
+                                                 pframes_count, d_frames_ptr, nframes, d_out_ptr, cap, stream), "m2v_strip_encode_begin")
+
+    def strip_encode_end(self):
+        """m2v_strip_encode_end: the sizes all-gather, the one host wait, the strips to the output rank, the assembly there.
+        Returns the stream's byte count on the output rank, 0 elsewhere."""
+        n = ctypes.c_size_t(0)
+        self._chk(self._L.m2v_strip_encode_end(self._h, ctypes.byref(n)), "m2v_strip_encode_end")
         return n.value
 
     def strip_stats(self):

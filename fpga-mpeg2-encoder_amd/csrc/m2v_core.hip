@@ -517,6 +517,7 @@ void m2v_destroy(m2v_enc *e)
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     e->d_frame_pos.release(); e->d_alloff.release(); e->d_halo.release(); e->d_strip_own.release(); e->d_gather.release();
     if (e->strip_graph.exec) (void)hipGraphExecDestroy(e->strip_graph.exec);
+    strip_flight_release(e);
     for (auto ev : e->ev_upl) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_up2) (void)hipEventDestroy(e->ev_up2);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -552,6 +553,7 @@ int m2v_reset(m2v_enc *e)
     e->fifo.clear(); e->fifo_rd = 0; e->end_pending = false;
     // a strip sequence abandoned between m2v_strip_begin and m2v_strip_finish: back to the full frame
     e->strip_active = false;
+    e->strip_inflight = false;
     e->strip_stream = nullptr;
     e->strip_nf = 0;
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
@@ -580,7 +582,7 @@ int m2v_geometry(const m2v_enc *e, uint32_t xsize16, uint32_t ysize16, int *widt
 int m2v_set_option(m2v_enc *e, const char *name, long long value)
 {
     if (!e || !name) return M2V_E_PARAM;
-    if (e->resident_inflight || e->strip_active) {      // the sequence in flight was planned with the current options
+    if (e->resident_inflight || e->strip_active || e->strip_inflight) {      // the sequence in flight was planned with the current options
         e->set_err("m2v_set_option: a %s sequence is in flight", e->resident_inflight ? "resident" : "strip");
         return M2V_E_STATE;
     }

@@ -60,6 +60,7 @@ struct DevBuf {
 };
 
 struct KStat { int launches = 0; double ms = 0, units = 0; };
+struct StripFlight;
 
 
 struct TimedLaunch { hipEvent_t a, b; int kernel; double units; int count; };
@@ -204,6 +205,8 @@ struct m2v_enc {
     std::vector<Step> plan_steps;
     size_t plan_nf = 0;
     bool strip_active = false;            // between m2v_strip_begin and m2v_strip_finish
+    bool strip_inflight = false;          // between m2v_strip_encode_begin and m2v_strip_encode_end
+    StripFlight *flight = nullptr;        // ... what the second half needs to know of the first (m2v_strips.hip)
     hipStream_t strip_stream = nullptr;
     DevBuf<uint8_t> d_segs;               // CopySeg table of the strip assembly (written by k_strip_layout)
     DevBuf<unsigned long long> d_frame_pos;   // where every frame's headers start in the assembled stream (k_strip_layout)
@@ -321,6 +324,9 @@ struct Timer {
         }
     }
 };
+
+// ---- m2v_strips.hip ----
+void strip_flight_release(m2v_enc *e);
 
 // ---- m2v_launch.hip: everything that touches device code ----
 // The constant tables live in each device's copy of the code object: uploaded once per device, whichever thread creates the first

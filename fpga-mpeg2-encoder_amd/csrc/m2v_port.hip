@@ -390,6 +390,7 @@ static int push_beats_impl(m2v_enc *e, void *argp)
     auto *a = (PushBeatsArgs *)argp;
     if (e->strip_active) { e->set_err("m2v_push_*: a strip sequence is open (m2v_strip_finish or m2v_reset first)"); return M2V_E_STATE; }
     if (e->resident_inflight) { e->set_err("m2v_push_*: a resident sequence is in flight (m2v_encode_resident_end first)"); return M2V_E_STATE; }
+    if (e->strip_inflight) { e->set_err("m2v_push_*: a strip sequence is in flight (m2v_strip_encode_end first)"); return M2V_E_STATE; }
     if (e->state == m2v_enc::ENDED) return M2V_OK;              // dropped while the sequence ends (RTL:1045-1058)
     size_t i = 0;
     if (a->n == 0) {
@@ -503,6 +504,7 @@ static int push_frames_impl(m2v_enc *e, void *argp)
     auto *a = (PushFramesArgs *)argp;
     if (e->strip_active) { e->set_err("m2v_push_*: a strip sequence is open (m2v_strip_finish or m2v_reset first)"); return M2V_E_STATE; }
     if (e->resident_inflight) { e->set_err("m2v_push_*: a resident sequence is in flight (m2v_encode_resident_end first)"); return M2V_E_STATE; }
+    if (e->strip_inflight) { e->set_err("m2v_push_*: a strip sequence is in flight (m2v_strip_encode_end first)"); return M2V_E_STATE; }
     // option direct_upload = 2 promises that a pushed range is free once the NEXT m2v_push_frames has returned - whatever that next
     // call turns out to be: frames dropped while the sequence ends, no frames at all, or frames from ordinary memory (the staging path)
     auto settle_deferred = [&] {

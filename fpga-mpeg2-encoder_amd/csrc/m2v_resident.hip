@@ -23,7 +23,7 @@ static int resident_end_impl(m2v_enc *e, void *argp)
 static int resident_impl(m2v_enc *e, void *argp)
 {
     auto *a = (ResidentArgs *)argp;
-    if (e->state != m2v_enc::IDLE || e->strip_active || e->resident_inflight) { e->set_err("m2v_encode_resident: encoder busy"); return M2V_E_STATE; }
+    if (e->state != m2v_enc::IDLE || e->strip_active || e->resident_inflight || e->strip_inflight) { e->set_err("m2v_encode_resident: encoder busy"); return M2V_E_STATE; }
     e->resident_empty = false;
     if (a->n == 0) {                                    // no beat: the sequence never starts
         if (a->bytes) *a->bytes = 0;

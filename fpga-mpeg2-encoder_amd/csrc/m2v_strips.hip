@@ -20,7 +20,7 @@ struct StripBeginArgs { uint32_t xs, ys, pf; const uint8_t *d_in; size_t n; int 
 static int strip_begin_impl(m2v_enc *e, void *argp)
 {
     auto *a = (StripBeginArgs *)argp;
-    if (e->state != m2v_enc::IDLE || e->strip_active || e->resident_inflight) { e->set_err("m2v_strip_begin: encoder busy"); return M2V_E_STATE; }
+    if (e->state != m2v_enc::IDLE || e->strip_active || e->resident_inflight || e->strip_inflight) { e->set_err("m2v_strip_begin: encoder busy"); return M2V_E_STATE; }
     Geom g = make_geom(e, a->xs, a->ys);
     if (a->n == 0 || a->row0 < 0 || a->row1 > g.mbh || a->row0 >= a->row1) { e->set_err("m2v_strip_begin: bad rows / no frames"); return M2V_E_PARAM; }
     g.row0 = a->row0; g.row1 = a->row1; g.strip = 1;
@@ -220,7 +220,7 @@ struct StripAsmArgs { uint32_t xs, ys, pf; size_t n; int nranks; const void *con
 static int strip_assemble_impl(m2v_enc *e, void *argp)
 {
     auto *a = (StripAsmArgs *)argp;
-    if (e->strip_active || e->resident_inflight || e->state != m2v_enc::IDLE) { e->set_err("m2v_strip_assemble: encoder busy"); return M2V_E_STATE; }
+    if (e->strip_active || e->resident_inflight || e->strip_inflight || e->state != m2v_enc::IDLE) { e->set_err("m2v_strip_assemble: encoder busy"); return M2V_E_STATE; }
     if (((uintptr_t)a->d_out & 15u) != 0) { e->set_err("m2v_strip_assemble: d_out must be 16-byte aligned"); return M2V_E_PARAM; }
     if (a->nranks > kMaxStripRanks) { e->set_err("m2v_strip_assemble: at most %d strips", kMaxStripRanks); return M2V_E_PARAM; }
     for (int r = 0; r < a->nranks; ++r)
@@ -309,11 +309,43 @@ struct StripSeq {
     PeerState *peer;    // non-null: the peer form of the step (one launch, rows stored into the neighbours' landing blocks)
 };
 
+// One strip sequence between its launch and its collection: what m2v_strip_encode_end (or the second half of m2v_strip_encode) needs to
+// know about what m2v_strip_encode_begin enqueued.  Lives with the handle (m2v_enc::flight, allocated on first use).
+struct m2v::StripFlight {
+    StripEncodeArgs a{};
+    StripSeq q{};
+    Geom full{};
+    bool defer_sizes = false;       // the sizes all-gather has not been issued yet (it is the first thing the collection does)
+    bool use_peer = false;
+    PeerState *pst = nullptr;
+    int fail = 0;
+    std::string fail_text;
+    hipStream_t s = nullptr;
+    int graph_used = 0;
+    std::vector<hipEvent_t> marks;
+};
+
+static StripFlight &flight_of(m2v_enc *e)
+{
+    if (!e->flight) e->flight = new StripFlight();
+    return *e->flight;
+}
+
 // Enqueues the sequence on s (and the handle's side / comm streams, forked from and joined back into s by events): no allocation,
 // no synchronisation, no host state of the handle changed - this is what is recorded into the graph.  `fail` (direct mode only):
 // see above; local work is skipped once it is set, the exchanges are not.
+// everybody's per-frame sizes (and the marks of a failed / retrying rank): the one collective behind a strip's slices
+static void strip_enqueue_sizes(m2v_enc *e, hipStream_t s, const StripSeq &q, int fail)
+{
+    if (q.world <= 1) return;
+    if (fail) (void)hipMemsetAsync(e->d_frame_off.p, 0xFF, (q.nf + 1) * sizeof(unsigned long long), s);        // the mark
+    q.comm->allgather_u64(q.rank, e->d_frame_off.p, e->d_alloff.p, q.nf + 1, s);
+    const hipError_t ce = hipMemcpyAsync(e->h_asm, e->d_alloff.p, (size_t)q.world * (q.nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (ce != hipSuccess && !fail) throw HipError{ce, "hipMemcpyAsync(all-gathered sizes)"};
+}
+
 static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q, bool recording, int &fail, std::string &fail_text,
-                                   std::vector<hipEvent_t> *marks, double *us_in_comm)
+                                   std::vector<hipEvent_t> *marks, double *us_in_comm, bool with_sizes = true)
 {
     using clk = std::chrono::steady_clock;
     auto local = [&](auto &&fn) {
@@ -460,36 +492,24 @@ static void strip_enqueue_sequence(m2v_enc *e, hipStream_t s, const StripSeq &q,
         HIPCHK(hipMemcpyAsync(e->h_strip, e->d_frame_off.p, (q.nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(e->h_strip + (q.nf + 1) * sizeof(unsigned long long), e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
     });
-    if (q.world > 1) {
-        if (fail) (void)hipMemsetAsync(e->d_frame_off.p, 0xFF, (q.nf + 1) * sizeof(unsigned long long), s);        // the mark
-        q.comm->allgather_u64(q.rank, e->d_frame_off.p, e->d_alloff.p, q.nf + 1, s);
-        const hipError_t ce = hipMemcpyAsync(e->h_asm, e->d_alloff.p, (size_t)q.world * (q.nf + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
-        if (ce != hipSuccess && !fail) throw HipError{ce, "hipMemcpyAsync(all-gathered sizes)"};
-    }
+    if (with_sizes) strip_enqueue_sizes(e, s, q, fail);
 }
 
-static int strip_encode_impl(m2v_enc *e, void *argp)
+// One strip sequence between its launch and its collection (m2v_enc::flight).  m2v_strip_encode = launch + collect in one call;
+// m2v_strip_encode_begin = launch with the sizes all-gather DEFERRED, m2v_strip_encode_end = that all-gather + collect.
+//
+// Why the all-gather waits for _end: two handles taking turns from one thread on ONE base communicator issue their collectives in one
+// deterministic order on every rank - and RCCL runs the operations of a communicator in the order they were issued, whatever stream
+// each is on.  begin(A) begin(B) end(A) must therefore not put B's all-gather (which sits behind ALL of B's kernels) in front of A's
+// gather: issued in _end the order is sizes(A), strips(A), sizes(B), strips(B) ... - the order they become ready in.
+static int strip_launch_attempt(m2v_enc *e, StripFlight &F)
 {
-    auto *a = (StripEncodeArgs *)argp;
     using clk = std::chrono::steady_clock;
+    StripEncodeArgs *a = &F.a;
+    StripSeq &q = F.q;
     const int rank = a->rank, world = a->world;
-    const Geom full = make_geom(e, a->xs, a->ys);
-    if (world < 1 || world > kMaxStripRanks || world > full.mbh || rank < 0 || rank >= world || a->dst < 0 || a->dst >= world ||
-        (world > 1 && (!a->comm || a->comm->world != world))) {
-        e->set_err("m2v_strip_encode: bad rank / world / communicator");
-        return M2V_E_PARAM;
-    }
-    if (e->state != m2v_enc::IDLE || e->strip_active || e->resident_inflight) { e->set_err("m2v_strip_encode: encoder busy"); return M2V_E_STATE; }
-    // contiguous strips, sizes differing by at most one row, the first mbh % world ranks get the extra row (parallel.partition_rows)
-    const int base = full.mbh / world, rem = full.mbh % world;
-    const int row0 = rank * base + std::min(rank, rem), row1 = row0 + base + (rank < rem ? 1 : 0);
-    const size_t nf = a->n;
-    const uint32_t gop = (a->pf & 0xFFu) + 1u;
-
-    // ---- plan and buffers.  Everything up to here was the same on every rank; from here on a failure is this rank's alone and
-    //      must not break the collective call order (see the head of this section) ----
-    int fail = 0;
-    std::string fail_text;
+    int &fail = F.fail;
+    std::string &fail_text = F.fail_text;
     auto local = [&](auto &&fn) {
         if (fail) return;
         try { fn(); }
@@ -499,53 +519,18 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
             (void)hipGetLastError();
         }
     };
-    if (kDebug && (e->ablate & (1 << 21))) { fail = M2V_E_HIP; fail_text = "injected failure (ablate bit 21)"; }    // -DM2V_DEBUG: the failure protocol under test
-    // a bad output buffer is the output rank's alone to know: a local failure like any other (the other ranks are told through the
-    // size table, nobody is left waiting in an exchange); with one rank it is simply the answer
-    if (rank == a->dst && (!a->d_out || ((uintptr_t)a->d_out & 15u) != 0)) {
-        const char *why = !a->d_out ? "the output rank needs d_out" : "d_out must be 16-byte aligned";
-        if (world == 1) { e->set_err("m2v_strip_encode: %s", why); return M2V_E_PARAM; }
-        fail = M2V_E_PARAM; fail_text = why;
-    }
-    StripSeq q{};
-    q.comm = a->comm; q.rank = rank; q.world = world; q.row0 = row0; q.row1 = row1;
-    q.up = row0 > 0; q.down = row1 < full.mbh;
-    q.fused = !e->conformant && e->dct_mfma && !e->keep_recon;
-    q.gop = gop; q.nf = nf; q.W = full.W;
-    q.steps = (int)std::min<size_t>(gop, nf);
-    q.strip_cap = nf * ((size_t)(row1 - row0) * full.mbw * 1216 + (size_t)(row1 - row0) * 8 + 64) + 256;     // worst case
-    const size_t halo_cap = (size_t)halo_frames_of_step(nf, gop, 0) * (size_t)(3 * e->VL) * (size_t)full.W;
-    // the buffers an exchange touches come first: with them a rank can keep the call order whatever else fails
-    e->d_halo.ensure(4 * halo_cap + 64);
-    e->d_frame_off.ensure(nf + 1);
-    if (world > 1) {
-        e->d_alloff.ensure((size_t)world * (nf + 1));
-        ensure_pinned(e->h_asm, e->h_asm_cap, (size_t)world * (nf + 1) * sizeof(unsigned long long));
-    }
-    q.send_up = e->d_halo.p; q.send_down = q.send_up + halo_cap; q.recv_up = q.send_down + halo_cap; q.recv_down = q.recv_up + halo_cap;
-    // peer transport (m2v_comm.hpp, PeerComm): the usual form of the step, a connected communicator that has not fallen back, and a
-    // step's rows fitting its landing buffers - all of it the same on every rank
-    PeerState *const pst = a->comm ? a->comm->peer() : nullptr;
-    bool use_peer = pst && pst->connected && !pst->degraded && world > 1 && q.fused && halo_cap <= pst->cap && pst->world == world && pst->rank == rank &&
-                    halo_frames_of_step(nf, gop, 0) <= kPeerSlots;
-    q.mbw = full.mbw;
-    hipStream_t s = nullptr;
-    std::vector<hipEvent_t> marks;
-    int graph_used = 0;
-    hipEvent_t g0 = nullptr, g1 = nullptr;
-    const void *strips[kMaxStripRanks] = {};
-    const unsigned long long *d_all = nullptr;
-    int failed_rank = -1;
-    // Twice at most: a peer sequence in which some rank's wait ran out of budget (every rank reads that in the all-gathered sizes) is
-    // encoded again, exchanged through the base communicator, and the communicator stays there.
-    for (int attempt = 0;; ++attempt) {
-    q.peer = use_peer ? pst : nullptr;
+    const Geom &full = F.full;
+    const size_t nf = a->n;
+    const uint32_t gop = q.gop;
+    PeerState *const pst = F.pst;
+    q.peer = F.use_peer ? pst : nullptr;
     int r = M2V_OK;
     local([&] {
-        StripBeginArgs b{a->xs, a->ys, a->pf, a->d_in, a->n, row0, row1, a->s};
+        StripBeginArgs b{a->xs, a->ys, a->pf, a->d_in, a->n, q.row0, q.row1, a->s};
         r = strip_begin_impl(e, &b);
     });
     if (r < 0) return r;                                    // (parameters: the same answer on every rank)
+    hipStream_t &s = F.s;
     s = e->strip_active ? e->strip_stream : (a->s ? a->s : e->stream);
     local([&] {
         if ((int)e->plan_steps.size() != q.steps) throw HipError{hipErrorInvalidValue, "strip plan and step count disagree"};
@@ -572,10 +557,11 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     // ---- the sequence: recorded graph, or call by call ----
     // profile: GPU events around the exchange of every step: halo_total = edge rows (and their halo) written .. neighbour rows and
     // interior rows both there; halo_exposed = how much of that came after the interior rows were done
-    marks.clear();
+    F.marks.clear();
     double us_in_comm = 0;                 // host time inside the communicator (a local communicator blocks there until the neighbour thread has posted)
     const auto t_loop = clk::now();
     m2v_enc::StripGraph &sg = e->strip_graph;
+    int &graph_used = F.graph_used;
     graph_used = 0;
     // (the general form - options conformant / dct_mfma = 0 - is enqueued call by call: it issues the exchange on a stream of its own,
     // and RCCL 2.26 crashes when its send / recv group is recorded on a stream that joined the recording through an event)
@@ -583,13 +569,15 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     // is enqueued call by call unless the caller opts in with option strip_graph = 1: a recording with cross-rank ncclSend / ncclRecv
     // inside has never run on hardware, the ranks of a job do not necessarily record on the same call, and on one GPU the recorded
     // form is no faster for an inner rank (profiles/r04_experiments.txt item 1).  The peer form is never recorded: its counter set
-    // and its launch arguments change from sequence to sequence, and it is five launches per step shorter to begin with.
+    // and its launch arguments change from sequence to sequence, and it is five launches per step shorter to begin with.  Nor is a
+    // sequence whose sizes all-gather is deferred (m2v_strip_encode_begin): the recording ends with that all-gather.
     const bool graph_wanted = e->strip_graph_opt > 0 || (e->strip_graph_opt < 0 && (!a->comm || a->comm->graph_by_default()));
     // (a recording of more than one rank's form has parallel branches - edge rows and interior rows on a stream each; with the runtime limited
     // to ONE hardware queue, GPU_MAX_HW_QUEUES=1, hipGraphLaunch of such a graph crashes inside the runtime, hip::Graph::UpdateStreams: found
     // by running the suite with that setting, profiles/r05_experiments.txt item 16 - so no recording there)
     static const bool one_queue = [] { const char *v = getenv("GPU_MAX_HW_QUEUES"); return v && atoi(v) == 1; }();
-    const bool graph_ok = graph_wanted && !q.peer && !sg.broken && !fail && !e->profile && (world == 1 || (q.fused && !one_queue)) && (!a->comm || a->comm->capturable());
+    const bool graph_ok = graph_wanted && !F.defer_sizes && !q.peer && !sg.broken && !fail && !e->profile && (world == 1 || (q.fused && !one_queue)) &&
+                          (!a->comm || a->comm->capturable());
     if (graph_ok) {
         // everything a recording references exists before the key (which holds the allocation generation) is taken: the output rank's
         // assembly tables are allocated here, not after the host wait - a rank must not find its own recording stale on the next call
@@ -597,7 +585,7 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     }
     if (graph_ok && !fail) {
         const std::vector<unsigned long long> key = {alloc_generation().load(), (unsigned long long)full.W, (unsigned long long)full.H, (unsigned long long)full.Q,
-            (unsigned long long)row0, (unsigned long long)row1, (unsigned long long)nf, (unsigned long long)gop, (unsigned long long)rank,
+            (unsigned long long)q.row0, (unsigned long long)q.row1, (unsigned long long)nf, (unsigned long long)gop, (unsigned long long)rank,
             (unsigned long long)world, (unsigned long long)(uintptr_t)a->comm, (unsigned long long)q.fused, (unsigned long long)e->VL,
             (unsigned long long)e->conformant, (unsigned long long)e->dct_mfma};
         if (sg.exec && sg.key == key) graph_used = 1;
@@ -642,7 +630,7 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         HIPCHK(hipGraphLaunch(sg.exec, s));
         sg.launches++;
     } else {
-        strip_enqueue_sequence(e, s, q, false, fail, fail_text, e->profile && !q.peer ? &marks : nullptr, &us_in_comm);
+        strip_enqueue_sequence(e, s, q, false, fail, fail_text, e->profile && !q.peer ? &F.marks : nullptr, &us_in_comm, !F.defer_sizes);
         // what this call allocated on the way (the launches' block tables on a shape's first call) belongs to the shape that was seen:
         // the next call of it finds everything in place and records
         if (graph_ok && !fail && !sg.seen.empty()) sg.seen[0] = alloc_generation().load();
@@ -659,59 +647,153 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     e->strip_stats.peer = q.peer ? 1 : 0;
     e->strip_stats.host_us_per_step = std::chrono::duration<double, std::micro>(clk::now() - t_loop).count() / std::max(1, q.steps);
     e->strip_stats.comm_us_per_step = us_in_comm / std::max(1, q.steps);
-    g0 = g1 = nullptr;
-    if (e->profile && !fail) { g0 = pool_event(e); timer_break(e); HIPCHK(hipEventRecord(g0, s)); }     // from here: gather, final assembly
+    return M2V_OK;
+}
 
-    // ---- the one host wait; strips to the output rank; final assembly ----
-    for (auto &sp : strips) sp = nullptr;
-    d_all = e->d_frame_off.p;
-    failed_rank = fail ? rank : -1;
-    if (world > 1) {
-        const hipError_t se = hipStreamSynchronize(s);      // the sizes decide the receive counts
-        if (se != hipSuccess && !fail) throw HipError{se, "hipStreamSynchronize(strip sequence)"};
-        const unsigned long long *all = (const unsigned long long *)e->h_asm;
-        int retry_rank = -1;
-        for (int k = 0; k < world; ++k) {
-            const unsigned long long mark = all[(size_t)k * (nf + 1) + nf];
-            if (mark == kStripPoison && failed_rank < 0) failed_rank = k;
-            if (mark == kStripRetry && retry_rank < 0) retry_rank = k;
-        }
-        if (failed_rank < 0 && retry_rank >= 0) {
-            if (!q.peer || attempt > 0) throw HipError{hipErrorUnknown, "a retry mark in the size table of a sequence that was not in the peer form"};
-            // no error: the sequence again, the rows exchanged through the base communicator - on every rank, they all read the same table
-            pst->degraded = true;
-            pst->giveups++;
-            use_peer = false;
-            collect_timers(e);
-            continue;
-        }
-        if (failed_rank < 0) {
-            // (an overflow of this strip's buffer - impossible with the worst-case size above - is reported at the end: the other ranks
-            // are waiting in the gather, and a rank that left now would leave them there)
-            size_t sizes[kMaxStripRanks] = {}, total_in = 0;
-            for (int k = 0; k < world; ++k) {
-                sizes[k] = (size_t)all[(size_t)k * (nf + 1) + nf];
-                if (k != a->dst) total_in += (sizes[k] + 255) & ~(size_t)255;
-            }
-            void *bufs[kMaxStripRanks] = {};
-            if (rank == a->dst) {
-                local([&] { e->d_gather.ensure(total_in + 256); });
-                size_t off = 0;
-                for (int k = 0; k < world; ++k) {
-                    if (k == a->dst) { strips[k] = e->d_strip_own.p; continue; }
-                    bufs[k] = e->d_gather.p + off;
-                    strips[k] = bufs[k];
-                    off += (sizes[k] + 255) & ~(size_t)255;
-                }
-            }
-            if (fail) throw HipError{hipErrorOutOfMemory, "no room for the other ranks' strips on the output rank"};     // (they are already sending: nothing to keep in order any more)
-            a->comm->gather(rank, a->dst, e->d_strip_own.p, sizes, bufs, s);
-            d_all = e->d_alloff.p;
-        }
-    } else {
-        strips[0] = e->d_strip_own.p;
+// parameters, the strip's rows, the buffers every exchange touches, the first attempt
+static int strip_launch(m2v_enc *e, StripFlight &F, const StripEncodeArgs &args, bool defer_sizes)
+{
+    F = StripFlight{};
+    e->strip_inflight = false;
+    F.a = args;
+    F.defer_sizes = defer_sizes;
+    StripEncodeArgs *a = &F.a;
+    const int rank = a->rank, world = a->world;
+    F.full = make_geom(e, a->xs, a->ys);
+    const Geom &full = F.full;
+    if (world < 1 || world > kMaxStripRanks || world > full.mbh || rank < 0 || rank >= world || a->dst < 0 || a->dst >= world ||
+        (world > 1 && (!a->comm || a->comm->world != world))) {
+        e->set_err("m2v_strip_encode: bad rank / world / communicator");
+        return M2V_E_PARAM;
     }
-    break;
+    if (e->state != m2v_enc::IDLE || e->strip_active || e->resident_inflight) { e->set_err("m2v_strip_encode: encoder busy"); return M2V_E_STATE; }
+    // contiguous strips, sizes differing by at most one row, the first mbh % world ranks get the extra row (parallel.partition_rows)
+    const int base = full.mbh / world, rem = full.mbh % world;
+    const int row0 = rank * base + std::min(rank, rem), row1 = row0 + base + (rank < rem ? 1 : 0);
+    const size_t nf = a->n;
+    const uint32_t gop = (a->pf & 0xFFu) + 1u;
+
+    // ---- plan and buffers.  Everything up to here was the same on every rank; from here on a failure is this rank's alone and
+    //      must not break the collective call order (see the head of this section) ----
+    if (kDebug && (e->ablate & (1 << 21))) { F.fail = M2V_E_HIP; F.fail_text = "injected failure (ablate bit 21)"; }    // -DM2V_DEBUG: the failure protocol under test
+    // a bad output buffer is the output rank's alone to know: a local failure like any other (the other ranks are told through the
+    // size table, nobody is left waiting in an exchange); with one rank it is simply the answer
+    if (rank == a->dst && (!a->d_out || ((uintptr_t)a->d_out & 15u) != 0)) {
+        const char *why = !a->d_out ? "the output rank needs d_out" : "d_out must be 16-byte aligned";
+        if (world == 1) { e->set_err("m2v_strip_encode: %s", why); return M2V_E_PARAM; }
+        F.fail = M2V_E_PARAM; F.fail_text = why;
+    }
+    StripSeq &q = F.q;
+    q.comm = a->comm; q.rank = rank; q.world = world; q.row0 = row0; q.row1 = row1;
+    q.up = row0 > 0; q.down = row1 < full.mbh;
+    q.fused = !e->conformant && e->dct_mfma && !e->keep_recon;
+    q.gop = gop; q.nf = nf; q.W = full.W;
+    q.steps = (int)std::min<size_t>(gop, nf);
+    q.strip_cap = nf * ((size_t)(row1 - row0) * full.mbw * 1216 + (size_t)(row1 - row0) * 8 + 64) + 256;     // worst case
+    const size_t halo_cap = (size_t)halo_frames_of_step(nf, gop, 0) * (size_t)(3 * e->VL) * (size_t)full.W;
+    // the buffers an exchange touches come first: with them a rank can keep the call order whatever else fails
+    e->d_halo.ensure(4 * halo_cap + 64);
+    e->d_frame_off.ensure(nf + 1);
+    if (world > 1) {
+        e->d_alloff.ensure((size_t)world * (nf + 1));
+        ensure_pinned(e->h_asm, e->h_asm_cap, (size_t)world * (nf + 1) * sizeof(unsigned long long));
+    }
+    q.send_up = e->d_halo.p; q.send_down = q.send_up + halo_cap; q.recv_up = q.send_down + halo_cap; q.recv_down = q.recv_up + halo_cap;
+    // peer transport (m2v_comm.hpp, PeerComm): the usual form of the step, a connected communicator that has not fallen back, and a
+    // step's rows fitting its landing buffers - all of it the same on every rank
+    F.pst = a->comm ? a->comm->peer() : nullptr;
+    PeerState *const pst = F.pst;
+    F.use_peer = pst && pst->connected && !pst->degraded && world > 1 && q.fused && halo_cap <= pst->cap && pst->world == world && pst->rank == rank &&
+                 halo_frames_of_step(nf, gop, 0) <= kPeerSlots;
+    q.mbw = full.mbw;
+    const int r = strip_launch_attempt(e, F);
+    if (r < 0) return r;
+    e->strip_inflight = true;
+    return M2V_OK;
+}
+
+// the one host wait; strips to the output rank; final assembly
+static int strip_collect(m2v_enc *e, StripFlight &F, size_t *bytes)
+{
+    StripEncodeArgs *a = &F.a;
+    StripSeq &q = F.q;
+    const int rank = a->rank, world = a->world;
+    const size_t nf = a->n;
+    const Geom &full = F.full;
+    PeerState *const pst = F.pst;
+    int &fail = F.fail;
+    auto local = [&](auto &&fn) {
+        if (fail) return;
+        try { fn(); }
+        catch (const HipError &h) {
+            fail = h.e == hipErrorOutOfMemory ? M2V_E_NOMEM : M2V_E_HIP;
+            F.fail_text = std::string(h.what) + ": " + hipGetErrorString(h.e);
+            (void)hipGetLastError();
+        }
+    };
+    e->strip_inflight = false;
+    hipStream_t s = F.s;
+    hipEvent_t g0 = nullptr, g1 = nullptr;
+    const void *strips[kMaxStripRanks] = {};
+    const unsigned long long *d_all = nullptr;
+    int failed_rank = -1;
+    // Twice at most: a peer sequence in which some rank's wait ran out of budget (every rank reads that in the all-gathered sizes) is
+    // encoded again, exchanged through the base communicator, and the communicator stays there.
+    for (int attempt = 0;; ++attempt) {
+        if (F.defer_sizes) { strip_enqueue_sizes(e, s, q, fail); F.defer_sizes = false; }      // (see the head of this section)
+        g0 = g1 = nullptr;
+        if (e->profile && !fail) { g0 = pool_event(e); timer_break(e); HIPCHK(hipEventRecord(g0, s)); }     // from here: gather, final assembly
+        for (auto &sp : strips) sp = nullptr;
+        d_all = e->d_frame_off.p;
+        failed_rank = fail ? rank : -1;
+        if (world > 1) {
+            const hipError_t se = hipStreamSynchronize(s);      // the sizes decide the receive counts
+            if (se != hipSuccess && !fail) throw HipError{se, "hipStreamSynchronize(strip sequence)"};
+            const unsigned long long *all = (const unsigned long long *)e->h_asm;
+            int retry_rank = -1;
+            for (int k = 0; k < world; ++k) {
+                const unsigned long long mark = all[(size_t)k * (nf + 1) + nf];
+                if (mark == kStripPoison && failed_rank < 0) failed_rank = k;
+                if (mark == kStripRetry && retry_rank < 0) retry_rank = k;
+            }
+            if (failed_rank < 0 && retry_rank >= 0) {
+                if (!q.peer || attempt > 0) throw HipError{hipErrorUnknown, "a retry mark in the size table of a sequence that was not in the peer form"};
+                // no error: the sequence again, the rows exchanged through the base communicator - on every rank, they all read the same table
+                pst->degraded = true;
+                pst->giveups++;
+                F.use_peer = false;
+                collect_timers(e);
+                const int r = strip_launch_attempt(e, F);
+                if (r < 0) return r;
+                continue;
+            }
+            if (failed_rank < 0) {
+                // (an overflow of this strip's buffer - impossible with the worst-case size above - is reported at the end: the other ranks
+                // are waiting in the gather, and a rank that left now would leave them there)
+                size_t sizes[kMaxStripRanks] = {}, total_in = 0;
+                for (int k = 0; k < world; ++k) {
+                    sizes[k] = (size_t)all[(size_t)k * (nf + 1) + nf];
+                    if (k != a->dst) total_in += (sizes[k] + 255) & ~(size_t)255;
+                }
+                void *bufs[kMaxStripRanks] = {};
+                if (rank == a->dst) {
+                    local([&] { e->d_gather.ensure(total_in + 256); });
+                    size_t off = 0;
+                    for (int k = 0; k < world; ++k) {
+                        if (k == a->dst) { strips[k] = e->d_strip_own.p; continue; }
+                        bufs[k] = e->d_gather.p + off;
+                        strips[k] = bufs[k];
+                        off += (sizes[k] + 255) & ~(size_t)255;
+                    }
+                }
+                if (fail) throw HipError{hipErrorOutOfMemory, "no room for the other ranks' strips on the output rank"};     // (they are already sending: nothing to keep in order any more)
+                a->comm->gather(rank, a->dst, e->d_strip_own.p, sizes, bufs, s);
+                d_all = e->d_alloff.p;
+            }
+        } else {
+            strips[0] = e->d_strip_own.p;
+        }
+        break;
     }   // attempt
     if (failed_rank >= 0) {
         // (a rank that did not get as far as its scans has not cleared the next sequence's arrival counters either: the peer form is
@@ -719,7 +801,7 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
         if (pst) pst->degraded = true;
         (void)hipStreamSynchronize(s);
         collect_timers(e);
-        if (fail) { e->set_err("m2v_strip_encode: %s", fail_text.c_str()); return fail; }
+        if (fail) { e->set_err("m2v_strip_encode: %s", F.fail_text.c_str()); return fail; }
         e->set_err("m2v_strip_encode: rank %d of the job failed", failed_rank);
         return M2V_E_HIP;
     }
@@ -741,6 +823,7 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     }
     if (e->profile) {
         double tot = 0, exp = 0;
+        const std::vector<hipEvent_t> &marks = F.marks;
         for (size_t k = 0; k + 3 <= marks.size(); k += 3) {       // per step: edges done (main), interior done (side), both + halo there (main)
             float m1 = 0, m2 = 0;
             if (hipEventElapsedTime(&m1, marks[k], marks[k + 2]) == hipSuccess) tot += m1;
@@ -753,8 +836,31 @@ static int strip_encode_impl(m2v_enc *e, void *argp)
     }
     collect_timers(e);
     e->strip_stream = nullptr;                               // synchronised above: nothing of the sequence is left on the caller's stream
-    if (a->bytes) *a->bytes = out_bytes;
+    if (bytes) *bytes = out_bytes;
     return M2V_OK;
+}
+
+static int strip_encode_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripEncodeArgs *)argp;
+    if (e->strip_inflight) { e->set_err("m2v_strip_encode: a strip sequence is in flight on this handle (m2v_strip_encode_end first)"); return M2V_E_STATE; }
+    StripFlight &F = flight_of(e);
+    const int r = strip_launch(e, F, *a, false);
+    if (r < 0) return r;
+    return strip_collect(e, F, a->bytes);
+}
+
+static int strip_encode_begin_impl(m2v_enc *e, void *argp)
+{
+    auto *a = (StripEncodeArgs *)argp;
+    if (e->strip_inflight) { e->set_err("m2v_strip_encode_begin: a strip sequence is in flight on this handle already"); return M2V_E_STATE; }
+    return strip_launch(e, flight_of(e), *a, true);
+}
+
+static int strip_encode_end_impl(m2v_enc *e, void *argp)
+{
+    if (!e->strip_inflight) { e->set_err("m2v_strip_encode_end: nothing in flight"); return M2V_E_STATE; }
+    return strip_collect(e, flight_of(e), (size_t *)argp);
 }
 
 int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_rank, uint32_t xsize16, uint32_t ysize16,
@@ -764,9 +870,40 @@ int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_ra
     if (!e || !d_frames444 || nframes == 0) return M2V_E_PARAM;
     StripEncodeArgs a{comm, rank, world, dst_rank, xsize16, ysize16, pframes_count, (const uint8_t *)d_frames444, nframes, (uint8_t *)d_out, cap,
                       out_bytes, (hipStream_t)hip_stream};
+    const bool was_inflight = e->strip_inflight;
     const int r = guard(e, strip_encode_impl, &a);
+    if (r < 0 && !was_inflight) e->strip_inflight = false;
     if (r < 0 && e->strip_active) strip_close(e);            // a failed sequence does not leave the handle in strip mode
-    if (r < 0 && comm) comm->abort();                         // ... and the other ranks of an in-process communicator do not wait for it for ever
+    if (r < 0 && comm && !was_inflight) comm->abort();        // ... and the other ranks of an in-process communicator do not wait for it for ever
+    return r;
+}
+
+int m2v_strip_encode_begin(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_rank, uint32_t xsize16, uint32_t ysize16,
+                           uint32_t pframes_count, const void *d_frames444, size_t nframes, void *d_out, size_t cap, void *hip_stream)
+{
+    if (!e || !d_frames444 || nframes == 0) return M2V_E_PARAM;
+    StripEncodeArgs a{comm, rank, world, dst_rank, xsize16, ysize16, pframes_count, (const uint8_t *)d_frames444, nframes, (uint8_t *)d_out, cap,
+                      nullptr, (hipStream_t)hip_stream};
+    const bool was_inflight = e->strip_inflight;
+    const int r = guard(e, strip_encode_begin_impl, &a);
+    if (r < 0 && !was_inflight) {
+        e->strip_inflight = false;
+        if (e->strip_active) strip_close(e);
+        if (comm) comm->abort();
+    }
+    return r;
+}
+
+int m2v_strip_encode_end(m2v_enc *e, size_t *out_bytes)
+{
+    if (!e) return M2V_E_PARAM;
+    m2v_comm *comm = e->strip_inflight && e->flight ? e->flight->a.comm : nullptr;
+    const int r = guard(e, strip_encode_end_impl, out_bytes);
+    if (r < 0 && comm) {                                     // (comm: there was a sequence to collect)
+        e->strip_inflight = false;
+        if (e->strip_active) strip_close(e);
+        comm->abort();
+    }
     return r;
 }
 
@@ -992,3 +1129,10 @@ int m2v_comm_selftest_captured(m2v_comm *c, int rank, const void *d_send, void *
 const char *m2v_comm_last_error(void) { return t_comm_err.c_str(); }
 
 }  // extern "C"
+
+void m2v::strip_flight_release(m2v_enc *e)
+{
+    delete e->flight;
+    e->flight = nullptr;
+    e->strip_inflight = false;
+}

@@ -137,24 +137,42 @@ def _p2p_wait(reqs, back):
         t.copy_(h)
 
 
+def encode_strips_begin(engine, rank, world, dist=None, dst=0, timings=None):
+    """First half of encode_strips(): the GOP steps with their halo exchanges and the strip's slices (everything that depends on nothing
+    the other half produces).  -> the state encode_strips_end() takes.  Two engines taking turns - begin(A), begin(B), end(A), begin(A'),
+    end(B) ... - is the call order of m2v_strip_encode_begin / _end on two handles: every collective of a sequence's SECOND half (sizes
+    all-gather, strips to the output rank) is issued in end(), so that on every rank the collectives come in one and the same order and
+    none of them sits in front of another sequence's whole first half."""
+    ctx = engine.stream_ctx() if hasattr(engine, "stream_ctx") else None
+    if ctx is None:
+        return _encode_strips_begin(engine, rank, world, dist, dst, timings)
+    with ctx:
+        return _encode_strips_begin(engine, rank, world, dist, dst, timings)
+
+
+def encode_strips_end(state):
+    """Second half: sizes to everyone, strips to the output rank, assembly there.  Returns the stream on rank `dst`, None elsewhere."""
+    engine = state["engine"]
+    ctx = engine.stream_ctx() if hasattr(engine, "stream_ctx") else None
+    if ctx is None:
+        return _encode_strips_end(state)
+    with ctx:
+        out = _encode_strips_end(state)
+    # the result was produced on the engine's stream: whatever the caller enqueues next on ITS stream comes after it
+    engine.torch.cuda.current_stream(engine.tstream.device).wait_stream(engine.tstream)
+    return out
+
+
 def encode_strips(engine, rank, world, dist=None, dst=0, timings=None):
     """Encode one sequence as `world` macroblock-row strips.  Returns the stream (engine tensor) on rank `dst`, None
     elsewhere.  `dist` = torch.distributed (initialised) or None for world == 1.
     timings: optional dict; with an engine that has `mark()` (GPU events on the engine's stream) it receives, in ms,
     "halo_exposed" (time the stream waited for neighbour rows after the interior rows were done), "halo_total" (from the
     edge rows being packed to the neighbour rows being there) and "gather" (sizes + strips to the output rank + assembly)."""
-    ctx = engine.stream_ctx() if hasattr(engine, "stream_ctx") else None
-    if ctx is None:
-        return _encode_strips(engine, rank, world, dist, dst, timings)
-    with ctx:
-        out = _encode_strips(engine, rank, world, dist, dst, timings)
-    # the result was produced on the engine's stream: whatever the caller enqueues next on ITS stream comes after it
-    engine.torch.cuda.current_stream(engine.tstream.device).wait_stream(engine.tstream)
-    return out
+    return encode_strips_end(encode_strips_begin(engine, rank, world, dist, dst, timings))
 
 
-def _encode_strips(engine, rank, world, dist, dst, timings=None):
-    import torch
+def _encode_strips_begin(engine, rank, world, dist, dst, timings=None):
     mark = engine.mark if (timings is not None and hasattr(engine, "mark")) else (lambda: None)
     marks = []
     rows = partition_rows(engine.mbh, world)
@@ -188,6 +206,14 @@ def _encode_strips(engine, rank, world, dist, dst, timings=None):
         if nbytes:
             engine.halo_in(j, recv_up if rank > 0 else None, recv_down if rank < world - 1 else None)
     strip, off = engine.finish()
+    return {"engine": engine, "rank": rank, "world": world, "dist": dist, "dst": dst, "timings": timings, "mark": mark, "marks": marks,
+            "strip": strip, "off": off}
+
+
+def _encode_strips_end(state):
+    import torch
+    engine, rank, world, dist, dst, timings = (state[k] for k in ("engine", "rank", "world", "dist", "dst", "timings"))
+    mark, marks, strip, off = (state[k] for k in ("mark", "marks", "strip", "off"))
     g0 = mark()
 
     def done(out):
@@ -223,6 +249,17 @@ def encode_strips_native(enc, comm, rank, world, clip, xsize16, ysize16, pframes
     Returns the stream (a view of `out`) on rank `dst`, None elsewhere; the call has synchronised `stream` when it returns."""
     n = enc.strip_encode(comm, rank, world, clip.data_ptr(), int(clip.shape[0]), xsize16, ysize16, pframes_count,
                          out.data_ptr() if out is not None else None, int(out.numel()) if out is not None else 0, dst, stream)
+    return out[:n] if rank == dst and out is not None else None
+
+
+def encode_strips_native_begin(enc, comm, rank, world, clip, xsize16, ysize16, pframes_count, out=None, stream=0, dst=0):
+    """m2v_strip_encode_begin: nothing is waited for; collect with encode_strips_native_end(enc, out, rank, dst)"""
+    enc.strip_encode_begin(comm, rank, world, clip.data_ptr(), int(clip.shape[0]), xsize16, ysize16, pframes_count,
+                           out.data_ptr() if out is not None else None, int(out.numel()) if out is not None else 0, dst, stream)
+
+
+def encode_strips_native_end(enc, out, rank, dst=0):
+    n = enc.strip_encode_end()
     return out[:n] if rank == dst and out is not None else None
 
 

@@ -291,6 +291,22 @@ const char *m2v_comm_kind(const m2v_comm *c);
 int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_rank, uint32_t xsize16, uint32_t ysize16,
                      uint32_t pframes_count, const void *d_frames444, size_t nframes, void *d_out, size_t cap, size_t *out_bytes,
                      void *hip_stream);
+/*
+ * The same sequence in two halves, so that ONE thread keeps two strip sequences in flight on two handles (as m2v_encode_resident_begin /
+ * _end do for the whole frame): _begin enqueues the GOP steps and this strip's slices and returns; _end issues the all-gather of the sizes,
+ * does the one host wait, sends / receives the strips and, on the output rank, assembles the stream; when it returns the handle's stream
+ * is synchronised and *out_bytes holds the byte count (0 on the other ranks).  Between the two calls the handle takes no other work
+ * (M2V_E_STATE).  Handles that take turns each need a peer communicator of their own (landing block, arrival counters) - over ONE shared
+ * base communicator: every collective of a sequence's second half is issued by _end, so the ranks issue their collectives in one and the
+ * same order (begin A, begin B, end A, begin A', end B ...) and RCCL, which runs a communicator's operations in issue order whatever
+ * stream each is on, never holds one sequence's strips behind another sequence's kernels.  What it hides: the host's wait for the sizes,
+ * the sizes exchange and, on the output rank, the gather and the final assembly - all of it beside the other sequence's kernels.
+ * Slices are independent (RTL:2704-2715), GOPs closed (RTL:2656): nothing in the stream depends on how many sequences are under way.
+ */
+int m2v_strip_encode_begin(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_rank, uint32_t xsize16, uint32_t ysize16,
+                           uint32_t pframes_count, const void *d_frames444, size_t nframes, void *d_out, size_t cap, void *hip_stream);
+int m2v_strip_encode_end(m2v_enc *e, size_t *out_bytes);
+
 /* Timings of the last m2v_strip_encode on this handle: host microseconds per GOP step and how much of that was spent inside the
  * communicator (RCCL: enqueueing; a local communicator blocks there until the neighbour thread has posted) - always - and, with
  * option "profile", the GPU-event times in ms: halo_total (edge rows packed .. neighbour rows there, summed over the steps),

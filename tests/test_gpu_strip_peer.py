@@ -102,6 +102,104 @@ def test_peer_counter_sets_survive_sequences_of_different_gop_counts(world):
     print("alternating GOP counts, %d ranks: %r, last form %r" % (world, stats[0], forms[0]))
 
 
+def run_turns(M, d_clips, W, H, pf, VL, world, turns, use_peer=True, rotate=True):
+    """`world` rank threads on GPU 0; every rank keeps TWO strip sequences in flight from its one thread: two handles taking turns
+    (m2v_strip_encode_begin / _end), a peer communicator each over ONE shared local base communicator; sequence k encodes
+    d_clips[k % len] and, with rotate, is assembled on rank k % world.  -> {sequence index: stream bytes}, [peer stats of rank 0's two]"""
+    import threading
+    import torch
+    base = M.StripComm.local(world)
+    cap = M.parallel.strip_output_bound(max(int(c.shape[0]) for c in d_clips), W, H)
+    torch.cuda.synchronize()
+    got, errs, stats = {}, [], [None]
+    lock = threading.Lock()
+
+    def work(r):
+        encs, comms, outs = [], [], []
+        try:
+            for k in range(2):
+                encs.append(M.Mpeg2Encoder(7, 7, VL, 2))
+                comms.append(M.StripComm.peer(base, r, 0) if use_peer else base)      # collective: every thread, the same order
+                outs.append(torch.empty(cap, dtype=torch.uint8, device="cuda:0"))
+            busy = [None, None]
+
+            def collect(h):
+                seq, dst = busy[h]
+                o = M.parallel.encode_strips_native_end(encs[h], outs[h], r, dst)
+                if r == dst:
+                    with lock:
+                        got[seq] = o.cpu().numpy().tobytes()
+                busy[h] = None
+            for seq in range(turns):
+                h = seq % 2
+                if busy[h] is not None:
+                    collect(h)
+                dst = seq % world if rotate else 0
+                M.parallel.encode_strips_native_begin(encs[h], comms[h], r, world, d_clips[seq % len(d_clips)], W // 16, H // 16, pf, outs[h], dst=dst)
+                busy[h] = (seq, dst)
+            for h in ((turns % 2), 1 - (turns % 2)):                  # oldest first
+                if busy[h] is not None:
+                    collect(h)
+            if r == 0 and use_peer:
+                stats[0] = [c.peer_stats() for c in comms]
+        except Exception as ex:  # noqa: BLE001
+            errs.append((r, ex))
+        finally:
+            if use_peer:
+                for c in comms:
+                    c.close()
+            for e in encs:
+                e.close()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    try:
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=240)
+        assert not any(t.is_alive() for t in th), "a rank is stuck"
+        assert not errs, errs
+        return got, stats[0]
+    finally:
+        base.close()
+
+
+@pytest.mark.parametrize("world,use_peer", [(2, True), (4, True), (3, False), (1, False)])
+def test_two_strip_sequences_in_flight_from_one_thread(world, use_peer):
+    """m2v_strip_encode_begin / _end: nine sequences of two different clips (different GOP counts), two in flight per rank, the output rank
+    rotating; every stream is the oracle's.  With the peer form every handle has its own landing block over the one base communicator;
+    without it (world 3: the base communicator's own exchange inside _begin; world 1: nothing to exchange) the halves are the same."""
+    import torch
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    W, H, pf, VL = 128, 96, 2, 3
+    clips = [M.synth.clip(W, H, 9, clip_index=360 + world, scene_len=4), M.synth.clip(W, H, 4, clip_index=370 + world)]
+    want = [orc.encode(c, W // 16, H // 16, pf, 7, 7, VL, 2) for c in clips]
+    d = [torch.from_numpy(np.ascontiguousarray(c)).to("cuda:0") for c in clips]
+    if world == 1:
+        # one rank: no communicator at all
+        enc = [M.Mpeg2Encoder(7, 7, VL, 2) for _ in range(2)]
+        outs = [torch.empty(M.parallel.strip_output_bound(9, W, H), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+        try:
+            M.parallel.encode_strips_native_begin(enc[0], None, 0, 1, d[0], W // 16, H // 16, pf, outs[0])
+            M.parallel.encode_strips_native_begin(enc[1], None, 0, 1, d[1], W // 16, H // 16, pf, outs[1])
+            with pytest.raises(M.M2VError):                       # busy between the halves
+                enc[0].push_frames(W // 16, H // 16, pf, clips[0][:1])
+            assert M.parallel.encode_strips_native_end(enc[0], outs[0], 0).cpu().numpy().tobytes() == want[0]
+            assert M.parallel.encode_strips_native_end(enc[1], outs[1], 0).cpu().numpy().tobytes() == want[1]
+            with pytest.raises(M.M2VError):                       # nothing in flight any more
+                enc[0].strip_encode_end()
+            assert enc[0].encode(clips[1], W // 16, H // 16, pf) == want[1]          # and the handle is free again
+        finally:
+            for e in enc:
+                e.close()
+        return
+    got, stats = run_turns(M, d, W, H, pf, VL, world, turns=9, use_peer=use_peer)
+    assert sorted(got) == list(range(9))
+    assert [got[k] == want[k % 2] for k in range(9)] == [True] * 9
+    print("two in flight, %d ranks, peer=%s: %r" % (world, use_peer, stats))
+
+
 PEER_THREADS_CHILD = r'''
 import json, sys
 import numpy as np

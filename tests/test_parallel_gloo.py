@@ -177,6 +177,73 @@ def test_encode_strips_gloo(world, W, H, n, pf, VL):
     assert [r[3] for r in res] == M.parallel.partition_rows(H // 16, world)
 
 
+def _turns_worker(rank, world, port, q):
+    """Two engines (two different sequences) taking turns on ONE process group: begin A, begin B, end A, begin A', end B, ... with the
+    output rank rotating - the call order of m2v_strip_encode_begin / _end on two handles.  Every collective is logged; the log must
+    be the same sequence of (kind, sequence) on every rank, and a sequence's sizes all-gather must come right before its strips."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        W, H, pf, VL = 96, 96, 2, 2
+        clips = [M.synth.clip(W, H, 7, clip_index=71), M.synth.clip(W, H, 5, clip_index=72)]
+        engs = [OracleStripEngine(c, W // 16, H // 16, pf, VL) for c in clips]
+        log, current = [], [None]
+        real_ag, real_batch = dist.all_gather, dist.batch_isend_irecv
+
+        def ag(out, t, *a, **k):
+            log.append(("sizes", current[0]))
+            return real_ag(out, t, *a, **k)
+
+        def batch(ops):
+            log.append(("p2p", current[0]))
+            return real_batch(ops)
+        dist.all_gather, dist.batch_isend_irecv = ag, batch
+        P = M.parallel
+        results, state, seq = [], [None, None], 0
+        order = []
+        for turn in range(6):                        # handles 0, 1, 0, 1, ...
+            h = turn % 2
+            if state[h] is not None:
+                current[0] = state[h][1]
+                order.append(("end", state[h][1]))
+                results.append((state[h][1], state[h][2], P.encode_strips_end(state[h][0])))
+            current[0] = seq
+            dst = seq % world
+            order.append(("begin", seq))
+            state[h] = (P.encode_strips_begin(engs[h], rank, world, dist, dst=dst), seq, dst)
+            seq += 1
+        for h in (0, 1):
+            current[0] = state[h][1]
+            results.append((state[h][1], state[h][2], P.encode_strips_end(state[h][0])))
+        ok = all((out == engs[k % 2].stream_bytes) if rank == dst else out is None for k, dst, out in results)
+        # a sequence's sizes exchange is followed at once by its own strips' transfer (world 2: both ranks take part in it) - never by
+        # another sequence's collectives
+        tidy = all(i + 1 < len(log) and log[i + 1] == ("p2p", k) for i, (kind, k) in enumerate(log) if kind == "sizes")
+        q.put((rank, bool(ok), bool(tidy), [x for x in log if x[0] == "sizes"], len(results)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_strip_sequences_in_flight_from_one_thread_gloo():
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_turns_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok and tidy for _, ok, tidy, _, _ in res), res
+    assert res[0][3] == res[1][3] == [("sizes", k) for k in range(6)]          # the sizes exchanges in sequence order, the same on every rank
+    assert all(n == 6 for *_, n in res)
+
+
 def test_partition_and_sequence_split():
     P = M.parallel
     for mbh in (4, 13, 72, 128):
