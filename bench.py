@@ -12,30 +12,44 @@ the same K steps as one blocking m2v_encode_resident call after the other (what 
 
 N > 1: one rank per GPU.  Either the caller starts the ranks (torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE /
 MASTER_* in the environment), or - WORLD_SIZE unset - this process starts them itself: `python bench.py --gpus 8` alone is an
-8-rank job (launch_ranks(): N children before anything touches the GPU, rank 0's JSON line relayed, worst exit code).
+8-rank job (bench_launch.launch_ranks(): N children before anything touches the GPU, rank 0's JSON line relayed, worst exit code).
 Every rank encodes its own clip (BASELINE config c4: independent sequences, no data-path collective) -> "scaling": "weak";
---mode strips is config c5 (ONE sequence, macroblock-row strips, RCCL halo exchange) -> "scaling": "strong".
+--mode strips is config c5 (ONE sequence, macroblock-row strips, RCCL halo exchange or peer stores) -> "scaling": "strong".
 Rank 0 prints ONE JSON line; "n_gpus" is the world size the process group reports ("ranks_seen").
-"""
+
+What an unattended `bench.py --gpus N` (N > 1) runs, in order (bench_launch.py): the c4 measurement on N ranks; then, its line in hand
+and not yet printed, config c5 twice as N FRESH child processes each under a hard wall-clock bound - halo through RCCL, then the peer
+transport - whose results (or a stated error: timeout, exit code) become `strips: {rccl, peer}` of the c4 line; then the line, once.
+
+The legs live in modules of their own: bench_util.py (parity comparison, sensors, provenance of the counter passes, queue placement),
+bench_launch.py (ranks, strips legs, --dry-launch), bench_strips.py (config c5), bench_e2e.py (the port contract, host to host)."""
 import argparse
 import json
 import os
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+import bench_launch  # noqa: E402  (no torch, no HIP: the launcher imports it before it starts its children)
+import bench_util  # noqa: E402
+from bench_util import (FPGA_MPIXELS, HBM_PEAK_GBS, compare_with_per_gop_oracle, gop_time_code, gpu_sensors, hbm_copy_rate,  # noqa: E402,F401
+                        kernel_source_sha, pmc_traffic, pmc_valu_busy, rtl_sim_probe, sensors_verdict, settle_queue_placement, source_shas,
+                        split_gops, sysfs_card_of, visible_gpus)
 
 W, H, XS16, YS16 = 1920, 1152, 120, 72
 PFRAMES, GOPS = 8, 10
 XL = YL = 7
 VL, Q = 3, 2
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
-FPGA_MPIXELS = 268.0           # README.md:22, Kintex-7 (BASELINE.md section 1)
 LIB_DEFAULT_SPLIT_STREAMS = 2  # option split_streams as m2v_create leaves it (csrc/m2v_host.hpp)
 
 
-GOP_CODE, END_CODE = b"\x00\x00\x01\xb8", b"\x00\x00\x01\xb7"
+def config():
+    """the workload's parameters as the legs in other modules take them (main() rewrites the globals for --config c2)"""
+    return types.SimpleNamespace(W=W, H=H, XS16=XS16, YS16=YS16, PFRAMES=PFRAMES, GOPS=GOPS, XL=XL, YL=YL, VL=VL, Q=Q,
+                                 LIB_DEFAULT_SPLIT_STREAMS=LIB_DEFAULT_SPLIT_STREAMS)
 
 
 def cpu_baseline(frames_np):
@@ -50,90 +64,6 @@ def cpu_baseline(frames_np):
     what = "first GOP (%d frames, 1 I + %d P)" % (n, n - 1) if PFRAMES else "first %d I frames" % n
     return dict(value=round(n * W * H / dt * 1e-6, 4), unit="MPixels/s", cores=1, kind="port",
                 sample="%s of the benchmark clip, oracle/m2v_oracle.c, %.1f s" % (what, dt))
-
-
-def kernel_source_sha(path):
-    """sha256 of the kernel source as the compiler sees it: comments dropped, runs of white space collapsed - a reworded comment does
-    not make the counter passes stale (tools/make_pmc_traffic.py computes the same)"""
-    import hashlib
-    import re
-    text = open(path, encoding="utf-8").read()
-    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
-    text = re.sub(r"//[^\n]*", " ", text)
-    return hashlib.sha256(" ".join(text.split()).encode()).hexdigest()
-
-
-def source_shas():
-    """What the running tree is: git HEAD (if this is a checkout) and the sha256 of the kernel source (kernel_source_sha).  profiles/pmc_traffic.json
-    carries the same two values for the tree its PMC passes ran on (tools/profile_round.sh)."""
-    import subprocess
-    ksha = kernel_source_sha(os.path.join(ROOT, "fpga-mpeg2-encoder_amd", "csrc", "m2v_kernels.hpp"))
-    try:
-        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
-    except Exception:  # noqa: BLE001
-        head = None
-    return head, ksha
-
-
-def pmc_traffic(key):
-    """roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
-    MI355X_MICROARCH.md), collected by tools/profile_round.sh in separate rocprofv3 runs of this same command and kept in
-    profiles/pmc_traffic.json together with the tree they measured.  `traffic_stale` says whether the kernel source has changed
-    since (a counter pass cannot run inside the timed job: it serialises the dispatches)."""
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    out = {"traffic": None}
-    try:
-        t = json.load(open(tpath))
-    except Exception:  # noqa: BLE001
-        return out
-    if t.get(key) is None:
-        return out
-    head, ksha = source_shas()
-    out.update({"traffic": t[key], "traffic_source": "profiles/pmc_traffic.json (separate --pmc passes of this command)",
-                "traffic_measured_at": {"head": t.get("head"), "kernel_sha": t.get("kernel_sha")},
-                "running": {"head": head, "kernel_sha": ksha},
-                "traffic_stale": t.get("kernel_sha") != ksha})
-    return out
-
-
-def gop_time_code(n):
-    """bytes 4..7 of a group_of_pictures_header for sequence frame number n (24 fps time code, closed_gop = 1,
-    RTL:2645-2656, 2685-2698): the one field of a GOP that depends on where it sits in the sequence"""
-    hh = min(n // 86400, 63)
-    return ((hh << 26) | (((n // 1440) % 60) << 20) | (1 << 19) | (((n // 24) % 60) << 13) | ((n % 24) << 7) | (2 << 5)).to_bytes(4, "big")
-
-
-def split_gops(data):
-    """-> (bytes before the first GOP header, [bytes of each GOP], bytes from the sequence end code on)"""
-    idx, pos = [], data.find(GOP_CODE)
-    while pos >= 0:
-        idx.append(pos)
-        pos = data.find(GOP_CODE, pos + 4)
-    end = data.rfind(END_CODE)
-    return data[:idx[0]], [data[a:b] for a, b in zip(idx, idx[1:] + [end])], data[end:]
-
-
-def compare_with_per_gop_oracle(gpu_stream_bytes, oracle_gop_streams, gop):
-    """The GPU stream of a multi-GOP sequence against the oracle's streams of its GOPs, each encoded as a sequence of
-    its own (closed GOPs): sequence headers, every GOP (header, time code computed here, all pictures) and the end
-    code + final-word padding.  -> list of problems (empty = byte-identical)"""
-    head, gops, tail = split_gops(gpu_stream_bytes)
-    bad = []
-    if len(gops) != len(oracle_gop_streams):
-        bad.append("GPU stream has %d GOPs, expected %d" % (len(gops), len(oracle_gop_streams)))
-    for k, ref in enumerate(oracle_gop_streams[:len(gops)]):
-        rhead, rgops, _ = split_gops(ref)
-        if k == 0 and head != rhead:
-            bad.append("sequence headers differ")
-        if gops[k][:4] != GOP_CODE or gops[k][4:8] != gop_time_code(k * gop):
-            bad.append("GOP %d: header / time code" % k)
-        if len(rgops) != 1 or gops[k][8:] != rgops[0][8:]:
-            bad.append("GOP %d: pictures differ from the oracle" % k)
-    body = len(gpu_stream_bytes) - len(tail)
-    want_total = ((body + 4) // 32 + 1) * 32                      # end code, then the final 32-byte word always leaves (RTL:2932-2937)
-    if tail != END_CODE + bytes(want_total - body - 4):
-        bad.append("end code / final padding")
-    return bad
 
 
 def cpu_baseline_all_cores(clip_np, gpu_stream_bytes):
@@ -162,570 +92,6 @@ def cpu_baseline_all_cores(clip_np, gpu_stream_bytes):
     return base, parity
 
 
-def rtl_sim_probe():
-    """the RTL under a Verilog simulator is the parity oracle and CPU baseline the metric names.  It
-    runs wherever `iverilog` + `vvp` are installed and M2V_RTL points at mpeg2encoder.v (tools/run_rtl_oracle.py); this
-    image and the GPU box have neither, so the line says so instead of pretending."""
-    import shutil
-    iv, vvp, ver, rtl = shutil.which("iverilog"), shutil.which("vvp"), shutil.which("verilator"), os.environ.get("M2V_RTL")
-    if not (((iv and vvp) or ver) and rtl and os.path.exists(rtl)):
-        return {"available": False, "iverilog": iv, "vvp": vvp, "verilator": ver, "rtl": rtl,
-                "note": "RTL oracle unavailable: no Verilog simulator / RTL file on this host; parity is against oracle/m2v_oracle.c "
-                        "(line-cited C restatement of the RTL, parity unpinned by the reference - DESIGN.md section 5)"}
-    import subprocess
-    t0 = time.perf_counter()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_rtl_oracle.py"), "--rtl", rtl], capture_output=True, text=True)
-    lines = r.stdout.strip().splitlines()
-    try:
-        verdict = json.loads(lines[-1])           # the tool's last line: RTL vs oracle vs product (m2v_tb), known answers, simulator
-    except (ValueError, IndexError):
-        verdict = {"available": True}
-    # the RTL against the ORACLE is what pins parity; the tool's exit code also covers RTL against the product and the known answers
-    verdict.update({"identical_to_oracle": bool(verdict.get("rtl_equals_oracle")) if "rtl_equals_oracle" in verdict else None,
-                    "tool_exit_code": r.returncode, "seconds": round(time.perf_counter() - t0, 1), "cores": 1, "log": lines[-10:-1]})
-    return verdict
-
-
-def end_to_end(M, clip_np, want_bytes):
-    """The port contract from host memory to host memory: m2v_push_frames ... m2v_pull (32-byte words back on the host),
-    one GOP per push, drained as it goes, chunks of two GOPs double buffered.  PCIe inclusive; reported next to `value`,
-    never as `value`.  Two kinds of caller memory: page-locked frames (capture buffers, pinned tensors) are uploaded
-    straight from the caller's buffer; pageable frames (a plain numpy array) go through the handle's pinned staging."""
-    import numpy as np
-    import torch
-    n = clip_np.shape[0]
-    gop = PFRAMES + 1 if PFRAMES else 16          # frames per push (config c2: every frame is a GOP; 16 at a time)
-
-    outbuf = np.empty(clip_np.shape[0] * W * H * 3 // 2 + 4096, np.uint8)      # the caller's own output buffer: m2v_pull writes into it
-
-    def run(frames, best_of=4, deferred=False, one_call=False):
-        enc = M.Mpeg2Encoder(XL, YL, VL, Q)
-        try:
-            enc.set_option("batch_frames", gop)
-            if deferred:
-                enc.set_option("direct_upload", 2)
-            best, data = 1e9, b""
-            for _ in range(best_of):
-                t0 = time.perf_counter()
-                pos = 0
-                for k in range(0, n, gop):
-                    if one_call:
-                        pos += enc.push_frames_pull(XS16, YS16, PFRAMES, frames[k:k + gop], outbuf, pos)[0]
-                    else:
-                        enc.push_frames(XS16, YS16, PFRAMES, frames[k:k + gop])
-                        pos += enc.pull_into(outbuf, pos)[0]
-                enc.sequence_stop()
-                last = False
-                while not last:
-                    m, last = enc.pull_into(outbuf, pos)
-                    pos += m
-                best = min(best, time.perf_counter() - t0)
-                data = outbuf[:pos].tobytes()
-        finally:
-            enc.close()
-        return best, data
-
-    t_page, d_page = run(clip_np)
-    pinned_t = torch.from_numpy(clip_np).pin_memory()
-    pinned = pinned_t.numpy()
-    t_pin, d_pin = run(pinned)
-    t_def, d_def = run(pinned, deferred=True)
-    t_one, d_one = run(pinned, one_call=True)
-
-    def run_two(best_of=6):
-        """two callers at once - two threads, a handle and a page-locked copy of the clip each: one caller's turn-around between its
-        pushes (pull, the next push's set-up) is covered by the other's upload"""
-        import threading
-        srcs = [pinned, pinned_t.clone().pin_memory().numpy()]
-        encs = [M.Mpeg2Encoder(XL, YL, VL, Q) for _ in srcs]
-        res, best = [b"", b""], 1e9
-        try:
-            for e in encs:
-                e.set_option("batch_frames", gop)
-
-            def caller(i):
-                out = []
-                for k in range(0, n, gop):
-                    encs[i].push_frames(XS16, YS16, PFRAMES, srcs[i][k:k + gop])
-                    out.append(encs[i].pull(1 << 24)[0])
-                encs[i].sequence_stop()
-                out.append(encs[i].pull_all())
-                res[i] = b"".join(out)
-            for _ in range(best_of):
-                th = [threading.Thread(target=caller, args=(i,)) for i in range(2)]
-                t0 = time.perf_counter()
-                for x in th:
-                    x.start()
-                for x in th:
-                    x.join()
-                best = min(best, time.perf_counter() - t0)
-                if os.environ.get("M2V_BENCH_VERBOSE"):
-                    print("two callers: %.2f ms" % ((time.perf_counter() - t0) * 1e3), file=sys.stderr)
-        finally:
-            for e in encs:
-                e.close()
-        return best, res
-
-    t_two, d_two = run_two()
-    # what the link gives a plain copy of the same page-locked bytes on this box (the bound the path can be held against)
-    dev_t = torch.empty_like(pinned_t, device="cuda")
-    dev_t.copy_(pinned_t, non_blocking=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(4):
-        dev_t.copy_(pinned_t, non_blocking=True)
-    torch.cuda.synchronize()
-    h2d = 4 * pinned_t.numel() / (time.perf_counter() - t0)
-    del dev_t
-    px = n * W * H
-    return {"value": round(px / t_pin * 1e-6, 1), "unit": "MPixels/s", "frames": n, "best_of": 4,
-            "input_GBps": round(px * 3 / t_pin * 1e-9, 2), "identical_to_resident_stream": d_pin == want_bytes and d_page == want_bytes,
-            "path": "m2v_push_frames -> m2v_pull (into the caller's output buffer), frames in page-locked host memory uploaded straight from "
-                    "the caller's buffer (hipMemcpyAsync on an upload stream; the call returns when its frames have been read: it waits for the fence-free "
-                    "event the chunk's kernels wait for), stream bytes back to the host by a kernel; chunk k+1 uploads while chunk k "
-                    "encodes, batch_frames=%d" % gop,
-            "pageable_source": {"value": round(px / t_page * 1e-6, 1), "input_GBps": round(px * 3 / t_page * 1e-9, 2),
-                                "path": "the same from a plain numpy array: copied into the handle's pinned staging by 8 threads first"},
-            "two_callers": {"value": round(2 * px / t_two * 1e-6, 1), "input_GBps": round(2 * px * 3 / t_two * 1e-9, 2),
-                            "identical": all(d == want_bytes for d in d_two),
-                            "path": "two threads, a handle and a page-locked clip each, at the same time (aggregate of both sequences)"},
-            # option direct_upload = 2 (opt-in: a pushed range stays unchanged until the NEXT push / stop has returned): the push returns
-            # while its frames are still being read and the calls' transfers alternate between two upload streams, so the copy engine
-            # sets the next one up while the running one drains - what two callers do for each other, from one thread
-            "deferred_upload": {"value": round(px / t_def * 1e-6, 1), "input_GBps": round(px * 3 / t_def * 1e-9, 2), "identical": d_def == want_bytes,
-                                "fraction_of_measured_h2d": round(px * 3 / t_def / h2d, 3),
-                                "path": "the same loop with option direct_upload = 2"},
-            # both port groups in one call (m2v_push_frames_pull): the stream bytes of completed chunks are copied into the caller's buffer while
-            # the call's frames cross the link - the same loop, one call per GOP instead of two
-            "one_call": {"value": round(px / t_one * 1e-6, 1), "input_GBps": round(px * 3 / t_one * 1e-9, 2), "identical": d_one == want_bytes,
-                         "fraction_of_measured_h2d": round(px * 3 / t_one / h2d, 3), "path": "m2v_push_frames_pull per GOP, then stop and drain"},
-            "pcie_bound_MPixels": round(63e9 / 3 * 1e-6, 0),
-            "h2d_copy_measured_GBps": round(h2d * 1e-9, 1), "fraction_of_measured_h2d": round(px * 3 / t_pin / h2d, 3)}
-
-
-def gpu_sensors(index=0):
-    """Clocks / power / temperature of GPU `index` as amdgpu's sysfs files give them (no subprocess, no SMI library: readable by an
-    ordinary user where the files exist at all); None for what cannot be read.  Cards are taken in the order of their PCI addresses,
-    which is the order HIP enumerates them in when no *_VISIBLE_DEVICES variable reorders it."""
-    import glob
-    cards = []
-    for d in glob.glob("/sys/class/drm/card[0-9]*/device"):
-        if os.path.exists(os.path.join(d, "pp_dpm_sclk")):
-            cards.append((os.path.realpath(d), d))
-    cards.sort()
-    if index >= len(cards):
-        return None
-    d = cards[index][1]
-
-    def current(name):                       # "1: 2400Mhz *" marks the level in use
-        try:
-            for ln in open(os.path.join(d, name)):
-                if ln.rstrip().endswith("*"):
-                    return int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
-        except (OSError, ValueError, IndexError):
-            pass
-        return None
-
-    def hwmon(name, scale):
-        for f in glob.glob(os.path.join(d, "hwmon", "hwmon*", name)):
-            try:
-                return round(int(open(f).read().strip()) * scale, 1)
-            except (OSError, ValueError):
-                pass
-        return None
-    out = {"sclk_mhz": current("pp_dpm_sclk"), "mclk_mhz": current("pp_dpm_mclk"),
-           "power_w": hwmon("power1_average", 1e-6) or hwmon("power1_input", 1e-6), "temp_c": hwmon("temp1_input", 1e-3)}
-    return out if any(v is not None for v in out.values()) else None
-
-
-def visible_gpus():
-    """How many GPUs a rank of this job would see, WITHOUT touching the HIP runtime (the launcher must not initialise the GPU
-    before it starts its children): the *_VISIBLE_DEVICES list if one is set, else the KFD topology's nodes that have SIMDs.
-    None when neither can be read (then the ranks themselves check, as before)."""
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if v is not None:
-            return len([x for x in v.split(",") if x.strip() != ""])
-    import glob
-    n, seen = 0, False
-    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
-        try:
-            for ln in open(f):
-                k, _, val = ln.partition(" ")
-                if k == "simd_count":
-                    seen = True
-                    n += int(val) > 0
-        except (OSError, ValueError):
-            pass
-    return n if seen else None
-
-
-def hbm_copy_rate(torch, dev):
-    """Achievable HBM bandwidth of this device with a plain device-to-device copy (read + write bytes), GB/s."""
-    n = 1 << 30
-    a = torch.empty(n, dtype=torch.uint8, device=dev)
-    b = torch.empty_like(a)
-    b.copy_(a)
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return 10 * 2.0 * n / (e0.elapsed_time(e1) * 1e-3) * 1e-9
-
-
-def bench_strips(args, M, torch, dist, rank, local_rank, world, dev):
-    """Config c5: one 2048x2048 (XL=YL=7) I+P sequence, 128 macroblock rows cut into `world` strips; the +-6 luma /
-    +-3 chroma reference rows cross xGMI once per GOP step (fpga-mpeg2-encoder_amd/parallel.py).  Strong scaling: the
-    total work is fixed.  The line carries what the sequences mode carries (roofline of this rank's P-frame launches,
-    CPU baseline, whole-stream check against the oracle on rank 0) plus the halo / gather time per step."""
-    Ws = Hs = 2048
-    gop = PFRAMES + 1
-    nframes = args.gops * gop
-    backend = dist.get_backend() if dist is not None else None
-    clip = M.synth.clip_torch(Ws, Hs, nframes, clip_index=0, device=dev)        # every rank holds the same clip
-    enc = M.Mpeg2Encoder(7, 7, VL, Q, device=local_rank)
-    # The loop: native (m2v_strip_encode: the GOP steps and the RCCL send / recv issued from C++) whenever the ranks can talk
-    # RCCL - and for one rank, which has nothing to exchange.  parallel.encode_strips (the Python statement of the same call
-    # order, point-to-point ops through torch.distributed) is what the 1-GPU test hook (gloo, shared device) runs, and the
-    # agreed fallback should librccl refuse to initialise.
-    # Sequences in flight on this rank (--strip-inflight K): K stacks of (handle, communicator[, peer communicator on top]), one host thread each
-    # in the timed loop - while one thread sits in its host waits (the sizes, the final sync) the others' kernels run.  Stack 0 is the one every
-    # other leg of this function uses.  Collective calls are made stack by stack, in the same order on every rank.
-    K = max(1, args.strip_inflight)
-    loop, why = "native", None
-    stacks = []                                   # [enc, comm, base_comm]
-    if os.environ.get("M2V_STRIP_LOOP") == "python" or (world > 1 and backend != "nccl"):
-        loop, why = "python", "M2V_STRIP_LOOP=python" if os.environ.get("M2V_STRIP_LOOP") == "python" else "backend %s" % backend
-        K = 1
-    for k in range(K):
-        stacks.append([enc if k == 0 else M.Mpeg2Encoder(7, 7, VL, Q, device=local_rank), None, None])
-    if loop == "native" and world > 1:
-        # (StripComm.rccl is collective: a failure to make the id on rank 0 reaches every rank through its broadcast and all of them
-        # land in the except branch together; a rank stuck in ncclCommInitRank because another one never arrived ends its process
-        # after init_timeout, and the launcher tears the job down.  The vote below runs after every rank has returned from it.)
-        ok = 1
-        try:
-            for st in stacks:
-                st[1] = M.StripComm.rccl(rank, world, local_rank, dist, init_timeout=float(os.environ.get("M2V_RCCL_INIT_TIMEOUT", "180")))
-        except Exception as ex:  # noqa: BLE001
-            ok, why = 0, "m2v_comm_init_rccl: %s" % ex
-        t = torch.tensor([ok], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) == 0:
-            loop, why = "python", why or "another rank could not initialise RCCL natively"
-            for st in stacks:
-                if st[1] is not None:
-                    st[1].close()
-                    st[1] = None
-            K = 1
-        elif args.transport == "peer":
-            # the peer transport on top of the RCCL communicator (which keeps moving sizes and strips, and the halo if a wait ever runs
-            # out of budget); creating it is collective (the landing blocks' IPC handles are all-gathered through RCCL).  A rank that
-            # cannot - the vote again - leaves every rank on plain RCCL.
-            ok, made, peer_why = 1, [], None
-            try:
-                for st in stacks:
-                    made.append(M.StripComm.peer(st[1], rank, local_rank, halo_bytes=args.gops * 9 * VL // 3 * Ws + 4096))
-            except Exception as ex:  # noqa: BLE001
-                ok, peer_why = 0, "m2v_comm_init_peer: %s" % ex
-            t = torch.tensor([ok], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t.item()) == 1:
-                for st, pc in zip(stacks, made):
-                    st[2], st[1] = st[1], pc
-            else:
-                why = peer_why if not ok else "another rank could not set the peer transport up"
-                for pc in made:
-                    pc.close()
-    comm, base_comm = stacks[0][1], stacks[0][2]
-    torch.cuda.synchronize()
-    out = None
-    if loop == "native":
-        d_outs = [torch.empty(M.parallel.strip_output_bound(nframes, Ws, Hs), dtype=torch.uint8, device=dev) if rank == 0 else None for _ in stacks]
-        d_out = d_outs[0]
-
-        def step(timings=None, k=0):
-            return M.parallel.encode_strips_native(stacks[k][0], stacks[k][1], rank, world, clip, 128, 128, PFRAMES, d_outs[k])
-    else:
-        eng = M.parallel.GpuStripEngine(enc, clip, 128, 128, PFRAMES, dev)
-
-        def step(timings=None):
-            return M.parallel.encode_strips(eng, rank, world, dist, timings=timings)
-    def describe():
-        """what this rank was running, for the failure path of ANY rank (stderr: rank 0's stdout carries the JSON line only)"""
-        d = {"rank": rank, "ranks_seen": dist.get_world_size() if dist is not None else 1, "strip_loop": loop, "strip_loop_why": why,
-             "transport": comm.kind if comm is not None else None, "dist_backend": backend, "device": dev}
-        if base_comm is not None:
-            d["peer"] = comm.peer_stats()
-        if loop == "native":
-            try:
-                d["strip_graph"] = enc.strip_graph_stats()
-                d["last_error"] = enc._L.m2v_last_error(enc._h).decode()
-            except Exception as ex:  # noqa: BLE001
-                d["strip_graph"] = "unreadable: %s" % ex
-        return d
-
-    def guarded(fn, *a):
-        try:
-            return fn(*a)
-        except BaseException as ex:
-            sys.stderr.write("bench.py --mode strips: rank %d failed: %s\n  state: %s\n" % (rank, ex, json.dumps(describe())))
-            sys.stderr.flush()
-            raise
-
-    for _ in range((20 if args.prewarm > 0 else 0) + args.warmup):     # fixed count: every rank takes part in the halo exchange
-        out = guarded(step)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = guarded(step)
-    barrier()
-    dt = time.perf_counter() - t0
-    # the same K steps with --strip-inflight sequences in flight: thread k runs steps k, k + K, ... on stack k (the same split on every rank:
-    # a stack's collectives pair up across the ranks)
-    dt_fly = None
-    if K > 1 and loop == "native":
-        import threading
-        errs = []
-
-        def worker(k, count):
-            try:
-                for _ in range(count):
-                    step(None, k)
-            except BaseException as ex:  # noqa: BLE001
-                errs.append((k, ex))
-        for phase in ("warm", "timed"):
-            counts = [len(range(k, args.steps if phase == "timed" else max(4 * K, args.warmup), K)) for k in range(K)]
-            th = [threading.Thread(target=worker, args=(k, counts[k])) for k in range(K)]
-            barrier()
-            t0 = time.perf_counter()
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
-            barrier()
-            dt_fly = time.perf_counter() - t0
-            if errs:
-                sys.stderr.write("bench.py --mode strips: rank %d, sequences in flight: %r\n  state: %s\n" % (rank, errs, json.dumps(describe())))
-                raise errs[0][1]
-    graph_stats = enc.strip_graph_stats() if loop == "native" else None      # the timed steps: one recorded hipGraph launch each?
-    host_us_timed = enc.strip_stats().get("host_us_per_step") if loop == "native" else None
-    # one more pass with per-launch HIP events (option profile) and the exchange bracketed by events on the engine's stream
-    enc.set_option("profile", 1)
-    timings = {}
-    guarded(step, timings)
-    guarded(step, timings)
-    if loop == "native":
-        timings = enc.strip_stats()
-    launches, ms_p, px_p = enc.kernel_stats(0)
-    _, ms_i, _ = enc.kernel_stats(1)
-    _, ms_asm, _ = enc.kernel_stats(3)
-    _, ms_fin, _ = enc.kernel_stats(2)
-    _, ms_scan, _ = enc.kernel_stats(4)
-    enc.set_option("profile", 0)
-    host_us, host_out = timings.get("host_us_per_step"), timings.get("host_us_per_step_outside_comm")
-    if dist is not None:
-        t = torch.tensor([dt, timings.get("halo_exposed", 0.0), timings.get("halo_total", 0.0), timings.get("gather", 0.0), dt_fly or 0.0],
-                         dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, timings["halo_exposed"], timings["halo_total"], timings["gather"], dt_fly_max = (float(v) for v in t.tolist())
-        dt_fly = dt_fly_max if dt_fly is not None else None
-    if rank == 0:
-        px = nframes * Ws * Hs
-        rows = M.parallel.partition_rows(128, world)[0]
-        strip_px = (rows[1] - rows[0]) * 16 * Ws
-        alg_bytes = args.gops * ((PFRAMES - 1) * 6.0 + 4.5) * strip_px          # this rank's P-frame launches of one step
-        achieved = alg_bytes / (ms_p * 1e-3) * 1e-9 if ms_p > 0 else 0.0
-        line = {
-            "metric": "MPixels/s encoded, 2048x2048 I+P, macroblock-row strips", "value": round(args.steps * px / (dt_fly or dt) * 1e-6, 2),
-            "unit": "MPixels/s", "n_gpus": dist.get_world_size() if dist is not None else 1,
-            "ranks_seen": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round((dt_fly or dt) / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": round(args.steps * px / (dt_fly or dt) * 1e-6 / FPGA_MPIXELS, 3), "dtype": "u8", "data": "synthetic",
-            # `value`: the K steps with `sequences_in_flight` of them under way on every rank (one host thread, handle and communicator stack each);
-            # one sequence at a time - what earlier rounds reported - beside it
-            "sequences_in_flight": K if dt_fly is not None else 1,
-            "one_sequence_at_a_time": {"value": round(args.steps * px / dt * 1e-6, 2), "ms_per_step": round(dt / args.steps * 1e3, 3)},
-            "config": {"workload": "c5: ONE 2048x2048 yuv444p sequence, %d GOPs of 1 I + %d P, VECTOR_LEVEL=3 Q_LEVEL=2, "
-                                   "%d strips of macroblock rows, halo = 9 rows x 2048 B per frame per direction"
-                                   % (args.gops, PFRAMES, world), "frames": nframes,
-                       "stream_bytes": int(out.numel()) if out is not None else None,
-                       "baseline": "FPGA Kintex-7 268 MPixels/s (README.md:22)",
-                       "strip_loop": loop, "strip_loop_why": why, "dist_backend": backend,
-                       "transport": comm.kind if comm is not None else None,
-                       "transport_asked_for": args.transport if world > 1 else None,
-                       "peer": comm.peer_stats() if base_comm is not None else None,
-                       "gop_steps_ran_as": enc.strip_last_form() if loop == "native" else "python loop",
-                       "strip_graph": graph_stats,
-                       "launched_by": os.environ.get("M2V_BENCH_LAUNCHED_BY", "caller")},
-            "roofline": {"bound": "hbm", "kernel": "k_mb<3,true> on rank 0's strip (%d macroblock rows), P-frame launches of one step" % (rows[1] - rows[0]),
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "launches_per_step": launches, "kernel_ms_per_step": round(ms_p, 3),
-                         "algorithmic_bytes_per_step": round(alg_bytes),
-                         "timed_in": "extra pass with option profile (HIP events around every launch on the engine's stream)"},
-            "exchange_ms_per_step": {"halo_exposed": round(timings.get("halo_exposed", 0.0), 3), "halo_total": round(timings.get("halo_total", 0.0), 3),
-                                     "gather_and_assembly": round(timings.get("gather", 0.0), 3),
-                                     "host_us_per_gop_step": round(host_us, 1) if host_us is not None else None,
-                                     "host_us_per_gop_step_in_the_timed_steps": round(host_us_timed, 1) if host_us_timed is not None else None,
-                                     "host_us_per_gop_step_outside_the_communicator": round(host_out, 1) if host_out is not None else None,
-                                     "note": "max over ranks; halo_exposed = stream time spent waiting for neighbour rows after the "
-                                             "interior rows were done, halo_total = from edge rows packed to neighbour rows there"},
-            "kernel_ms_per_step": {"k_mb_P": round(ms_p, 3), "k_mb_I": round(ms_i, 3), "scans": round(ms_scan, 3),
-                                   "k_assemble": round(ms_asm, 3), "k_strip_layout + k_strip_assemble": round(ms_fin, 3)},
-        }
-        if not args.no_cpu_baseline:
-            from concurrent.futures import ThreadPoolExecutor
-            from oracle import m2v_oracle_ctypes as orc
-            orc.build()
-            clip_np = clip.cpu().numpy()
-            t1 = time.perf_counter()
-            first = orc.encode(clip_np[:gop], 128, 128, PFRAMES, 7, 7, VL, Q)
-            d1 = time.perf_counter() - t1
-            line["cpu_baseline"] = dict(value=round(gop * Ws * Hs / d1 * 1e-6, 4), unit="MPixels/s", cores=1, kind="port",
-                                        sample="first GOP (%d frames) of the 2048x2048 clip, oracle/m2v_oracle.c, %.1f s" % (gop, d1))
-            with ThreadPoolExecutor(args.gops) as ex:
-                refs = [first] + list(ex.map(lambda k: orc.encode(clip_np[k * gop:(k + 1) * gop], 128, 128, PFRAMES, 7, 7, VL, Q),
-                                             range(1, args.gops)))
-            bad = compare_with_per_gop_oracle(out.cpu().numpy().tobytes(), refs, gop)
-            line["parity_check"] = {"gops_compared": args.gops, "stream_bytes_compared": int(out.numel()), "identical_to_oracle": not bad,
-                                    "problems": bad[:5]}
-            line["rtl_sim"] = rtl_sim_probe()
-        print(json.dumps(line))
-        sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()                               # nobody frees a landing block a neighbour may still be storing into
-    for st in stacks:
-        st[0].close()
-        if st[1] is not None:
-            st[1].close()
-        if st[2] is not None:
-            st[2].close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def launch_ranks(nranks, argv):
-    """`python bench.py --gpus N` with no launcher around it: start the N ranks here.  This process has not imported torch and
-    has made no HIP call (a process that initialised the GPU must never exec or fork GPU work), it only starts N children
-    of this same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's stdout (the ONE JSON line)
-    and returns the worst exit code.  The other ranks' stdout goes to stderr.  A rank that dies takes the job down:
-    the survivors (exact PIDs, never a pattern) are terminated instead of waiting in a collective for ever."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:                          # a free rendezvous port on the loopback interface
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(nranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), M2V_BENCH_LAUNCHED_BY="bench.py")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=ROOT))
-    line0 = procs[0].stdout
-    worst, live = 0, set(range(nranks))
-    relayed = []
-    import threading
-
-    def relay():
-        for raw in line0:
-            relayed.append(raw)
-            sys.stdout.buffer.write(raw)
-            sys.stdout.buffer.flush()
-    t = threading.Thread(target=relay, daemon=True)
-    t.start()
-    # A failed rank ends the job: the others get 20 s to finish on their own, then SIGTERM, and - a rank blocked in an RCCL
-    # collective or a driver call may ignore that - SIGKILL 10 s later.  The same clean-up runs when the launcher itself is
-    # interrupted or terminated, so no rank is left behind holding a GPU.  Children are ended by their exact PIDs.
-    import signal
-
-    def on_term(signum, frame):
-        raise KeyboardInterrupt
-    old_term = signal.signal(signal.SIGTERM, on_term)
-    grace, grace_kill = (float(x) for x in os.environ.get("M2V_BENCH_GRACE", "20,10").split(","))
-    deadline, stage = None, 0          # stage 0: waiting, 1: SIGTERM sent, 2: SIGKILL sent
-    try:
-        while live:
-            for r in list(live):
-                rc = procs[r].poll()
-                if rc is None:
-                    continue
-                live.discard(r)
-                if rc != 0:
-                    worst = worst or rc
-                    if deadline is None:
-                        sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks in %.0f s\n" % (r, rc, grace))
-                        deadline = time.time() + grace
-            if deadline is not None and time.time() > deadline and stage < 2:
-                for r in live:
-                    (procs[r].terminate if stage == 0 else procs[r].kill)()
-                stage += 1
-                deadline = time.time() + grace_kill
-            time.sleep(0.05)
-    except KeyboardInterrupt:
-        worst = worst or 130
-        for pr in procs:
-            if pr.poll() is None:
-                pr.terminate()
-        t_kill = time.time() + grace_kill
-        while time.time() < t_kill and any(pr.poll() is None for pr in procs):
-            time.sleep(0.05)
-        for pr in procs:
-            if pr.poll() is None:
-                pr.kill()
-        for pr in procs:
-            pr.wait()
-    finally:
-        signal.signal(signal.SIGTERM, old_term)
-    t.join(timeout=10.0)
-    return worst
-
-
-def dry_launch(args, rank, world):
-    """--dry-launch: the rendezvous alone, no encoder - runs without a GPU (gloo), which is how tests/ checks on CPU that
-    `bench.py --gpus N` really is an N-rank job.  Every rank contributes 1 to an all-reduce; rank 0 prints the line."""
-    import torch
-    import torch.distributed as dist
-    backend = os.environ.get("M2V_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-    if os.environ.get("M2V_BENCH_TEST_FAIL_RANK") == str(rank):        # tests/test_bench_launch.py: a rank that dies early
-        return 3
-    if os.environ.get("M2V_BENCH_TEST_DEAF_RANK") == str(rank):        # ... and one that is stuck and ignores SIGTERM
-        import signal
-        signal.signal(signal.SIGTERM, signal.SIG_IGN)
-        with open(os.environ["M2V_BENCH_TEST_PIDFILE"], "w") as f:
-            f.write(str(os.getpid()))
-        time.sleep(600)
-        return 0
-    seen, total = 1, 1
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend, rank=rank, world_size=world)
-        t = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t)
-        seen, total = dist.get_world_size(), int(t.item())
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_gpus": seen, "ranks_seen": seen, "ranks_counted": total, "gpus_arg": args.gpus,
-                          "backend": backend if world > 1 else None, "mode": args.mode,
-                          "launched_by": os.environ.get("M2V_BENCH_LAUNCHED_BY", "caller")}))
-        sys.stdout.flush()
-    return 0 if total == world == seen else 1
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -751,9 +117,17 @@ def main():
                          "enqueued with m2v_encode_resident_begin and collected with _end when its handle comes round again; 1 = one "
                          "handle, every step a synchronous m2v_encode_resident call (what rounds 1 and 2 timed)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling aid: skip kernel phases (output invalid), see Geom::ablate")
-    ap.add_argument("--strip-inflight", type=int, default=1,
-                    help="--mode strips: sequences in flight per rank in the timed loop (that many host threads, each with a handle and a communicator "
-                         "stack of its own).  1 (default): one blocking m2v_strip_encode after the other, as in earlier rounds")
+    ap.add_argument("--strip-inflight", type=int, default=2,
+                    help="--mode strips: sequences in flight per rank from ONE thread: that many handles taking turns through m2v_strip_encode_begin / "
+                         "_end (with --transport peer a landing block each) over one base communicator.  1: blocking calls only")
+    ap.add_argument("--strip-threads", type=int, default=0,
+                    help="--mode strips, opt-in (the round-5 form): K host threads per rank, each with a handle and a communicator stack of its own")
+    ap.add_argument("--rotate-dst", action="store_true",
+                    help="--mode strips: with sequences in flight, sequence i is assembled on rank i mod N (no single rank carries every gather)")
+    ap.add_argument("--strips-legs", choices=["auto", "off"], default="auto",
+                    help="N > 1, default mode: after the c4 measurement run config c5 (--mode strips; RCCL halo, then --transport peer) as fresh child "
+                         "processes under a time bound and attach the results to the c4 line as `strips` (bench_launch.py).  off: the c4 line alone")
+    ap.add_argument("--strips-steps", type=int, default=40, help="steps of each strips leg")
     ap.add_argument("--transport", choices=["rccl", "peer"], default=os.environ.get("M2V_STRIP_TRANSPORT", "rccl"),
                     help="--mode strips, N > 1: how the halo rows travel.  rccl (default): ncclSend / ncclRecv per GOP step.  peer: the edge-row "
                          "kernel stores them straight into the neighbour's landing block (hipIpc-mapped) and counts their arrival - one launch "
@@ -768,14 +142,21 @@ def main():
         have = visible_gpus()
         if not args.dry_launch and os.environ.get("M2V_BENCH_SHARE_GPU") != "1" and have is not None and have < args.gpus:
             raise SystemExit("bench.py: --gpus %d but %d GPU(s) visible on this node (one rank per GPU): nothing was started" % (args.gpus, have))
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        if not bench_launch.legs_wanted(args, args.gpus):
+            sys.exit(bench_launch.launch_ranks(args.gpus, sys.argv[1:])[0])
+        # the default N > 1 job: the c4 ranks (their line kept, not relayed), then config c5 twice as fresh ranks under a time bound,
+        # then the c4 line - once, last - with `strips` added.  A strips leg never costs the line or changes the exit code.
+        rc, lines, _ = bench_launch.launch_ranks(args.gpus, sys.argv[1:], relay=False)
+        strips = bench_launch.legs_from_launcher(args) if rc == 0 else {"skipped": "the c4 ranks failed (exit code %d)" % rc}
+        bench_launch.attach_and_print(lines, strips)
+        sys.exit(rc)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if args.dry_launch:
-        sys.exit(dry_launch(args, rank, world))
+        sys.exit(bench_launch.dry_launch(args, rank, world))
 
     global W, H, XS16, YS16, PFRAMES
     if args.config == "c2":                    # BASELINE configs[1]: 640x480, I frames only, Q_LEVEL 2 - DCT + quantiser + VLC, no search
@@ -813,7 +194,8 @@ def main():
     if dist is not None:
         dist.barrier()
     if args.mode == "strips":
-        return bench_strips(args, M, torch, dist, rank, local_rank, world, dev)
+        import bench_strips
+        return bench_strips.bench_strips(args, config(), M, torch, dist, rank, local_rank, world, dev)
     gop = PFRAMES + 1
     nframes = args.gops * gop
     clip = M.synth.clip_torch(W, H, nframes, clip_index=rank, device=dev)       # resident in HBM
@@ -887,14 +269,9 @@ def main():
     def sync_steps(steps):                     # one blocking call after the other on one handle
         return [step() for _ in range(steps)][-1]
 
-    # How the K sequences are submitted is settled in the warm-up: --inflight handles taking turns, or one blocking call after the
-    # other.  Taking turns wins by ~8 % when the handles' streams sit on different hardware queues of the HIP runtime; whether they do
-    # is the runtime's choice, and one box in ten puts two streams of a process on ONE queue - the sequences then run one after the
-    # other (profiles/r04_queue_ab.txt reproduces it with GPU_MAX_HW_QUEUES=1).  So the placement is checked, untimed, and repaired:
-    # a handle whose sequences do not overlap with the other one's gets a NEW stream (the runtime deals its streams to the queues in
-    # turn: option stream_priority = 0 makes one), up to three times; if that does not help, a stream of another priority - those
-    # never share a queue with default-priority ones (overlap guaranteed, ~3 % behind the best placement).  Blocking calls are the
-    # last resort.  The line says what happened (`config.queue_placement`).
+    # How the K sequences are submitted - two handles taking turns, or one blocking call after the other - is settled in the warm-up by an
+    # untimed probe of both forms, and a bad placement of the two handles' streams on the runtime's hardware queues is repaired
+    # (bench_util.settle_queue_placement: what is probed, the decision table and its thresholds).  The line says what happened.
     submission = "in_flight" if nh > 1 else "blocking"
     placement = None
     if nh > 1:
@@ -905,31 +282,24 @@ def main():
         def probe_fly():
             run_steps(2 * nh)
             return min(timed(probe)[0], timed(probe)[0])
-        p_sync = min(timed(probe, sync_steps)[0], timed(probe, sync_steps)[0])
-        # the yardstick for "no overlap": the same sequences strictly one after the other on ONE stream
-        enc.set_option("split_streams", 1)
-        p_serial = min(timed(probe, sync_steps)[0], timed(probe, sync_steps)[0])
-        enc.set_option("split_streams", args.split if args.split >= 0 else LIB_DEFAULT_SPLIT_STREAMS)
-        p_fly = probe_fly()
-        placement = {"new_streams": 0, "priority": 0, "probe_ms_per_step": {"blocking": round(p_sync / probe * 1e3, 3), "one_stream": round(p_serial / probe * 1e3, 3),
-                                                                             "in_flight": [round(p_fly / probe * 1e3, 3)]}}
 
-        def overlapping(t_fly):                # in flight must beat the one-stream form by 4 % to count as overlapping
-            return t_fly <= 0.96 * p_serial
-        # The repair re-streams ONE handle, the last one: with the default two handles that is the pair; with --inflight > 2 the others
-        # keep the streams they were created with (more than two in flight buys nothing, DESIGN.md section 2, and is not repaired).
-        while not overlapping(p_fly) and placement["new_streams"] < 3 and args.split < 0:
-            encs[-1].set_option("stream_priority", 0)            # a fresh stream: the next hardware queue in the runtime's rotation
-            placement["new_streams"] += 1
-            p_fly = probe_fly()
-            placement["probe_ms_per_step"]["in_flight"].append(round(p_fly / probe * 1e3, 3))
-        if not overlapping(p_fly) and args.split < 0:
-            encs[-1].set_option("stream_priority", 1)
-            placement["priority"] = 1
-            p_fly = probe_fly()
-            placement["probe_ms_per_step"]["in_flight"].append(round(p_fly / probe * 1e3, 3))
-        if p_sync < p_fly:
-            submission = "blocking"
+        def probe_blocking():
+            return min(timed(probe, sync_steps)[0], timed(probe, sync_steps)[0])
+
+        def probe_one_stream():                # the yardstick for "no overlap": the same sequences strictly one after the other on ONE stream
+            enc.set_option("split_streams", 1)
+            t = min(timed(probe, sync_steps)[0], timed(probe, sync_steps)[0])
+            enc.set_option("split_streams", args.split if args.split >= 0 else LIB_DEFAULT_SPLIT_STREAMS)
+            return t
+
+        def restream(kind):
+            # ONE handle is re-streamed, the last one: with the default two handles that is the pair; with --inflight > 2 the others keep
+            # the streams they were created with (more than two in flight buys nothing, DESIGN.md section 2, and is not repaired).
+            # new_stream: option stream_priority = 0 makes a fresh stream - the next hardware queue in the runtime's rotation;
+            # priority: a stream of another priority never shares a queue with default-priority ones
+            encs[-1].set_option("stream_priority", 0 if kind == "new_stream" else 1)
+        submission, placement = settle_queue_placement(probe_fly, probe_blocking, probe_one_stream, restream, repair_allowed=args.split < 0,
+                                                       per_step=1.0 / probe)
     # THE timed region: K steps of the encoder as shipped (no in-band timers)
     dt, nbytes = timed(args.steps, run_steps if submission == "in_flight" else sync_steps)
     # the same K steps the other way (rounds 1 and 2 reported the blocking form as `value`)
@@ -943,7 +313,13 @@ def main():
     if args.sustain > 0:
         fn = run_steps if submission == "in_flight" else sync_steps
         per = max(2 * nh, int(0.5 / max(dt / args.steps, 1e-6)))
-        s0 = gpu_sensors(local_rank)
+        # the card this rank's HIP device IS, by PCI address (a lease that shows HIP one GPU of eight still lists all eight in sysfs)
+        try:
+            bus_id = M.device_pci_bus_id(local_rank)
+        except Exception:  # noqa: BLE001
+            bus_id = None
+        card = sysfs_card_of(bus_id)
+        s0 = gpu_sensors(card)
         # the sensors again every 0.1 s WHILE the loop runs, from a thread of their own (read between two windows the GPU has just gone
         # idle and shows its idle clock)
         import threading
@@ -951,7 +327,7 @@ def main():
 
         def sampler():
             while not stop_sampling.wait(0.1):
-                x = gpu_sensors(local_rank)
+                x = gpu_sensors(card)
                 if x:
                     samples.append(x)
         th = threading.Thread(target=sampler, daemon=True)
@@ -967,7 +343,8 @@ def main():
         t_all = time.perf_counter() - t_begin
         stop_sampling.set()
         th.join(timeout=2.0)
-        s1 = gpu_sensors(local_rank)
+        s1 = gpu_sensors(card)
+        plausible, why_not = sensors_verdict(samples)
 
         def spread(key):
             v = [x[key] for x in samples if x.get(key) is not None]
@@ -977,9 +354,12 @@ def main():
                      "value": round(per * len(wins) * nframes * W * H / sum(wins) * 1e-6, 2), "unit": "MPixels/s (this rank)",
                      "window_min": round(min(rate), 2), "window_max": round(max(rate), 2),
                      "first_window": round(rate[0], 2), "last_window": round(rate[-1], 2),
-                     "submission": submission, "sensors_start": s0, "sensors_end": s1,
-                     "sensors_during": {"sclk_mhz": spread("sclk_mhz"), "power_w": spread("power_w"), "every_s": 0.1},
-                     "sensors_source": "amdgpu sysfs (pp_dpm_sclk / pp_dpm_mclk / hwmon)" if (s0 or s1) else "not readable on this host"}
+                     "submission": submission, "sensors_card": {"pci_bus_id": bus_id, "sysfs": os.path.dirname(card) if card else None},
+                     "sensors_plausible": plausible, "sensors_not_plausible_because": why_not,
+                     "sensors_start": s0 if plausible else None, "sensors_end": s1 if plausible else None,
+                     "sensors_during": {"sclk_mhz": spread("sclk_mhz"), "power_w": spread("power_w"), "temp_c": spread("temp_c"), "every_s": 0.1} if plausible else None,
+                     "sensors_source": "amdgpu sysfs of the card at the HIP device's PCI address (pp_dpm_sclk / pp_dpm_mclk / hwmon)" if card else
+                                       "not readable on this host (no /sys/class/drm card at PCI address %s)" % bus_id}
     # second pass, same K steps, for the per-kernel numbers: option "profile" brackets every launch with HIP events on the
     # launch stream and keeps the whole chunk on ONE stream, so that a launch's duration is the kernel alone on the GPU
     enc.set_option("profile", 1)
@@ -1053,7 +433,7 @@ def main():
                                          "ms_per_step": round(dt_fly / args.steps * 1e3, 3), "handles": nh},
             "roofline": dict({"bound": "hbm", "kernel": dom_name,
                               "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 5)}, **traffic,
+                              "frac": round(achieved / HBM_PEAK_GBS, 5)}, **traffic, **pmc_valu_busy(tkey),
                              **{"launches_per_step": dom_launches, "avg_launch_ms": round(dom_ms / max(dom_launches, 1), 4),
                                 "algorithmic_bytes_per_launch": round(alg_bytes / max(dom_launches, 1))}),
             "kernel_ms_per_step": {"k_mb_P": round(ms, 3), "k_mb_I": round(msi, 3), "k_assemble": round(ms3, 3),
@@ -1097,11 +477,29 @@ def main():
             out["roofline"]["hbm_copy_measured"] = round(copy, 1)
             out["roofline"]["frac_of_measured_copy"] = round(achieved / copy, 5) if copy > 0 else None
             if not args.no_e2e:
-                out["end_to_end"] = end_to_end(M, clip_np, gpu_bytes)
-        print(json.dumps(out))
-        sys.stdout.flush()
+                import bench_e2e
+                out["end_to_end"] = bench_e2e.end_to_end(M, config(), clip_np, gpu_bytes)
     for h in set(encs + [enc]):
         h.close()
+    if bench_launch.legs_wanted(args, world) and os.environ.get("M2V_BENCH_LAUNCHED_BY", "caller") == "caller":
+        # The driver's form of the N > 1 job (torch.distributed.run started this rank): config c5 now, as ONE fresh child process per
+        # rank and leg on a rendezvous port of its own, under a wall-clock bound - a child, never an exec: this process has touched the
+        # GPU.  Whatever the legs do, the c4 line below is printed, once, last (bench_launch.py).
+        strips = None
+        try:
+            del clip, d_outs, d_out
+            torch.cuda.empty_cache()
+            ports = torch.tensor([bench_launch.free_port() for _ in bench_launch.LEGS] if rank == 0 else [0] * len(bench_launch.LEGS),
+                                 dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.broadcast(ports, src=0)
+            strips = bench_launch.legs_from_rank(args, rank, world, [int(x) for x in ports.tolist()])
+        except Exception as ex:  # noqa: BLE001
+            strips = {"error": "could not start the strips legs: %r" % (ex,)}
+        if rank == 0:
+            out["strips"] = strips
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

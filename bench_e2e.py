@@ -1,0 +1,160 @@
+"""bench_e2e.py — the `end_to_end` object of the bench line: the port contract from host memory to host memory (PCIe inclusive;
+reported next to `value`, never as `value`).  Every leg pushes the benchmark clip one GOP per call, drains the stream as it goes
+(m2v_pull into the caller's own buffer), stops, drains the rest; best of a few repetitions; the bytes are compared with the resident
+path's.  Legs: planar frames (m2v_push_frames) from page-locked and from pageable memory, deferred upload, push + pull in one call,
+two callers - and the LITERAL port contract (RTL:24-28, TB:224-234): 4-pixel beats on three arrays (m2v_push_beats) and the same beats
+as packed YUV samples (m2v_push_packed), which stay interleaved until they are in HBM."""
+import os
+import sys
+import time
+
+
+def end_to_end(M, cfg, clip_np, want_bytes):
+    import numpy as np
+    import torch
+    W, H, XS16, YS16, PFRAMES, XL, YL, VL, Q = cfg.W, cfg.H, cfg.XS16, cfg.YS16, cfg.PFRAMES, cfg.XL, cfg.YL, cfg.VL, cfg.Q
+    n = clip_np.shape[0]
+    gop = PFRAMES + 1 if PFRAMES else 16          # frames per push (config c2: every frame is a GOP; 16 at a time)
+
+    outbuf = np.empty(clip_np.shape[0] * W * H * 3 // 2 + 4096, np.uint8)      # the caller's own output buffer: m2v_pull writes into it
+
+    def drive(push, best_of=4, options=()):
+        """push(enc, k) hands frames [k, k + gop) to the encoder and returns the bytes it pulled meanwhile"""
+        enc = M.Mpeg2Encoder(XL, YL, VL, Q)
+        try:
+            enc.set_option("batch_frames", gop)
+            for name, val in options:
+                enc.set_option(name, val)
+            best, data = 1e9, b""
+            for _ in range(best_of):
+                t0 = time.perf_counter()
+                pos = 0
+                for k in range(0, n, gop):
+                    pos += push(enc, k, pos)
+                enc.sequence_stop()
+                last = False
+                while not last:
+                    m, last = enc.pull_into(outbuf, pos)
+                    pos += m
+                best = min(best, time.perf_counter() - t0)
+                data = outbuf[:pos].tobytes()
+        finally:
+            enc.close()
+        return best, data
+
+    def frames_leg(frames, deferred=False, one_call=False):
+        def push(enc, k, pos):
+            if one_call:
+                return enc.push_frames_pull(XS16, YS16, PFRAMES, frames[k:k + gop], outbuf, pos)[0]
+            enc.push_frames(XS16, YS16, PFRAMES, frames[k:k + gop])
+            return enc.pull_into(outbuf, pos)[0]
+        return drive(push, options=(("direct_upload", 2),) if deferred else ())
+
+    t_page, d_page = frames_leg(clip_np)
+    pinned_t = torch.from_numpy(clip_np).pin_memory()
+    pinned = pinned_t.numpy()
+    t_pin, d_pin = frames_leg(pinned)
+    t_def, d_def = frames_leg(pinned, deferred=True)
+    t_one, d_one = frames_leg(pinned, one_call=True)
+
+    # ---- the literal port contract: beats.  Three arrays of 4-pixel beats (the module's i_Y / i_U / i_V lanes), a GOP's worth per call ----
+    planes = [np.ascontiguousarray(pinned[:, c]).reshape(-1) for c in range(3)]       # frame after frame, raster order: beat b = pixels 4b .. 4b + 3
+    fpx = W * H
+
+    def push_beats(enc, k, pos):
+        a, b = k * fpx, min(n, k + gop) * fpx
+        enc.push_beats(XS16, YS16, PFRAMES, planes[0][a:b], planes[1][a:b], planes[2][a:b])
+        return enc.pull_into(outbuf, pos)[0]
+    t_beats, d_beats = drive(push_beats)
+
+    # ---- ... and as packed YUV24 samples (what a capture card delivers), page-locked and pageable ----
+    packed_t = torch.from_numpy(np.ascontiguousarray(np.moveaxis(clip_np, 1, -1))).pin_memory()      # [n, H, W, 3]
+    packed = packed_t.numpy().reshape(-1)
+
+    def packed_leg(src):
+        def push(enc, k, pos):
+            enc.push_packed(XS16, YS16, PFRAMES, src[k * fpx * 3:min(n, k + gop) * fpx * 3], "yuv24")
+            return enc.pull_into(outbuf, pos)[0]
+        return drive(push)
+    t_pk, d_pk = packed_leg(packed)
+    t_pkpage, d_pkpage = packed_leg(np.array(packed))
+
+    def run_two(best_of=6):
+        """two callers at once - two threads, a handle and a page-locked copy of the clip each: one caller's turn-around between its
+        pushes (pull, the next push's set-up) is covered by the other's upload"""
+        import threading
+        srcs = [pinned, pinned_t.clone().pin_memory().numpy()]
+        encs = [M.Mpeg2Encoder(XL, YL, VL, Q) for _ in srcs]
+        res, best = [b"", b""], 1e9
+        try:
+            for e in encs:
+                e.set_option("batch_frames", gop)
+
+            def caller(i):
+                out = []
+                for k in range(0, n, gop):
+                    encs[i].push_frames(XS16, YS16, PFRAMES, srcs[i][k:k + gop])
+                    out.append(encs[i].pull(1 << 24)[0])
+                encs[i].sequence_stop()
+                out.append(encs[i].pull_all())
+                res[i] = b"".join(out)
+            for _ in range(best_of):
+                th = [threading.Thread(target=caller, args=(i,)) for i in range(2)]
+                t0 = time.perf_counter()
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                best = min(best, time.perf_counter() - t0)
+                if os.environ.get("M2V_BENCH_VERBOSE"):
+                    print("two callers: %.2f ms" % ((time.perf_counter() - t0) * 1e3), file=sys.stderr)
+        finally:
+            for e in encs:
+                e.close()
+        return best, res
+
+    t_two, d_two = run_two()
+    # what the link gives a plain copy of the same page-locked bytes on this box (the bound the path can be held against)
+    dev_t = torch.empty_like(pinned_t, device="cuda")
+    dev_t.copy_(pinned_t, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        dev_t.copy_(pinned_t, non_blocking=True)
+    torch.cuda.synchronize()
+    h2d = 4 * pinned_t.numel() / (time.perf_counter() - t0)
+    del dev_t
+    px = n * W * H
+
+    def leg(t, data, path, **more):
+        d = {"value": round(px / t * 1e-6, 1), "input_GBps": round(px * 3 / t * 1e-9, 2), "identical": data == want_bytes,
+             "fraction_of_measured_h2d": round(px * 3 / t / h2d, 3), "path": path}
+        d.update(more)
+        return d
+    return {"value": round(px / t_pin * 1e-6, 1), "unit": "MPixels/s", "frames": n, "best_of": 4,
+            "input_GBps": round(px * 3 / t_pin * 1e-9, 2), "identical_to_resident_stream": d_pin == want_bytes and d_page == want_bytes,
+            "path": "m2v_push_frames -> m2v_pull (into the caller's output buffer), frames in page-locked host memory uploaded straight from "
+                    "the caller's buffer (hipMemcpyAsync on an upload stream; the call returns when its frames have been read: it waits for the fence-free "
+                    "event the chunk's kernels wait for), stream bytes back to the host by a kernel; chunk k+1 uploads while chunk k "
+                    "encodes, batch_frames=%d" % gop,
+            "pageable_source": {"value": round(px / t_page * 1e-6, 1), "input_GBps": round(px * 3 / t_page * 1e-9, 2),
+                                "path": "the same from a plain numpy array: copied into the handle's pinned staging by 8 threads first"},
+            "two_callers": {"value": round(2 * px / t_two * 1e-6, 1), "input_GBps": round(2 * px * 3 / t_two * 1e-9, 2),
+                            "identical": all(d == want_bytes for d in d_two),
+                            "path": "two threads, a handle and a page-locked clip each, at the same time (aggregate of both sequences)"},
+            # option direct_upload = 2 (opt-in: a pushed range stays unchanged until the NEXT push / stop has returned): the push returns
+            # while its frames are still being read and the calls' transfers alternate between two upload streams, so the copy engine
+            # sets the next one up while the running one drains - what two callers do for each other, from one thread
+            "deferred_upload": leg(t_def, d_def, "the same loop with option direct_upload = 2"),
+            # both port groups in one call (m2v_push_frames_pull): the stream bytes of completed chunks are copied into the caller's buffer while
+            # the call's frames cross the link - the same loop, one call per GOP instead of two
+            "one_call": leg(t_one, d_one, "m2v_push_frames_pull per GOP, then stop and drain"),
+            # RTL:24-28 / TB:224-234 as they are: beats.  Three arrays: three host copies per call into the pinned planar staging, then as the
+            # pageable planar path.  Packed: the caller's bytes go up as they are (page-locked: straight from the caller's buffer), k_unpack444
+            # turns them into planes on the device in front of the chunk's kernels
+            "beats": leg(t_beats, d_beats, "m2v_push_beats, a GOP's beats per call from three (page-locked) arrays: memcpy into the pinned staging"),
+            "packed_yuv24": leg(t_pk, d_pk, "m2v_push_packed (YUV24), a GOP's beats per call from page-locked memory: uploaded as they are, "
+                                            "de-interleaved on the device (k_unpack444)",
+                                pageable_source=leg(t_pkpage, d_pkpage, "the same from a plain numpy array: through the packed pinned staging")),
+            "pcie_bound_MPixels": round(63e9 / 3 * 1e-6, 0),
+            "h2d_copy_measured_GBps": round(h2d * 1e-9, 1), "fraction_of_measured_h2d": round(px * 3 / t_pin / h2d, 3)}

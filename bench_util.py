@@ -73,8 +73,11 @@ def pmc_valu_busy(key):
     if v is None:
         return {}
     _, ksha = source_shas()
-    return {"valu_busy": v, "valu_busy_source": t["valu_busy"].get("source"),
-            "valu_busy_stale": t["valu_busy"].get("kernel_sha", t.get("kernel_sha")) != ksha}
+    out = {"valu_busy": v, "valu_busy_source": t["valu_busy"].get("source"),
+           "valu_busy_stale": t["valu_busy"].get("kernel_sha", t.get("kernel_sha")) != ksha}
+    if t["valu_busy"].get(key + "_while_resident") is not None:
+        out["valu_busy_while_resident"] = t["valu_busy"][key + "_while_resident"]
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------

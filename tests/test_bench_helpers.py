@@ -54,11 +54,16 @@ def test_traffic_carries_the_tree_it_was_measured_on(tmp_path, monkeypatch):
     (tmp_path / "b.hpp").write_text(text + "\nint x;\n")
     assert bench.kernel_source_sha(str(tmp_path / "a.hpp")) == ksha != bench.kernel_source_sha(str(tmp_path / "b.hpp"))
     (tmp_path / "profiles").mkdir()
-    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    import bench_util
+    monkeypatch.setattr(bench_util, "ROOT", str(tmp_path))
     assert bench.pmc_traffic("k_mb_p_bytes_per_launch") == {"traffic": None}            # no file: null, nothing invented
-    monkeypatch.setattr(bench, "source_shas", lambda: (head, ksha))
+    monkeypatch.setattr(bench_util, "source_shas", lambda: (head, ksha))
     for recorded, stale in ((ksha, False), ("0" * 64, True), (None, True)):
         (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps({"k_mb_p_bytes_per_launch": 136489472, "head": "abc", "kernel_sha": recorded}))
         t = bench.pmc_traffic("k_mb_p_bytes_per_launch")
         assert t["traffic"] == 136489472 and t["traffic_stale"] is stale and t["traffic_measured_at"]["head"] == "abc"
         assert bench.pmc_traffic("k_mb_i_c2_bytes_per_launch") == {"traffic": None}     # a key the passes did not measure
+    # the vector ALU's share of the launch's SIMD-cycles rides in the same file (tools/make_pmc_traffic.py)
+    assert bench.pmc_valu_busy("k_mb_p_bytes_per_launch") == {}
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps({"kernel_sha": ksha, "valu_busy": {"k_mb_p_bytes_per_launch": 0.88, "source": "x", "kernel_sha": ksha}}))
+    assert bench.pmc_valu_busy("k_mb_p_bytes_per_launch") == {"valu_busy": 0.88, "valu_busy_source": "x", "valu_busy_stale": False}

@@ -27,6 +27,34 @@ def test_gpus_n_starts_n_ranks_by_itself(n):
     assert len(lines) == 1, "exactly one JSON line (rank 0's): %r" % r.stdout
     assert lines[0]["n_gpus"] == n and lines[0]["ranks_seen"] == n and lines[0]["ranks_counted"] == n
     assert lines[0]["launched_by"] == "bench.py" and lines[0]["backend"] == "gloo"
+    # ... and the one line also carries config c5: the two strips legs ran as fresh ranks after the c4 ranks had exited
+    st = lines[0]["strips"]
+    assert set(st) == {"rccl", "peer"}
+    for name in ("rccl", "peer"):
+        assert st[name]["dry_launch"] is True and st[name]["ranks_seen"] == n and st[name]["mode"] == "strips" and st[name]["transport"] == name
+
+
+def test_a_strips_leg_that_hangs_or_fails_never_costs_the_c4_line():
+    """the peer leg never comes back (env switch): ended by its PIDs when the bound passes, reported as a timeout INSIDE the intact c4
+    line, exit code 0; the RCCL leg beside it is fine.  Then a leg whose ranks exit with an error: a stated exit code, same line."""
+    import time
+    t0 = time.time()
+    r, lines = run(["--gpus", "2", "--dry-launch"], {"M2V_DIST_BACKEND": "gloo", "M2V_BENCH_TEST_HANG_LEG": "peer", "M2V_BENCH_LEG_TIMEOUT": "12"}, timeout=240)
+    took = time.time() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks_counted"] == 2
+    st = lines[0]["strips"]
+    assert st["rccl"].get("dry_launch") is True and "error" not in st["rccl"]
+    assert st["peer"]["error"] == "timeout" and 12 <= st["peer"]["seconds"] < 40
+    assert took < 120
+    r, lines = run(["--gpus", "2", "--dry-launch"], {"M2V_DIST_BACKEND": "gloo", "M2V_BENCH_TEST_FAIL_LEG": "rccl"}, timeout=240)
+    assert r.returncode == 0 and len(lines) == 1
+    assert lines[0]["strips"]["rccl"]["error"] == "exit code 5" and lines[0]["strips"]["peer"].get("dry_launch") is True
+
+
+def test_strips_legs_can_be_switched_off():
+    r, lines = run(["--gpus", "2", "--dry-launch", "--strips-legs", "off"], {"M2V_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0 and len(lines) == 1 and "strips" not in lines[0]
 
 
 def test_one_gpu_needs_no_launcher():
@@ -45,6 +73,21 @@ def test_under_torch_distributed_run_the_ranks_are_not_started_twice():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["launched_by"] == "caller"
+    # the driver's form: every rank started ONE child per strips leg on a rendezvous port of the leg's own
+    st = lines[0]["strips"]
+    assert st["rccl"]["dry_launch"] is True and st["rccl"]["ranks_seen"] == 2 and st["peer"]["ranks_seen"] == 2 and st["peer"]["transport"] == "peer"
+
+
+def test_under_torch_distributed_run_a_hanging_leg_is_ended_by_every_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update({"M2V_DIST_BACKEND": "gloo", "M2V_BENCH_TEST_HANG_LEG": "rccl", "M2V_BENCH_LEG_TIMEOUT": "10"})
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["ranks_counted"] == 2
+    assert lines[0]["strips"]["rccl"]["error"] == "timeout" and lines[0]["strips"]["peer"].get("dry_launch") is True
 
 
 def test_gpus_argument_must_match_the_launcher():
@@ -117,5 +160,68 @@ def test_visible_gpus_and_sensors_read_without_the_runtime(monkeypatch):
     monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
     n = bench.visible_gpus()                       # the KFD topology of this host (no GPU here: 0, or None where /sys/class/kfd is absent)
     assert n is None or n >= 0
-    s = bench.gpu_sensors(99)
-    assert s is None                               # no such card: nothing invented
+    assert bench.gpu_sensors(None) is None and bench.gpu_sensors("/nonexistent/card") is None      # no such card: nothing invented
+
+
+def test_sensors_come_from_the_card_at_the_hip_devices_pci_address(tmp_path):
+    """A lease that shows HIP one GPU of a node's eight still lists eight cards in sysfs: the card is picked by the PCI address
+    m2v_device_pci_bus_id reports, never by its position (round 5 read card 0 - somebody else's idle GPU: 111 MHz, 249.0 W flat)."""
+    sys.path.insert(0, ROOT)
+    import bench_util as bu
+    pci = tmp_path / "devices"
+    drm = tmp_path / "drm"
+    drm.mkdir()
+    addrs = ["0000:05:00.0", "0000:c1:00.0", "0000:e5:00.0"]
+    for k, a in enumerate(addrs):
+        d = pci / a
+        (d / "hwmon" / "hwmon3").mkdir(parents=True)
+        busy = a == "0000:c1:00.0"
+        (d / "pp_dpm_sclk").write_text("0: 132Mhz %s\n1: 2400Mhz %s\n" % ("" if busy else "*", "*" if busy else ""))
+        (d / "pp_dpm_mclk").write_text("0: 900Mhz *\n")
+        (d / "hwmon" / "hwmon3" / "power1_average").write_text("%d\n" % (910000000 if busy else 249000000))
+        (d / "hwmon" / "hwmon3" / "temp1_input").write_text("61000\n")
+        (drm / ("card%d" % k)).mkdir()
+        os.symlink(str(d), str(drm / ("card%d" % k) / "device"))
+        (drm / ("card%d-DP-1" % k)).mkdir()                  # a connector: not a card
+    card = bu.sysfs_card_of("0000:C1:00.0", drm_root=str(drm))
+    assert card is not None and os.path.realpath(card).endswith("0000:c1:00.0")
+    s = bu.gpu_sensors(card)
+    assert s == {"sclk_mhz": 2400, "mclk_mhz": 900, "power_w": 910.0, "temp_c": 61.0}
+    assert bu.sysfs_card_of("0000:aa:00.0", drm_root=str(drm)) is None and bu.sysfs_card_of(None, drm_root=str(drm)) is None
+    idle = bu.gpu_sensors(bu.sysfs_card_of(addrs[0], drm_root=str(drm)))
+    assert idle["sclk_mhz"] == 132
+    # the verdict on samples taken while the loop ran
+    assert bu.sensors_verdict([s] * 3 + [dict(s, power_w=905.0)] * 7) == (True, None)
+    ok, why = bu.sensors_verdict([idle] * 20)
+    assert not ok and "idle" in why
+    ok, why = bu.sensors_verdict([dict(s)] * 20)
+    assert not ok and "constant" in why
+    assert bu.sensors_verdict([]) == (False, "no sensor file readable")
+
+
+def test_queue_placement_decision_table():
+    """fake probe timings in, submission form out (bench_util.settle_queue_placement): overlap at once; one stream shared, repaired by
+    the second new stream; never repaired by new streams, then by a stream of another priority; nothing helps -> blocking calls;
+    repair not allowed (--split given)."""
+    sys.path.insert(0, ROOT)
+    import bench_util as bu
+    G = bu.PLACEMENT_OVERLAP_GAIN
+
+    def settle(fly_times, t_block, t_one, allowed=True):
+        it, acts = iter(fly_times), []
+        sub, rec = bu.settle_queue_placement(lambda: next(it), lambda: t_block, lambda: t_one, acts.append, repair_allowed=allowed)
+        return sub, rec, acts
+    sub, rec, acts = settle([0.90], 0.97, 1.00)
+    assert sub == "in_flight" and acts == [] and rec["new_streams"] == 0 and rec["priority"] == 0
+    sub, rec, acts = settle([1.00, 0.99, 0.91], 0.97, 1.00)
+    assert sub == "in_flight" and acts == ["new_stream", "new_stream"] and rec["new_streams"] == 2 and len(rec["probe_ms_per_step"]["in_flight"]) == 3
+    sub, rec, acts = settle([1.00, 1.00, 1.00, 1.00, 0.93], 0.97, 1.00)
+    assert sub == "in_flight" and acts == ["new_stream"] * bu.PLACEMENT_MAX_NEW_STREAMS + ["priority"] and rec["priority"] == 1
+    sub, rec, acts = settle([1.00] * 5, 0.97, 1.00)
+    assert sub == "blocking" and len(acts) == bu.PLACEMENT_MAX_NEW_STREAMS + 1
+    sub, rec, acts = settle([1.00], 0.97, 1.00, allowed=False)
+    assert sub == "blocking" and acts == []
+    # the threshold itself: exactly at the gain counts as overlapping, a hair above does not
+    assert bu.placement_next_action(G * 1.0, 1.0, 0, False) == "keep" and bu.placement_next_action(G * 1.0 + 1e-9, 1.0, 0, False) == "new_stream"
+    assert bu.placement_next_action(1.0, 1.0, bu.PLACEMENT_MAX_NEW_STREAMS, False) == "priority"
+    assert bu.placement_next_action(1.0, 1.0, bu.PLACEMENT_MAX_NEW_STREAMS, True) == "keep"

@@ -4,7 +4,12 @@
 on the I-frame kernel, which reads exactly its 3 B/px of input) TOGETHER WITH the tree they were measured on: the git HEAD (passed
 in: the GPU box has no .git) and the sha256 of the kernel source.  bench.py compares that sha with the running tree and says
 "traffic_stale" when they differ.
-    python tools/make_pmc_traffic.py <c3 pmc_hbm.json> <c2 pmc_hbm.json or -> <git head or -> > pmc_traffic.json"""
+`valu_busy` (from the SQ counter pass, tools/pmc_sq.sh): the vector ALU's share of the dominant kernel's SIMD-cycles - the roof that
+binds it.  Two denominators, both from counters of the same file, no clock assumed:
+    valu_busy                  4 x SQ_ACTIVE_INST_VALU (quad-cycles -> cycles, summed over all SIMDs) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs):
+                               of the whole dispatch window, the profiler's serialised start and drain included
+    valu_busy_while_resident   ... / (1024 x SQ_BUSY_CYCLES / 32 shader engines): of the cycles in which the shader engines held waves
+    python tools/make_pmc_traffic.py <c3 pmc_hbm.json> <c2 pmc_hbm.json or -> <git head or -> [<c3 pmc_sq.json>] > pmc_traffic.json"""
 import hashlib
 import re
 import json
@@ -45,4 +50,27 @@ if i:
     # measured on a 128-frame launch (rocprofv3 --pmc segfaults in this image with the 256-frame clip), stated for bench.py's 256-frame launch
     out.update({"k_mb_i_c2_bytes_per_launch": round((2 * i["FETCH_SIZE"] + i["WRITE_SIZE"]) * 1024 * 2), "c2_fetch_kib_128_frames": i["FETCH_SIZE"],
                 "c2_write_kib_128_frames": i["WRITE_SIZE"], "c2_algorithmic_bytes_per_launch": round(256 * 3.0 * 640 * 480)})
+sq = json.load(open(sys.argv[4])) if len(sys.argv) > 4 and os.path.exists(sys.argv[4]) else {}
+
+
+def sq_kernel(needle):
+    hits = [v for name, v in sq.items() if needle in name and "SQ_ACTIVE_INST_VALU" in v and "SQ_BUSY_CYCLES" in v]
+    return max(hits, key=lambda v: v.get("SQ_WAVES", 0)) if hits else None
+
+
+vb = {}
+for key, needle in (("k_mb_p_bytes_per_launch", "k_mb<3, true"), ("k_mb_i_bytes_per_launch", "k_mb<1, false")):       # (I frames run the VL-independent instantiation)
+    k = sq_kernel(needle)
+    if not k:
+        continue
+    simd_cycles_valu = 4.0 * k["SQ_ACTIVE_INST_VALU"]
+    if k.get("GRBM_GUI_ACTIVE"):
+        vb[key] = round(simd_cycles_valu / (1024.0 * k["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    vb[key + "_while_resident"] = round(simd_cycles_valu / (1024.0 * k["SQ_BUSY_CYCLES"] / 32.0), 4)
+    vb[key + "_per_wave"] = {"valu_quad_cycles": round(k["SQ_ACTIVE_INST_VALU"] / k["SQ_WAVES"], 1), "vector_instructions": round(k["SQ_INSTS_VALU"] / k["SQ_WAVES"], 1),
+                             "scalar_instructions": round(k["SQ_INSTS_SALU"] / k["SQ_WAVES"], 1), "lds_instructions": round(k["SQ_INSTS_LDS"] / k["SQ_WAVES"], 1)}
+if vb:
+    vb.update({"kernel_sha": ksha, "source": "tools/pmc_sq.sh: rocprofv3 --pmc SQ_* / GRBM_* passes of `bench.py --inflight 1 --split 1 --steps 1 --warmup 1`; "
+                                            "4 x SQ_ACTIVE_INST_VALU / (1024 x GRBM_GUI_ACTIVE / 8), `_while_resident`: / (1024 x SQ_BUSY_CYCLES / 32)"})
+    out["valu_busy"] = vb
 print(json.dumps(out, indent=1))

@@ -30,10 +30,10 @@ timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RA
 step raw_c2w
 timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/raw_c2w -o w -- python3 bench.py --config c2 --gops 128 --inflight 1 --split 1 --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline --no-e2e --sustain 0 > /dev/null 2>&1
 python3 tools/summarize_pmc.py $RAW/raw_c2f $RAW/raw_c2w > $OUT/c2_pmc_hbm.json
-python3 tools/make_pmc_traffic.py $OUT/pmc_hbm.json $OUT/c2_pmc_hbm.json $HEAD > $OUT/pmc_traffic.json
 step sq
 timeout 600 sh tools/pmc_sq.sh $OUT/sq > /dev/null 2>&1
 cp $OUT/sq/summary.json $OUT/pmc_sq.json
+python3 tools/make_pmc_traffic.py $OUT/pmc_hbm.json $OUT/c2_pmc_hbm.json $HEAD $OUT/pmc_sq.json > $OUT/pmc_traffic.json
 rm -rf $RAW $OUT/sq
 cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
 step bench
