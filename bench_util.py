@@ -62,9 +62,10 @@ def pmc_traffic(key):
 
 
 def pmc_valu_busy(key):
-    """roofline.valu_busy: the fraction of the launch's SIMD-cycles in which the vector ALU was issuing (SQ_ACTIVE_INST_VALU x 4 /
-    (SQ_BUSY_CU_CYCLES-derived SIMD-cycles), computed by tools/make_pmc_traffic.py from the committed SQ counter pass and kept in
-    profiles/pmc_traffic.json under `valu_busy`): which roof binds the dominant kernel is this number, not the HBM fraction."""
+    """roofline.valu_busy: the fraction of the dispatch's SIMD-cycles in which the vector ALU was executing (4 x SQ_ACTIVE_INST_VALU /
+    (1024 x GRBM_GUI_ACTIVE / 8); `valu_busy_while_resident`: of the cycles the shader engines held waves, SQ_BUSY_CYCLES / 32), computed
+    by tools/make_pmc_traffic.py from the committed SQ counter pass and kept in profiles/pmc_traffic.json under `valu_busy`: which roof
+    binds the dominant kernel is this number, not the HBM fraction."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:  # noqa: BLE001

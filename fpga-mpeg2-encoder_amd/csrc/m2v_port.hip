@@ -405,6 +405,9 @@ static int push_beats_impl(m2v_enc *e, void *argp)
     if (src.kind) packed_fmt(src.kind - 1, sf);
     // packed samples in page-locked memory (capture buffers) cross PCIe from where they are
     const bool pinned = src.kind != 0 && e->direct_upload && page_locked_range(src.y - sf.oy, a->n * 4 * (size_t)sf.stride);
+    // ... and so do whole frames of beats on three page-locked arrays: one strided copy per plane (rows = frames)
+    const bool pinned3 = src.kind == 0 && e->direct_upload && a->n >= bpf && page_locked_range(src.y, a->n * 4) && page_locked_range(src.u, a->n * 4) &&
+                         page_locked_range(src.v, a->n * 4);
     bool direct_pending = false;
     while (i < a->n) {
         m2v_enc::HostStage &h = e->st();
@@ -428,6 +431,23 @@ static int push_beats_impl(m2v_enc *e, void *argp)
             }
         } else if (e->beat_pos == 0) {
             e->cur_kind = 0;
+            const size_t whole = std::min((a->n - i) / bpf, e->batch_frames - e->buffered);
+            if (pinned3 && whole >= 1) {
+                const size_t fb = (size_t)g.ysz * 3;
+                h.d_in.ensure(e->batch_frames * fb);
+                if (h.uploaded < e->buffered)           // frames staged on the host earlier in this chunk go first (push_frames_impl does the same)
+                    HIPCHK(hipMemcpyAsync(h.d_in.p + h.uploaded * fb, h.h_in + h.uploaded * fb, (e->buffered - h.uploaded) * fb, hipMemcpyHostToDevice, e->up_stream));
+                const uint8_t *pl[3] = {src.y + i * 4, src.u + i * 4, src.v + i * 4};
+                for (int c = 0; c < 3; ++c)
+                    HIPCHK(hipMemcpy2DAsync(h.d_in.p + e->buffered * fb + (size_t)c * g.ysz, fb, pl[c], g.ysz, g.ysz, whole, hipMemcpyHostToDevice, e->up_stream));
+                h.uploaded = e->buffered + whole;
+                e->up_unsynced = true; e->up_wait_ev = nullptr;
+                direct_pending = true;
+                i += whole * bpf;
+                e->buffered += whole;
+                if (e->buffered == e->batch_frames && !(a->stop && i == a->n)) flush_buffered(e, false);
+                continue;
+            }
         }
         const size_t take = std::min(a->n - i, bpf - e->beat_pos);
         if (e->cur_kind == 0 && src.kind == 0) {

@@ -23,11 +23,22 @@ def run_bench(argv, timeout=900):
 
 
 def test_sequences_mode_two_ranks():
-    line = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0.2", "--no-cpu-baseline", "--gops", "2"])
+    line = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0.2", "--no-cpu-baseline", "--gops", "2", "--strips-steps", "6"])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
     assert line["config"]["launched_by"] == "bench.py" and line["config"]["dist_backend"] == "gloo"
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
     assert line["parity_check"]["ranks_checked"] == 2 and line["parity_check"]["identical_to_oracle"] is True     # every rank, its own clip
+    # the ONE line also carries config c5: both strips legs ran as fresh ranks after the c4 ranks had exited.  On this hook (gloo, one GPU)
+    # the RCCL leg runs the Python loop over gloo; the peer leg runs the NATIVE loop - landing blocks shared between the two processes through
+    # hipIpc handles, sizes and strips through a communicator over gloo - two sequences in flight per rank, the output rank rotating
+    st = line["strips"]
+    for name in ("rccl", "peer"):
+        assert "error" not in st[name], st[name]
+        assert st[name]["value"] > 0 and st[name]["n_gpus"] == 2 and st[name]["identical_to_oracle"] is True, st[name]
+    assert st["rccl"]["strip_loop"] == "python"
+    assert st["peer"]["strip_loop"] == "native" and st["peer"]["transport"].startswith("peer+") and st["peer"]["sequences_in_flight"] == 2
+    assert st["peer"]["in_flight_output_rank_rotating"]["value"] > 0 and st["peer"]["peer_sequences"] + st["peer"]["giveups"] > 0
+    print("strips legs on the shared-GPU hook:", {k: (v["value"], v["ms_per_sequence"], v.get("giveups")) for k, v in st.items()})
 
 
 def test_strips_mode_two_ranks_whole_stream_parity():
@@ -35,6 +46,15 @@ def test_strips_mode_two_ranks_whole_stream_parity():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "strong"
     assert line["config"]["strip_loop"] == "python"            # gloo between two processes on one GPU: the reference loop
     assert line["parity_check"]["identical_to_oracle"] is True and line["parity_check"]["gops_compared"] == 2
+
+
+def test_strips_mode_two_ranks_peer_transport_between_processes_in_flight():
+    line = run_bench(["--gpus", "2", "--mode", "strips", "--transport", "peer", "--rotate-dst", "--steps", "6", "--warmup", "2", "--prewarm", "0", "--gops", "2"])
+    assert line["n_gpus"] == 2 and line["config"]["strip_loop"] == "native" and line["config"]["transport"] == "peer+callbacks"
+    assert line["sequences_in_flight"] == 2 and line["in_flight_output_rank_0"]["identical_to_the_blocking_call"] is True
+    assert line["in_flight_output_rank_rotating"]["value"] > 0
+    assert line["parity_check"]["identical_to_oracle"] is True
+    assert len(line["per_rank_ms_per_step"]["ranks"]) == 2
 
 
 def test_strips_mode_one_rank_runs_the_native_loop():

@@ -275,6 +275,7 @@ def test_packed_and_planar_beats_mixed_inside_frames_and_chunks(env):
     packs = {l: _packed_of(clip, l) for l in layouts}
     pinned = {l: torch.from_numpy(packs[l][0]).pin_memory().numpy() for l in layouts}
     yb, ub, vb = (np.ascontiguousarray(clip[:, c]).reshape(-1) for c in range(3))
+    yp, up_, vp = (torch.from_numpy(a).pin_memory().numpy() for a in (yb, ub, vb))       # the three beat arrays page-locked: whole frames go up from there
     rng = np.random.default_rng(99)
     enc = M.Mpeg2Encoder(6, 6, 2, 3)
     try:
@@ -282,9 +283,11 @@ def test_packed_and_planar_beats_mixed_inside_frames_and_chunks(env):
         b, total = 0, n * bpf
         while b < total:
             take = int(min(total - b, rng.choice([1, 7, bpf // 3, bpf, 2 * bpf + 5, 3 * bpf])))
-            kind = int(rng.integers(0, 9))
+            kind = int(rng.integers(0, 11))
             if kind == 0:
                 enc.push_beats(W // 16, H // 16, pf, yb[4 * b:4 * (b + take)], ub[4 * b:4 * (b + take)], vb[4 * b:4 * (b + take)])
+            elif kind >= 9:
+                enc.push_beats(W // 16, H // 16, pf, yp[4 * b:4 * (b + take)], up_[4 * b:4 * (b + take)], vp[4 * b:4 * (b + take)])
             else:
                 l = layouts[(kind - 1) % 4]
                 src = pinned[l] if kind > 4 else packs[l][0]

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Prints the headline numbers of a bench.py JSON line read from stdin (helper for quick GPU iterations):
-    python bench.py | python tools/bench_brief.py"""
+    python bench.py | python tools/bench_brief.py      or      python tools/bench_brief.py bench.json"""
 import json
 import sys
 
-line = [l for l in sys.stdin.read().splitlines() if l.startswith("{")]
+text = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
+line = [l for l in text.splitlines() if l.startswith("{")]
 if not line:
     print("no JSON line on stdin")
     sys.exit(1)
