@@ -614,6 +614,14 @@ __device__ __forceinline__ void search_rows(const uint32_t *s_cur, uint32_t ae, 
     }
 }
 
+// Measurement aid of experiment 19 (profiles/r06_experiments.txt; tools/variant_build.sh ub=-DM2V_EXP19_QSAD_PER_STEP=3): with 3 every
+// step of the VECTOR_LEVEL 3 search drops its fourth v_qsad - a quarter of the search's vector cycles gone, results INVALID - which
+// bounds from above what any re-packing of the search's 39 dead candidate slots (of 208) could buy.  4 = the kernel as shipped.
+#ifndef M2V_EXP19_QSAD_PER_STEP
+#define M2V_EXP19_QSAD_PER_STEP 4
+#endif
+constexpr int kExp19QsadPerStep = M2V_EXP19_QSAD_PER_STEP;
+
 // The same for VECTOR_LEVEL 3 with the helper lanes (see kS3Cur above): 13 steps, the current row through a per-lane address,
 // the helpers' running sums stored after steps 2, 5, 8, 11 with EXEC narrowed to them (hmask) inside the asm statement.
 typedef const __attribute__((address_space(3))) u32x4_t *LdsU4;
@@ -637,7 +645,7 @@ __device__ __forceinline__ void search_rows13(uint32_t cur, uint32_t cur12, uint
         acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w01, c.x, acc);
         acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w12, c.y, acc);
         acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w23, c.z, acc);
-        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w34, c.w, acc);
+        if constexpr (kExp19QsadPerStep >= 4) acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w34, c.w, acc);
         if constexpr (RR == 2 || RR == 5 || RR == 8)
             asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %1, %0 offset:%3\n\ts_mov_b64 exec, -1"
                          : : "v"(acc), "v"(flush), "s"(hmask), "n"((RR / 3) * 8) : "memory");

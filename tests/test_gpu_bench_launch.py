@@ -41,6 +41,25 @@ def test_sequences_mode_two_ranks():
     print("strips legs on the shared-GPU hook:", {k: (v["value"], v["ms_per_sequence"], v.get("giveups")) for k, v in st.items()})
 
 
+def test_the_drivers_form_torch_distributed_run_also_measures_the_strips():
+    """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2: the ranks are somebody else's children and have touched the GPU
+    when their c4 work is done - each then starts ONE child per strips leg (never an exec) and rank 0 prints the c4 line with `strips`, last"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"M2V_BENCH_SHARE_GPU": "1", "M2V_DIST_BACKEND": "gloo"})
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0.2",
+                        "--gops", "2", "--strips-steps", "4", "--sustain", "0"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["launched_by"] == "caller" and line["parity_check"]["identical_to_oracle"] is True
+    st = line["strips"]
+    assert "error" not in st["rccl"] and "error" not in st["peer"], st
+    assert st["rccl"]["identical_to_oracle"] is True and st["peer"]["identical_to_oracle"] is True
+    assert st["peer"]["strip_loop"] == "native" and st["peer"]["n_gpus"] == 2
+
+
 def test_strips_mode_two_ranks_whole_stream_parity():
     line = run_bench(["--gpus", "2", "--mode", "strips", "--steps", "2", "--warmup", "1", "--prewarm", "0", "--gops", "2"])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "strong"

@@ -102,7 +102,7 @@ def test_peer_counter_sets_survive_sequences_of_different_gop_counts(world):
     print("alternating GOP counts, %d ranks: %r, last form %r" % (world, stats[0], forms[0]))
 
 
-def run_turns(M, d_clips, W, H, pf, VL, world, turns, use_peer=True, rotate=True):
+def run_turns(M, d_clips, W, H, pf, VL, world, turns, use_peer=True, rotate=True, Q=2, general=False):
     """`world` rank threads on GPU 0; every rank keeps TWO strip sequences in flight from its one thread: two handles taking turns
     (m2v_strip_encode_begin / _end), a peer communicator each over ONE shared local base communicator; sequence k encodes
     d_clips[k % len] and, with rotate, is assembled on rank k % world.  -> {sequence index: stream bytes}, [peer stats of rank 0's two]"""
@@ -118,7 +118,9 @@ def run_turns(M, d_clips, W, H, pf, VL, world, turns, use_peer=True, rotate=True
         encs, comms, outs = [], [], []
         try:
             for k in range(2):
-                encs.append(M.Mpeg2Encoder(7, 7, VL, 2))
+                encs.append(M.Mpeg2Encoder(7, 7, VL, Q))
+                if general:
+                    encs[-1].set_option("dct_mfma", 0)            # the general form of the step (pack / unpack kernels, an exchange stream)
                 comms.append(M.StripComm.peer(base, r, 0) if use_peer else base)      # collective: every thread, the same order
                 outs.append(torch.empty(cap, dtype=torch.uint8, device="cuda:0"))
             busy = [None, None]

@@ -3,10 +3,13 @@
 one GPU, the in-process communicator) with strips down to ONE macroblock row, every VECTOR_LEVEL / Q_LEVEL, GOP lengths
 from intra-only to 255, sequences that end inside a GOP, every content kind of tests/test_gpu_fuzz.py; the fused edge-row
 kernel and the general form (pack / unpack kernels) of the step.
-usage (GPU box): python tools/fuzz_strips.py [cases] [seed] [peer]
+usage (GPU box): python tools/fuzz_strips.py [cases] [seed] [peer] [turns]
 "peer": every case with two or more ranks also through the peer transport (landing blocks, arrival counters; a hardware queue per rank is
 asked for so that the ranks' launches do not wait behind each other's waiting blocks) - the number of sequences that really ran in the
-peer form is printed at the end."""
+peer form is printed at the end.
+"turns": every case also with TWO sequences in flight per rank from one thread (m2v_strip_encode_begin / _end on two handles, the case's clip and
+its first frames alone taking turns - different GOP counts on one communicator -, the output rank rotating), in the peer form when "peer" is
+given too, else through the in-process communicator."""
 import os
 import sys
 
@@ -21,9 +24,11 @@ import gpu_util as G
 from oracle import m2v_oracle_ctypes as orc
 from test_gpu_fuzz import make_content
 from test_gpu_strips import run_native_strips
-from test_gpu_strip_peer import run_peer_threads
+from test_gpu_strip_peer import run_peer_threads, run_turns
 
-with_peer = len(sys.argv) > 3 and sys.argv[3] == "peer"
+with_peer = "peer" in sys.argv[3:]
+with_turns = "turns" in sys.argv[3:]
+turn_runs = 0
 peer_runs = peer_form = peer_fallbacks = 0
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
@@ -58,9 +63,35 @@ for case in range(n_cases):
         except Exception as ex:  # noqa: BLE001
             ok = False
             print("   peer:", repr(ex)[:300])
+    if with_turns and ok:
+        try:
+            short = clip[:max(1, n // 2)]
+            want2 = [want, orc.encode(short, W // 16, H // 16, pf, 7, 7, VL, Q)]
+            d2 = [d_clip, torch.from_numpy(np.ascontiguousarray(short)).to("cuda:0")]
+            if world == 1:
+                encs = [G.M.Mpeg2Encoder(7, 7, VL, Q) for _ in range(2)]
+                outs = [torch.empty(G.M.parallel.strip_output_bound(n, W, H), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+                try:
+                    for k in range(2):
+                        G.M.parallel.encode_strips_native_begin(encs[k], None, 0, 1, d2[k], W // 16, H // 16, pf, outs[k])
+                    tg = {k: G.M.parallel.encode_strips_native_end(encs[k], outs[k], 0).cpu().numpy().tobytes() for k in range(2)}
+                finally:
+                    for e_ in encs:
+                        e_.close()
+            else:
+                tg, _ = run_turns(G.M, d2, W, H, pf, VL, world, turns=5, use_peer=with_peer and not general, Q=Q, general=general)
+            ok = all(tg[k] == want2[k % 2] for k in tg) and len(tg) == (2 if world == 1 else 5)
+            turn_runs += 1
+            if not ok:
+                print("    two sequences IN FLIGHT differ", sorted(tg), [tg[k] == want2[k % 2] for k in sorted(tg)])
+        except Exception as ex:  # noqa: BLE001
+            ok = False
+            print("   turns:", repr(ex)[:300])
     bad += not ok
     print("case %2d %4dx%-4d ranks=%d n=%d pf=%3d VL=%d Q=%d %s  %7d bytes  %s" % (case, W, H, world, n, pf, VL, Q, "general" if general else "fused  ", len(want), "ok" if ok else "MISMATCH"), flush=True)
 if with_peer:
     print("peer transport: %d cases x 2 sequences, %d sequences ran in the peer form, %d fell back" % (peer_runs, peer_form, peer_fallbacks))
+if with_turns:
+    print("two sequences in flight (begin / end): %d cases" % turn_runs)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

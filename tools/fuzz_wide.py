@@ -32,9 +32,21 @@ for case in range(n_cases):
         got2 = enc.encode(clip, W // 16, H // 16, pf)
         enc.set_option("split_streams", 1)
         got3 = enc.encode(clip, W // 16, H // 16, pf)
+        # the beats as packed samples, a random layout, pushes that line up with nothing (m2v_push_packed: interleaved until in HBM)
+        layout = ["yuv24", "uyv24", "yuvx32", "ayuv32"][int(rng.integers(0, 4))]
+        y, u, v = clip[:, 0], clip[:, 1], clip[:, 2]
+        pad = np.full_like(y, 0x3C)
+        order = {"yuv24": (y, u, v), "uyv24": (u, y, v), "yuvx32": (y, u, v, pad), "ayuv32": (pad, y, u, v)}[layout]
+        packed = np.ascontiguousarray(np.stack(order, axis=-1)).reshape(-1)
+        bpp, beats, b = len(order), n * W * H // 4, 0
+        while b < beats:
+            take = int(min(beats - b, rng.choice([1, 333, W * H // 4, 2 * (W * H // 4) + 7])))
+            enc.push_packed(W // 16, H // 16, pf, packed[4 * bpp * b:4 * bpp * (b + take)], layout, stop_with_last=(b + take == beats))
+            b += take
+        got4 = enc.pull_all()
     finally:
         enc.close()
-    ok = got == want and got2 == want and got3 == want
+    ok = got == want and got2 == want and got3 == want and got4 == want
     bad += not ok
     print("case %2d %4dx%-4d n=%d pf=%3d VL=%d Q=%d batch=%2d  %7d bytes  %s" % (case, W, H, n, pf, VL, Q, bf, len(want), "ok" if ok else "MISMATCH"))
 print("mismatches:", bad)
