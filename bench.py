@@ -117,7 +117,7 @@ def main():
                          "enqueued with m2v_encode_resident_begin and collected with _end when its handle comes round again; 1 = one "
                          "handle, every step a synchronous m2v_encode_resident call (what rounds 1 and 2 timed)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling aid: skip kernel phases (output invalid), see Geom::ablate")
-    ap.add_argument("--strip-inflight", type=int, default=2,
+    ap.add_argument("--strip-inflight", type=int, default=3,
                     help="--mode strips: sequences in flight per rank from ONE thread: that many handles taking turns through m2v_strip_encode_begin / "
                          "_end (with --transport peer a landing block each) over one base communicator.  1: blocking calls only")
     ap.add_argument("--strip-threads", type=int, default=0,

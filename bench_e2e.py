@@ -58,14 +58,18 @@ def end_to_end(M, cfg, clip_np, want_bytes):
     t_one, d_one = frames_leg(pinned, one_call=True)
 
     # ---- the literal port contract: beats.  Three arrays of 4-pixel beats (the module's i_Y / i_U / i_V lanes), a GOP's worth per call ----
-    planes = [np.ascontiguousarray(pinned[:, c]).reshape(-1) for c in range(3)]       # frame after frame, raster order: beat b = pixels 4b .. 4b + 3
+    planes_t = [torch.from_numpy(np.ascontiguousarray(clip_np[:, c])).pin_memory() for c in range(3)]     # page-locked, frame after frame, raster order:
+    planes = [t.numpy().reshape(-1) for t in planes_t]                                                   # beat b = pixels 4b .. 4b + 3
     fpx = W * H
 
-    def push_beats(enc, k, pos):
-        a, b = k * fpx, min(n, k + gop) * fpx
-        enc.push_beats(XS16, YS16, PFRAMES, planes[0][a:b], planes[1][a:b], planes[2][a:b])
-        return enc.pull_into(outbuf, pos)[0]
-    t_beats, d_beats = drive(push_beats)
+    def beats_leg(src):
+        def push(enc, k, pos):
+            a, b = k * fpx, min(n, k + gop) * fpx
+            enc.push_beats(XS16, YS16, PFRAMES, src[0][a:b], src[1][a:b], src[2][a:b])
+            return enc.pull_into(outbuf, pos)[0]
+        return drive(push)
+    t_beats, d_beats = beats_leg(planes)
+    t_beatspage, d_beatspage = beats_leg([np.array(p) for p in planes])
 
     # ---- ... and as packed YUV24 samples (what a capture card delivers), page-locked and pageable ----
     packed_t = torch.from_numpy(np.ascontiguousarray(np.moveaxis(clip_np, 1, -1))).pin_memory()      # [n, H, W, 3]
@@ -149,10 +153,11 @@ def end_to_end(M, cfg, clip_np, want_bytes):
             # both port groups in one call (m2v_push_frames_pull): the stream bytes of completed chunks are copied into the caller's buffer while
             # the call's frames cross the link - the same loop, one call per GOP instead of two
             "one_call": leg(t_one, d_one, "m2v_push_frames_pull per GOP, then stop and drain"),
-            # RTL:24-28 / TB:224-234 as they are: beats.  Three arrays: three host copies per call into the pinned planar staging, then as the
-            # pageable planar path.  Packed: the caller's bytes go up as they are (page-locked: straight from the caller's buffer), k_unpack444
+            # RTL:24-28 / TB:224-234 as they are: beats.  Packed: the caller's bytes go up as they are (page-locked: straight from the caller's buffer), k_unpack444
             # turns them into planes on the device in front of the chunk's kernels
-            "beats": leg(t_beats, d_beats, "m2v_push_beats, a GOP's beats per call from three (page-locked) arrays: memcpy into the pinned staging"),
+            "beats": leg(t_beats, d_beats, "m2v_push_beats, a GOP's beats per call from three page-locked arrays: whole frames go up with one strided "
+                                          "copy per plane (rows = frames), straight from the caller's arrays",
+                         pageable_source=leg(t_beatspage, d_beatspage, "the same from plain numpy arrays: three host copies per call into the pinned planar staging")),
             "packed_yuv24": leg(t_pk, d_pk, "m2v_push_packed (YUV24), a GOP's beats per call from page-locked memory: uploaded as they are, "
                                             "de-interleaved on the device (k_unpack444)",
                                 pageable_source=leg(t_pkpage, d_pkpage, "the same from a plain numpy array: through the packed pinned staging")),

@@ -31,6 +31,30 @@ void parallel_copy(uint8_t *dst, const uint8_t *src, size_t bytes, int threads)
     for (auto &t : pool) t.join();
 }
 
+// fn(k) for k in [0, count), dealt to up to `threads` threads (the calling one included) when the items move 8 MB or more in all and
+// at least 1 MB each thread (the planes of a run of whole frames: one core moves ~25 GB/s, the link takes twice that)
+template <typename F>
+void parallel_items(size_t count, size_t bytes_each, int threads, F fn)
+{
+    const size_t total = count * bytes_each;
+    const size_t n = total < (8u << 20) ? 1 : std::min<size_t>((size_t)std::max(threads, 1), std::min(count, total >> 20));
+    auto run = [&](size_t k0, size_t k1) { for (size_t k = k0; k < k1; ++k) fn(k); };
+    if (n <= 1) { run(0, count); return; }
+    std::vector<std::thread> pool;
+    pool.reserve(n - 1);
+    try {
+        for (size_t t = 1; t < n; ++t) pool.emplace_back(run, count * t / n, count * (t + 1) / n);
+    } catch (...) {                     // no more threads to be had: the ones that started finish, the rest is done here
+        const size_t started = pool.size() + 1;
+        run(0, count / n);
+        run(count * started / n, count);
+        for (auto &t : pool) t.join();
+        return;
+    }
+    run(0, count / n);
+    for (auto &t : pool) t.join();
+}
+
 void ensure_staging(m2v_enc *e, int idx = -1)
 {
     m2v_enc::HostStage &h = idx < 0 ? e->st() : e->hs[idx];
@@ -443,6 +467,20 @@ static int push_beats_impl(m2v_enc *e, void *argp)
                 h.uploaded = e->buffered + whole;
                 e->up_unsynced = true; e->up_wait_ev = nullptr;
                 direct_pending = true;
+                i += whole * bpf;
+                e->buffered += whole;
+                if (e->buffered == e->batch_frames && !(a->stop && i == a->n)) flush_buffered(e, false);
+                continue;
+            }
+            if (whole >= 2) {
+                // whole frames from ordinary memory: the three planes of each into its slot of the pinned staging, a few threads at work
+                const size_t fb = (size_t)g.ysz * 3, ysz = g.ysz;
+                const uint8_t *pl[3] = {src.y + i * 4, src.u + i * 4, src.v + i * 4};
+                uint8_t *const d0 = h.h_in + e->buffered * fb;
+                parallel_items(3 * whole, ysz, e->copy_threads, [=](size_t k) {
+                    const size_t c = k / whole, f = k % whole;
+                    memcpy(d0 + f * fb + c * ysz, pl[c] + f * ysz, ysz);
+                });
                 i += whole * bpf;
                 e->buffered += whole;
                 if (e->buffered == e->batch_frames && !(a->stop && i == a->n)) flush_buffered(e, false);
