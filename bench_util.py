@@ -263,14 +263,19 @@ def hbm_copy_rate(torch, dev):
 # guaranteed, ~3 % behind the best placement).  Blocking calls are the last resort.  The thresholds live here, once.
 # ---------------------------------------------------------------------------------------------------------------------
 PLACEMENT_OVERLAP_GAIN = 0.96            # in flight must beat the one-stream form by 4 % to count as overlapping
+PLACEMENT_BEATS_BLOCKING = 0.985         # ... or the blocking form by 1.5 %: then there is nothing to repair, whatever the streams sit on
 PLACEMENT_MAX_NEW_STREAMS = 3
 
 
-def placement_next_action(t_in_flight, t_one_stream, new_streams, priority_tried, repair_allowed=True):
+def placement_next_action(t_in_flight, t_one_stream, new_streams, priority_tried, repair_allowed=True, t_blocking=None):
     """One row of the decision table: given the probe times (seconds for the same number of sequences) -> "keep" (the sequences overlap,
     or nothing more can be tried), "new_stream" (give the last handle a fresh stream and probe again) or "priority" (give it a stream of
-    another priority and probe again)."""
+    another priority and probe again).  A GPU at its power limit gains little from ANY overlap (profiles/r06_experiments.txt item 23:
+    blocking 1.021 ms, one stream 1.024, in flight 0.993 - and 1.03 - 1.05 after the re-streamings): when in flight already beats the
+    blocking form the placement is left alone - a re-streaming cannot be taken back."""
     if t_in_flight <= PLACEMENT_OVERLAP_GAIN * t_one_stream or not repair_allowed:
+        return "keep"
+    if t_blocking is not None and t_in_flight <= PLACEMENT_BEATS_BLOCKING * t_blocking:
         return "keep"
     if new_streams < PLACEMENT_MAX_NEW_STREAMS:
         return "new_stream"
@@ -293,9 +298,9 @@ def settle_queue_placement(probe_in_flight, probe_blocking, probe_one_stream, re
     rec = {"new_streams": 0, "priority": 0,
            "probe_ms_per_step": {"blocking": round(t_sync * per_step * 1e3, 3), "one_stream": round(t_serial * per_step * 1e3, 3),
                                  "in_flight": [round(t_fly * per_step * 1e3, 3)]},
-           "thresholds": {"overlap_gain": PLACEMENT_OVERLAP_GAIN, "max_new_streams": PLACEMENT_MAX_NEW_STREAMS}}
+           "thresholds": {"overlap_gain": PLACEMENT_OVERLAP_GAIN, "beats_blocking": PLACEMENT_BEATS_BLOCKING, "max_new_streams": PLACEMENT_MAX_NEW_STREAMS}}
     while True:
-        act = placement_next_action(t_fly, t_serial, rec["new_streams"], rec["priority"] != 0, repair_allowed)
+        act = placement_next_action(t_fly, t_serial, rec["new_streams"], rec["priority"] != 0, repair_allowed, t_sync)
         if act == "keep":
             break
         restream(act)

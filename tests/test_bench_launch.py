@@ -221,6 +221,11 @@ def test_queue_placement_decision_table():
     assert sub == "blocking" and len(acts) == bu.PLACEMENT_MAX_NEW_STREAMS + 1
     sub, rec, acts = settle([1.00], 0.97, 1.00, allowed=False)
     assert sub == "blocking" and acts == []
+    # a power-capped GPU: no form overlaps by 4 %, but in flight beats the blocking form as it is - left alone (a re-streaming cannot be undone)
+    sub, rec, acts = settle([0.993, 1.029], 1.021, 1.024)
+    assert sub == "in_flight" and acts == [] and rec["probe_ms_per_step"]["in_flight"] == [993.0]
+    sub, rec, acts = settle([1.010, 0.95], 1.021, 1.024)           # ... within 1.5 % of it: repaired as before
+    assert acts == ["new_stream"] and sub == "in_flight"
     # the threshold itself: exactly at the gain counts as overlapping, a hair above does not
     assert bu.placement_next_action(G * 1.0, 1.0, 0, False) == "keep" and bu.placement_next_action(G * 1.0 + 1e-9, 1.0, 0, False) == "new_stream"
     assert bu.placement_next_action(1.0, 1.0, bu.PLACEMENT_MAX_NEW_STREAMS, False) == "priority"
