@@ -59,7 +59,7 @@ def sq_kernel(needle):
 
 
 vb = {}
-for key, needle in (("k_mb_p_bytes_per_launch", "k_mb<3, true"), ("k_mb_i_bytes_per_launch", "k_mb<1, false")):       # (I frames run the VL-independent instantiation)
+for key, needle in (("k_mb_p_bytes_per_launch", "k_mb<3, true"), ("k_mb_i_c2_bytes_per_launch", "k_mb<1, false")):    # (I frames run the VL-independent instantiation: config c2's kernel, counted here on c3's I launches)
     k = sq_kernel(needle)
     if not k:
         continue
