@@ -16,6 +16,7 @@ import torch
 import gpu_util as G
 from oracle import m2v_oracle_ctypes as orc
 from test_gpu_strips import run_native_strips
+from test_gpu_strip_peer import run_turns
 
 M = G.M
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 6
@@ -52,7 +53,7 @@ def worker(t):
     for it in range(R):
         c = cases[int(r.integers(0, len(cases)))]
         W, H, n, pf, VL, Q, clip, want = c
-        kind = int(r.integers(0, 5))
+        kind = int(r.integers(0, 7))
         t_begin = time.perf_counter()
         try:
             if kind == 0:
@@ -96,6 +97,45 @@ def worker(t):
                     ok = out[:pos].tobytes() == want
                 finally:
                     e.close()
+            elif kind == 5:
+                # the beat entry points: packed samples / three arrays, page-locked or not, calls that line up with nothing (round 6: packed bytes
+                # are de-interleaved on the device, whole frames of beats upload as strided copies)
+                e = M.Mpeg2Encoder(7, 7, VL, Q)
+                try:
+                    e.set_option("batch_frames", int(r.choice([1, 2, 5, 96])))
+                    layout = ["yuv24", "uyv24", "yuvx32", "ayuv32", None][int(r.integers(0, 5))]
+                    pin = bool(r.integers(0, 2))
+                    y, u, v = clip[:, 0], clip[:, 1], clip[:, 2]
+                    if layout is None:
+                        arrs = [np.ascontiguousarray(a).reshape(-1) for a in (y, u, v)]
+                        if pin:
+                            arrs = [torch.from_numpy(a).pin_memory().numpy() for a in arrs]
+                        bpp = 1
+                    else:
+                        pad = np.full_like(y, 0x11)
+                        order = {"yuv24": (y, u, v), "uyv24": (u, y, v), "yuvx32": (y, u, v, pad), "ayuv32": (pad, y, u, v)}[layout]
+                        pk = np.ascontiguousarray(np.stack(order, axis=-1)).reshape(-1)
+                        pk = torch.from_numpy(pk).pin_memory().numpy() if pin else pk
+                        bpp = len(order)
+                    beats, b, bpf = n * W * H // 4, 0, W * H // 4
+                    while b < beats:
+                        take = int(min(beats - b, r.choice([7, bpf // 2 + 1, bpf, 2 * bpf, 3 * bpf + 5])))
+                        stop = b + take == beats
+                        if layout is None:
+                            e.push_beats(W // 16, H // 16, pf, arrs[0][4 * b:4 * (b + take)], arrs[1][4 * b:4 * (b + take)], arrs[2][4 * b:4 * (b + take)], stop_with_last=stop)
+                        else:
+                            e.push_packed(W // 16, H // 16, pf, pk[4 * bpp * b:4 * bpp * (b + take)], layout, stop_with_last=stop)
+                        b += take
+                    ok = e.pull_all() == want
+                finally:
+                    e.close()
+            elif kind == 6:
+                # strip sequences in flight from one thread per rank (m2v_strip_encode_begin / _end), the ranks further threads, peer form or not
+                world = int(r.integers(2, min(4, H // 16) + 1))
+                d = torch.from_numpy(np.ascontiguousarray(clip)).cuda()
+                torch.cuda.synchronize()
+                got, _ = run_turns(M, [d], W, H, pf, VL, world, turns=4, use_peer=bool(r.integers(0, 2)), Q=Q)
+                ok = len(got) == 4 and all(g == want for g in got.values())
             else:
                 world = int(r.integers(1, min(5, H // 16) + 1))
                 d = torch.from_numpy(np.ascontiguousarray(clip)).cuda()
