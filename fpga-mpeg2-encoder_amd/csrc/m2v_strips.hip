@@ -316,6 +316,7 @@ struct m2v::StripFlight {
     StripSeq q{};
     Geom full{};
     bool defer_sizes = false;       // the sizes all-gather has not been issued yet (it is the first thing the collection does)
+    bool halves = false;            // launched by m2v_strip_encode_begin (a rank that does not own the output then leaves _end without the final wait)
     bool use_peer = false;
     PeerState *pst = nullptr;
     int fail = 0;
@@ -657,6 +658,7 @@ static int strip_launch(m2v_enc *e, StripFlight &F, const StripEncodeArgs &args,
     e->strip_inflight = false;
     F.a = args;
     F.defer_sizes = defer_sizes;
+    F.halves = defer_sizes;
     StripEncodeArgs *a = &F.a;
     const int rank = a->rank, world = a->world;
     F.full = make_geom(e, a->xs, a->ys);
@@ -812,7 +814,13 @@ static int strip_collect(m2v_enc *e, StripFlight &F, size_t *bytes)
         if (!e->st().h_ctl) HIPCHK(hipHostMalloc((void **)&e->st().h_ctl, 2 * sizeof(StreamCtl)));
         HIPCHK(hipMemcpyAsync(e->st().h_ctl, e->d_ctl.p, sizeof(StreamCtl), hipMemcpyDeviceToHost, s));
     } else if (e->profile) { g1 = pool_event(e); timer_break(e); HIPCHK(hipEventRecord(g1, s)); }
-    HIPCHK(hipStreamSynchronize(s));
+    // The final wait.  The output rank's caller reads d_out next; the blocking call promises a synchronised stream.  A rank that only SENT its
+    // strip leaves m2v_strip_encode_end without it: everything the host reads (sizes, this strip's control word) was complete at the wait for
+    // the sizes, the send reads d_strip_own on this handle's stream and the handle's next sequence is ordered behind it there - and a send
+    // completes when the output rank has posted its receive, so waiting for it would tie every rank's host to the output rank's pace,
+    // sequence by sequence, which is exactly what sequences in flight are there to undo.
+    const bool final_wait = rank == a->dst || !F.halves || e->profile;
+    if (final_wait) HIPCHK(hipStreamSynchronize(s));
     {
         const StreamCtl *c = (const StreamCtl *)(e->h_strip + (nf + 1) * sizeof(unsigned long long));
         if (c->overflow) { e->set_err("strip buffer too small"); return M2V_E_OVERFLOW; }
@@ -834,8 +842,10 @@ static int strip_collect(m2v_enc *e, StripFlight &F, size_t *bytes)
         e->strip_stats.halo_total_ms = tot;
         e->strip_stats.halo_exposed_ms = exp;
     }
-    collect_timers(e);
-    e->strip_stream = nullptr;                               // synchronised above: nothing of the sequence is left on the caller's stream
+    if (final_wait) {
+        collect_timers(e);
+        e->strip_stream = nullptr;                           // synchronised above: nothing of the sequence is left on the caller's stream
+    }                                                        // (else: m2v_reset / m2v_destroy / the next sequence's waits take care of it)
     if (bytes) *bytes = out_bytes;
     return M2V_OK;
 }

@@ -294,8 +294,10 @@ int m2v_strip_encode(m2v_enc *e, m2v_comm *comm, int rank, int world, int dst_ra
 /*
  * The same sequence in two halves, so that ONE thread keeps two strip sequences in flight on two handles (as m2v_encode_resident_begin /
  * _end do for the whole frame): _begin enqueues the GOP steps and this strip's slices and returns; _end issues the all-gather of the sizes,
- * does the one host wait, sends / receives the strips and, on the output rank, assembles the stream; when it returns the handle's stream
- * is synchronised and *out_bytes holds the byte count (0 on the other ranks).  Between the two calls the handle takes no other work
+ * does the one host wait, sends / receives the strips and, on the output rank, assembles the stream; when it returns on the output rank
+ * the handle's stream is synchronised, d_out is complete and *out_bytes holds the byte count.  On the other ranks (*out_bytes = 0) the
+ * strip may still be on its way to the output rank: the handle's next call is ordered behind it on its stream (m2v_reset and m2v_destroy
+ * wait for it), and a caller-owned hip_stream has to be synchronised by the caller before it is destroyed.  Between the two calls the handle takes no other work
  * (M2V_E_STATE).  Handles that take turns each need a peer communicator of their own (landing block, arrival counters) - over ONE shared
  * base communicator: every collective of a sequence's second half is issued by _end, so the ranks issue their collectives in one and the
  * same order (begin A, begin B, end A, begin A', end B ...) and RCCL, which runs a communicator's operations in issue order whatever
