@@ -113,6 +113,35 @@ def test_plain_c_caller_encodes_one_sequence_as_strips(tmp_path, nranks, W, H, p
     assert out.read_bytes() == orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
 
 
+@pytest.mark.parametrize("nranks,K", [(3, 2), (2, 3), (1, 2)])
+def test_plain_c_caller_keeps_strip_sequences_in_flight(tmp_path, nranks, K):
+    """integration/strip_inflight_caller.c (gcc, C99, pthreads): every rank keeps K strip sequences in flight from its one thread
+    (m2v_strip_encode_begin / _end on K handles taking turns), a peer communicator per handle over one in-process base communicator, the
+    output rank rotating - the C form of `bench.py --mode strips --transport peer --rotate-dst`.  Seven
+    sequences of the same clip: every stream the oracle's, written by the rank it was assembled on."""
+    import m2v_load
+    from oracle import m2v_oracle_ctypes as orc
+    M = m2v_load.load()
+    M.build()
+    libdir = os.path.join(ROOT, "fpga-mpeg2-encoder_amd")
+    exe = str(tmp_path / "strip_inflight_caller")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+           os.path.join(ROOT, "integration", "strip_inflight_caller.c"), "-L" + libdir, "-lm2v_mi355x", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    W, H, pf, n, nseq = 160, 128, 3, 9, 7
+    clip = M.synth.clip(W, H, n, clip_index=150 + nranks, scene_len=5)
+    (tmp_path / "in.yuv").write_bytes(clip.tobytes())
+    r = subprocess.run([exe, str(tmp_path / "in.yuv"), str(W), str(H), str(pf), str(nranks), str(nseq), str(K), str(tmp_path / "out")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "%d in flight per rank" % K in r.stdout
+    want = orc.encode(clip, W // 16, H // 16, pf, 7, 7, 3, 2)
+    for i in range(nseq):
+        assert (tmp_path / ("out.%d.m2v" % i)).read_bytes() == want, "sequence %d" % i
+
+
 def test_plain_c_caller_keeps_two_sequences_in_flight(tmp_path):
     """integration/pipeline_caller.c (gcc, C99): m2v_encode_resident_begin / _end on two handles taking turns - the submission form
     bench.py's timed loop uses - from plain C.  Seven sequences of the same clip: every stream identical, and the oracle's."""
