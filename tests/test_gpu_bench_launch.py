@@ -36,7 +36,7 @@ def test_sequences_mode_two_ranks():
         assert "error" not in st[name], st[name]
         assert st[name]["value"] > 0 and st[name]["n_gpus"] == 2 and st[name]["identical_to_oracle"] is True, st[name]
     assert st["rccl"]["strip_loop"] == "python"
-    assert st["peer"]["strip_loop"] == "native" and st["peer"]["transport"].startswith("peer+") and st["peer"]["sequences_in_flight"] == 2
+    assert st["peer"]["strip_loop"] == "native" and st["peer"]["transport"].startswith("peer+") and st["peer"]["sequences_in_flight"] == 3
     assert st["peer"]["in_flight_output_rank_rotating"]["value"] > 0 and st["peer"]["peer_sequences"] + st["peer"]["giveups"] > 0
     print("strips legs on the shared-GPU hook:", {k: (v["value"], v["ms_per_sequence"], v.get("giveups")) for k, v in st.items()})
 
@@ -70,7 +70,7 @@ def test_strips_mode_two_ranks_whole_stream_parity():
 def test_strips_mode_two_ranks_peer_transport_between_processes_in_flight():
     line = run_bench(["--gpus", "2", "--mode", "strips", "--transport", "peer", "--rotate-dst", "--steps", "6", "--warmup", "2", "--prewarm", "0", "--gops", "2"])
     assert line["n_gpus"] == 2 and line["config"]["strip_loop"] == "native" and line["config"]["transport"] == "peer+callbacks"
-    assert line["sequences_in_flight"] == 2 and line["in_flight_output_rank_0"]["identical_to_the_blocking_call"] is True
+    assert line["sequences_in_flight"] == 3 and line["in_flight_output_rank_0"]["identical_to_the_blocking_call"] is True
     assert line["in_flight_output_rank_rotating"]["value"] > 0
     assert line["parity_check"]["identical_to_oracle"] is True
     assert len(line["per_rank_ms_per_step"]["ranks"]) == 2
