@@ -117,20 +117,32 @@ def _bench(argv, timeout=1500):
 def test_bench_strips_on_two_gpus_with_real_rccl():
     """config c5 over two devices, one process per GPU, RCCL send / recv of the halo rows from C++ (strip_loop native): the
     assembled stream is the oracle's"""
-    r, lines = _bench(["--gpus", "2", "--mode", "strips", "--steps", "3", "--warmup", "1", "--prewarm", "0.2", "--gops", "2"])
+    r, lines = _bench(["--gpus", "2", "--mode", "strips", "--rotate-dst", "--steps", "6", "--warmup", "1", "--prewarm", "0.2", "--gops", "2"])
     assert r.returncode == 0, r.stderr[-3000:]
     d = lines[-1]
     assert d["n_gpus"] == 2 and d["config"]["strip_loop"] == "native", d["config"]
     assert d["parity_check"]["identical_to_oracle"] is True
+    # three sequences in flight per rank from one thread on the ONE RCCL communicator, output rank fixed and rotating
+    assert d["sequences_in_flight"] == 3 and d["in_flight_output_rank_0"]["identical_to_the_blocking_call"] is True
+    assert d["in_flight_output_rank_rotating"]["value"] > 0
 
 
 @need2
 def test_bench_sequences_on_two_gpus():
     """config c4 with two ranks: independent sequences, no collective on the data path; both ranks' streams checked"""
-    r, lines = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm", "0.2", "--gops", "2", "--no-cpu-baseline", "--no-e2e"])
+    r, lines = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm", "0.2", "--gops", "2", "--no-cpu-baseline", "--no-e2e", "--strips-steps", "6"])
     assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
     d = lines[-1]
     assert d["n_gpus"] == 2 and d["parity_check"]["identical_to_oracle"] is True
+    # the one line also carries config c5 over the two devices: RCCL halo, then peer stores across xGMI - numbers, or a stated error that
+    # did not cost the c4 line (printed either way: this is the first contact)
+    print("strips legs on two GPUs:", json.dumps(d["strips"])[:2000])
+    assert set(d["strips"]) == {"rccl", "peer"}
+    for name in ("rccl", "peer"):
+        leg = d["strips"][name]
+        assert "error" in leg or (leg["n_gpus"] == 2 and leg["identical_to_oracle"] is True and leg["value"] > 0), leg
+    assert "error" not in d["strips"]["rccl"], d["strips"]["rccl"]
 
 
 @need2
@@ -192,7 +204,7 @@ def test_peer_transport_with_ranks_on_two_devices(world):
 def test_bench_strips_on_two_gpus_with_the_peer_transport():
     """config c5 over two devices, one process per GPU: landing blocks mapped through hipIpc handles (all-gathered over RCCL), the
     halo rows stored across xGMI by the edge-row kernel itself; sizes and strips through RCCL.  The stream is the oracle's."""
-    r, lines = _bench(["--gpus", "2", "--mode", "strips", "--transport", "peer", "--steps", "3", "--warmup", "1", "--prewarm", "0.2", "--gops", "2"])
+    r, lines = _bench(["--gpus", "2", "--mode", "strips", "--transport", "peer", "--rotate-dst", "--steps", "6", "--warmup", "1", "--prewarm", "0.2", "--gops", "2"])
     assert r.returncode == 0, r.stderr[-3000:]
     d = lines[-1]
     assert d["n_gpus"] == 2 and d["config"]["strip_loop"] == "native" and d["config"]["transport"] == "peer+rccl", d["config"]
