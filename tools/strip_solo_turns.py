@@ -20,11 +20,12 @@ ap.add_argument("--peer", type=int, default=1)
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--seconds", type=float, default=1.5)
 ap.add_argument("--ranks", type=int, nargs="+", default=None)
+ap.add_argument("--gops", type=int, default=10, help="GOPs (of 1 I + 8 P) in the sequence: a GOP step is ONE launch over the step's frames of all GOPs")
 ap.add_argument("--split", type=int, nargs="+", default=[-1], help="option split_streams of the handles (GOP groups on a stream each); -1 = the library's default")
 args = ap.parse_args()
 M = m2v_load.load()
 W = H = 2048
-pf, n, world = 8, 90, args.world
+pf, n, world = 8, 9 * args.gops, args.world
 clip = M.synth.clip_torch(W, H, n, clip_index=0, device="cuda:0")
 torch.cuda.synchronize()
 for K, split in [(k, sp) for k in args.handles for sp in args.split]:
@@ -56,14 +57,15 @@ for K, split in [(k, sp) for k in args.handles for sp in args.split]:
                     done += 1
             return done
         try:
-            run(count=300)
+            run(count=max(30, 3000 // args.gops))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             seqs = run(limit_s=args.seconds)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             print(json.dumps({"handles_in_flight": K, "split_streams": split, "rank": rank, "world": world, "base": base.kind, "peer": comms[0].peer_stats() if args.peer else None,
-                              "form": encs[0].strip_last_form(), "sequences": seqs, "ms_per_sequence": round(dt / seqs * 1e3, 4)}), flush=True)
+                              "form": encs[0].strip_last_form(), "gops": args.gops, "sequences": seqs, "ms_per_sequence": round(dt / seqs * 1e3, 4),
+                              "ms_per_90_frames": round(dt / seqs * 1e3 * 10 / args.gops, 4)}), flush=True)
         finally:
             for c in comms:
                 if c is not base:
