@@ -128,6 +128,10 @@ def main():
                     help="N > 1, default mode: after the c4 measurement run config c5 (--mode strips; RCCL halo, then --transport peer) as fresh child "
                          "processes under a time bound and attach the results to the c4 line as `strips` (bench_launch.py).  off: the c4 line alone")
     ap.add_argument("--strips-steps", type=int, default=40, help="steps of each strips leg")
+    ap.add_argument("--long-gops", type=int, default=-1,
+                    help="--mode strips: also time the in-flight loop on a sequence of this many GOPs (a GOP step is ONE launch over the step's frames of all "
+                         "GOPs: longer sequences make larger launches; reported per 90 frames as `in_flight_long_sequence`).  -1 (default): 40 in the strips "
+                         "legs of the default N > 1 job, off in a plain --mode strips run; 0: off")
     ap.add_argument("--transport", choices=["rccl", "peer"], default=os.environ.get("M2V_STRIP_TRANSPORT", "rccl"),
                     help="--mode strips, N > 1: how the halo rows travel.  rccl (default): ncclSend / ncclRecv per GOP step.  peer: the edge-row "
                          "kernel stores them straight into the neighbour's landing block (hipIpc-mapped) and counts their arrival - one launch "

@@ -128,7 +128,8 @@ def leg_argv(args, transport_flags):
     """the command line of one strips leg: the job's size and warm-up, the leg's own step count, two sequences in flight from one thread
     with the output rank rotating; the whole-stream oracle check stays on"""
     a = ["--gpus", str(args.gpus), "--mode", "strips", "--steps", str(args.strips_steps), "--warmup", str(min(args.warmup, 10)),
-         "--gops", str(args.gops), "--prewarm", str(min(args.prewarm, 0.5)), "--rotate-dst", "--strips-legs", "off"] + transport_flags
+         "--gops", str(args.gops), "--prewarm", str(min(args.prewarm, 0.5)), "--rotate-dst", "--strips-legs", "off",
+         "--long-gops", str(40 if args.long_gops < 0 else args.long_gops)] + transport_flags
     if args.dry_launch:
         a.append("--dry-launch")
     return a
@@ -162,6 +163,7 @@ def summarize_leg(lines, rc, timed_out, seconds, stderr_tail=None):
             "scaling": line.get("scaling"), "sequences_in_flight": line.get("sequences_in_flight"), "in_flight_form": line.get("in_flight_form"),
             "one_sequence_at_a_time": line.get("one_sequence_at_a_time"), "in_flight_output_rank_0": line.get("in_flight_output_rank_0"),
             "in_flight_output_rank_rotating": line.get("in_flight_output_rank_rotating"),
+            "in_flight_long_sequence": line.get("in_flight_long_sequence"),
             "transport": cfg.get("transport"), "transport_asked_for": cfg.get("transport_asked_for"), "strip_loop": cfg.get("strip_loop"),
             "strip_loop_why": cfg.get("strip_loop_why"), "gop_steps_ran_as": cfg.get("gop_steps_ran_as"),
             "peer_sequences": sum(p["peer_sequences"] for p in peer) if peer else None,

@@ -75,7 +75,8 @@ def bench_strips(args, cfg, M, torch, dist, rank, local_rank, world, dev):
                 ok, made, peer_why = 1, [], None
                 try:
                     for k in range(K):
-                        made.append(M.StripComm.peer(comms[k], rank, local_rank, halo_bytes=args.gops * 9 * VL // 3 * Ws + 4096))
+                        # (a landing buffer holds one GOP step's rows of ALL GOPs: sized for the longest sequence this run encodes)
+                        made.append(M.StripComm.peer(comms[k], rank, local_rank, halo_bytes=max(args.gops, args.long_gops) * 3 * VL * Ws + 4096))
                 except Exception as ex:  # noqa: BLE001
                     ok, peer_why = 0, "m2v_comm_init_peer: %s" % ex
                 t = torch.tensor([ok], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
@@ -165,7 +166,7 @@ def bench_strips(args, cfg, M, torch, dist, rank, local_rank, world, dev):
     dt, out = timed(lambda: [step() for _ in range(args.steps)][-1])
     # ---- sequences in flight from one thread (turns), the output rank fixed and - if asked for - rotating ----
     dt_turns = dt_rot = dt_thr = None
-    turns_identical = None
+    turns_identical = long_res = None
     if loop == "native" and K > 1 and not threads_form:
         for e in encs:
             e.set_option("split_streams", 1)  # in flight the sequences themselves are what overlaps: one stream each (tools/strip_solo_turns.py)
@@ -176,6 +177,25 @@ def bench_strips(args, cfg, M, torch, dist, rank, local_rank, world, dev):
         if rotate:
             guarded(run_turns, max(2 * K, 2 * world), True)
             dt_rot, _ = timed(run_turns, args.steps, True)
+        # ---- the same in-flight loop on a LONGER sequence: a GOP step is one launch over the step's frames of ALL GOPs, so G GOPs make every launch
+        #      G / gops times as large and the ramp and drain of the nine launches weigh that much less (profiles/r06_experiments.txt item 20) ----
+        if args.long_gops > 0 and args.long_gops != args.gops:
+            n_long = args.long_gops * gop
+            clip_s, outs_s = clip, d_outs
+            long_res = None
+            try:
+                clip = M.synth.clip_torch(Ws, Hs, n_long, clip_index=0, device=dev)
+                d_outs = [torch.empty(n_long * Ws * Hs * 3 // 2, dtype=torch.uint8, device=dev) if (rank == 0 or rotate) else None for _ in range(K)]
+                torch.cuda.synchronize()
+                steps_long = max(2 * K, args.steps * args.gops // args.long_gops)
+                guarded(run_turns, 2 * K, rotate)
+                barrier()
+                t0 = time.perf_counter()
+                guarded(run_turns, steps_long, rotate)
+                barrier()
+                long_res = (time.perf_counter() - t0, steps_long, n_long, enc.strip_last_form())
+            finally:
+                clip, d_outs = clip_s, outs_s
         for e in encs:
             e.set_option("split_streams", cfg.LIB_DEFAULT_SPLIT_STREAMS)
     # ---- the same with K host threads (opt-in): thread k runs steps k, k + K, ... on stack k (the same split on every rank) ----
@@ -223,9 +243,10 @@ def bench_strips(args, cfg, M, torch, dist, rank, local_rank, world, dev):
     if dist is not None:
         on = dev if backend == "nccl" else "cpu"
         t = torch.tensor([dt, timings.get("halo_exposed", 0.0), timings.get("halo_total", 0.0), timings.get("gather", 0.0), dt_turns or 0.0, dt_rot or 0.0,
-                          dt_thr or 0.0], dtype=torch.float64, device=on)
+                          dt_thr or 0.0, long_res[0] if long_res else 0.0], dtype=torch.float64, device=on)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, timings["halo_exposed"], timings["halo_total"], timings["gather"], m_turns, m_rot, m_thr = (float(v) for v in t.tolist())
+        dt, timings["halo_exposed"], timings["halo_total"], timings["gather"], m_turns, m_rot, m_thr, m_long = (float(v) for v in t.tolist())
+        long_res = (m_long,) + tuple(long_res[1:]) if long_res else None
         dt_turns, dt_rot, dt_thr = (m if x is not None else None for x, m in ((dt_turns, m_turns), (dt_rot, m_rot), (dt_thr, m_thr)))
         mine = torch.tensor([ms_p, ms_i, ms_scan + ms_asm, timings.get("halo_exposed", 0.0)], dtype=torch.float64, device=on)
         every = [torch.empty_like(mine) for _ in range(world)]
@@ -254,6 +275,11 @@ def bench_strips(args, cfg, M, torch, dist, rank, local_rank, world, dev):
             "one_sequence_at_a_time": {"value": rate(dt), "ms_per_step": per(dt)},
             "in_flight_output_rank_0": {"value": rate(dt_turns), "ms_per_step": per(dt_turns), "identical_to_the_blocking_call": turns_identical} if dt_turns else None,
             "in_flight_output_rank_rotating": {"value": rate(dt_rot), "ms_per_step": per(dt_rot)} if dt_rot else None,
+            "in_flight_long_sequence": {"gops": args.long_gops, "frames": long_res[2], "sequences": long_res[1],
+                                        "value": round(long_res[1] * long_res[2] * Ws * Hs / long_res[0] * 1e-6, 2),
+                                        "ms_per_90_frames": round(long_res[0] / long_res[1] * 1e3 * 90 / long_res[2], 4),
+                                        "output_rank": "rotating" if rotate else "rank 0", "gop_steps_ran_as": long_res[3],
+                                        "note": "the same loop on a sequence of %d GOPs: a GOP step is one launch over all GOPs' frames" % args.long_gops} if long_res else None,
             "config": {"workload": "c5: ONE 2048x2048 yuv444p sequence, %d GOPs of 1 I + %d P, VECTOR_LEVEL=3 Q_LEVEL=2, "
                                    "%d strips of macroblock rows, halo = 9 rows x 2048 B per frame per direction"
                                    % (args.gops, PFRAMES, world), "frames": nframes,

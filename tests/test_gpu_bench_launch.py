@@ -23,7 +23,7 @@ def run_bench(argv, timeout=900):
 
 
 def test_sequences_mode_two_ranks():
-    line = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0.2", "--no-cpu-baseline", "--gops", "2", "--strips-steps", "6"])
+    line = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0.2", "--no-cpu-baseline", "--gops", "2", "--strips-steps", "6", "--long-gops", "6"])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
     assert line["config"]["launched_by"] == "bench.py" and line["config"]["dist_backend"] == "gloo"
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
@@ -38,6 +38,8 @@ def test_sequences_mode_two_ranks():
     assert st["rccl"]["strip_loop"] == "python"
     assert st["peer"]["strip_loop"] == "native" and st["peer"]["transport"].startswith("peer+") and st["peer"]["sequences_in_flight"] == 3
     assert st["peer"]["in_flight_output_rank_rotating"]["value"] > 0 and st["peer"]["peer_sequences"] + st["peer"]["giveups"] > 0
+    long = st["peer"]["in_flight_long_sequence"]
+    assert long["gops"] == 6 and long["frames"] == 54 and long["value"] > 0 and long["gop_steps_ran_as"] in ("peer", "calls")
     print("strips legs on the shared-GPU hook:", {k: (v["value"], v["ms_per_sequence"], v.get("giveups")) for k, v in st.items()})
 
 
@@ -48,7 +50,7 @@ def test_the_drivers_form_torch_distributed_run_also_measures_the_strips():
     env.update({"M2V_BENCH_SHARE_GPU": "1", "M2V_DIST_BACKEND": "gloo"})
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0.2",
-                        "--gops", "2", "--strips-steps", "4", "--sustain", "0"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+                        "--gops", "2", "--strips-steps", "4", "--long-gops", "4", "--sustain", "0"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -130,7 +130,7 @@ def test_bench_strips_on_two_gpus_with_real_rccl():
 @need2
 def test_bench_sequences_on_two_gpus():
     """config c4 with two ranks: independent sequences, no collective on the data path; both ranks' streams checked"""
-    r, lines = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm", "0.2", "--gops", "2", "--no-cpu-baseline", "--no-e2e", "--strips-steps", "6"])
+    r, lines = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm", "0.2", "--gops", "2", "--no-cpu-baseline", "--no-e2e", "--strips-steps", "6", "--long-gops", "8"])
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1
     d = lines[-1]
