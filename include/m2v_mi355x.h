@@ -333,7 +333,9 @@ int m2v_strip_graph_stats(const m2v_enc *e, int *last_call_was_graph, int *recor
  * "copy_threads" (default 8: threads m2v_push_frames uses to copy large inputs into pinned memory),
  * "direct_upload" (default 1: frames handed to m2v_push_frames in page-locked host memory - hipHostMalloc / hipHostRegister -
  * are uploaded straight from the caller's buffer, without the copy into the handle's pinned staging; the call returns when
- * the upload of its frames has completed, the encoding continues asynchronously.  2 = the same with the completion DEFERRED: the
+ * the upload of its frames has completed, the encoding continues asynchronously.  The same holds for m2v_push_packed (the packed
+ * bytes go up as they are and are de-interleaved on the device) and for whole frames of m2v_push_beats on three page-locked arrays
+ * (one strided copy per plane); these two always return with their bytes read.  2 = the same with the completion DEFERRED: the
  * call returns while its frames are still being read, and what it waits for is the PREVIOUS call's upload - the caller keeps a
  * pushed range unchanged until the next m2v_push_frames, m2v_sequence_stop or m2v_upload_wait on the handle has returned; the copy
  * engine then always has the next transfer queued behind the running one, which is what a single caller needs to keep the link
