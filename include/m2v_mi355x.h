@@ -112,6 +112,9 @@ long long m2v_pull(m2v_enc *e, uint8_t *dst, size_t cap, int *last);
  * m2v_pull into dst, with the same results and return value as that pair - except that the words of completed chunks are
  * copied into dst WHILE this call's frames cross the link, not between two transfers.  For a caller with one thread and frames in
  * page-locked memory the link then only idles for the caller's own turn-around.
+ * On an error (negative return) nothing that was encoded is lost: words that had already been copied into dst inside the failed call are
+ * put back at the front of the output FIFO and come out of the next m2v_pull; the contents of dst are then undefined.  After a device
+ * error the handle is good for m2v_pull, m2v_reset and m2v_destroy only.
  */
 long long m2v_push_frames_pull(m2v_enc *e, uint32_t xsize16, uint32_t ysize16, uint32_t pframes_count,
                                const uint8_t *frames444, size_t nframes, uint8_t *dst, size_t cap, int *last);
