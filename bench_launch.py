@@ -54,7 +54,29 @@ def _end(procs, grace_kill):
             pass
 
 
-def launch_ranks(nranks, argv, relay=True, deadline_s=None, extra_env=None):
+def _tee_stderr(pipe, keep, limit=4096):
+    """a child's stderr passed through to ours as it comes, the last few KB kept (what an error entry of `strips` quotes)"""
+    for raw in pipe:
+        try:
+            sys.stderr.buffer.write(raw)
+            sys.stderr.buffer.flush()
+        except Exception:  # noqa: BLE001
+            pass
+        keep.append(raw)
+        while sum(len(x) for x in keep) > limit and len(keep) > 1:
+            keep.pop(0)
+
+
+def error_text(keep):
+    """the most telling line of a rank's stderr: the last one that names a failure, else the last one at all"""
+    lines = b"".join(keep).decode(errors="replace").splitlines()
+    for ln in reversed(lines):
+        if any(w in ln for w in ("failed", "Error", "error", "rror:")) and "amdgpu.ids" not in ln:
+            return ln.strip()[-400:]
+    return lines[-1].strip()[-400:] if lines else None
+
+
+def launch_ranks(nranks, argv, relay=True, deadline_s=None, extra_env=None, keep_stderr=None):
     """Starts `bench.py argv` as `nranks` ranks and waits for them.  -> (worst exit code, rank 0's stdout lines as bytes, timed_out).
     relay: rank 0's stdout is passed through as it arrives (the ONE JSON line); otherwise it is only kept.  The other ranks' stdout goes
     to stderr.  A rank that dies takes the job down: the survivors get M2V_BENCH_GRACE seconds to finish on their own, then SIGTERM,
@@ -67,8 +89,10 @@ def launch_ranks(nranks, argv, relay=True, deadline_s=None, extra_env=None):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), M2V_BENCH_LAUNCHED_BY="bench.py")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
         env.update(extra_env or {})
-        procs.append(subprocess.Popen([sys.executable, BENCH] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=ROOT))
+        procs.append(subprocess.Popen([sys.executable, BENCH] + argv, env=env, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=subprocess.PIPE if (r == 0 and keep_stderr is not None) else None))
+    if keep_stderr is not None:
+        threading.Thread(target=_tee_stderr, args=(procs[0].stderr, keep_stderr), daemon=True).start()
     line0 = procs[0].stdout
     worst, live = 0, set(range(nranks))
     kept = []
@@ -147,11 +171,14 @@ def summarize_leg(lines, rc, timed_out, seconds, stderr_tail=None):
         except (ValueError, UnicodeDecodeError):
             continue
     if timed_out:
-        return {"error": "timeout", "bound_s": LEG_TIMEOUT_S, "seconds": round(seconds, 1)}
+        d = {"error": "timeout", "bound_s": LEG_TIMEOUT_S, "seconds": round(seconds, 1)}
+        if stderr_tail:
+            d["rank0_said"] = stderr_tail
+        return d
     if rc != 0 or line is None:
         d = {"error": "exit code %d" % rc if rc != 0 else "no line from rank 0", "seconds": round(seconds, 1)}
         if stderr_tail:
-            d["stderr_tail"] = stderr_tail[-600:]
+            d["rank0_said"] = stderr_tail
         return d
     if line.get("dry_launch"):
         return {"dry_launch": True, "ranks_seen": line.get("ranks_seen"), "mode": line.get("mode"), "transport": line.get("transport"),
@@ -182,9 +209,10 @@ def legs_from_launcher(args):
     for name, flags in LEGS:
         t0 = time.time()
         try:
+            err_keep = []
             rc, lines, timed_out = launch_ranks(args.gpus, leg_argv(args, flags), relay=False, deadline_s=LEG_TIMEOUT_S,
-                                                extra_env={"M2V_BENCH_GRACE": "5,5", "M2V_BENCH_LEG": name})
-            out[name] = summarize_leg(lines, rc, timed_out, time.time() - t0)
+                                                extra_env={"M2V_BENCH_GRACE": "5,5", "M2V_BENCH_LEG": name}, keep_stderr=err_keep)
+            out[name] = summarize_leg(lines, rc, timed_out, time.time() - t0, error_text(err_keep))
         except Exception as ex:  # noqa: BLE001   (a leg never costs the c4 line)
             out[name] = {"error": "launcher: %r" % (ex,), "seconds": round(time.time() - t0, 1)}
     return out
@@ -203,12 +231,13 @@ def legs_from_rank(args, rank, world, ports):
         t0 = time.time()
         try:
             pr = subprocess.Popen([sys.executable, BENCH] + leg_argv(args, flags), env=env, cwd=ROOT,
-                                  stdout=subprocess.PIPE if rank == 0 else sys.stderr, stderr=sys.stderr)
-            lines = []
+                                  stdout=subprocess.PIPE if rank == 0 else sys.stderr, stderr=subprocess.PIPE if rank == 0 else None)
+            lines, err_keep = [], []
             rd = None
             if rank == 0:
                 rd = threading.Thread(target=lambda: lines.extend(pr.stdout), daemon=True)
                 rd.start()
+                threading.Thread(target=_tee_stderr, args=(pr.stderr, err_keep), daemon=True).start()
             timed_out = False
             try:
                 pr.wait(timeout=LEG_TIMEOUT_S)
@@ -218,7 +247,7 @@ def legs_from_rank(args, rank, world, ports):
             if rd is not None:
                 rd.join(timeout=10.0)
             if rank == 0:
-                out[name] = summarize_leg(lines, pr.returncode if pr.returncode is not None else -9, timed_out, time.time() - t0)
+                out[name] = summarize_leg(lines, pr.returncode if pr.returncode is not None else -9, timed_out, time.time() - t0, error_text(err_keep))
         except Exception as ex:  # noqa: BLE001
             if rank == 0:
                 out[name] = {"error": "rank 0: %r" % (ex,), "seconds": round(time.time() - t0, 1)}

@@ -166,7 +166,7 @@ def bench_strips(args, cfg, M, torch, dist, rank, local_rank, world, dev):
     dt, out = timed(lambda: [step() for _ in range(args.steps)][-1])
     # ---- sequences in flight from one thread (turns), the output rank fixed and - if asked for - rotating ----
     dt_turns = dt_rot = dt_thr = None
-    turns_identical = long_res = None
+    turns_identical = None
     if loop == "native" and K > 1 and not threads_form:
         for e in encs:
             e.set_option("split_streams", 1)  # in flight the sequences themselves are what overlaps: one stream each (tools/strip_solo_turns.py)
@@ -177,25 +177,6 @@ def bench_strips(args, cfg, M, torch, dist, rank, local_rank, world, dev):
         if rotate:
             guarded(run_turns, max(2 * K, 2 * world), True)
             dt_rot, _ = timed(run_turns, args.steps, True)
-        # ---- the same in-flight loop on a LONGER sequence: a GOP step is one launch over the step's frames of ALL GOPs, so G GOPs make every launch
-        #      G / gops times as large and the ramp and drain of the nine launches weigh that much less (profiles/r06_experiments.txt item 20) ----
-        if args.long_gops > 0 and args.long_gops != args.gops:
-            n_long = args.long_gops * gop
-            clip_s, outs_s = clip, d_outs
-            long_res = None
-            try:
-                clip = M.synth.clip_torch(Ws, Hs, n_long, clip_index=0, device=dev)
-                d_outs = [torch.empty(n_long * Ws * Hs * 3 // 2, dtype=torch.uint8, device=dev) if (rank == 0 or rotate) else None for _ in range(K)]
-                torch.cuda.synchronize()
-                steps_long = max(2 * K, args.steps * args.gops // args.long_gops)
-                guarded(run_turns, 2 * K, rotate)
-                barrier()
-                t0 = time.perf_counter()
-                guarded(run_turns, steps_long, rotate)
-                barrier()
-                long_res = (time.perf_counter() - t0, steps_long, n_long, enc.strip_last_form())
-            finally:
-                clip, d_outs = clip_s, outs_s
         for e in encs:
             e.set_option("split_streams", cfg.LIB_DEFAULT_SPLIT_STREAMS)
     # ---- the same with K host threads (opt-in): thread k runs steps k, k + K, ... on stack k (the same split on every rank) ----
@@ -243,15 +224,65 @@ def bench_strips(args, cfg, M, torch, dist, rank, local_rank, world, dev):
     if dist is not None:
         on = dev if backend == "nccl" else "cpu"
         t = torch.tensor([dt, timings.get("halo_exposed", 0.0), timings.get("halo_total", 0.0), timings.get("gather", 0.0), dt_turns or 0.0, dt_rot or 0.0,
-                          dt_thr or 0.0, long_res[0] if long_res else 0.0], dtype=torch.float64, device=on)
+                          dt_thr or 0.0], dtype=torch.float64, device=on)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, timings["halo_exposed"], timings["halo_total"], timings["gather"], m_turns, m_rot, m_thr, m_long = (float(v) for v in t.tolist())
-        long_res = (m_long,) + tuple(long_res[1:]) if long_res else None
+        dt, timings["halo_exposed"], timings["halo_total"], timings["gather"], m_turns, m_rot, m_thr = (float(v) for v in t.tolist())
         dt_turns, dt_rot, dt_thr = (m if x is not None else None for x, m in ((dt_turns, m_turns), (dt_rot, m_rot), (dt_thr, m_thr)))
         mine = torch.tensor([ms_p, ms_i, ms_scan + ms_asm, timings.get("halo_exposed", 0.0)], dtype=torch.float64, device=on)
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank = [[round(float(v), 3) for v in x.tolist()] for x in every]
+    # ---- the in-flight loop once more on a LONGER sequence: a GOP step is one launch over the step's frames of ALL GOPs, so G GOPs make every launch
+    #      G / gops times as large and the ramp and drain of the nine launches weigh that much less (profiles/r06_experiments.txt item 20).  Last, and on its
+    #      own feet: everything else of the line has been measured; a rank that cannot allocate the long clip makes every rank skip (a vote), and a failure
+    #      inside the loop - the same call fails on every rank, that is the strip protocol - becomes an entry in the line, not the end of the leg ----
+    long_res = long_err = None
+    if loop == "native" and K > 1 and not threads_form and args.long_gops > 0 and args.long_gops != args.gops:
+        n_long = args.long_gops * gop
+        clip_s, outs_s = clip, d_outs
+        ok = 1
+        try:
+            clip = M.synth.clip_torch(Ws, Hs, n_long, clip_index=0, device=dev)
+            d_outs = [torch.empty(n_long * Ws * Hs * 3 // 2, dtype=torch.uint8, device=dev) if (rank == 0 or rotate) else None for _ in range(K)]
+            torch.cuda.synchronize()
+        except Exception as ex:  # noqa: BLE001
+            ok, long_err = 0, "rank %d: %s" % (rank, str(ex)[:200])
+        if dist is not None:
+            t = torch.tensor([ok], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                ok, long_err = 0, long_err or "another rank could not allocate the long sequence"
+        if ok:
+            try:
+                for e in encs:
+                    e.set_option("split_streams", 1)
+                steps_long = max(2 * K, args.steps * args.gops // args.long_gops)
+                run_turns(2 * K, rotate)
+                barrier()
+                t0 = time.perf_counter()
+                run_turns(steps_long, rotate)
+                barrier()
+                t_long = time.perf_counter() - t0
+                if dist is not None:
+                    t = torch.tensor([t_long], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    t_long = float(t.item())
+                long_res = (t_long, steps_long, n_long, enc.strip_last_form())
+            except Exception as ex:  # noqa: BLE001
+                long_err = "rank %d: %s" % (rank, str(ex)[:300])
+                sys.stderr.write("bench.py --mode strips: the long-sequence loop failed on rank %d: %s\n  state: %s\n" % (rank, ex, json.dumps(describe())))
+                for e in encs:                 # sequences begun and never collected: dropped (every rank does the same)
+                    try:
+                        e.reset()
+                    except Exception:  # noqa: BLE001
+                        pass
+        clip, d_outs = clip_s, outs_s
+        torch.cuda.empty_cache()
+        for e in encs:
+            try:
+                e.set_option("split_streams", cfg.LIB_DEFAULT_SPLIT_STREAMS)
+            except Exception:  # noqa: BLE001
+                pass
     dt_fly = dt_thr if threads_form else (dt_rot if rotate else dt_turns)
     if rank == 0:
         px = nframes * Ws * Hs
@@ -279,7 +310,8 @@ def bench_strips(args, cfg, M, torch, dist, rank, local_rank, world, dev):
                                         "value": round(long_res[1] * long_res[2] * Ws * Hs / long_res[0] * 1e-6, 2),
                                         "ms_per_90_frames": round(long_res[0] / long_res[1] * 1e3 * 90 / long_res[2], 4),
                                         "output_rank": "rotating" if rotate else "rank 0", "gop_steps_ran_as": long_res[3],
-                                        "note": "the same loop on a sequence of %d GOPs: a GOP step is one launch over all GOPs' frames" % args.long_gops} if long_res else None,
+                                        "note": "the same loop on a sequence of %d GOPs: a GOP step is one launch over all GOPs' frames" % args.long_gops} if long_res else
+                                       ({"error": long_err, "gops": args.long_gops} if long_err else None),
             "config": {"workload": "c5: ONE 2048x2048 yuv444p sequence, %d GOPs of 1 I + %d P, VECTOR_LEVEL=3 Q_LEVEL=2, "
                                    "%d strips of macroblock rows, halo = 9 rows x 2048 B per frame per direction"
                                    % (args.gops, PFRAMES, world), "frames": nframes,

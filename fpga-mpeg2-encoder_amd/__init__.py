@@ -200,6 +200,10 @@ class Mpeg2Encoder:
             raise M2VError("%s failed (%d): %s" % (what, r, self._L.m2v_last_error(self._h).decode()))
         return r
 
+    def reset(self):
+        """m2v_reset (`rstn` low, RTL:1028-1039): whatever is in flight on the handle is waited for and dropped, the handle is idle again"""
+        self._chk(self._L.m2v_reset(self._h), "m2v_reset")
+
     def set_option(self, name, value):
         self._chk(self._L.m2v_set_option(self._h, name.encode(), int(value)), "m2v_set_option(%s)" % name)
 
