@@ -223,12 +223,12 @@ def bench_strips(args, cfg, M, torch, dist, rank, local_rank, world, dev):
     per_rank = None
     if dist is not None:
         on = dev if backend == "nccl" else "cpu"
+        mine = torch.tensor([ms_p, ms_i, ms_scan + ms_asm, timings.get("halo_exposed", 0.0)], dtype=torch.float64, device=on)     # (this rank's, before the max)
         t = torch.tensor([dt, timings.get("halo_exposed", 0.0), timings.get("halo_total", 0.0), timings.get("gather", 0.0), dt_turns or 0.0, dt_rot or 0.0,
                           dt_thr or 0.0], dtype=torch.float64, device=on)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, timings["halo_exposed"], timings["halo_total"], timings["gather"], m_turns, m_rot, m_thr = (float(v) for v in t.tolist())
         dt_turns, dt_rot, dt_thr = (m if x is not None else None for x, m in ((dt_turns, m_turns), (dt_rot, m_rot), (dt_thr, m_thr)))
-        mine = torch.tensor([ms_p, ms_i, ms_scan + ms_asm, timings.get("halo_exposed", 0.0)], dtype=torch.float64, device=on)
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank = [[round(float(v), 3) for v in x.tolist()] for x in every]
