@@ -26,7 +26,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 BENCH = os.path.join(ROOT, "bench.py")
 
-LEG_TIMEOUT_S = float(os.environ.get("M2V_BENCH_LEG_TIMEOUT", "150"))       # wall clock per strips leg, start of the children to their exit
+LEG_TIMEOUT_S = float(os.environ.get("M2V_BENCH_LEG_TIMEOUT", "180"))       # wall clock per strips leg, start of the children to their exit
 LEGS = (("rccl", ["--transport", "rccl"]), ("peer", ["--transport", "peer"]))
 
 
