@@ -117,9 +117,11 @@ def main():
                          "enqueued with m2v_encode_resident_begin and collected with _end when its handle comes round again; 1 = one "
                          "handle, every step a synchronous m2v_encode_resident call (what rounds 1 and 2 timed)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling aid: skip kernel phases (output invalid), see Geom::ablate")
-    ap.add_argument("--strip-inflight", type=int, default=3,
+    ap.add_argument("--strip-inflight", type=int, default=-1,
                     help="--mode strips: sequences in flight per rank from ONE thread: that many handles taking turns through m2v_strip_encode_begin / "
-                         "_end (with --transport peer a landing block each) over one base communicator.  1: blocking calls only")
+                         "_end (with --transport peer a landing block each) over one base communicator.  1: blocking calls only.  -1 (default): 3 with "
+                         "the peer transport, 2 with the RCCL form of the step (one rank of 8 alone on a GPU: 0.250 / 0.264 ms per sequence with 3 / 2 "
+                         "in flight in the peer form, 0.390 / 0.363 in the RCCL form - profiles/r06_experiments.txt item 20)")
     ap.add_argument("--strip-threads", type=int, default=0,
                     help="--mode strips, opt-in (the round-5 form): K host threads per rank, each with a handle and a communicator stack of its own")
     ap.add_argument("--rotate-dst", action="store_true",

@@ -25,7 +25,8 @@ def bench_strips(args, cfg, M, torch, dist, rank, local_rank, world, dev):
     nframes = args.gops * gop
     backend = dist.get_backend() if dist is not None else None
     clip = M.synth.clip_torch(Ws, Hs, nframes, clip_index=0, device=dev)        # every rank holds the same clip
-    K = max(1, args.strip_threads if args.strip_threads > 1 else args.strip_inflight)
+    inflight = args.strip_inflight if args.strip_inflight > 0 else (3 if args.transport == "peer" else 2)
+    K = max(1, args.strip_threads if args.strip_threads > 1 else inflight)
     threads_form = args.strip_threads > 1
     # The loop: native (m2v_strip_encode*: the GOP steps and the exchange issued from C++) whenever the ranks have a communicator the
     # library can drive - RCCL between GPUs; for one rank nothing; with the 1-GPU test hook (gloo, shared device) and --transport peer a
