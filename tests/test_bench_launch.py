@@ -230,3 +230,32 @@ def test_queue_placement_decision_table():
     assert bu.placement_next_action(G * 1.0, 1.0, 0, False) == "keep" and bu.placement_next_action(G * 1.0 + 1e-9, 1.0, 0, False) == "new_stream"
     assert bu.placement_next_action(1.0, 1.0, bu.PLACEMENT_MAX_NEW_STREAMS, False) == "priority"
     assert bu.placement_next_action(1.0, 1.0, bu.PLACEMENT_MAX_NEW_STREAMS, True) == "keep"
+
+
+def test_a_strips_legs_line_becomes_an_entry_and_a_failure_a_stated_error():
+    """bench_launch.summarize_leg / error_text: rank 0's stdout of a strips leg (noise lines of the backend in front of the JSON line allowed) -> the
+    entry of `strips`; no line, a non-zero exit code or a timeout -> {"error": ...} quoting the most telling line of rank 0's stderr"""
+    sys.path.insert(0, ROOT)
+    import bench_launch as bl
+    line = {"value": 1234.5, "unit": "MPixels/s", "ms_per_step": 0.25, "n_gpus": 8, "scaling": "strong", "sequences_in_flight": 3, "steps": 40,
+            "in_flight_form": "one thread", "one_sequence_at_a_time": {"value": 1000.0, "ms_per_step": 0.31}, "in_flight_output_rank_0": {"value": 1200.0},
+            "in_flight_output_rank_rotating": {"value": 1234.5}, "in_flight_long_sequence": {"gops": 40, "ms_per_90_frames": 0.24},
+            "config": {"transport": "peer+rccl", "transport_asked_for": "peer", "strip_loop": "native", "strip_loop_why": None, "gop_steps_ran_as": "peer",
+                       "peer": [{"peer_sequences": 50, "giveups": 0, "fell_back": False}, {"peer_sequences": 49, "giveups": 1, "fell_back": True}]},
+            "exchange_ms_per_step": {"halo_exposed": 0.0, "halo_total": 0.0, "gather_and_assembly": 0.05}, "roofline": {"frac": 0.11},
+            "parity_check": {"identical_to_oracle": True}, "per_rank_ms_per_step": {"columns": ["k_mb_P"], "ranks": [[0.2]] * 8}}
+    out = [b"[Gloo] Rank 0 is connected to 7 peer ranks\n", (json.dumps(line) + "\n").encode()]
+    e = bl.summarize_leg(out, 0, False, 33.3)
+    assert e["value"] == 1234.5 and e["ms_per_sequence"] == 0.25 and e["n_gpus"] == 8 and e["identical_to_oracle"] is True and e["seconds"] == 33.3
+    assert e["transport"] == "peer+rccl" and e["peer_sequences"] == 99 and e["giveups"] == 1 and e["fell_back"] is True
+    assert e["in_flight_long_sequence"]["gops"] == 40 and e["roofline_frac"] == 0.11 and "error" not in e
+    stderr = [b"/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", b"Traceback (most recent call last):\n",
+              b"bench.py --mode strips: rank 3 failed: m2v_strip_encode_end failed (-5): out of memory\n", b"  state: {...}\n"]
+    said = bl.error_text(stderr)
+    assert "rank 3 failed" in said
+    assert bl.summarize_leg(out, 1, False, 5.0, said) == {"error": "exit code 1", "seconds": 5.0, "rank0_said": said}
+    assert bl.summarize_leg([], 0, False, 5.0)["error"] == "no line from rank 0"
+    t = bl.summarize_leg(out, 124, True, 180.2, said)
+    assert t["error"] == "timeout" and t["rank0_said"] == said and t["bound_s"] == bl.LEG_TIMEOUT_S
+    assert bl.error_text([]) is None and bl.error_text([b"all fine\n"]) == "all fine"
+
