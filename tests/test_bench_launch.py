@@ -39,14 +39,14 @@ def test_a_strips_leg_that_hangs_or_fails_never_costs_the_c4_line():
     line, exit code 0; the RCCL leg beside it is fine.  Then a leg whose ranks exit with an error: a stated exit code, same line."""
     import time
     t0 = time.time()
-    r, lines = run(["--gpus", "2", "--dry-launch"], {"M2V_DIST_BACKEND": "gloo", "M2V_BENCH_TEST_HANG_LEG": "peer", "M2V_BENCH_LEG_TIMEOUT": "12"}, timeout=240)
+    r, lines = run(["--gpus", "2", "--dry-launch"], {"M2V_DIST_BACKEND": "gloo", "M2V_BENCH_TEST_HANG_LEG": "peer", "M2V_BENCH_LEG_TIMEOUT": "25"}, timeout=400)
     took = time.time() - t0
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks_counted"] == 2
     st = lines[0]["strips"]
     assert st["rccl"].get("dry_launch") is True and "error" not in st["rccl"]
-    assert st["peer"]["error"] == "timeout" and 12 <= st["peer"]["seconds"] < 40
-    assert took < 120
+    assert st["peer"]["error"] == "timeout" and 25 <= st["peer"]["seconds"] < 60          # (the bound is generous: a loaded box imports torch slowly)
+    assert took < 240
     r, lines = run(["--gpus", "2", "--dry-launch"], {"M2V_DIST_BACKEND": "gloo", "M2V_BENCH_TEST_FAIL_LEG": "rccl"}, timeout=240)
     assert r.returncode == 0 and len(lines) == 1
     assert lines[0]["strips"]["rccl"]["error"] == "exit code 5" and lines[0]["strips"]["peer"].get("dry_launch") is True
@@ -80,7 +80,7 @@ def test_under_torch_distributed_run_the_ranks_are_not_started_twice():
 
 def test_under_torch_distributed_run_a_hanging_leg_is_ended_by_every_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    env.update({"M2V_DIST_BACKEND": "gloo", "M2V_BENCH_TEST_HANG_LEG": "rccl", "M2V_BENCH_LEG_TIMEOUT": "10"})
+    env.update({"M2V_DIST_BACKEND": "gloo", "M2V_BENCH_TEST_HANG_LEG": "rccl", "M2V_BENCH_LEG_TIMEOUT": "25"})
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
                        capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
