@@ -588,15 +588,26 @@ __device__ __forceinline__ uint32_t vlc_tile_symbols_intra(const int16_t *zig, u
 typedef __attribute__((address_space(3))) uint32_t LdsU32;
 struct QsadRow { unsigned long long w01, w12, w23, w34; };    // the four overlapping 8-byte reference operands of one window row
 
-// full-pel search, rows RR..15 of the macroblock.  The operands of row RR were issued one row earlier into `p`; this
-// step issues row RR + 1 into `q`, waits until only those four reads are outstanding (LDS returns in order), then
-// runs the four v_qsad of row RR.  ae / ao: LDS byte addresses of this lane's even / odd pairs in window row dy.
-template <int RR, int WS>
-__device__ __forceinline__ void search_rows(const uint32_t *s_cur, uint32_t ae, uint32_t ao, unsigned long long &acc,
-                                            QsadRow &p, QsadRow &q)
+// full-pel search: the operands of a window row are issued one row ahead of their v_qsad (p / q alternate), by hand-issued ds_read_b64 - left to
+// itself the compiler fuses them into ds_read2_b64, which runs at half the LDS rate (MI355X_MICROARCH.md, LDS table).  ae / ao: LDS byte addresses
+// of the lane's even / odd dword pairs in its first window row.
+// Measurement aid of experiment 19 (profiles/r06_experiments.txt; tools/variant_build.sh ub=-DM2V_EXP19_QSAD_PER_STEP=3): with 3 every
+// step of the VECTOR_LEVEL 3 search drops its fourth v_qsad - a quarter of the search's vector cycles gone, results INVALID - which
+// bounds from above what any re-packing of the search's 39 dead candidate slots (of 208) could buy.  4 = the kernel as shipped.
+#ifndef M2V_EXP19_QSAD_PER_STEP
+#define M2V_EXP19_QSAD_PER_STEP 4
+#endif
+constexpr int kExp19QsadPerStep = M2V_EXP19_QSAD_PER_STEP;
+
+typedef const __attribute__((address_space(3))) u32x4_t *LdsU4;
+typedef const __attribute__((address_space(3))) u32x2_t *LdsU2;
+// VECTOR_LEVEL 1 / 2 (round 6): the (dy, dx group) pairs of the small ranges are few - 10 and 27 - so every pair is given to SEVERAL lanes, each
+// running a part of the macroblock's sixteen rows: NR rows per lane instead of 16.  cur: LDS byte address of the part's first current row.
+template <int RR, int NR, int WS>
+__device__ __forceinline__ void search_rows_part(uint32_t cur, uint32_t ae, uint32_t ao, unsigned long long &acc, QsadRow &p, QsadRow &q)
 {
-    if constexpr (RR < 16) {
-        if constexpr (RR + 1 < 16) {
+    if constexpr (RR < NR) {
+        if constexpr (RR + 1 < NR) {
             asm volatile("ds_read_b64 %0, %8 offset:%10\n\tds_read_b64 %1, %9 offset:%10\n\t"
                          "ds_read_b64 %2, %8 offset:%11\n\tds_read_b64 %3, %9 offset:%11\n\t"
                          "s_waitcnt lgkmcnt(4)"
@@ -606,26 +617,17 @@ __device__ __forceinline__ void search_rows(const uint32_t *s_cur, uint32_t ae, 
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p.w01), "+v"(p.w12), "+v"(p.w23), "+v"(p.w34));
         }
-        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w01, s_cur[RR * 4 + 0], acc);
-        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w12, s_cur[RR * 4 + 1], acc);
-        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w23, s_cur[RR * 4 + 2], acc);
-        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w34, s_cur[RR * 4 + 3], acc);
-        search_rows<RR + 1, WS>(s_cur, ae, ao, acc, q, p);
+        const u32x4_t c = *(LdsU4)(uintptr_t)(cur + RR * 16);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w01, c.x, acc);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w12, c.y, acc);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w23, c.z, acc);
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(p.w34, c.w, acc);
+        search_rows_part<RR + 1, NR, WS>(cur, ae, ao, acc, q, p);
     }
 }
 
-// Measurement aid of experiment 19 (profiles/r06_experiments.txt; tools/variant_build.sh ub=-DM2V_EXP19_QSAD_PER_STEP=3): with 3 every
-// step of the VECTOR_LEVEL 3 search drops its fourth v_qsad - a quarter of the search's vector cycles gone, results INVALID - which
-// bounds from above what any re-packing of the search's 39 dead candidate slots (of 208) could buy.  4 = the kernel as shipped.
-#ifndef M2V_EXP19_QSAD_PER_STEP
-#define M2V_EXP19_QSAD_PER_STEP 4
-#endif
-constexpr int kExp19QsadPerStep = M2V_EXP19_QSAD_PER_STEP;
-
 // The same for VECTOR_LEVEL 3 with the helper lanes (see kS3Cur above): 13 steps, the current row through a per-lane address,
 // the helpers' running sums stored after steps 2, 5, 8, 11 with EXEC narrowed to them (hmask) inside the asm statement.
-typedef const __attribute__((address_space(3))) u32x4_t *LdsU4;
-typedef const __attribute__((address_space(3))) u32x2_t *LdsU2;
 template <int RR>
 __device__ __forceinline__ void search_rows13(uint32_t cur, uint32_t cur12, uint32_t ae, uint32_t ao, uint32_t flush, unsigned long long hmask,
                                               unsigned long long &acc, QsadRow &p, QsadRow &q)
@@ -1114,9 +1116,16 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
         {
             uint32_t key = 0xFFFFFFFFu;
             // dy = dyi - YR, dx = 4*gq - 8 + j
-            const int dyi = VL == 3 ? s3_dy(lane) : lane >> 2, gq = VL == 3 ? s3_group(lane) : lane & 3;
+            // VECTOR_LEVEL 1 / 2: kPairs (dy, group) pairs - only the groups that hold a live dx: 1 and 2 (dx -4 .. 3) for +-2, 1 .. 3 for +-4 -, each
+            // given to kParts lanes kLanesPerPart apart, lane (part, pair) running rows [part * kNR, + kNR).  The lanes beyond the last pair
+            // repeat its work (their loads stay inside the window) and own nothing.
+            constexpr int kParts = VL == 1 ? 4 : VL == 2 ? 2 : 1, kLanesPerPart = 64 / kParts, kPairs = VL == 1 ? 10 : VL == 2 ? 27 : 64, kNR = 16 / kParts;
+            const int part = VL == 3 ? 0 : lane / kLanesPerPart, pair0 = lane & (kLanesPerPart - 1), pair = pair0 < kPairs ? pair0 : kPairs - 1;
+            const int dyi = VL == 3 ? s3_dy(lane) : VL == 1 ? pair >> 1 : (pair * 11) >> 5;
+            const int gq = VL == 3 ? s3_group(lane) : VL == 1 ? 1 + (pair & 1) : 1 + pair - 3 * dyi;
+            const bool owner = VL == 3 || (part == 0 && pair0 < kPairs);
             const uint32_t sl_cb4 = sl.cb4, sl_dead_lo = sl.dead_lo, sl_dead_hi = sl.dead_hi;
-            if ((VL == 3 || dyi <= 2 * YR) && !(kDebug && (g.ablate & 1))) {
+            if (!(kDebug && (g.ablate & 1))) {
                 unsigned long long acc = 0;
                 QsadRow ra, rb{};
                 if constexpr (VL == 3) {
@@ -1139,12 +1148,25 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     // in copy A, the other one in copy B (which holds dword j + 1 at index j)
                     // hand-issued ds_read_b64, one row ahead (left to itself the compiler fuses them into ds_read2_b64,
                     // which runs at half the LDS rate - MI355X_MICROARCH.md, LDS table)
-                    const uint32_t *const pe = (gq & 1) ? s_winb + dyi * kWS + gq - 1 : s_win + dyi * kWS + gq;
-                    const uint32_t *const po = (gq & 1) ? s_win + dyi * kWS + gq + 1 : s_winb + dyi * kWS + gq;
+                    const int wrow = dyi + kNR * part;                 // the window row of the part's first macroblock row
+                    const uint32_t *const pe = (gq & 1) ? s_winb + wrow * kWS + gq - 1 : s_win + wrow * kWS + gq;
+                    const uint32_t *const po = (gq & 1) ? s_win + wrow * kWS + gq + 1 : s_winb + wrow * kWS + gq;
                     const uint32_t ae = (uint32_t)(uintptr_t)(LdsU32 *)pe, ao = (uint32_t)(uintptr_t)(LdsU32 *)po;
                     asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %5 offset:8"
                                  : "=&v"(ra.w01), "=&v"(ra.w12), "=&v"(ra.w23), "=&v"(ra.w34) : "v"(ae), "v"(ao));
-                    search_rows<0, kWS>(s_cur, ae, ao, acc, ra, rb);
+                    search_rows_part<0, kNR, kWS>((uint32_t)(uintptr_t)(LdsU32 *)s_cur + (uint32_t)(part * kNR * 16), ae, ao, acc, ra, rb);
+                    // the parts' sums of a pair sit kLanesPerPart lanes apart: folded with the lane swaps (two rows of 32, then two rows of 16).
+                    // No field carries into its neighbour: a complete SAD is at most 65280.
+                    uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+                    {
+                        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+                        lo = a[0] + a[1]; hi = b[0] + b[1];
+                    }
+                    if constexpr (kParts == 4) {
+                        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+                        lo = a[0] + a[1]; hi = b[0] + b[1];
+                    }
+                    acc = ((unsigned long long)hi << 32) | lo;
                 }
                 // minimum SAD; among equals the largest dy, then the largest dx (RTL:1694-1710): key = sad << 8 | (255 - index),
                 // index = dy' << 4 | dx + 8.  A SAD >= 4096 kills a candidate (RTL:1669-1670): such keys are >= 1 << 20 and lose
@@ -1170,7 +1192,7 @@ __global__ __launch_bounds__(64, 8) void k_mb(const FrameJob *__restrict__ jobs,
                     for (int j = 0; j < 4; ++j) {
                         const uint32_t sad = (uint32_t)(acc >> (16 * j)) & 0xFFFFu;
                         const uint32_t k = (sad << 8) | (cbase - (uint32_t)j);
-                        const bool ok = rowok && (uint32_t)(d0 + j) <= span;
+                        const bool ok = owner && rowok && (uint32_t)(d0 + j) <= span;
                         if (ok && k < key) key = k;
                     }
                 }
